@@ -1,0 +1,142 @@
+/*
+ * rr_hip.h -- C ABI of librr_hip.so, the MI355X (gfx950) Muskingum routing engine.
+ *
+ * Drop-in boundary: these entry points replace the reference's kernel boundary, i.e. the three
+ * numba functions and the UH convolution that the reference's routers call once per input file
+ * (citations relative to the reference repository root):
+ *
+ *   rr_rapid_route      <- rapid_route      river_route/routers/_numba_kernels.py:49-84
+ *                          (call site river_route/routers/RapidMuskingum.py:27-32)
+ *   rr_muskingum_route  <- muskingum_route  river_route/routers/_numba_kernels.py:8-46
+ *                          (call site river_route/routers/Muskingum.py:281-286)
+ *   rr_unit_route       <- unit_route       river_route/routers/_numba_kernels.py:88-171
+ *                          (call site river_route/routers/UnitMuskingum.py:82-92)
+ *   rr_uh_convolve      <- UnitHydrograph.convolve  river_route/uhkernels/UnitHydrograph.py:77-107
+ *                          (call site river_route/routers/UnitMuskingum.py:75)
+ *   rr_plan_create      <- the CSC structure the routers take from tools.adjacency_matrix
+ *                          (river_route/tools.py:75-109; river_route/routers/Muskingum.py:189-192)
+ *   rr_plan_set_coeffs  <- the coefficient vectors of Muskingum._set_muskingum_coefficients
+ *                          (river_route/routers/Muskingum.py:172-193) and c4_dt of RapidMuskingum.py:24
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all floating point is IEEE fp64; CSC indices are int32
+ *     (what scipy hands the reference); hw/inner positions are implied by the adjacency.
+ *   - every function returns RR_OK (0) or a negative RR_E_* code and never throws; the message of
+ *     the last failure on the calling thread is rr_last_error().
+ *   - arrays are C-contiguous; 2-D arrays are (time, reach) row-major in PARAMS-FILE reach order,
+ *     exactly as the reference passes them.  The engine keeps its own permuted device layout.
+ *   - `*_dev` variants take DEVICE pointers (valid on the plan's GPU) and a hipStream_t passed as
+ *     void*; they only enqueue work.  The un-suffixed variants take HOST pointers, copy in/out,
+ *     and return when the results are in the caller's buffers.
+ *   - a plan is bound to one GPU and is not thread-safe; use one plan per thread/stream.
+ *   - there is NO CPU fallback: without a usable gfx950 device every compute call fails with
+ *     RR_E_NO_DEVICE.  rr_plan_create(device = RR_DEVICE_NONE) builds a host-only plan whose
+ *     layout can be inspected (rr_plan_info / rr_plan_layout) but which cannot compute.
+ */
+#ifndef RR_HIP_H
+#define RR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RR_OK 0
+#define RR_E_INVALID (-1)         /* bad argument (null pointer, negative size, malformed CSC) */
+#define RR_E_NOT_TOPOLOGICAL (-2) /* a CSC entry has row <= column: reaches not sorted upstream -> downstream */
+#define RR_E_HIP (-3)             /* HIP runtime failure; text in rr_last_error() */
+#define RR_E_NO_DEVICE (-4)       /* no usable GPU, or host-only plan asked to compute */
+#define RR_E_STATE (-5)           /* call order (e.g. route before rr_plan_set_coeffs) */
+#define RR_E_ALLOC (-6)           /* host or device allocation failed */
+#define RR_E_UNSUPPORTED (-7)     /* structure outside what the engine handles */
+
+#define RR_DEVICE_NONE (-1)
+
+typedef struct rr_plan rr_plan;
+
+/* ---- library ---- */
+int rr_version(void);             /* major*10000 + minor*100 + patch */
+const char *rr_last_error(void);  /* thread-local, never NULL */
+int rr_device_count(void);        /* number of visible HIP devices, 0 when there is none */
+
+/* ---- plan: network structure analysis + device-resident layout ---- */
+
+/* n reaches; CSC of A[down, up] = 1 with n columns: csc_indptr[n+1], csc_indices[csc_indptr[n]].
+ * Validates what tools.adjacency_matrix guarantees (row > column for every entry).  device is a
+ * HIP device ordinal or RR_DEVICE_NONE. */
+int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indices, int device, rr_plan **out);
+void rr_plan_destroy(rr_plan *plan);
+
+/* info[0]=n, [1]=edges, [2]=depth (reaches on the longest flow path), [3]=widest level,
+ * [4]=headwaters, [5]=outlets, [6]=1 if the engine's order equals params order (no permutation pass),
+ * [7]=device ordinal or -1. */
+int rr_plan_info(const rr_plan *plan, int64_t info[8]);
+
+/* Engine layout for inspection/tests (any pointer may be NULL): perm[n] params index held at each
+ * engine position; lag[n] pipeline lag of each position (ticks behind the farthest headwater);
+ * child_ptr[n+1] engine-position range [child_ptr[p], child_ptr[p+1]) of the reaches flowing into p. */
+int rr_plan_layout(const rr_plan *plan, int32_t *perm, int32_t *lag, int32_t *child_ptr);
+
+/* Coefficients in params order.  lhs_off_data[e] is the off-diagonal of (I - diag(c1) A) for CSC entry e,
+ * i.e. -c1[row(e)] (Muskingum.py:192); c2, c3 per reach; c4_dt per reach or NULL (channel-only / unit). */
+int rr_plan_set_coeffs(rr_plan *plan, const double *lhs_off_data, const double *c2, const double *c3,
+                       const double *c4_dt);
+
+/* Tuning / measurement.  rows_per_chunk: time rows moved per permutation launch (default 32).
+ * sample_every > 0: bracket every sample_every-th routing-step launch with HIP events. */
+int rr_plan_set_options(rr_plan *plan, int64_t rows_per_chunk, int64_t sample_every);
+
+/* prof[0]=routing-step launches of the last route call, [1]=launches sampled, [2]=sum of sampled
+ * durations (ms), [3]=min (ms), [4]=max (ms), [5]=reaches updated by the sampled launches,
+ * [6]=ms between the first and the last routing-step launch of the call (permutation passes included),
+ * [7]=reach-steps of the call.  Synchronises the plan's last stream. */
+int rr_plan_profile(rr_plan *plan, double prof[8]);
+
+/* ---- routing, host pointers (the reference's kernel boundary) ---- */
+
+/* q_t[n] in: initial state, out: state after the last sub-step.  qlateral[T*n], discharge[T*n].
+ * discharge[t, i] = max(mean over the nsub sub-steps of step t of q[i], 0). */
+int rr_rapid_route(rr_plan *plan, double *q_t, const double *qlateral, double *discharge,
+                   int64_t num_runoff_steps, int64_t num_substeps);
+
+/* discharge[num_output_steps * n]; each output row averages num_routing_per_output sub-steps. */
+int rr_muskingum_route(rr_plan *plan, double *q_t, double *discharge,
+                       int64_t num_output_steps, int64_t num_routing_per_output);
+
+/* Plan built on the FULL adjacency; headwaters are the reaches with no upstream entry, inner reaches the
+ * rest, both in ascending params order (UnitMuskingum.py:41-44).  q_ch[n_inner], q_full[n_inner] in/out;
+ * convolved_lateral[T*n], discharge[T*n] over all n reaches. */
+int rr_unit_route(rr_plan *plan, double *q_ch, double *q_full, const double *convolved_lateral,
+                  double *discharge, int64_t num_runoff_steps, int64_t num_substeps);
+
+/* kernel[n_ks*n], state[n_ks*n] in/out (carry-over), lateral[T*n] -> out[T*n].  No plan needed. */
+int rr_uh_convolve(int device, const double *kernel, double *state, const double *lateral, double *out,
+                   int64_t T, int64_t n_ks, int64_t n);
+
+/* ---- routing, device pointers + stream ---- */
+
+/* As above with device pointers.  qlateral has ql_rows rows and step t reads row t % ql_rows;
+ * discharge has out_rows rows and step t writes row t % out_rows (pass T for plain arrays). */
+int rr_rapid_route_dev(rr_plan *plan, double *q_t, const double *qlateral, int64_t ql_rows,
+                       double *discharge, int64_t out_rows, int64_t num_runoff_steps, int64_t num_substeps,
+                       void *stream);
+int rr_muskingum_route_dev(rr_plan *plan, double *q_t, double *discharge, int64_t out_rows,
+                           int64_t num_output_steps, int64_t num_routing_per_output, void *stream);
+int rr_unit_route_dev(rr_plan *plan, double *q_ch, double *q_full, const double *convolved_lateral,
+                      int64_t conv_rows, double *discharge, int64_t out_rows,
+                      int64_t num_runoff_steps, int64_t num_substeps, void *stream);
+int rr_uh_convolve_dev(int device, const double *kernel, double *state, const double *lateral, double *out,
+                       int64_t T, int64_t n_ks, int64_t n, void *stream);
+
+/* ---- small device helpers so a host language needs no HIP binding of its own ---- */
+int rr_dev_malloc(int device, int64_t bytes, void **out);
+int rr_dev_free(int device, void *ptr);
+int rr_dev_upload(int device, void *dst_dev, const void *src_host, int64_t bytes);
+int rr_dev_download(int device, void *dst_host, const void *src_dev, int64_t bytes);
+int rr_dev_synchronize(int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RR_HIP_H */

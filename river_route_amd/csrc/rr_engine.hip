@@ -1,0 +1,951 @@
+// rr_engine.hip -- gfx950 kernels, the streaming executor and the C ABI of librr_hip.so.
+//
+// The math (river_route/routers/_numba_kernels.py:63-84 in gather form):
+//   q+[i] = c3[i] q[i] + c4dt[i] ql[t,i] + c2[i] * sum_{u in up(i)} q[u] + sum_{u in up(i)} c1[i] q+[u]
+// The second sum is a sparse triangular solve down the river tree.  Instead of sweeping the tree level by
+// level inside one time step, the engine PIPELINES time down the tree: at routing tick tau the reach at
+// engine position p advances its own sub-step  ts = tau - lag[p]  (lag = levels between p and the farthest
+// headwater of the whole network).  Because lag(down) = lag(up) + 1 on every edge, the upstream values a
+// reach needs -- q+[u] at ts and q[u] at ts-1 -- are exactly what its upstream reaches wrote one and two
+// ticks ago.  Every tick is therefore one dependency-free, fully coalesced streaming kernel over all
+// reaches; there are T*nsub + depth - 1 ticks in a call.  State lives in three rotating buffers X[tau % 3].
+//
+// Layout: rr_plan.hpp.  No CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rr_hip.h"
+#include "rr_plan.hpp"
+
+#define RR_VERSION_NUM 100
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return fail(RR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));                 \
+    } while (0)
+
+constexpr int kBlock = 256;
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+
+struct TickArgs {
+    const int32_t *child_ptr;  // [n+1]
+    const int32_t *lag;        // [n]
+    const double *w;           // [n] c1 of the downstream reach, stored at the UPSTREAM position
+    const double *c2, *c3, *c4;
+    const double *xa;          // values written one tick ago
+    const double *xb;          // values written two ticks ago
+    double *xc;                // this tick's values
+    double *isum;              // running sum over the sub-steps of one output row (nsub > 1 only)
+    const double *in;          // lateral rows, engine order (NULL for channel-only)
+    double *out;               // discharge rows, engine order
+    int64_t in_ld, out_ld;
+    uint32_t in_rows, out_rows;
+    int32_t p_lo, p_hi;        // active engine positions
+    int64_t tau;               // tick
+    int64_t total_substeps;    // T * nsub
+    uint32_t nsub;
+    double inv_nsub;
+};
+
+// One routing tick for Muskingum / RapidMuskingum.  One reach per lane; positions are lag-ordered so a
+// wave reads contiguous spans of every array, including the upstream values (rr_plan.hpp).
+template <bool HAS_LATERAL, bool SINGLE_SUBSTEP>
+__global__ __launch_bounds__(kBlock) void k_tick(const TickArgs a)
+{
+    const int32_t p = a.p_lo + (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (p >= a.p_hi) return;
+    const int64_t ts = a.tau - (int64_t)a.lag[p];
+    if (ts < 0 || ts >= a.total_substeps) return;
+    uint32_t t, s;
+    if (SINGLE_SUBSTEP) { t = (uint32_t)ts; s = 0; }
+    else { t = (uint32_t)((uint64_t)ts / a.nsub); s = (uint32_t)((uint64_t)ts - (uint64_t)t * a.nsub); }
+
+    const int32_t u0 = a.child_ptr[p], u1 = a.child_ptr[p + 1];
+    double r = a.c3[p] * a.xa[p];
+    if (HAS_LATERAL) r += a.c4[p] * a.in[(int64_t)(t % a.in_rows) * a.in_ld + p];
+    const double c2 = a.c2[p];
+    for (int32_t u = u0; u < u1; ++u) r += c2 * a.xb[u];
+    for (int32_t u = u0; u < u1; ++u) r += a.w[u] * a.xa[u];
+    a.xc[p] = r;
+
+    if (SINGLE_SUBSTEP) {
+        a.out[(int64_t)(t % a.out_rows) * a.out_ld + p] = r > 0.0 ? r : 0.0;
+    } else {
+        const double acc = (s == 0 ? 0.0 : a.isum[p]) + r;
+        if (s + 1 == a.nsub) {
+            const double v = acc * a.inv_nsub;
+            a.out[(int64_t)(t % a.out_rows) * a.out_ld + p] = v > 0.0 ? v : 0.0;
+        } else {
+            a.isum[p] = acc;
+        }
+    }
+}
+
+struct UnitTickArgs {
+    TickArgs t;
+    const uint16_t *hw_children;  // [n] count of headwater tributaries (stored first among the upstream range)
+    double *qch;                  // [n] channel-only discharge of inner reaches, updated in place
+};
+
+// One routing tick for UnitMuskingum (river_route/routers/_numba_kernels.py:113-171 in gather form).
+// A headwater publishes its convolved lateral l_t as both its "old" and "new" discharge; an inner reach
+// routes q_ch and publishes q_full = q_ch + l_t.
+template <bool SINGLE_SUBSTEP>
+__global__ __launch_bounds__(kBlock) void k_tick_unit(const UnitTickArgs ua)
+{
+    const TickArgs &a = ua.t;
+    const int32_t p = a.p_lo + (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (p >= a.p_hi) return;
+    const int64_t ts = a.tau - (int64_t)a.lag[p];
+    if (ts < 0 || ts >= a.total_substeps) return;
+    uint32_t t, s;
+    if (SINGLE_SUBSTEP) { t = (uint32_t)ts; s = 0; }
+    else { t = (uint32_t)((uint64_t)ts / a.nsub); s = (uint32_t)((uint64_t)ts - (uint64_t)t * a.nsub); }
+
+    const double lat = a.in[(int64_t)(t % a.in_rows) * a.in_ld + p];
+    const int32_t u0 = a.child_ptr[p], u1 = a.child_ptr[p + 1];
+    if (u0 == u1) {  // headwater: discharge is the lateral inflow, unclamped and un-averaged (lines 122-123)
+        a.xc[p] = lat;
+        if (s == 0) a.out[(int64_t)(t % a.out_rows) * a.out_ld + p] = lat;
+        return;
+    }
+    const int32_t uh = u0 + (int32_t)ua.hw_children[p];
+    double r = a.c3[p] * ua.qch[p];
+    const double c2 = a.c2[p];
+    for (int32_t u = u0; u < uh; ++u) r += c2 * a.xa[u];   // headwater tributaries: "old" value is l_t too
+    for (int32_t u = uh; u < u1; ++u) r += c2 * a.xb[u];
+    for (int32_t u = u0; u < u1; ++u) r += a.w[u] * a.xa[u];
+    ua.qch[p] = r;
+    const double qfull = r + lat;
+    a.xc[p] = qfull;
+
+    if (SINGLE_SUBSTEP) {
+        a.out[(int64_t)(t % a.out_rows) * a.out_ld + p] = qfull > 0.0 ? qfull : 0.0;
+    } else {
+        const double acc = (s == 0 ? 0.0 : a.isum[p]) + qfull;
+        if (s + 1 == a.nsub) {
+            const double v = acc * a.inv_nsub;
+            a.out[(int64_t)(t % a.out_rows) * a.out_ld + p] = v > 0.0 ? v : 0.0;
+        } else {
+            a.isum[p] = acc;
+        }
+    }
+}
+
+// ring[(t % ring_rows), p] = src[((t - src_t0) % src_rows), perm[p]] for t in [t0, t0 + nrows)
+__global__ __launch_bounds__(kBlock) void k_permute_in(double *ring, int64_t ring_ld, uint32_t ring_rows,
+                                                       const double *src, int64_t src_ld, uint32_t src_rows,
+                                                       int64_t src_t0, const int32_t *perm, int32_t n,
+                                                       int64_t t0, int32_t nrows, int32_t rows_per_block)
+{
+    const int32_t p = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (p >= n) return;
+    const int32_t i = perm[p];
+    const int32_t r0 = (int32_t)blockIdx.y * rows_per_block;
+    const int32_t r1 = min(nrows, r0 + rows_per_block);
+    for (int32_t r = r0; r < r1; ++r) {
+        const int64_t t = t0 + r;
+        ring[(int64_t)((uint64_t)t % ring_rows) * ring_ld + p] =
+            src[(int64_t)((uint64_t)(t - src_t0) % src_rows) * src_ld + i];
+    }
+}
+
+// dst[((t - dst_t0) % dst_rows), i] = ring[(t % ring_rows), inv[i]]
+__global__ __launch_bounds__(kBlock) void k_permute_out(double *dst, int64_t dst_ld, uint32_t dst_rows,
+                                                        int64_t dst_t0, const double *ring, int64_t ring_ld,
+                                                        uint32_t ring_rows, const int32_t *inv, int32_t n,
+                                                        int64_t t0, int32_t nrows, int32_t rows_per_block)
+{
+    const int32_t i = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (i >= n) return;
+    const int32_t p = inv[i];
+    const int32_t r0 = (int32_t)blockIdx.y * rows_per_block;
+    const int32_t r1 = min(nrows, r0 + rows_per_block);
+    for (int32_t r = r0; r < r1; ++r) {
+        const int64_t t = t0 + r;
+        dst[(int64_t)((uint64_t)(t - dst_t0) % dst_rows) * dst_ld + i] =
+            ring[(int64_t)((uint64_t)t % ring_rows) * ring_ld + p];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_state_in(double *x0, double *x1, double *x2, const double *q_t,
+                                                     const int32_t *perm, int32_t n)
+{
+    const int32_t p = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (p >= n) return;
+    const double v = q_t[perm[p]];
+    x0[p] = v; x1[p] = v; x2[p] = v;
+}
+
+// q_t[i] = value written at the reach's last tick, lag + total_substeps - 1
+__global__ __launch_bounds__(kBlock) void k_state_out(double *q_t, const double *x, int64_t n64,
+                                                      const int32_t *lag, const int32_t *inv, int32_t n,
+                                                      int64_t total_substeps)
+{
+    const int32_t i = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (i >= n) return;
+    const int32_t p = inv[i];
+    const int64_t last = (int64_t)lag[p] + total_substeps - 1;
+    q_t[i] = x[(last % 3) * n64 + p];
+}
+
+__global__ __launch_bounds__(kBlock) void k_unit_state_in(double *x0, double *x1, double *x2, double *qch,
+                                                          const double *q_ch, const double *q_full,
+                                                          const int32_t *inner_pos, int32_t n_inner)
+{
+    const int32_t k = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (k >= n_inner) return;
+    const int32_t p = inner_pos[k];
+    const double v = q_full[k];
+    x0[p] = v; x1[p] = v; x2[p] = v;
+    qch[p] = q_ch[k];
+}
+
+__global__ __launch_bounds__(kBlock) void k_unit_state_out(double *q_ch, double *q_full, const double *x,
+                                                           int64_t n64, const double *qch, const int32_t *lag,
+                                                           const int32_t *inner_pos, int32_t n_inner,
+                                                           int64_t total_substeps)
+{
+    const int32_t k = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (k >= n_inner) return;
+    const int32_t p = inner_pos[k];
+    const int64_t last = (int64_t)lag[p] + total_substeps - 1;
+    q_full[k] = x[(last % 3) * n64 + p];
+    q_ch[k] = qch[p];
+}
+
+// Unit-hydrograph convolution, direct form (UnitHydrograph.py:93-107):
+//   out[t, i] = [t < n_ks] state[t, i] + sum_{s=0}^{min(t, n_ks-1)} kernel[s, i] * lateral[t - s, i]
+// One reach per lane, TB consecutive outputs per thread held in registers; per tap one kernel value and one
+// new lateral value are loaded and the TB-wide window slides in registers.
+template <int TB>
+__global__ __launch_bounds__(kBlock) void k_uh_convolve(const double *__restrict__ kernel,
+                                                        const double *__restrict__ state,
+                                                        const double *__restrict__ lateral,
+                                                        double *__restrict__ out, int64_t T, int32_t n_ks, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int64_t t0 = (int64_t)blockIdx.y * TB;
+    double acc[TB], win[TB];
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+        const int64_t t = t0 + j;
+        acc[j] = (t < n_ks && t < T) ? state[t * n + i] : 0.0;
+        win[j] = (t < T) ? lateral[t * n + i] : 0.0;   // lateral[t0 + j - s] for s = 0
+    }
+    for (int32_t s = 0; s < n_ks; ++s) {
+        const double kv = kernel[(int64_t)s * n + i];
+#pragma unroll
+        for (int j = 0; j < TB; ++j) acc[j] += kv * win[j];
+        // slide: win[j] <- lateral[t0 + j - (s+1)]
+#pragma unroll
+        for (int j = TB - 1; j > 0; --j) win[j] = win[j - 1];
+        const int64_t tn = t0 - (s + 1);
+        win[0] = (tn >= 0) ? lateral[tn * n + i] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < TB; ++j)
+        if (t0 + j < T) out[(t0 + j) * n + i] = acc[j];
+}
+
+// Carry-over tail: new_state[s, i] = buf[T + s, i] for s < n_ks - 1, 0 for s = n_ks - 1 (lines 103-105), where
+// buf[m] = sum_{s'} kernel[s'] lateral[m - s'] (+ state[m] when m < n_ks).
+__global__ __launch_bounds__(kBlock) void k_uh_tail(const double *__restrict__ kernel,
+                                                    const double *__restrict__ state,
+                                                    const double *__restrict__ lateral,
+                                                    double *__restrict__ new_state, int64_t T, int32_t n_ks, int64_t n)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int32_t s = (int32_t)blockIdx.y;
+    if (s == n_ks - 1) { new_state[(int64_t)s * n + i] = 0.0; return; }
+    const int64_t m = T + s;
+    double acc = m < n_ks ? state[m * n + i] : 0.0;
+    for (int32_t k = s + 1; k < n_ks; ++k) {
+        const int64_t tt = m - k;
+        if (tt < 0) break;
+        acc += kernel[(int64_t)k * n + i] * lateral[tt * n + i];
+    }
+    new_state[(int64_t)s * n + i] = acc;
+}
+
+inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// plan object
+// ------------------------------------------------------------------------------------------------
+
+struct rr_plan {
+    rr::HostPlan h;
+    int device = RR_DEVICE_NONE;
+    bool coeffs_set = false, has_c4 = false;
+    int64_t chunk_rows = 32, sample_every = 0;
+
+    int32_t *d_child_ptr = nullptr, *d_lag = nullptr, *d_perm = nullptr, *d_inv = nullptr, *d_inner_pos = nullptr;
+    uint16_t *d_hwc = nullptr;
+    double *d_w = nullptr, *d_c2 = nullptr, *d_c3 = nullptr, *d_c4 = nullptr;
+    double *d_x = nullptr, *d_isum = nullptr, *d_qch = nullptr;
+    double *d_ring = nullptr;
+    int64_t ring_cap = 0;  // doubles
+    double *d_stage = nullptr;
+    int64_t stage_cap = 0;
+
+    // profile of the last route call
+    std::vector<hipEvent_t> ev;
+    std::vector<int64_t> ev_reaches;
+    hipEvent_t ev_first = nullptr, ev_last = nullptr;
+    int64_t prof_launches = 0, prof_samples = 0, prof_reach_steps = 0;
+    hipStream_t last_stream = nullptr;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(T **p, int64_t count)
+{
+    *p = nullptr;
+    if (count <= 0) count = 1;
+    hipError_t e = hipMalloc((void **)p, (size_t)count * sizeof(T));
+    if (e != hipSuccess)
+        return fail(RR_E_ALLOC, std::string("hipMalloc of ") + std::to_string((size_t)count * sizeof(T)) +
+                                    " bytes failed: " + hipGetErrorString(e));
+    return RR_OK;
+}
+
+template <typename T>
+int dev_upload(T *dst, const std::vector<T> &src)
+{
+    if (src.empty()) return RR_OK;
+    HIPCHK(hipMemcpy(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RR_OK;
+}
+
+int need_device(const rr_plan *plan)
+{
+    if (!plan) return fail(RR_E_INVALID, "null plan");
+    if (plan->device < 0)
+        return fail(RR_E_NO_DEVICE, "this plan is host-only (RR_DEVICE_NONE): the HIP engine has no CPU fallback");
+    HIPCHK(hipSetDevice(plan->device));
+    return RR_OK;
+}
+
+int ensure_ring(rr_plan *P, int64_t doubles)
+{
+    if (P->ring_cap >= doubles) return RR_OK;
+    if (P->d_ring) { (void)hipFree(P->d_ring); P->d_ring = nullptr; P->ring_cap = 0; }
+    int rc = dev_alloc(&P->d_ring, doubles);
+    if (rc) return rc;
+    P->ring_cap = doubles;
+    return RR_OK;
+}
+
+int ensure_stage(rr_plan *P, int64_t doubles)
+{
+    if (P->stage_cap >= doubles) return RR_OK;
+    if (P->d_stage) { (void)hipFree(P->d_stage); P->d_stage = nullptr; P->stage_cap = 0; }
+    int rc = dev_alloc(&P->d_stage, doubles);
+    if (rc) return rc;
+    P->stage_cap = doubles;
+    return RR_OK;
+}
+
+enum class Mode { Rapid, Muskingum, Unit };
+
+// Where the (time, reach) rows in params order come from / go to.
+struct Rows {
+    const double *dev_in = nullptr;   // device array, rows_in rows
+    const double *host_in = nullptr;  // host array, T rows
+    int64_t rows_in = 0;
+    double *dev_out = nullptr;
+    double *host_out = nullptr;
+    int64_t rows_out = 0;
+};
+
+// The streaming executor shared by the three routers.  Enqueues everything on `stream`.
+int route_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io, hipStream_t stream)
+{
+    const rr::HostPlan &H = P->h;
+    const int64_t n = H.n;
+    const int64_t total = T * nsub;
+    const int64_t dmax = H.depth - 1;
+    const bool has_in = mode != Mode::Muskingum;
+    const bool host_io = io.host_out != nullptr || io.host_in != nullptr;
+    const bool direct = H.identity && !host_io;   // engine order == params order: stream the caller's arrays
+    const int64_t C = std::max<int64_t>(1, P->chunk_rows);
+
+    P->prof_launches = P->prof_samples = 0;
+    P->prof_reach_steps = n * total;
+    P->ev_reaches.clear();
+    P->last_stream = stream;
+    if (n == 0 || total == 0) return RR_OK;
+
+    // ---- work ring in engine order: lateral rows come in, discharge rows overwrite them in place ----
+    const int64_t lag_rows = (dmax + nsub - 1) / nsub;
+    const int64_t ring_rows = direct ? 0 : std::min<int64_t>(T, lag_rows + 2 * C + 2);
+    if (ring_rows > 0xFFFFFFFFLL || T > 0x7FFFFFFFLL) return fail(RR_E_INVALID, "route: too many time rows");
+    if (!direct) {
+        int rc = ensure_ring(P, ring_rows * n);
+        if (rc) return rc;
+    }
+    if (host_io) {
+        int rc = ensure_stage(P, C * n);
+        if (rc) return rc;
+    }
+
+    TickArgs a{};
+    a.child_ptr = P->d_child_ptr; a.lag = P->d_lag; a.w = P->d_w; a.c2 = P->d_c2; a.c3 = P->d_c3; a.c4 = P->d_c4;
+    a.isum = P->d_isum;
+    a.total_substeps = total; a.nsub = (uint32_t)nsub; a.inv_nsub = 1.0 / (double)nsub;
+    if (direct) {
+        a.in = io.dev_in; a.in_ld = n; a.in_rows = (uint32_t)std::max<int64_t>(1, io.rows_in);
+        a.out = io.dev_out; a.out_ld = n; a.out_rows = (uint32_t)io.rows_out;
+    } else {
+        a.in = has_in ? P->d_ring : nullptr; a.in_ld = n; a.in_rows = (uint32_t)ring_rows;
+        a.out = P->d_ring; a.out_ld = n; a.out_rows = (uint32_t)ring_rows;
+    }
+    UnitTickArgs ua{};
+    ua.hw_children = P->d_hwc; ua.qch = P->d_qch;
+
+    const int rows_per_block = 8;
+    auto load_rows = [&](int64_t r0, int64_t r1) -> int {   // params order -> ring
+        if (direct || !has_in) return RR_OK;
+        const int nrows = (int)(r1 - r0);
+        dim3 g((unsigned)((n + kBlock - 1) / kBlock), (unsigned)((nrows + rows_per_block - 1) / rows_per_block));
+        if (io.host_in) {
+            HIPCHK(hipMemcpyAsync(P->d_stage, io.host_in + r0 * n, (size_t)nrows * n * sizeof(double),
+                                  hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(k_permute_in, g, dim3(kBlock), 0, stream, P->d_ring, n, (uint32_t)ring_rows,
+                               (const double *)P->d_stage, n, (uint32_t)C, r0, P->d_perm, (int32_t)n, r0, nrows,
+                               rows_per_block);
+            HIPCHK(hipStreamSynchronize(stream));   // the stage is reused by the next chunk
+        } else {
+            hipLaunchKernelGGL(k_permute_in, g, dim3(kBlock), 0, stream, P->d_ring, n, (uint32_t)ring_rows,
+                               io.dev_in, n, (uint32_t)io.rows_in, (int64_t)0, P->d_perm, (int32_t)n, r0, nrows,
+                               rows_per_block);
+        }
+        return RR_OK;
+    };
+    auto store_rows = [&](int64_t r0, int64_t r1) -> int {   // ring -> params order
+        if (direct) return RR_OK;
+        for (int64_t b0 = r0; b0 < r1; b0 += C) {
+            const int nrows = (int)std::min<int64_t>(C, r1 - b0);
+            dim3 g((unsigned)((n + kBlock - 1) / kBlock), (unsigned)((nrows + rows_per_block - 1) / rows_per_block));
+            if (io.host_out) {
+                hipLaunchKernelGGL(k_permute_out, g, dim3(kBlock), 0, stream, P->d_stage, n, (uint32_t)C, b0,
+                                   (const double *)P->d_ring, n, (uint32_t)ring_rows, P->d_inv, (int32_t)n, b0,
+                                   nrows, rows_per_block);
+                HIPCHK(hipMemcpyAsync(io.host_out + b0 * n, P->d_stage, (size_t)nrows * n * sizeof(double),
+                                      hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+            } else {
+                hipLaunchKernelGGL(k_permute_out, g, dim3(kBlock), 0, stream, io.dev_out, n,
+                                   (uint32_t)io.rows_out, (int64_t)0, (const double *)P->d_ring, n,
+                                   (uint32_t)ring_rows, P->d_inv, (int32_t)n, b0, nrows, rows_per_block);
+            }
+        }
+        return RR_OK;
+    };
+
+    const int64_t total_ticks = total + dmax;
+    const size_t max_samples = P->sample_every > 0 ? (size_t)std::min<int64_t>(4096, total_ticks / P->sample_every + 1) : 0;
+    while (P->ev.size() < 2 * max_samples) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        P->ev.push_back(e);
+    }
+    if (!P->ev_first) { HIPCHK(hipEventCreate(&P->ev_first)); HIPCHK(hipEventCreate(&P->ev_last)); }
+
+    auto launch_tick = [&](int64_t tau) -> int {
+        // active lags: tau - total < lag <= tau
+        const int64_t lag_lo = std::max<int64_t>(0, tau - total + 1), lag_hi = std::min<int64_t>(tau, dmax);
+        const int64_t p_lo = H.lag_start[lag_lo], p_hi = H.lag_start[lag_hi + 1];
+        if (p_hi <= p_lo) return RR_OK;
+        a.p_lo = (int32_t)p_lo; a.p_hi = (int32_t)p_hi; a.tau = tau;
+        a.xc = P->d_x + (tau % 3) * n;
+        a.xa = P->d_x + ((tau + 2) % 3) * n;
+        a.xb = P->d_x + ((tau + 1) % 3) * n;
+        const bool sample = P->sample_every > 0 && (P->prof_launches % P->sample_every) == 0 &&
+                            (size_t)P->prof_samples < max_samples;
+        if (sample) HIPCHK(hipEventRecord(P->ev[2 * P->prof_samples], stream));
+        const dim3 g = grid1(p_hi - p_lo);
+        if (mode == Mode::Unit) {
+            ua.t = a;
+            if (nsub == 1) hipLaunchKernelGGL(k_tick_unit<true>, g, dim3(kBlock), 0, stream, ua);
+            else hipLaunchKernelGGL(k_tick_unit<false>, g, dim3(kBlock), 0, stream, ua);
+        } else if (mode == Mode::Rapid) {
+            if (nsub == 1) hipLaunchKernelGGL((k_tick<true, true>), g, dim3(kBlock), 0, stream, a);
+            else hipLaunchKernelGGL((k_tick<true, false>), g, dim3(kBlock), 0, stream, a);
+        } else {
+            if (nsub == 1) hipLaunchKernelGGL((k_tick<false, true>), g, dim3(kBlock), 0, stream, a);
+            else hipLaunchKernelGGL((k_tick<false, false>), g, dim3(kBlock), 0, stream, a);
+        }
+        if (sample) {
+            HIPCHK(hipEventRecord(P->ev[2 * P->prof_samples + 1], stream));
+            P->ev_reaches.push_back(p_hi - p_lo);
+            ++P->prof_samples;
+        }
+        ++P->prof_launches;
+        return RR_OK;
+    };
+
+    int64_t rows_loaded = 0, rows_stored = 0, tau = 0;
+    HIPCHK(hipEventRecord(P->ev_first, stream));
+    while (rows_stored < T) {
+        if (rows_loaded < T) {
+            const int64_t r1 = std::min(T, rows_loaded + C);
+            int rc = load_rows(rows_loaded, r1);
+            if (rc) return rc;
+            rows_loaded = r1;
+        }
+        const int64_t tau_end = rows_loaded < T ? rows_loaded * nsub : total_ticks;
+        for (; tau < tau_end; ++tau) {
+            int rc = launch_tick(tau);
+            if (rc) return rc;
+        }
+        // row t is final once the outlet-most reaches passed it: tick (t+1)*nsub - 1 + dmax
+        int64_t done = tau >= total_ticks ? T : (tau - dmax) / nsub;
+        if (tau - dmax < 0) done = 0;
+        done = std::min(done, T);
+        if (done > rows_stored) {
+            int rc = store_rows(rows_stored, done);
+            if (rc) return rc;
+            rows_stored = done;
+        }
+    }
+    HIPCHK(hipEventRecord(P->ev_last, stream));
+    HIPCHK(hipGetLastError());
+    return RR_OK;
+}
+
+int check_route_args(rr_plan *P, bool need_c4, int64_t T, int64_t nsub)
+{
+    int rc = need_device(P);
+    if (rc) return rc;
+    if (!P->coeffs_set) return fail(RR_E_STATE, "route called before rr_plan_set_coeffs");
+    if (need_c4 && !P->has_c4) return fail(RR_E_STATE, "rr_rapid_route needs c4_dt (rr_plan_set_coeffs got NULL)");
+    if (T < 0 || nsub < 1) return fail(RR_E_INVALID, "route: need num steps >= 0 and sub-steps >= 1");
+    if (nsub > 0x7FFFFFFF) return fail(RR_E_INVALID, "route: too many sub-steps");
+    return RR_OK;
+}
+
+int rapid_like(rr_plan *P, Mode mode, double *q_t, const Rows &io, int64_t T, int64_t nsub, hipStream_t stream,
+               bool q_on_host)
+{
+    const int64_t n = P->h.n;
+    if (n == 0 || T == 0) return RR_OK;
+    double *d_q = q_t;
+    double *tmp = nullptr;
+    if (q_on_host) {
+        int rc = dev_alloc(&tmp, n);
+        if (rc) return rc;
+        d_q = tmp;
+        hipError_t e = hipMemcpyAsync(d_q, q_t, n * sizeof(double), hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) { (void)hipFree(tmp); return fail(RR_E_HIP, hipGetErrorString(e)); }
+    }
+    hipLaunchKernelGGL(k_state_in, grid1(n), dim3(kBlock), 0, stream, P->d_x, P->d_x + n, P->d_x + 2 * n,
+                       (const double *)d_q, P->d_perm, (int32_t)n);
+    int rc = route_core(P, mode, T, nsub, io, stream);
+    if (rc == RR_OK) {
+        hipLaunchKernelGGL(k_state_out, grid1(n), dim3(kBlock), 0, stream, d_q, (const double *)P->d_x, n,
+                           P->d_lag, P->d_inv, (int32_t)n, T * nsub);
+        if (q_on_host) {
+            hipError_t e = hipMemcpyAsync(q_t, d_q, n * sizeof(double), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) rc = fail(RR_E_HIP, hipGetErrorString(e));
+        }
+    }
+    if (tmp) { (void)hipStreamSynchronize(stream); (void)hipFree(tmp); }
+    return rc;
+}
+
+int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io, int64_t T, int64_t nsub,
+              hipStream_t stream, bool q_on_host)
+{
+    const int64_t n = P->h.n, ni = (int64_t)P->h.inner_pos.size();
+    if (n == 0 || T == 0) return RR_OK;
+    double *d_qch = q_ch, *d_qfull = q_full, *tmp = nullptr;
+    if (q_on_host) {
+        int rc = dev_alloc(&tmp, 2 * std::max<int64_t>(ni, 1));
+        if (rc) return rc;
+        d_qch = tmp; d_qfull = tmp + std::max<int64_t>(ni, 1);
+        hipError_t e = hipMemcpyAsync(d_qch, q_ch, ni * sizeof(double), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_qfull, q_full, ni * sizeof(double), hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) { (void)hipFree(tmp); return fail(RR_E_HIP, hipGetErrorString(e)); }
+    }
+    hipError_t e0 = hipMemsetAsync(P->d_x, 0, 3 * n * sizeof(double), stream);
+    if (e0 != hipSuccess) { if (tmp) (void)hipFree(tmp); return fail(RR_E_HIP, hipGetErrorString(e0)); }
+    if (ni > 0)
+        hipLaunchKernelGGL(k_unit_state_in, grid1(ni), dim3(kBlock), 0, stream, P->d_x, P->d_x + n, P->d_x + 2 * n,
+                           P->d_qch, (const double *)d_qch, (const double *)d_qfull, P->d_inner_pos, (int32_t)ni);
+    int rc = route_core(P, Mode::Unit, T, nsub, io, stream);
+    if (rc == RR_OK && ni > 0) {
+        hipLaunchKernelGGL(k_unit_state_out, grid1(ni), dim3(kBlock), 0, stream, d_qch, d_qfull,
+                           (const double *)P->d_x, n, (const double *)P->d_qch, P->d_lag, P->d_inner_pos,
+                           (int32_t)ni, T * nsub);
+        if (q_on_host) {
+            hipError_t e = hipMemcpyAsync(q_ch, d_qch, ni * sizeof(double), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(q_full, d_qfull, ni * sizeof(double), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) rc = fail(RR_E_HIP, hipGetErrorString(e));
+        }
+    }
+    if (tmp) { (void)hipStreamSynchronize(stream); (void)hipFree(tmp); }
+    return rc;
+}
+
+int uh_convolve_core(const double *d_kernel, double *d_state, const double *d_lateral, double *d_out, int64_t T,
+                     int64_t n_ks, int64_t n, hipStream_t stream)
+{
+    if (T < 1 || n_ks < 1 || n < 0) return fail(RR_E_INVALID, "rr_uh_convolve: need T >= 1, n_ks >= 1, n >= 0");
+    if (n == 0) return RR_OK;
+    if (n_ks > 0x7FFFFFFF || T > 0x7FFFFFFFLL * 8) return fail(RR_E_INVALID, "rr_uh_convolve: sizes out of range");
+    constexpr int TB = 8;
+    double *d_tail = nullptr;
+    int rc = dev_alloc(&d_tail, n_ks * n);
+    if (rc) return rc;
+    dim3 g((unsigned)((n + kBlock - 1) / kBlock), (unsigned)((T + TB - 1) / TB));
+    hipLaunchKernelGGL(k_uh_convolve<TB>, g, dim3(kBlock), 0, stream, d_kernel, (const double *)d_state, d_lateral,
+                       d_out, T, (int32_t)n_ks, n);
+    dim3 gt((unsigned)((n + kBlock - 1) / kBlock), (unsigned)n_ks);
+    hipLaunchKernelGGL(k_uh_tail, gt, dim3(kBlock), 0, stream, d_kernel, (const double *)d_state, d_lateral, d_tail,
+                       T, (int32_t)n_ks, n);
+    hipError_t e = hipMemcpyAsync(d_state, d_tail, (size_t)n_ks * n * sizeof(double), hipMemcpyDeviceToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);   // d_tail is freed below
+    (void)hipFree(d_tail);
+    if (e != hipSuccess) return fail(RR_E_HIP, hipGetErrorString(e));
+    HIPCHK(hipGetLastError());
+    return RR_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+
+extern "C" {
+
+int rr_version(void) { return RR_VERSION_NUM; }
+
+const char *rr_last_error(void) { return g_err.c_str(); }
+
+int rr_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+void rr_plan_destroy(rr_plan *P)
+{
+    if (!P) return;
+    if (P->device >= 0 && hipSetDevice(P->device) == hipSuccess) {
+        void *ptrs[] = {P->d_child_ptr, P->d_lag, P->d_perm, P->d_inv, P->d_inner_pos, P->d_hwc, P->d_w, P->d_c2,
+                        P->d_c3, P->d_c4, P->d_x, P->d_isum, P->d_qch, P->d_ring, P->d_stage};
+        for (void *p : ptrs) if (p) (void)hipFree(p);
+        for (hipEvent_t e : P->ev) (void)hipEventDestroy(e);
+        if (P->ev_first) (void)hipEventDestroy(P->ev_first);
+        if (P->ev_last) (void)hipEventDestroy(P->ev_last);
+    }
+    delete P;
+}
+
+int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indices, int device, rr_plan **out)
+{
+    if (!out) return fail(RR_E_INVALID, "rr_plan_create: null out");
+    *out = nullptr;
+    rr_plan *P = new (std::nothrow) rr_plan();
+    if (!P) return fail(RR_E_ALLOC, "rr_plan_create: out of memory");
+    std::string err;
+    int rc = rr::build_host_plan(n, csc_indptr, csc_indices, P->h, err);
+    if (rc) { delete P; return fail(rc, err); }
+    if (device != RR_DEVICE_NONE) {
+        int count = rr_device_count();
+        if (device < 0 || device >= count) {
+            delete P;
+            return fail(RR_E_NO_DEVICE, "rr_plan_create: HIP device " + std::to_string(device) + " not available (" +
+                                            std::to_string(count) + " visible)");
+        }
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) { delete P; return fail(RR_E_HIP, hipGetErrorString(e)); }
+        P->device = device;
+        const rr::HostPlan &H = P->h;
+        const int64_t ni = (int64_t)H.inner_pos.size();
+        rc = dev_alloc(&P->d_child_ptr, n + 1);
+        if (!rc) rc = dev_alloc(&P->d_lag, n);
+        if (!rc) rc = dev_alloc(&P->d_perm, n);
+        if (!rc) rc = dev_alloc(&P->d_inv, n);
+        if (!rc) rc = dev_alloc(&P->d_inner_pos, ni);
+        if (!rc) rc = dev_alloc(&P->d_hwc, n);
+        if (!rc) rc = dev_alloc(&P->d_w, n);
+        if (!rc) rc = dev_alloc(&P->d_c2, n);
+        if (!rc) rc = dev_alloc(&P->d_c3, n);
+        if (!rc) rc = dev_alloc(&P->d_c4, n);
+        if (!rc) rc = dev_alloc(&P->d_x, 3 * n);
+        if (!rc) rc = dev_alloc(&P->d_isum, n);
+        if (!rc) rc = dev_alloc(&P->d_qch, n);
+        if (!rc) rc = dev_upload(P->d_child_ptr, H.child_ptr);
+        if (!rc) rc = dev_upload(P->d_lag, H.lag);
+        if (!rc) rc = dev_upload(P->d_perm, H.perm);
+        if (!rc) rc = dev_upload(P->d_inv, H.inv);
+        if (!rc) rc = dev_upload(P->d_inner_pos, H.inner_pos);
+        if (!rc) rc = dev_upload(P->d_hwc, H.hw_children);
+        if (rc) { rr_plan_destroy(P); return rc; }
+    }
+    *out = P;
+    return RR_OK;
+}
+
+int rr_plan_info(const rr_plan *P, int64_t info[8])
+{
+    if (!P || !info) return fail(RR_E_INVALID, "rr_plan_info: null argument");
+    info[0] = P->h.n; info[1] = P->h.n_edges; info[2] = P->h.depth; info[3] = P->h.widest_level;
+    info[4] = P->h.n_headwaters; info[5] = P->h.n_outlets; info[6] = P->h.identity ? 1 : 0; info[7] = P->device;
+    return RR_OK;
+}
+
+int rr_plan_layout(const rr_plan *P, int32_t *perm, int32_t *lag, int32_t *child_ptr)
+{
+    if (!P) return fail(RR_E_INVALID, "rr_plan_layout: null plan");
+    const size_t n = (size_t)P->h.n;
+    if (perm && n) std::memcpy(perm, P->h.perm.data(), n * sizeof(int32_t));
+    if (lag && n) std::memcpy(lag, P->h.lag.data(), n * sizeof(int32_t));
+    if (child_ptr) std::memcpy(child_ptr, P->h.child_ptr.data(), (n + 1) * sizeof(int32_t));
+    return RR_OK;
+}
+
+int rr_plan_set_options(rr_plan *P, int64_t rows_per_chunk, int64_t sample_every)
+{
+    if (!P) return fail(RR_E_INVALID, "rr_plan_set_options: null plan");
+    if (rows_per_chunk > 0) P->chunk_rows = rows_per_chunk;
+    if (sample_every >= 0) P->sample_every = sample_every;
+    return RR_OK;
+}
+
+int rr_plan_set_coeffs(rr_plan *P, const double *lhs_off_data, const double *c2, const double *c3, const double *c4_dt)
+{
+    int rc = need_device(P);
+    if (rc) return rc;
+    const rr::HostPlan &H = P->h;
+    const int64_t n = H.n;
+    if (n > 0 && (!c2 || !c3 || (H.n_edges > 0 && !lhs_off_data)))
+        return fail(RR_E_INVALID, "rr_plan_set_coeffs: null coefficient array");
+    std::vector<double> w(n), a2(n), a3(n), a4(n, 0.0);
+    for (int64_t p = 0; p < n; ++p) {
+        const int32_t i = H.perm[p];
+        const int32_t e = H.edge_of[i];
+        w[p] = e >= 0 ? -lhs_off_data[e] : 0.0;
+        a2[p] = c2[i];
+        a3[p] = c3[i];
+        if (c4_dt) a4[p] = c4_dt[i];
+    }
+    rc = dev_upload(P->d_w, w);
+    if (!rc) rc = dev_upload(P->d_c2, a2);
+    if (!rc) rc = dev_upload(P->d_c3, a3);
+    if (!rc) rc = dev_upload(P->d_c4, a4);
+    if (rc) return rc;
+    P->coeffs_set = true;
+    P->has_c4 = c4_dt != nullptr;
+    return RR_OK;
+}
+
+int rr_plan_profile(rr_plan *P, double prof[8])
+{
+    if (!P || !prof) return fail(RR_E_INVALID, "rr_plan_profile: null argument");
+    for (int k = 0; k < 8; ++k) prof[k] = 0.0;
+    prof[0] = (double)P->prof_launches;
+    prof[7] = (double)P->prof_reach_steps;
+    if (P->device < 0 || !P->ev_first || P->prof_launches == 0) return RR_OK;
+    HIPCHK(hipSetDevice(P->device));
+    HIPCHK(hipEventSynchronize(P->ev_last));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, P->ev_first, P->ev_last));
+    prof[6] = ms;
+    double sum = 0, mn = 1e300, mx = 0, reaches = 0;
+    for (int64_t k = 0; k < P->prof_samples; ++k) {
+        HIPCHK(hipEventElapsedTime(&ms, P->ev[2 * k], P->ev[2 * k + 1]));
+        sum += ms; mn = std::min<double>(mn, ms); mx = std::max<double>(mx, ms);
+        reaches += (double)P->ev_reaches[k];
+    }
+    prof[1] = (double)P->prof_samples; prof[2] = sum; prof[3] = P->prof_samples ? mn : 0.0; prof[4] = mx;
+    prof[5] = reaches;
+    return RR_OK;
+}
+
+// ---- device-pointer entry points ----
+
+int rr_rapid_route_dev(rr_plan *P, double *q_t, const double *qlateral, int64_t ql_rows, double *discharge,
+                       int64_t out_rows, int64_t T, int64_t nsub, void *stream)
+{
+    int rc = check_route_args(P, true, T, nsub);
+    if (rc) return rc;
+    if (P->h.n > 0 && T > 0 && (!q_t || !qlateral || !discharge || ql_rows < 1 || out_rows < 1))
+        return fail(RR_E_INVALID, "rr_rapid_route_dev: null array or empty row count");
+    Rows io; io.dev_in = qlateral; io.rows_in = ql_rows; io.dev_out = discharge; io.rows_out = out_rows;
+    return rapid_like(P, Mode::Rapid, q_t, io, T, nsub, (hipStream_t)stream, false);
+}
+
+int rr_muskingum_route_dev(rr_plan *P, double *q_t, double *discharge, int64_t out_rows, int64_t n_out,
+                           int64_t n_per_out, void *stream)
+{
+    int rc = check_route_args(P, false, n_out, n_per_out);
+    if (rc) return rc;
+    if (P->h.n > 0 && n_out > 0 && (!q_t || !discharge || out_rows < 1))
+        return fail(RR_E_INVALID, "rr_muskingum_route_dev: null array or empty row count");
+    Rows io; io.dev_out = discharge; io.rows_out = out_rows;
+    return rapid_like(P, Mode::Muskingum, q_t, io, n_out, n_per_out, (hipStream_t)stream, false);
+}
+
+int rr_unit_route_dev(rr_plan *P, double *q_ch, double *q_full, const double *conv, int64_t conv_rows,
+                      double *discharge, int64_t out_rows, int64_t T, int64_t nsub, void *stream)
+{
+    int rc = check_route_args(P, false, T, nsub);
+    if (rc) return rc;
+    if (P->h.n > 0 && T > 0 && (!conv || !discharge || conv_rows < 1 || out_rows < 1 ||
+                                (!P->h.inner_pos.empty() && (!q_ch || !q_full))))
+        return fail(RR_E_INVALID, "rr_unit_route_dev: null array or empty row count");
+    Rows io; io.dev_in = conv; io.rows_in = conv_rows; io.dev_out = discharge; io.rows_out = out_rows;
+    return unit_like(P, q_ch, q_full, io, T, nsub, (hipStream_t)stream, false);
+}
+
+int rr_uh_convolve_dev(int device, const double *kernel, double *state, const double *lateral, double *out,
+                       int64_t T, int64_t n_ks, int64_t n, void *stream)
+{
+    if (device < 0 || device >= rr_device_count()) return fail(RR_E_NO_DEVICE, "rr_uh_convolve: no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    if (n > 0 && (!kernel || !state || !lateral || !out)) return fail(RR_E_INVALID, "rr_uh_convolve: null array");
+    return uh_convolve_core(kernel, state, lateral, out, T, n_ks, n, (hipStream_t)stream);
+}
+
+// ---- host-pointer entry points (the reference's kernel boundary) ----
+
+int rr_rapid_route(rr_plan *P, double *q_t, const double *qlateral, double *discharge, int64_t T, int64_t nsub)
+{
+    int rc = check_route_args(P, true, T, nsub);
+    if (rc) return rc;
+    if (P->h.n > 0 && T > 0 && (!q_t || !qlateral || !discharge)) return fail(RR_E_INVALID, "rr_rapid_route: null array");
+    Rows io; io.host_in = qlateral; io.host_out = discharge;
+    rc = rapid_like(P, Mode::Rapid, q_t, io, T, nsub, nullptr, true);
+    if (rc == RR_OK) HIPCHK(hipStreamSynchronize(nullptr));
+    return rc;
+}
+
+int rr_muskingum_route(rr_plan *P, double *q_t, double *discharge, int64_t n_out, int64_t n_per_out)
+{
+    int rc = check_route_args(P, false, n_out, n_per_out);
+    if (rc) return rc;
+    if (P->h.n > 0 && n_out > 0 && (!q_t || !discharge)) return fail(RR_E_INVALID, "rr_muskingum_route: null array");
+    Rows io; io.host_out = discharge;
+    rc = rapid_like(P, Mode::Muskingum, q_t, io, n_out, n_per_out, nullptr, true);
+    if (rc == RR_OK) HIPCHK(hipStreamSynchronize(nullptr));
+    return rc;
+}
+
+int rr_unit_route(rr_plan *P, double *q_ch, double *q_full, const double *conv, double *discharge, int64_t T,
+                  int64_t nsub)
+{
+    int rc = check_route_args(P, false, T, nsub);
+    if (rc) return rc;
+    if (P->h.n > 0 && T > 0 && (!conv || !discharge || (!P->h.inner_pos.empty() && (!q_ch || !q_full))))
+        return fail(RR_E_INVALID, "rr_unit_route: null array");
+    Rows io; io.host_in = conv; io.host_out = discharge;
+    rc = unit_like(P, q_ch, q_full, io, T, nsub, nullptr, true);
+    if (rc == RR_OK) HIPCHK(hipStreamSynchronize(nullptr));
+    return rc;
+}
+
+int rr_uh_convolve(int device, const double *kernel, double *state, const double *lateral, double *out, int64_t T,
+                   int64_t n_ks, int64_t n)
+{
+    if (device < 0 || device >= rr_device_count()) return fail(RR_E_NO_DEVICE, "rr_uh_convolve: no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    if (T < 1 || n_ks < 1 || n < 0) return fail(RR_E_INVALID, "rr_uh_convolve: need T >= 1, n_ks >= 1, n >= 0");
+    if (n == 0) return RR_OK;
+    if (!kernel || !state || !lateral || !out) return fail(RR_E_INVALID, "rr_uh_convolve: null array");
+    double *d_k = nullptr, *d_s = nullptr, *d_l = nullptr, *d_o = nullptr;
+    int rc = dev_alloc(&d_k, n_ks * n);
+    if (!rc) rc = dev_alloc(&d_s, n_ks * n);
+    if (!rc) rc = dev_alloc(&d_l, T * n);
+    if (!rc) rc = dev_alloc(&d_o, T * n);
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = hipMemcpy(d_k, kernel, (size_t)n_ks * n * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_s, state, (size_t)n_ks * n * sizeof(double), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_l, lateral, (size_t)T * n * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = fail(RR_E_HIP, hipGetErrorString(e));
+    }
+    if (!rc) rc = uh_convolve_core(d_k, d_s, d_l, d_o, T, n_ks, n, nullptr);
+    if (!rc) {
+        e = hipMemcpy(out, d_o, (size_t)T * n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(state, d_s, (size_t)n_ks * n * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RR_E_HIP, hipGetErrorString(e));
+    }
+    for (double *p : {d_k, d_s, d_l, d_o}) if (p) (void)hipFree(p);
+    return rc;
+}
+
+// ---- device helpers ----
+
+int rr_dev_malloc(int device, int64_t bytes, void **out)
+{
+    if (!out || bytes < 0) return fail(RR_E_INVALID, "rr_dev_malloc: bad argument");
+    if (device < 0 || device >= rr_device_count()) return fail(RR_E_NO_DEVICE, "rr_dev_malloc: no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    hipError_t e = hipMalloc(out, (size_t)std::max<int64_t>(bytes, 1));
+    if (e != hipSuccess) return fail(RR_E_ALLOC, std::string("hipMalloc: ") + hipGetErrorString(e));
+    return RR_OK;
+}
+
+int rr_dev_free(int device, void *ptr)
+{
+    if (!ptr) return RR_OK;
+    if (device < 0 || device >= rr_device_count()) return fail(RR_E_NO_DEVICE, "rr_dev_free: no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipFree(ptr));
+    return RR_OK;
+}
+
+int rr_dev_upload(int device, void *dst_dev, const void *src_host, int64_t bytes)
+{
+    if (device < 0 || device >= rr_device_count()) return fail(RR_E_NO_DEVICE, "rr_dev_upload: no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    if (bytes > 0) HIPCHK(hipMemcpy(dst_dev, src_host, (size_t)bytes, hipMemcpyHostToDevice));
+    return RR_OK;
+}
+
+int rr_dev_download(int device, void *dst_host, const void *src_dev, int64_t bytes)
+{
+    if (device < 0 || device >= rr_device_count()) return fail(RR_E_NO_DEVICE, "rr_dev_download: no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    if (bytes > 0) HIPCHK(hipMemcpy(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost));
+    return RR_OK;
+}
+
+int rr_dev_synchronize(int device)
+{
+    if (device < 0 || device >= rr_device_count()) return fail(RR_E_NO_DEVICE, "rr_dev_synchronize: no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    return RR_OK;
+}
+
+}  // extern "C"

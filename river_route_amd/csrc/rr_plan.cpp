@@ -1,0 +1,136 @@
+#include "rr_plan.hpp"
+
+#include <algorithm>
+#include <limits>
+
+#include "../../include/rr_hip.h"
+
+namespace rr {
+
+int build_host_plan(int64_t n, const int32_t *indptr, const int32_t *indices, HostPlan &P, std::string &err)
+{
+    if (n < 0 || (n > 0 && (!indptr))) { err = "rr_plan_create: null csc_indptr or negative n"; return RR_E_INVALID; }
+    if (n > (int64_t)std::numeric_limits<int32_t>::max() - 1) { err = "rr_plan_create: n exceeds int32 range"; return RR_E_INVALID; }
+    P = HostPlan();
+    P.n = n;
+    if (n == 0) { P.child_ptr.assign(1, 0); P.lag_start.assign(1, 0); P.identity = true; return RR_OK; }
+    if (indptr[0] != 0) { err = "rr_plan_create: csc_indptr[0] must be 0"; return RR_E_INVALID; }
+
+    // ---- validate + downstream pointer (tools.py:94-106 guarantees these for the reference) ----
+    std::vector<int32_t> down(n, -1);
+    P.edge_of.assign(n, -1);
+    for (int64_t c = 0; c < n; ++c) {
+        const int64_t a = indptr[c], b = indptr[c + 1];
+        if (b < a) { err = "rr_plan_create: csc_indptr is not non-decreasing"; return RR_E_INVALID; }
+        if (b - a > 1) {
+            err = "rr_plan_create: reach " + std::to_string(c) + " has " + std::to_string(b - a) +
+                  " downstream reaches; the engine routes forests (one downstream per reach) only";
+            return RR_E_UNSUPPORTED;
+        }
+        if (b > a) {
+            if (!indices) { err = "rr_plan_create: null csc_indices"; return RR_E_INVALID; }
+            const int64_t r = indices[a];
+            if (r >= n || r < 0) { err = "rr_plan_create: csc row index out of range"; return RR_E_INVALID; }
+            if (r <= c) { err = "params_file must be topologically sorted upstream to downstream"; return RR_E_NOT_TOPOLOGICAL; }
+            down[c] = (int32_t)r;
+            P.edge_of[c] = (int32_t)a;
+        }
+    }
+    P.n_edges = indptr[n];
+
+    // ---- distance to outlet; downstream reaches have larger params indices, so walk backwards ----
+    std::vector<int32_t> dist(n);
+    int32_t dmax = 0;
+    for (int64_t c = n - 1; c >= 0; --c) {
+        dist[c] = down[c] < 0 ? 0 : dist[down[c]] + 1;
+        dmax = std::max(dmax, dist[c]);
+    }
+    P.depth = dmax + 1;
+
+    // ---- upstream lists (ascending params index), headwater flags ----
+    std::vector<int32_t> up_ptr(n + 1, 0);
+    for (int64_t c = 0; c < n; ++c) if (down[c] >= 0) ++up_ptr[down[c] + 1];
+    for (int64_t i = 0; i < n; ++i) up_ptr[i + 1] += up_ptr[i];
+    std::vector<int32_t> up_idx(P.n_edges), fill(up_ptr.begin(), up_ptr.end() - 1);
+    for (int64_t c = 0; c < n; ++c) if (down[c] >= 0) up_idx[fill[down[c]]++] = (int32_t)c;
+    auto is_hw = [&](int32_t i) { return up_ptr[i + 1] == up_ptr[i]; };
+
+    // ---- breadth-first order from the outlets; siblings: headwaters first, then ascending index ----
+    std::vector<int32_t> bfs;
+    bfs.reserve(n);
+    std::vector<int64_t> level_start;  // in bfs ranks, by distance D
+    level_start.push_back(0);
+    for (int64_t c = 0; c < n; ++c) if (down[c] < 0) bfs.push_back((int32_t)c);
+    P.n_outlets = (int64_t)bfs.size();
+    P.hw_children.assign(n, 0);
+    std::vector<uint16_t> hwc_by_node(n, 0);
+    size_t head = 0;
+    while (head < bfs.size()) {
+        const size_t level_end = bfs.size();
+        level_start.push_back((int64_t)level_end);
+        for (; head < level_end; ++head) {
+            const int32_t v = bfs[head];
+            int64_t nh = 0;
+            for (int32_t e = up_ptr[v]; e < up_ptr[v + 1]; ++e) if (is_hw(up_idx[e])) { bfs.push_back(up_idx[e]); ++nh; }
+            for (int32_t e = up_ptr[v]; e < up_ptr[v + 1]; ++e) if (!is_hw(up_idx[e])) bfs.push_back(up_idx[e]);
+            if (nh > 65535) { err = "rr_plan_create: a reach has more than 65535 headwater tributaries"; return RR_E_UNSUPPORTED; }
+            hwc_by_node[v] = (uint16_t)nh;
+        }
+    }
+    // the loop pushes one sentinel past the last non-empty level
+    while (level_start.size() > 1 && level_start[level_start.size() - 1] == level_start[level_start.size() - 2])
+        level_start.pop_back();
+    if ((int64_t)bfs.size() != n || (int64_t)level_start.size() != (int64_t)P.depth + 1) {
+        err = "rr_plan_create: internal error, breadth-first order incomplete";
+        return RR_E_INVALID;
+    }
+
+    // ---- engine positions: levels in DESCENDING distance, bfs order inside a level ----
+    P.perm.resize(n); P.inv.resize(n); P.lag.resize(n);
+    P.lag_start.assign(P.depth + 1, 0);
+    int64_t base = 0;
+    for (int32_t d = dmax; d >= 0; --d) {
+        const int64_t a = level_start[d], b = level_start[d + 1];
+        const int32_t lag = dmax - d;
+        P.lag_start[lag] = base;
+        P.widest_level = std::max(P.widest_level, b - a);
+        for (int64_t r = a; r < b; ++r) {
+            const int64_t p = base + (r - a);
+            P.perm[p] = bfs[r];
+            P.inv[bfs[r]] = (int32_t)p;
+            P.lag[p] = lag;
+        }
+        base += b - a;
+    }
+    P.lag_start[P.depth] = n;
+
+    P.child_ptr.resize(n + 1);
+    P.child_ptr[0] = 0;
+    P.identity = true;
+    for (int64_t p = 0; p < n; ++p) {
+        const int32_t v = P.perm[p];
+        P.child_ptr[p + 1] = P.child_ptr[p] + (up_ptr[v + 1] - up_ptr[v]);
+        P.hw_children[p] = hwc_by_node[v];
+        if (is_hw(v)) ++P.n_headwaters;
+        if (v != p) P.identity = false;
+    }
+    // self-check of the contiguity property the kernels rely on
+    for (int64_t p = 0; p < n; ++p) {
+        const int32_t v = P.perm[p];
+        int32_t q = P.child_ptr[p];
+        for (int pass = 0; pass < 2; ++pass)
+            for (int32_t e = up_ptr[v]; e < up_ptr[v + 1]; ++e)
+                if (is_hw(up_idx[e]) == (pass == 0)) {
+                    if (P.inv[up_idx[e]] != q || P.lag[q] != P.lag[p] - 1) {
+                        err = "rr_plan_create: internal error, upstream reaches not contiguous in engine order";
+                        return RR_E_INVALID;
+                    }
+                    ++q;
+                }
+    }
+    P.inner_pos.reserve(n - P.n_headwaters);
+    for (int64_t i = 0; i < n; ++i) if (!is_hw((int32_t)i)) P.inner_pos.push_back(P.inv[i]);
+    return RR_OK;
+}
+
+}  // namespace rr

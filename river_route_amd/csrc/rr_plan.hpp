@@ -1,0 +1,40 @@
+// Host-side network analysis for the routing engine: turns the reference's CSC adjacency
+// (river_route/tools.py:75-109) into the "lag-ordered" layout the HIP kernels stream over.
+//
+// Layout idea: every reach has exactly one downstream reach, so the distance D(i) to
+// its outlet satisfies D(up) = D(down) + 1 on EVERY edge.  Reaches are placed farthest-from-outlet first,
+// level by level, each level in the order of its downstream reaches.  Then
+//   * lag(p) = Dmax - D is non-decreasing in the engine position p;
+//   * the reaches flowing into position p occupy the contiguous position range
+//     [child_ptr[p], child_ptr[p+1]) and child_ptr is simply the running count of upstream reaches,
+//     so the adjacency needs no column-index array at all.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace rr {
+
+struct HostPlan {
+    int64_t n = 0;
+    int64_t n_edges = 0;
+    int32_t depth = 0;          // number of levels = Dmax + 1
+    int64_t widest_level = 0;
+    int64_t n_headwaters = 0;
+    int64_t n_outlets = 0;
+    bool identity = false;      // perm[p] == p for all p
+
+    std::vector<int32_t> perm;       // [n]   params index at engine position p
+    std::vector<int32_t> inv;        // [n]   engine position of params index i
+    std::vector<int32_t> lag;        // [n]   Dmax - D(perm[p]); non-decreasing in p
+    std::vector<int32_t> child_ptr;  // [n+1] prefix count of upstream reaches in engine order
+    std::vector<uint16_t> hw_children;  // [n] how many of p's upstream reaches are headwaters (they come first)
+    std::vector<int64_t> lag_start;  // [depth+1] first engine position with lag >= d
+    std::vector<int32_t> edge_of;    // [n]   CSC entry index of the edge leaving params index i, -1 at outlets
+    std::vector<int32_t> inner_pos;  // [n_inner] engine position of the k-th inner reach (ascending params order)
+};
+
+// Returns 0 or an RR_E_* code with a message in err.
+int build_host_plan(int64_t n, const int32_t *indptr, const int32_t *indices, HostPlan &plan, std::string &err);
+
+}  // namespace rr

@@ -1,0 +1,198 @@
+"""
+Python handle on an rr_plan (include/rr_hip.h): network layout + device-resident coefficients + route calls.
+Host arrays are numpy; `*_dev` methods take raw device addresses / torch tensors and a HIP stream handle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import RRError, check, ptr
+
+__all__ = ['Plan', 'RRError', 'uh_convolve', 'uh_convolve_dev', 'DeviceBuffer']
+
+
+def _f64(a, name):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if not a.flags['WRITEABLE']:
+        a = a.copy()
+    return a
+
+
+def _inplace_f64(a, name, shape):
+    if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags['C_CONTIGUOUS'] and a.flags['WRITEABLE']):
+        raise TypeError(f'{name} must be a writeable C-contiguous float64 numpy array (it is updated in place)')
+    if a.shape != shape:
+        raise ValueError(f'{name} has shape {a.shape}, expected {shape}')
+    return a
+
+
+class Plan:
+    """Structure analysis of one river network, bound to one GPU.  Built from the CSC adjacency the reference's
+    routers hold (river_route/routers/Muskingum.py:189-191)."""
+
+    def __init__(self, csc_indptr, csc_indices, device: int = 0):
+        indptr = np.ascontiguousarray(csc_indptr, dtype=np.int32)
+        indices = np.ascontiguousarray(csc_indices, dtype=np.int32)
+        if indptr.ndim != 1 or indptr.shape[0] < 1:
+            raise ValueError('csc_indptr must be a 1-D array of length n + 1')
+        self.n = int(indptr.shape[0] - 1)
+        if indices.shape[0] != int(indptr[-1]):
+            raise ValueError('csc_indices length does not match csc_indptr[-1]')
+        self.device = int(device)
+        self._h = C.c_void_p()
+        check(_lib.lib().rr_plan_create(self.n, ptr(indptr), ptr(indices) if indices.size else None,
+                                        self.device, C.byref(self._h)))
+        self._indptr, self._indices = indptr, indices
+        info = np.zeros(8, dtype=np.int64)
+        check(_lib.lib().rr_plan_info(self._h, ptr(info)))
+        self.n_edges, self.depth, self.widest_level, self.n_headwaters, self.n_outlets = (int(v) for v in info[1:6])
+        self.identity_order = bool(info[6])
+        self.n_inner = self.n - self.n_headwaters
+
+    # -- lifetime --
+    def close(self) -> None:
+        if getattr(self, '_h', None) is not None and self._h.value:
+            _lib.lib().rr_plan_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- inspection --
+    def layout(self):
+        """(perm, lag, child_ptr) of the engine order, see rr_plan_layout."""
+        perm = np.empty(self.n, dtype=np.int32)
+        lag = np.empty(self.n, dtype=np.int32)
+        child_ptr = np.empty(self.n + 1, dtype=np.int32)
+        check(_lib.lib().rr_plan_layout(self._h, ptr(perm), ptr(lag), ptr(child_ptr)))
+        return perm, lag, child_ptr
+
+    def set_options(self, rows_per_chunk: int = 0, sample_every: int = -1) -> None:
+        check(_lib.lib().rr_plan_set_options(self._h, int(rows_per_chunk), int(sample_every)))
+
+    def profile(self) -> dict:
+        p = np.zeros(8, dtype=np.float64)
+        check(_lib.lib().rr_plan_profile(self._h, ptr(p)))
+        return dict(launches=int(p[0]), sampled=int(p[1]), sampled_ms=float(p[2]), min_ms=float(p[3]),
+                    max_ms=float(p[4]), sampled_reaches=float(p[5]), region_ms=float(p[6]), reach_steps=float(p[7]))
+
+    # -- coefficients --
+    def set_coeffs(self, lhs_off_data, c2, c3, c4_dt=None) -> None:
+        lhs = _f64(lhs_off_data, 'lhs_off_data')
+        c2, c3 = _f64(c2, 'c2'), _f64(c3, 'c3')
+        if lhs.shape != (self.n_edges,) or c2.shape != (self.n,) or c3.shape != (self.n,):
+            raise ValueError('coefficient arrays do not match the plan (lhs_off_data per CSC entry, c2/c3 per reach)')
+        c4 = None
+        if c4_dt is not None:
+            c4 = _f64(c4_dt, 'c4_dt')
+            if c4.shape != (self.n,):
+                raise ValueError('c4_dt must have one value per reach')
+        check(_lib.lib().rr_plan_set_coeffs(self._h, ptr(lhs) if lhs.size else None, ptr(c2), ptr(c3), ptr(c4)))
+
+    # -- host-array routing: the reference's kernel boundary --
+    def rapid_route(self, q_t, qlateral, discharge_array, num_substeps: int) -> None:
+        ql = np.ascontiguousarray(qlateral, dtype=np.float64)
+        if ql.ndim != 2 or ql.shape[1] != self.n:
+            raise ValueError(f'qlateral must have shape (T, {self.n})')
+        T = ql.shape[0]
+        _inplace_f64(q_t, 'q_t', (self.n,))
+        _inplace_f64(discharge_array, 'discharge_array', (T, self.n))
+        check(_lib.lib().rr_rapid_route(self._h, ptr(q_t), ptr(ql), ptr(discharge_array), T, int(num_substeps)))
+
+    def muskingum_route(self, q_t, discharge_array, num_output_steps: int, num_routing_per_output: int) -> None:
+        _inplace_f64(q_t, 'q_t', (self.n,))
+        _inplace_f64(discharge_array, 'discharge_array', (int(num_output_steps), self.n))
+        check(_lib.lib().rr_muskingum_route(self._h, ptr(q_t), ptr(discharge_array), int(num_output_steps),
+                                            int(num_routing_per_output)))
+
+    def unit_route(self, q_ch, q_full, convolved_lateral, discharge_array, num_substeps: int) -> None:
+        conv = np.ascontiguousarray(convolved_lateral, dtype=np.float64)
+        if conv.ndim != 2 or conv.shape[1] != self.n:
+            raise ValueError(f'convolved_lateral must have shape (T, {self.n})')
+        T = conv.shape[0]
+        _inplace_f64(q_ch, 'q_ch', (self.n_inner,))
+        _inplace_f64(q_full, 'q_full', (self.n_inner,))
+        _inplace_f64(discharge_array, 'discharge_array', (T, self.n))
+        check(_lib.lib().rr_unit_route(self._h, ptr(q_ch), ptr(q_full), ptr(conv), ptr(discharge_array), T,
+                                       int(num_substeps)))
+
+    # -- device-pointer routing (enqueue only) --
+    def rapid_route_dev(self, q_t, qlateral, ql_rows, discharge, out_rows, T, num_substeps, stream=None) -> None:
+        check(_lib.lib().rr_rapid_route_dev(self._h, ptr(q_t), ptr(qlateral), int(ql_rows), ptr(discharge),
+                                            int(out_rows), int(T), int(num_substeps), stream))
+
+    def muskingum_route_dev(self, q_t, discharge, out_rows, num_output_steps, num_routing_per_output,
+                            stream=None) -> None:
+        check(_lib.lib().rr_muskingum_route_dev(self._h, ptr(q_t), ptr(discharge), int(out_rows),
+                                                int(num_output_steps), int(num_routing_per_output), stream))
+
+    def unit_route_dev(self, q_ch, q_full, convolved, conv_rows, discharge, out_rows, T, num_substeps,
+                       stream=None) -> None:
+        check(_lib.lib().rr_unit_route_dev(self._h, ptr(q_ch), ptr(q_full), ptr(convolved), int(conv_rows),
+                                           ptr(discharge), int(out_rows), int(T), int(num_substeps), stream))
+
+
+def uh_convolve(kernel, state, lateral, device: int = 0) -> np.ndarray:
+    """UnitHydrograph.convolve (river_route/uhkernels/UnitHydrograph.py:77-107) on the GPU.
+    kernel (n_ks, n); state (n_ks, n) updated in place; lateral (T, n) -> (T, n)."""
+    k = np.ascontiguousarray(kernel, dtype=np.float64)
+    lat = np.ascontiguousarray(lateral, dtype=np.float64)
+    n_ks, n = k.shape
+    _inplace_f64(state, 'state', (n_ks, n))
+    if lat.ndim != 2 or lat.shape[1] != n:
+        raise ValueError(f'lateral must have shape (T, {n})')
+    out = np.empty_like(lat)
+    check(_lib.lib().rr_uh_convolve(int(device), ptr(k), ptr(state), ptr(lat), ptr(out), lat.shape[0], n_ks, n))
+    return out
+
+
+def uh_convolve_dev(kernel, state, lateral, out, T, n_ks, n, device: int = 0, stream=None) -> None:
+    check(_lib.lib().rr_uh_convolve_dev(int(device), ptr(kernel), ptr(state), ptr(lateral), ptr(out), int(T),
+                                        int(n_ks), int(n), stream))
+
+
+class DeviceBuffer:
+    """A raw hipMalloc'd buffer for callers that do not use torch."""
+
+    def __init__(self, nbytes: int, device: int = 0):
+        self.device, self.nbytes = int(device), int(nbytes)
+        p = C.c_void_p()
+        check(_lib.lib().rr_dev_malloc(self.device, self.nbytes, C.byref(p)))
+        self.address = int(p.value or 0)
+
+    def upload(self, array: np.ndarray, offset: int = 0) -> 'DeviceBuffer':
+        a = np.ascontiguousarray(array)
+        check(_lib.lib().rr_dev_upload(self.device, self.address + offset, ptr(a), a.nbytes))
+        return self
+
+    def download(self, dtype, shape, offset: int = 0) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        check(_lib.lib().rr_dev_download(self.device, ptr(out), self.address + offset, out.nbytes))
+        return out
+
+    def free(self) -> None:
+        if self.address:
+            _lib.lib().rr_dev_free(self.device, self.address)
+            self.address = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def synchronize(device: int = 0) -> None:
+    check(_lib.lib().rr_dev_synchronize(int(device)))

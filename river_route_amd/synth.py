@@ -108,7 +108,7 @@ def synth_network(n: int, seed: int = NETWORK_SEED, params_seed: int = PARAMS_SE
                   order: str = 'random') -> SynthNetwork:
     """
     n-reach random-topology network.  order: 'random' (random topological order, default),
-    'bfs' (sorted by distance to the outlet, farthest first -- the layout the GPU plan uses internally),
+    'bfs' (the engine's own order: farthest-from-outlet level first; needs no permutation pass on the GPU),
     'levels' (sorted by distance from the headwaters).
     """
     if n < 1:
@@ -133,12 +133,19 @@ def synth_network(n: int, seed: int = NETWORK_SEED, params_seed: int = PARAMS_SE
     elif order == 'levels':
         perm = np.concatenate(levels)
     elif order == 'bfs':
-        dist = np.zeros(n, dtype=np.int64)
-        for nodes in reversed(levels):  # downstream nodes first
-            p = parent[nodes]
-            m = p >= 0
-            dist[nodes[m]] = dist[p[m]] + 1
-        perm = np.argsort(-dist, kind='stable')
+        # the engine's own order (rr_plan.hpp): farthest-from-outlet level first, each level in the order of
+        # its downstream reaches.  A params file sorted this way needs no permutation pass on the GPU.
+        from .engine import Plan
+        from ._lib import RR_DEVICE_NONE
+        first = np.concatenate(levels)
+        rank = np.empty(n, dtype=np.int64)
+        rank[first] = np.arange(n)
+        pf = parent[first]
+        down = np.where(pf >= 0, rank[np.maximum(pf, 0)], -1)
+        has = down >= 0
+        indptr = np.concatenate([[0], np.cumsum(has)]).astype(np.int32)
+        with Plan(indptr, down[has].astype(np.int32), device=RR_DEVICE_NONE) as plan:
+            perm = first[plan.layout()[0].astype(np.int64)]
     else:
         raise ValueError(f'unknown order {order!r}')
 
