@@ -84,11 +84,13 @@ int rr_plan_set_coeffs(rr_plan *plan, const double *lhs_off_data, const double *
                        const double *c4_dt);
 
 /* Tuning / measurement.  rows_per_chunk: time rows moved per permutation launch (default 32).
- * sample_every > 0: bracket every sample_every-th routing-step launch with HIP events. */
+ * sample_every >= 16: every sample_every-th routing-tick launch opens a HIP-event bracket around 16
+ * consecutive routing-tick launches on the call's stream (0 switches sampling off). */
 int rr_plan_set_options(rr_plan *plan, int64_t rows_per_chunk, int64_t sample_every);
 
-/* prof[0]=routing-step launches of the last route call, [1]=launches sampled, [2]=sum of sampled
- * durations (ms), [3]=min (ms), [4]=max (ms), [5]=reaches updated by the sampled launches,
+/* prof[0]=routing-tick launches of the last route call, [1]=launches inside brackets, [2]=sum of the bracket
+ * durations (ms), [3]/[4]=smallest/largest per-launch mean of a bracket (ms), [5]=reaches updated by the
+ * bracketed launches,
  * [6]=ms between the first and the last routing-step launch of the call (permutation passes included),
  * [7]=reach-steps of the call.  Synchronises the plan's last stream. */
 int rr_plan_profile(rr_plan *plan, double prof[8]);

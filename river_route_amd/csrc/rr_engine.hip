@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -38,6 +39,7 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
     } while (0)
 
 constexpr int kBlock = 256;
+constexpr int kSampleGroup = 16;   // routing-tick launches per HIP-event bracket
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -148,39 +150,80 @@ __global__ __launch_bounds__(kBlock) void k_tick_unit(const UnitTickArgs ua)
     }
 }
 
-// ring[(t % ring_rows), p] = src[((t - src_t0) % src_rows), perm[p]] for t in [t0, t0 + nrows)
-__global__ __launch_bounds__(kBlock) void k_permute_in(double *ring, int64_t ring_ld, uint32_t ring_rows,
-                                                       const double *src, int64_t src_ld, uint32_t src_rows,
-                                                       int64_t src_t0, const int32_t *perm, int32_t n,
-                                                       int64_t t0, int32_t nrows, int32_t rows_per_block)
+// ---- two-phase tiled permutation of (time, reach) rows, rr_plan.hpp / DESIGN.md section 4 ----
+constexpr int kPermThreads = 1024;
+constexpr int kPermE = 8;   // elements per thread: 8192-element (64 KiB) tiles
+
+// Row addressing of a (rows, ld) array read or written cyclically: row of step t is (t - t0) % rows.
+struct RowView {
+    double *base;
+    int64_t ld;
+    int64_t t0;
+    uint32_t rows;
+    __device__ __forceinline__ double *row(int64_t t) const { return base + (int64_t)((uint64_t)(t - t0) % rows) * ld; }
+};
+
+// Phase A: source tile -> LDS (sorted by destination tile) -> runs of the intermediate rows M[r, :].
+template <int E>
+__global__ __launch_bounds__(kPermThreads) void k_perm_a(const RowView src, double *__restrict__ m_rows, int64_t n,
+                                                         const uint16_t *__restrict__ slot_a,
+                                                         const int32_t *__restrict__ m_index, int64_t t0,
+                                                         int32_t nrows, int32_t rows_per_block)
 {
-    const int32_t p = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
-    if (p >= n) return;
-    const int32_t i = perm[p];
-    const int32_t r0 = (int32_t)blockIdx.y * rows_per_block;
-    const int32_t r1 = min(nrows, r0 + rows_per_block);
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int64_t base = (int64_t)blockIdx.x * (E * kPermThreads);
+    const int tid = threadIdx.x;
+    int32_t slot[E], mi[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int64_t i = base + k * kPermThreads + tid;
+        slot[k] = i < n ? (int32_t)slot_a[i] : -1;
+        mi[k] = i < n ? m_index[i] : -1;
+    }
+    const int32_t r0 = (int32_t)blockIdx.y * rows_per_block, r1 = min(nrows, r0 + rows_per_block);
     for (int32_t r = r0; r < r1; ++r) {
-        const int64_t t = t0 + r;
-        ring[(int64_t)((uint64_t)t % ring_rows) * ring_ld + p] =
-            src[(int64_t)((uint64_t)(t - src_t0) % src_rows) * src_ld + i];
+        const double *srow = src.row(t0 + r) + base;
+        double v[E];
+#pragma unroll
+        for (int k = 0; k < E; ++k) v[k] = slot[k] >= 0 ? srow[k * kPermThreads + tid] : 0.0;
+#pragma unroll
+        for (int k = 0; k < E; ++k) if (slot[k] >= 0) lds[slot[k]] = v[k];
+        __syncthreads();
+        double *mrow = m_rows + (int64_t)r * n;
+#pragma unroll
+        for (int k = 0; k < E; ++k) if (mi[k] >= 0) mrow[mi[k]] = lds[k * kPermThreads + tid];
+        __syncthreads();
     }
 }
 
-// dst[((t - dst_t0) % dst_rows), i] = ring[(t % ring_rows), inv[i]]
-__global__ __launch_bounds__(kBlock) void k_permute_out(double *dst, int64_t dst_ld, uint32_t dst_rows,
-                                                        int64_t dst_t0, const double *ring, int64_t ring_ld,
-                                                        uint32_t ring_rows, const int32_t *inv, int32_t n,
-                                                        int64_t t0, int32_t nrows, int32_t rows_per_block)
+// Phase B: one destination tile's bucket of M (contiguous) -> LDS at destination offsets -> coalesced rows.
+template <int E>
+__global__ __launch_bounds__(kPermThreads) void k_perm_b(const RowView dst, const double *__restrict__ m_rows,
+                                                         int64_t n, const uint16_t *__restrict__ slot_b, int64_t t0,
+                                                         int32_t nrows, int32_t rows_per_block)
 {
-    const int32_t i = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
-    if (i >= n) return;
-    const int32_t p = inv[i];
-    const int32_t r0 = (int32_t)blockIdx.y * rows_per_block;
-    const int32_t r1 = min(nrows, r0 + rows_per_block);
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int64_t base = (int64_t)blockIdx.x * (E * kPermThreads);
+    const int tid = threadIdx.x;
+    int32_t slot[E];
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        const int64_t g = base + k * kPermThreads + tid;
+        slot[k] = g < n ? (int32_t)slot_b[g] : -1;
+    }
+    const int32_t r0 = (int32_t)blockIdx.y * rows_per_block, r1 = min(nrows, r0 + rows_per_block);
     for (int32_t r = r0; r < r1; ++r) {
-        const int64_t t = t0 + r;
-        dst[(int64_t)((uint64_t)(t - dst_t0) % dst_rows) * dst_ld + i] =
-            ring[(int64_t)((uint64_t)t % ring_rows) * ring_ld + p];
+        const double *mrow = m_rows + (int64_t)r * n + base;
+        double v[E];
+#pragma unroll
+        for (int k = 0; k < E; ++k) v[k] = slot[k] >= 0 ? mrow[k * kPermThreads + tid] : 0.0;
+#pragma unroll
+        for (int k = 0; k < E; ++k) if (slot[k] >= 0) lds[slot[k]] = v[k];
+        __syncthreads();
+        double *drow = dst.row(t0 + r) + base;
+#pragma unroll
+        for (int k = 0; k < E; ++k) if (slot[k] >= 0) drow[k * kPermThreads + tid] = lds[k * kPermThreads + tid];
+        __syncthreads();
     }
 }
 
@@ -298,7 +341,7 @@ struct rr_plan {
     rr::HostPlan h;
     int device = RR_DEVICE_NONE;
     bool coeffs_set = false, has_c4 = false;
-    int64_t chunk_rows = 32, sample_every = 0;
+    int64_t chunk_rows = 16, sample_every = 0;
 
     int32_t *d_child_ptr = nullptr, *d_lag = nullptr, *d_perm = nullptr, *d_inv = nullptr, *d_inner_pos = nullptr;
     uint16_t *d_hwc = nullptr;
@@ -308,6 +351,12 @@ struct rr_plan {
     int64_t ring_cap = 0;  // doubles
     double *d_stage = nullptr;
     int64_t stage_cap = 0;
+    double *d_mrows = nullptr;   // intermediate rows of the tiled permutation
+    int64_t mrows_cap = 0;
+    // tiled permutations: [0] params order -> engine order (pi = perm), [1] engine -> params (pi = inv)
+    uint16_t *d_slot_a[2] = {nullptr, nullptr}, *d_slot_b[2] = {nullptr, nullptr};
+    int32_t *d_m_index[2] = {nullptr, nullptr};
+    int64_t perm_rows_per_block = 2;
 
     // profile of the last route call
     std::vector<hipEvent_t> ev;
@@ -368,6 +417,16 @@ int ensure_stage(rr_plan *P, int64_t doubles)
     return RR_OK;
 }
 
+int ensure_mrows(rr_plan *P, int64_t doubles)
+{
+    if (P->mrows_cap >= doubles) return RR_OK;
+    if (P->d_mrows) { (void)hipFree(P->d_mrows); P->d_mrows = nullptr; P->mrows_cap = 0; }
+    int rc = dev_alloc(&P->d_mrows, doubles);
+    if (rc) return rc;
+    P->mrows_cap = doubles;
+    return RR_OK;
+}
+
 enum class Mode { Rapid, Muskingum, Unit };
 
 // Where the (time, reach) rows in params order come from / go to.
@@ -425,22 +484,34 @@ int route_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io, h
     UnitTickArgs ua{};
     ua.hw_children = P->d_hwc; ua.qch = P->d_qch;
 
-    const int rows_per_block = 8;
+    // params order <-> engine order through the two-phase tiled permutation (k_perm_a / k_perm_b)
+    constexpr int E = kPermE;
+    const int64_t tile = (int64_t)E * kPermThreads;
+    const unsigned n_tiles = (unsigned)((n + tile - 1) / tile);
+    const int rpb = (int)std::max<int64_t>(1, P->perm_rows_per_block);
+    const size_t lds_bytes = (size_t)tile * sizeof(double);
+    if (!direct) {
+        int rc = ensure_mrows(P, C * n);
+        if (rc) return rc;
+    }
+    auto permute = [&](int which, const RowView &src, const RowView &dst, int64_t t0, int nrows) {
+        dim3 g(n_tiles, (unsigned)((nrows + rpb - 1) / rpb));
+        hipLaunchKernelGGL(k_perm_a<E>, g, dim3(kPermThreads), lds_bytes, stream, src, P->d_mrows, n,
+                           (const uint16_t *)P->d_slot_a[which], (const int32_t *)P->d_m_index[which], t0, nrows, rpb);
+        hipLaunchKernelGGL(k_perm_b<E>, g, dim3(kPermThreads), lds_bytes, stream, dst, (const double *)P->d_mrows, n,
+                           (const uint16_t *)P->d_slot_b[which], t0, nrows, rpb);
+    };
+    const RowView ring_view{P->d_ring, n, 0, (uint32_t)std::max<int64_t>(1, ring_rows)};
     auto load_rows = [&](int64_t r0, int64_t r1) -> int {   // params order -> ring
         if (direct || !has_in) return RR_OK;
         const int nrows = (int)(r1 - r0);
-        dim3 g((unsigned)((n + kBlock - 1) / kBlock), (unsigned)((nrows + rows_per_block - 1) / rows_per_block));
         if (io.host_in) {
             HIPCHK(hipMemcpyAsync(P->d_stage, io.host_in + r0 * n, (size_t)nrows * n * sizeof(double),
                                   hipMemcpyHostToDevice, stream));
-            hipLaunchKernelGGL(k_permute_in, g, dim3(kBlock), 0, stream, P->d_ring, n, (uint32_t)ring_rows,
-                               (const double *)P->d_stage, n, (uint32_t)C, r0, P->d_perm, (int32_t)n, r0, nrows,
-                               rows_per_block);
+            permute(0, RowView{P->d_stage, n, r0, (uint32_t)C}, ring_view, r0, nrows);
             HIPCHK(hipStreamSynchronize(stream));   // the stage is reused by the next chunk
         } else {
-            hipLaunchKernelGGL(k_permute_in, g, dim3(kBlock), 0, stream, P->d_ring, n, (uint32_t)ring_rows,
-                               io.dev_in, n, (uint32_t)io.rows_in, (int64_t)0, P->d_perm, (int32_t)n, r0, nrows,
-                               rows_per_block);
+            permute(0, RowView{const_cast<double *>(io.dev_in), n, 0, (uint32_t)io.rows_in}, ring_view, r0, nrows);
         }
         return RR_OK;
     };
@@ -448,18 +519,13 @@ int route_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io, h
         if (direct) return RR_OK;
         for (int64_t b0 = r0; b0 < r1; b0 += C) {
             const int nrows = (int)std::min<int64_t>(C, r1 - b0);
-            dim3 g((unsigned)((n + kBlock - 1) / kBlock), (unsigned)((nrows + rows_per_block - 1) / rows_per_block));
             if (io.host_out) {
-                hipLaunchKernelGGL(k_permute_out, g, dim3(kBlock), 0, stream, P->d_stage, n, (uint32_t)C, b0,
-                                   (const double *)P->d_ring, n, (uint32_t)ring_rows, P->d_inv, (int32_t)n, b0,
-                                   nrows, rows_per_block);
+                permute(1, ring_view, RowView{P->d_stage, n, b0, (uint32_t)C}, b0, nrows);
                 HIPCHK(hipMemcpyAsync(io.host_out + b0 * n, P->d_stage, (size_t)nrows * n * sizeof(double),
                                       hipMemcpyDeviceToHost, stream));
                 HIPCHK(hipStreamSynchronize(stream));
             } else {
-                hipLaunchKernelGGL(k_permute_out, g, dim3(kBlock), 0, stream, io.dev_out, n,
-                                   (uint32_t)io.rows_out, (int64_t)0, (const double *)P->d_ring, n,
-                                   (uint32_t)ring_rows, P->d_inv, (int32_t)n, b0, nrows, rows_per_block);
+                permute(1, ring_view, RowView{io.dev_out, n, 0, (uint32_t)io.rows_out}, b0, nrows);
             }
         }
         return RR_OK;
@@ -474,6 +540,8 @@ int route_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io, h
     }
     if (!P->ev_first) { HIPCHK(hipEventCreate(&P->ev_first)); HIPCHK(hipEventCreate(&P->ev_last)); }
 
+    bool bracket_open = false;
+    int64_t bracket_reaches = 0;
     auto launch_tick = [&](int64_t tau) -> int {
         // active lags: tau - total < lag <= tau
         const int64_t lag_lo = std::max<int64_t>(0, tau - total + 1), lag_hi = std::min<int64_t>(tau, dmax);
@@ -483,9 +551,12 @@ int route_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io, h
         a.xc = P->d_x + (tau % 3) * n;
         a.xa = P->d_x + ((tau + 2) % 3) * n;
         a.xb = P->d_x + ((tau + 1) % 3) * n;
-        const bool sample = P->sample_every > 0 && (P->prof_launches % P->sample_every) == 0 &&
-                            (size_t)P->prof_samples < max_samples;
-        if (sample) HIPCHK(hipEventRecord(P->ev[2 * P->prof_samples], stream));
+        // sampling: every sample_every-th launch opens a bracket of kSampleGroup consecutive launches, so the
+        // event overhead (~5 us per pair) is amortised and the figure is comparable with rocprofv3's per-kernel time
+        const int64_t phase = P->sample_every > 0 ? P->prof_launches % P->sample_every : -1;
+        const bool open_bracket = phase == 0 && (size_t)(P->prof_samples / kSampleGroup) < max_samples &&
+                                  P->sample_every >= kSampleGroup;
+        if (open_bracket) { HIPCHK(hipEventRecord(P->ev[2 * (P->prof_samples / kSampleGroup)], stream)); bracket_open = true; }
         const dim3 g = grid1(p_hi - p_lo);
         if (mode == Mode::Unit) {
             ua.t = a;
@@ -498,10 +569,15 @@ int route_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io, h
             if (nsub == 1) hipLaunchKernelGGL((k_tick<false, true>), g, dim3(kBlock), 0, stream, a);
             else hipLaunchKernelGGL((k_tick<false, false>), g, dim3(kBlock), 0, stream, a);
         }
-        if (sample) {
-            HIPCHK(hipEventRecord(P->ev[2 * P->prof_samples + 1], stream));
-            P->ev_reaches.push_back(p_hi - p_lo);
+        if (bracket_open) {
+            bracket_reaches += p_hi - p_lo;
             ++P->prof_samples;
+            if (P->prof_samples % kSampleGroup == 0) {
+                HIPCHK(hipEventRecord(P->ev[2 * (P->prof_samples / kSampleGroup) - 1], stream));
+                P->ev_reaches.push_back(bracket_reaches);
+                bracket_reaches = 0;
+                bracket_open = false;
+            }
         }
         ++P->prof_launches;
         return RR_OK;
@@ -531,6 +607,7 @@ int route_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io, h
             rows_stored = done;
         }
     }
+    if (bracket_open) P->prof_samples -= P->prof_samples % kSampleGroup;   // incomplete bracket: not counted
     HIPCHK(hipEventRecord(P->ev_last, stream));
     HIPCHK(hipGetLastError());
     return RR_OK;
@@ -660,7 +737,8 @@ void rr_plan_destroy(rr_plan *P)
     if (!P) return;
     if (P->device >= 0 && hipSetDevice(P->device) == hipSuccess) {
         void *ptrs[] = {P->d_child_ptr, P->d_lag, P->d_perm, P->d_inv, P->d_inner_pos, P->d_hwc, P->d_w, P->d_c2,
-                        P->d_c3, P->d_c4, P->d_x, P->d_isum, P->d_qch, P->d_ring, P->d_stage};
+                        P->d_c3, P->d_c4, P->d_x, P->d_isum, P->d_qch, P->d_ring, P->d_stage, P->d_mrows,
+                        P->d_slot_a[0], P->d_slot_a[1], P->d_slot_b[0], P->d_slot_b[1], P->d_m_index[0], P->d_m_index[1]};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         for (hipEvent_t e : P->ev) (void)hipEventDestroy(e);
         if (P->ev_first) (void)hipEventDestroy(P->ev_first);
@@ -675,6 +753,8 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
     *out = nullptr;
     rr_plan *P = new (std::nothrow) rr_plan();
     if (!P) return fail(RR_E_ALLOC, "rr_plan_create: out of memory");
+    if (const char *e = getenv("RR_CHUNK_ROWS")) P->chunk_rows = std::max(1, atoi(e));        // tuning knobs
+    if (const char *e = getenv("RR_PERM_ROWS_PER_BLOCK")) P->perm_rows_per_block = std::max(1, atoi(e));
     std::string err;
     int rc = rr::build_host_plan(n, csc_indptr, csc_indices, P->h, err);
     if (rc) { delete P; return fail(rc, err); }
@@ -709,6 +789,19 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         if (!rc) rc = dev_upload(P->d_inv, H.inv);
         if (!rc) rc = dev_upload(P->d_inner_pos, H.inner_pos);
         if (!rc) rc = dev_upload(P->d_hwc, H.hw_children);
+        if (!rc) {
+            const int32_t *pis[2] = {H.perm.data(), H.inv.data()};
+            for (int w = 0; w < 2 && !rc; ++w) {
+                rr::TiledPermutation tp;
+                rr::build_tiled_permutation(pis[w], n, kPermE * kPermThreads, tp);
+                rc = dev_alloc(&P->d_slot_a[w], n);
+                if (!rc) rc = dev_alloc(&P->d_slot_b[w], n);
+                if (!rc) rc = dev_alloc(&P->d_m_index[w], n);
+                if (!rc) rc = dev_upload(P->d_slot_a[w], tp.slot_a);
+                if (!rc) rc = dev_upload(P->d_slot_b[w], tp.slot_b);
+                if (!rc) rc = dev_upload(P->d_m_index[w], tp.m_index);
+            }
+        }
         if (rc) { rr_plan_destroy(P); return rc; }
     }
     *out = P;
@@ -781,9 +874,9 @@ int rr_plan_profile(rr_plan *P, double prof[8])
     HIPCHK(hipEventElapsedTime(&ms, P->ev_first, P->ev_last));
     prof[6] = ms;
     double sum = 0, mn = 1e300, mx = 0, reaches = 0;
-    for (int64_t k = 0; k < P->prof_samples; ++k) {
+    for (int64_t k = 0; k < P->prof_samples / kSampleGroup; ++k) {
         HIPCHK(hipEventElapsedTime(&ms, P->ev[2 * k], P->ev[2 * k + 1]));
-        sum += ms; mn = std::min<double>(mn, ms); mx = std::max<double>(mx, ms);
+        sum += ms; mn = std::min<double>(mn, ms / kSampleGroup); mx = std::max<double>(mx, ms / kSampleGroup);
         reaches += (double)P->ev_reaches[k];
     }
     prof[1] = (double)P->prof_samples; prof[2] = sum; prof[3] = P->prof_samples ? mn : 0.0; prof[4] = mx;

@@ -2,10 +2,42 @@
 
 #include <algorithm>
 #include <limits>
+#include <utility>
+#include <vector>
 
 #include "../../include/rr_hip.h"
 
 namespace rr {
+
+void build_tiled_permutation(const int32_t *pi, int64_t n, int32_t tile, TiledPermutation &T)
+{
+    T = TiledPermutation();
+    T.n = n;
+    T.tile = tile;
+    if (n == 0) return;
+    const int64_t nt = (n + tile - 1) / tile;
+    std::vector<int32_t> q_of(n);
+    for (int64_t q = 0; q < n; ++q) q_of[pi[q]] = (int32_t)q;
+    // run (b, a): elements of source tile a bound for destination tile b; M is ordered by (b, a, source index)
+    std::vector<int64_t> run(nt * nt + 1, 0);
+    for (int64_t i = 0; i < n; ++i) ++run[(int64_t)(q_of[i] / tile) * nt + i / tile + 1];
+    for (size_t k = 1; k < run.size(); ++k) run[k] += run[k - 1];
+    std::vector<int32_t> g_of(n);
+    for (int64_t i = 0; i < n; ++i) g_of[i] = (int32_t)run[(int64_t)(q_of[i] / tile) * nt + i / tile]++;
+    T.slot_a.resize(n); T.m_index.resize(n); T.slot_b.resize(n);
+    std::vector<std::pair<int32_t, int32_t>> tmp;
+    for (int64_t a = 0; a < nt; ++a) {
+        const int64_t i0 = a * tile, i1 = std::min<int64_t>(n, i0 + tile);
+        tmp.clear();
+        for (int64_t i = i0; i < i1; ++i) tmp.emplace_back(g_of[i], (int32_t)i);
+        std::sort(tmp.begin(), tmp.end());
+        for (size_t m = 0; m < tmp.size(); ++m) {
+            T.slot_a[tmp[m].second] = (uint16_t)m;
+            T.m_index[i0 + (int64_t)m] = tmp[m].first;
+        }
+    }
+    for (int64_t i = 0; i < n; ++i) T.slot_b[g_of[i]] = (uint16_t)(q_of[i] % tile);
+}
 
 int build_host_plan(int64_t n, const int32_t *indptr, const int32_t *indices, HostPlan &P, std::string &err)
 {

@@ -34,6 +34,22 @@ struct HostPlan {
     std::vector<int32_t> inner_pos;  // [n_inner] engine position of the k-th inner reach (ascending params order)
 };
 
+// Two-phase tiled permutation dst[q] = src[pi[q]].  A random 8-byte gather wastes 7/8
+// of every 64-byte sector it touches, and with eight private L2s no single pass can avoid that; instead
+//   phase A: each block reads one SOURCE tile coalesced, sorts it in LDS by destination tile and appends the
+//            pieces to an intermediate row M (runs of elements bound for the same destination tile);
+//   phase B: each block reads one DESTINATION tile's bucket of M (contiguous), places it in LDS and writes
+//            the destination tile coalesced.
+// Every global access of both phases is a contiguous run; LDS does the shuffling.
+struct TiledPermutation {
+    int64_t n = 0;
+    int32_t tile = 0;                // elements per tile
+    std::vector<uint16_t> slot_a;    // [n] LDS slot of source element i inside its tile (sorted by destination)
+    std::vector<int32_t> m_index;    // [n] for source tile a, sorted slot m: index in M  (stored at a*tile + m)
+    std::vector<uint16_t> slot_b;    // [n] for M index g: offset of its destination inside the destination tile
+};
+void build_tiled_permutation(const int32_t *pi, int64_t n, int32_t tile, TiledPermutation &out);
+
 // Returns 0 or an RR_E_* code with a message in err.
 int build_host_plan(int64_t n, const int32_t *indptr, const int32_t *indices, HostPlan &plan, std::string &err);
 
