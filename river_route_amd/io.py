@@ -1,0 +1,91 @@
+"""
+File I/O either side of the hot path, kept minimal: lateral-inflow netCDF in (io-file-schema of the reference:
+dims time x river_id, variable `qlateral`), discharge netCDF out (river_route/routers/Muskingum.py:337-351).
+netCDF4 / xarray are used when installed; otherwise scipy's NetCDF-3 reader/writer.
+"""
+from __future__ import annotations
+
+import re
+
+import numpy as np
+
+__all__ = ['read_qlateral', 'write_discharge']
+
+_UNIT_SECONDS = {'second': 1, 'seconds': 1, 'sec': 1, 'secs': 1, 's': 1, 'minute': 60, 'minutes': 60, 'min': 60,
+                 'hour': 3600, 'hours': 3600, 'h': 3600, 'hr': 3600, 'day': 86400, 'days': 86400, 'd': 86400}
+
+
+def _decode_cf_time(values: np.ndarray, units: str) -> np.ndarray:
+    m = re.match(r'\s*(\w+)\s+since\s+(.+?)\s*$', units)
+    if not m or m.group(1).lower() not in _UNIT_SECONDS:
+        raise ValueError(f'cannot decode time units {units!r}')
+    origin = np.datetime64(m.group(2).strip().replace(' ', 'T').rstrip('Z'), 's')
+    secs = np.round(np.asarray(values, dtype=np.float64) * _UNIT_SECONDS[m.group(1).lower()]).astype(np.int64)
+    return origin + secs.astype('timedelta64[s]')
+
+
+def read_qlateral(path, var_t: str = 'time', var: str = 'qlateral'):
+    """-> (dates datetime64[s][T], array float64[T, n]) as TransformMuskingum._qlateral_generator yields them
+    (river_route/routers/TransformMuskingum.py:33-36)."""
+    try:
+        import xarray as xr
+        with xr.open_dataset(path) as ds:
+            return ds[var_t].values.astype('datetime64[s]'), ds[var].values.astype(np.float64, copy=False)
+    except ImportError:
+        pass
+    try:
+        import netCDF4 as nc
+        with nc.Dataset(str(path)) as ds:
+            tv = ds[var_t]
+            dates = _decode_cf_time(np.asarray(tv[:]), tv.units)
+            return dates, np.asarray(ds[var][:], dtype=np.float64)
+    except ImportError:
+        pass
+    from scipy.io import netcdf_file
+    with netcdf_file(str(path), 'r', mmap=False) as ds:
+        tv = ds.variables[var_t]
+        units = tv.units.decode() if isinstance(tv.units, bytes) else tv.units
+        dates = _decode_cf_time(tv[:].copy(), units)
+        return dates, np.array(ds.variables[var][:], dtype=np.float64)
+
+
+def write_discharge(path, dates, q_array, river_ids, var_river_id='river_id', var_discharge='Q', routed_file=''):
+    """Discharge file with the reference's layout: dims (time, river_id); time f8 'seconds since <first date>';
+    ids i4; Q f4 with long_name / standard_name / aggregation_method / units attributes."""
+    dates = np.asarray(dates).astype('datetime64[s]')
+    origin = str(dates[0]).replace('T', ' ')
+    seconds = (dates - dates[0]).astype('timedelta64[s]').astype(np.int64)
+    attrs = dict(long_name='Discharge at catchment outlet', standard_name='discharge',
+                 aggregation_method='mean', units='m3 s-1')
+    try:
+        import netCDF4 as nc
+        with nc.Dataset(str(path), mode='w', format='NETCDF4') as ds:
+            ds.createDimension('time', size=q_array.shape[0])
+            ds.createDimension(var_river_id, size=q_array.shape[1])
+            ds.runoff_file = str(routed_file)
+            tv = ds.createVariable('time', 'f8', ('time',))
+            tv.units = f'seconds since {origin}'
+            tv[:] = seconds
+            iv = ds.createVariable(var_river_id, 'i4', (var_river_id,))
+            iv[:] = river_ids
+            fv = ds.createVariable(var_discharge, 'f4', ('time', var_river_id))
+            fv[:] = q_array
+            for k, v in attrs.items():
+                setattr(fv, k, v)
+        return
+    except ImportError:
+        pass
+    from scipy.io import netcdf_file
+    with netcdf_file(str(path), 'w', version=2) as ds:
+        ds.createDimension('time', q_array.shape[0])
+        ds.createDimension(var_river_id, q_array.shape[1])
+        ds.runoff_file = str(routed_file)
+        tv = ds.createVariable('time', 'f8', ('time',))
+        tv.units = f'seconds since {origin}'
+        tv[:] = seconds.astype(np.float64)
+        iv = ds.createVariable(var_river_id, 'i4', (var_river_id,))
+        iv[:] = np.asarray(river_ids).astype(np.int32)
+        fv = ds.createVariable(var_discharge, 'f4', ('time', var_river_id))
+        fv[:] = np.asarray(q_array, dtype=np.float32)
+        for k, v in attrs.items():
+            setattr(fv, k, v)

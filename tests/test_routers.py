@@ -1,0 +1,316 @@
+"""
+Router-level parity: the host-side mirror of the reference's Router API (Configs, Muskingum, RapidMuskingum,
+UnitMuskingum, UnitHydrograph, tools.adjacency_matrix) against tests/golden/routers.npz, which was produced by
+running the reference's own routers on the same in-memory inputs (tests/golden/make_golden.py).
+
+Two backends: on the GPU box the real HIP engine (`-m gpu`); on CPU the oracle is injected in place of the
+engine handle so the host logic (time-step algebra, state hand-off, resampling, f32 cast, writer protocol,
+config handling) is covered without a GPU.  The injection lives here, in tests/, never in the product.
+"""
+import json
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import scipy.sparse
+
+import river_route_amd as rr
+from river_route_amd import _lib
+from river_route_amd.routers import muskingum as musk_mod
+from river_route_amd import uhkernels as uhk_mod
+
+
+class OraclePlan:
+    """Stand-in for river_route_amd.engine.Plan backed by oracle/ (tests only)."""
+
+    def __init__(self, indptr, indices, device=0):
+        from conftest import unit_split
+        self.indptr, self.indices = np.asarray(indptr, np.int32), np.asarray(indices, np.int32)
+        self.n = len(self.indptr) - 1
+        self._split = unit_split(self.indptr, self.indices, self.n)
+
+    def close(self):
+        pass
+
+    def set_coeffs(self, lhs, c2, c3, c4_dt=None):
+        self.lhs, self.c2, self.c3, self.c4 = lhs, c2, c3, c4_dt
+
+    def rapid_route(self, q_t, ql, d, nsub):
+        from oracle import oracle
+        oracle.rapid_route(self.indptr, self.indices, self.lhs, self.c2, self.c3, self.c4, q_t, ql, d, nsub)
+
+    def muskingum_route(self, q_t, d, n_out, nrpo):
+        from oracle import oracle
+        oracle.muskingum_route(self.indptr, self.indices, self.lhs, self.c2, self.c3, q_t, d, n_out, nrpo)
+
+    def unit_route(self, q_ch, q_full, conv, d, nsub):
+        from oracle import oracle
+        hw_idx, inner_idx, A_in, A_hw = self._split
+        c1 = np.zeros(self.n)
+        c1[self.indices] = -self.lhs
+        c1i, c2i, c3i = c1[inner_idx], self.c2[inner_idx], self.c3[inner_idx]
+        oracle.unit_route(A_in.indptr, A_in.indices, -c1i[A_in.indices], A_in.indptr, A_in.indices, A_in.data,
+                          A_hw.indptr, A_hw.indices, A_hw.data, c1i, c2i, c3i, hw_idx, inner_idx, q_ch, q_full,
+                          np.ascontiguousarray(conv), d, nsub)
+
+
+def oracle_uh_convolve(kernel, state, lateral, device=0):
+    from oracle import oracle
+    uh = oracle.UnitHydrograph(kernel)
+    uh.state = state
+    return uh.convolve(lateral)
+
+
+@pytest.fixture(params=['oracle_injected', pytest.param('hip', marks=pytest.mark.gpu)])
+def backend(request, monkeypatch):
+    if request.param == 'oracle_injected':
+        monkeypatch.setattr(musk_mod, 'Plan', OraclePlan)
+        monkeypatch.setattr(uhk_mod, 'uh_convolve', oracle_uh_convolve)
+    return request.param
+
+
+@pytest.fixture
+def case(tmp_path, golden_routers):
+    g = golden_routers
+    params = tmp_path / 'params.parquet'
+    pd.DataFrame({'river_id': g['river_ids'], 'downstream_river_id': g['downstream_ids'], 'k': g['k'],
+                  'x': g['x']}).to_parquet(params)
+    init = tmp_path / 'init.parquet'
+    pd.DataFrame({'Q': g['q0']}).to_parquet(init)
+    files = []
+    for i in range(2):
+        f = tmp_path / f'ql{i}.nc'
+        f.touch()
+        files.append(str(f))
+    dates = [g[f'dates{i}'].astype('datetime64[s]') for i in range(2)]
+    return dict(g=g, tmp=tmp_path, params=str(params), init=str(init), files=files, dates=dates)
+
+
+def drive(cls, case, series, **cfg):
+    dates, files = case['dates'], case['files']
+
+    class InMemory(cls):
+        def _qlateral_generator(self):
+            for d, a, fin, fout in zip(dates, series, self.cfg.qlateral_files, self.cfg.discharge_files):
+                yield d, a, fin, fout
+
+    got = []
+    r = InMemory(params_file=case['params'], qlateral_files=files, discharge_dir=str(case['tmp']), log=False, **cfg)
+    r.set_write_discharges(lambda d, q, f, rf='': got.append((np.asarray(d), np.asarray(q), f, rf)))
+    assert r.route() is r
+    return r, got
+
+
+def check(case, tag, r, got):
+    g = case['g']
+    for i, (d, q, f, rf) in enumerate(got):
+        assert q.dtype == np.float32
+        np.testing.assert_array_equal(d.astype('datetime64[s]').astype(np.int64), g[f'{tag}/dates{i}'])
+        want = g[f'{tag}/q{i}']
+        # float32 outputs: <= 1 ulp(f32) of the reference
+        np.testing.assert_allclose(q, want, rtol=1.2e-7, atol=1e-10 * float(np.abs(want).max()))
+        assert os.path.basename(f) == f'discharge_ql{i}.nc' and rf == case['files'][i]
+    want = g[f'{tag}/final_state']
+    np.testing.assert_allclose(r.channel_state, want, rtol=1e-10, atol=1e-10 * float(np.abs(want).max()))
+
+
+def test_rapid_sequential(backend, case):
+    g = case['g']
+    r, got = drive(rr.RapidMuskingum, case, [g['vol0'], g['vol1']], channel_state_init_file=case['init'],
+                   dt_routing=900)
+    check(case, 'rapid_seq', r, got)
+    assert (r.dt_runoff, r.dt_routing, r.num_routing_steps_per_runoff) == (3600, 900, 4)
+
+
+def test_rapid_resample_to_dt_discharge(backend, case):
+    g = case['g']
+    r, got = drive(rr.RapidMuskingum, case, [g['vol0'], g['vol1']], channel_state_init_file=case['init'],
+                   dt_routing=1800, dt_discharge=3 * 3600)
+    check(case, 'rapid_seq_resample', r, got)
+    assert got[0][1].shape[0] == 8
+
+
+def test_rapid_ensemble_state_is_member_mean(backend, case):
+    g = case['g']
+    r, got = drive(rr.RapidMuskingum, case, [g['vol0'], g['vol1']], channel_state_init_file=case['init'],
+                   runoff_processing_mode='ensemble')
+    check(case, 'rapid_ens', r, got)
+
+
+def _unit_files(case):
+    g, tmp = case['g'], case['tmp']
+    kp = tmp / 'uh.npz'
+    scipy.sparse.save_npz(kp, scipy.sparse.csr_matrix(g['uh_kernel']))
+    us = tmp / 'uhstate.parquet'
+    pd.DataFrame(g['uh_state0'].T).to_parquet(us)
+    return str(kp), str(us)
+
+
+def test_unit_sequential_with_states(backend, case):
+    g = case['g']
+    kp, us = _unit_files(case)
+    final_uh = case['tmp'] / 'uh_final.parquet'
+    final_q = case['tmp'] / 'q_final.parquet'
+    r, got = drive(rr.UnitMuskingum, case, [g['depth0'], g['depth1']], channel_state_init_file=case['init'],
+                   dt_routing=1200, uh_kernel_file=kp, uh_state_init_file=us, uh_state_final_file=str(final_uh),
+                   channel_state_final_file=str(final_q))
+    check(case, 'unit_seq', r, got)
+    scale = float(np.abs(g['unit_seq/uh_state_final']).max())
+    np.testing.assert_allclose(r._uh.state, g['unit_seq/uh_state_final'], rtol=0, atol=1e-12 * scale)
+    # state files: UH state is (n_basins, n_kernel_steps); channel state one column Q (io-file-schema)
+    assert pd.read_parquet(final_uh).shape == (len(g['river_ids']), g['uh_kernel'].shape[0])
+    np.testing.assert_array_equal(pd.read_parquet(final_q)['Q'].to_numpy(), r.channel_state)
+    assert got[0][1].min() >= 0.0   # tests/test_unit_muskingum.py:60
+
+
+def test_unit_ensemble_keeps_uh_state_across_members(backend, case):
+    g = case['g']
+    kp, _ = _unit_files(case)
+    r, got = drive(rr.UnitMuskingum, case, [g['depth0'], g['depth1']], channel_state_init_file=case['init'],
+                   uh_kernel_file=kp, runoff_processing_mode='ensemble')
+    check(case, 'unit_ens', r, got)
+    scale = float(np.abs(g['unit_ens/uh_state_final']).max())
+    np.testing.assert_allclose(r._uh.state, g['unit_ens/uh_state_final'], rtol=0, atol=1e-12 * scale)
+
+
+def test_muskingum_channel_only(backend, case):
+    g = case['g']
+    got = []
+    m = rr.Muskingum(params_file=case['params'], discharge_files=[str(case['tmp'] / 'd.nc')], log=False,
+                     channel_state_init_file=case['init'], dt_routing=900, dt_total=6 * 3600, dt_discharge=1800,
+                     start_datetime='2021-03-04')
+    m.set_write_discharges(lambda d, q, f, rf='': got.append((np.asarray(d), np.asarray(q))))
+    m.route()
+    np.testing.assert_array_equal(got[0][0].astype('datetime64[s]').astype(np.int64), g['musk/dates'])
+    np.testing.assert_allclose(got[0][1], g['musk/q'], rtol=1.2e-7, atol=1e-10 * float(np.abs(g['musk/q']).max()))
+    np.testing.assert_allclose(m.channel_state, g['musk/final_state'], rtol=1e-10)
+    assert got[0][1].shape == (12, len(g['river_ids'])) and got[0][1].min() >= 0
+
+
+def test_second_route_continues_from_state(backend, case):
+    """Muskingum.py:117-118: channel_state persists on the object, so route() twice == one longer run."""
+    g = case['g']
+    r, got = drive(rr.RapidMuskingum, case, [g['vol0'], g['vol1']], channel_state_init_file=case['init'],
+                   dt_routing=900)
+    first = r.channel_state.copy()
+    r.route()
+    assert not np.allclose(first, r.channel_state)
+
+
+def test_netcdf_files_end_to_end(backend, case):
+    """Real files both sides: qlateral netCDF in, discharge netCDF out (NetCDF-3 via scipy when netCDF4 is absent)."""
+    from scipy.io import netcdf_file
+    from river_route_amd.io import read_qlateral
+    g, tmp = case['g'], case['tmp']
+    for i in range(2):
+        with netcdf_file(case['files'][i], 'w', version=2) as ds:
+            T, n = g[f'vol{i}'].shape
+            ds.createDimension('time', T)
+            ds.createDimension('river_id', n)
+            tv = ds.createVariable('time', 'f8', ('time',))
+            tv.units = 'seconds since 1970-01-01 00:00:00'
+            tv[:] = g[f'dates{i}'].astype(np.float64)
+            v = ds.createVariable('qlateral', 'f8', ('time', 'river_id'))
+            v[:] = g[f'vol{i}']
+    cfg = tmp / 'config.yaml'
+    import yaml
+    cfg.write_text(yaml.safe_dump(dict(params_file=case['params'], qlateral_files=case['files'],
+                                       discharge_dir=str(tmp), channel_state_init_file=case['init'],
+                                       dt_routing=900, log=False)))
+    r = rr.RapidMuskingum(str(cfg)).route()
+    for i in range(2):
+        out = tmp / f'discharge_ql{i}.nc'
+        assert out.exists()
+        with netcdf_file(str(out), 'r', mmap=False) as ds:
+            q = np.array(ds.variables['Q'][:])
+            ids = np.array(ds.variables['river_id'][:])
+            units = ds.variables['time'].units
+        assert q.dtype.kind == 'f' and q.dtype.itemsize == 4 and (units.decode() if isinstance(units, bytes) else units).startswith('seconds since')
+        np.testing.assert_array_equal(ids, g['river_ids'])
+        want = g[f'rapid_seq/q{i}']
+        np.testing.assert_allclose(q, want, rtol=1.2e-7, atol=1e-10 * float(np.abs(want).max()))
+    jcfg = tmp / 'config.json'
+    jcfg.write_text(json.dumps(dict(params_file=case['params'], qlateral_files=case['files'],
+                                    discharge_dir=str(tmp), log=False)))
+    assert rr.RapidMuskingum(str(jcfg), dt_routing=900).cfg.dt_routing == 900   # kwargs override the file
+
+
+# ---------------------------------------------------------------- config / validation behaviour (no compute)
+
+def test_configs_validation(tmp_path):
+    params = tmp_path / 'p.parquet'
+    params.touch()
+    with pytest.raises(ValueError, match='Provide discharge_dir'):
+        rr.Configs(params_file=str(params))
+    with pytest.raises(ValueError, match='not both'):
+        rr.Configs(params_file=str(params), discharge_dir=str(tmp_path), discharge_files=['a.nc'])
+    with pytest.raises(ValueError, match='Missing required config: params_file'):
+        rr.Configs(discharge_dir=str(tmp_path))
+    with pytest.raises(FileNotFoundError, match='params_file not found'):
+        rr.Configs(params_file=str(tmp_path / 'nope.parquet'), discharge_dir=str(tmp_path))
+    with pytest.raises(FileNotFoundError, match='qlateral_files: .* not found'):
+        rr.Configs(params_file=str(params), discharge_dir=str(tmp_path), qlateral_files=['missing.nc'])
+    with pytest.raises(NotADirectoryError, match='Output directory not found'):
+        rr.Configs(params_file=str(params), discharge_dir=str(tmp_path / 'nodir'))
+    with pytest.raises(NotADirectoryError, match='specified output path'):
+        rr.Configs(params_file=str(params), discharge_files=[str(tmp_path / 'nodir' / 'd.nc')])
+    with pytest.raises(ValueError, match="runoff_processing_mode must be one of"):
+        rr.Configs(params_file=str(params), discharge_dir=str(tmp_path), runoff_processing_mode='parallel')
+    with pytest.raises(TypeError):
+        rr.Configs(params_file=str(params), discharge_dir=str(tmp_path), not_a_key=1)
+    ql = tmp_path / 'jan.nc'
+    ql.touch()
+    c = rr.Configs(params_file='p.parquet' if False else str(params), discharge_dir=str(tmp_path), qlateral_files=str(ql),
+                   log=False)
+    assert c.qlateral_files == [str(ql)] and c.discharge_files == [str(tmp_path / 'discharge_jan.nc')]
+    assert c.progress_bar is False and os.path.isabs(c.params_file)
+    assert rr.Configs(params_file=str(params), discharge_dir=str(tmp_path)).discharge_files == \
+        [str(tmp_path / 'discharge.nc')]
+
+
+def test_router_required_keys_and_bad_config_suffix(tmp_path):
+    params = tmp_path / 'p.parquet'
+    params.touch()
+    with pytest.raises(RuntimeError, match='Unrecognized simulation config file type'):
+        rr.Muskingum(str(tmp_path / 'config.toml'))
+    with pytest.raises(ValueError, match='channel_state_init_file is required for Muskingum'):
+        rr.Muskingum(params_file=str(params), discharge_dir=str(tmp_path), log=False).route()
+    with pytest.raises(ValueError, match='uh_kernel_file is required for UnitMuskingum'):
+        rr.UnitMuskingum(params_file=str(params), discharge_dir=str(tmp_path), log=False).route()
+    with pytest.raises(ValueError, match='Provide qlateral_files or grid_runoff_files'):
+        rr.RapidMuskingum(params_file=str(params), discharge_dir=str(tmp_path), log=False).route()
+
+
+def test_time_step_rules(backend, case):
+    g = case['g']
+    with pytest.raises(ValueError, match='dt_runoff must be an integer multiple of dt_routing'):
+        drive(rr.RapidMuskingum, case, [g['vol0'], g['vol1']], dt_routing=1000)
+    with pytest.raises(ValueError, match='dt_runoff must be >= dt_routing'):
+        drive(rr.RapidMuskingum, case, [g['vol0'], g['vol1']], dt_routing=7200)
+    with pytest.raises(ValueError, match='dt_total must be an integer multiple of dt_discharge'):
+        drive(rr.RapidMuskingum, case, [g['vol0'], g['vol1']], dt_discharge=5 * 3600)
+
+
+def test_adjacency_matrix_matches_reference_structure(golden_kernels):
+    g = golden_kernels
+    for tag in ('docs9', 'tree1k', 'forest30'):
+        A = rr.tools.adjacency_matrix(g[f'{tag}/river_ids'], g[f'{tag}/downstream_ids'])
+        assert isinstance(A, scipy.sparse.csc_matrix) and A.dtype == np.float64
+        np.testing.assert_array_equal(A.indptr, g[f'{tag}/indptr'])
+        np.testing.assert_array_equal(A.indices, g[f'{tag}/indices'])
+    with pytest.raises(ValueError, match='topologically sorted'):          # tests/test_tools.py:48-53
+        rr.tools.adjacency_matrix(np.array([10, 20, 30]), np.array([20, -1, 10]))
+    with pytest.raises(ValueError, match='Unknown downstream_river_id'):   # tests/test_tools.py:56-60
+        rr.tools.adjacency_matrix(np.array([10, 20]), np.array([-1, 999]))
+
+
+def test_engine_order_is_a_valid_topological_order():
+    net = rr.synth.synth_network(3000)
+    order = rr.tools.engine_order(net.river_ids, net.downstream_ids)
+    rid, did = net.river_ids[order], net.downstream_ids[order]
+    A = rr.tools.adjacency_matrix(rid, did)      # raises if not upstream -> downstream
+    assert A.nnz == net.n - 1
+    from river_route_amd.engine import Plan
+    with Plan(A.indptr, A.indices, device=_lib.RR_DEVICE_NONE) as plan:
+        assert plan.identity_order
