@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument('--chunk-rows', type=int, default=16)
     ap.add_argument('--cpu-baseline-steps', type=int, default=96)
     ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0)
+    ap.add_argument('--exchange-rows', type=int, default=128,
+                    help='N>1: runoff steps per boundary-series message')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--traffic-bytes-per-launch', type=float, default=None,
                     help='HBM bytes per routing-tick launch from a separate rocprofv3 --pmc run (profiles/)')

@@ -131,6 +131,38 @@ int rr_unit_route_dev(rr_plan *plan, double *q_ch, double *q_full, const double 
 int rr_uh_convolve_dev(int device, const double *kernel, double *state, const double *lateral, double *out,
                        int64_t T, int64_t n_ks, int64_t n, void *stream);
 
+/* ---- partitioned networks (multi-GPU): boundary reaches and streaming calls ----
+ *
+ * A network cut into parts (rr_partition_forest) is routed one part per GPU.  In the part that holds the
+ * DOWNSTREAM end of a cut edge the upstream reach appears as a GHOST: a headwater column of the part's local
+ * network whose discharge at every sub-step is prescribed from `ghost_series`; in the part that owns it the
+ * reach is an EXPORT reach whose discharge after every sub-step is recorded in `export_series`.  Both series
+ * are device arrays of shape (T * nsub, n_ghost) / (T * nsub, n_export), row = sub-step.  The streaming
+ * calls keep the lag pipeline full while series arrive in batches (no drain between batches). */
+
+/* Reaches are LOCAL params indices of this plan.  Ghosts must be headwaters of the local network. */
+int rr_plan_set_boundary(rr_plan *plan, int64_t n_ghost, const int64_t *ghost_reaches, int64_t n_export,
+                         const int64_t *export_reaches);
+
+/* Opens a routing call on device arrays (has_lateral = 1: RapidMuskingum, 0: channel-only Muskingum).
+ * q_t[n]: initial state (ghost entries = the upstream reach's initial discharge). */
+int rr_stream_begin(rr_plan *plan, int has_lateral, const double *q_t, const double *lateral, int64_t lat_rows,
+                    double *discharge, int64_t out_rows, int64_t T, int64_t nsub, const double *ghost_series,
+                    double *export_series, void *stream);
+/* Enqueues every routing tick whose inputs are present: lateral rows [0, lateral_rows_ready) and ghost
+ * sub-steps [0, ghost_substeps_ready).  *export_substeps_ready = leading sub-steps of export_series that are
+ * final once the enqueued work has run. */
+int rr_stream_advance(rr_plan *plan, int64_t lateral_rows_ready, int64_t ghost_substeps_ready,
+                      int64_t *export_substeps_ready);
+/* Closes the call (all T steps must have been routed) and writes the final state to q_t[n] (may be NULL). */
+int rr_stream_end(rr_plan *plan, double *q_t);
+
+/* Cuts a forest into at most n_parts connected parts minimising the largest part (so the part graph is a
+ * forest too and boundary discharge flows one way).  part_of[n] receives the part of every reach, parts are
+ * numbered upstream-first; part_sizes[n_parts] (may be NULL) their sizes.  Host-only, needs no GPU. */
+int rr_partition_forest(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indices, int32_t n_parts,
+                        int32_t *part_of, int64_t *part_sizes);
+
 /* ---- small device helpers so a host language needs no HIP binding of its own ---- */
 int rr_dev_malloc(int device, int64_t bytes, void **out);
 int rr_dev_free(int device, void *ptr);

@@ -86,6 +86,11 @@ _SIGNATURES = {
     'rr_muskingum_route_dev': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     'rr_unit_route_dev': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
     'rr_uh_convolve_dev': (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    'rr_plan_set_boundary': (C.c_int, [_vp, _i64, _vp, _i64, _vp]),
+    'rr_stream_begin': (C.c_int, [_vp, C.c_int, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    'rr_stream_advance': (C.c_int, [_vp, _i64, _i64, C.POINTER(_i64)]),
+    'rr_stream_end': (C.c_int, [_vp, _vp]),
+    'rr_partition_forest': (C.c_int, [_i64, _vp, _vp, C.c_int32, _vp, _vp]),
     'rr_dev_malloc': (C.c_int, [C.c_int, _i64, C.POINTER(_vp)]),
     'rr_dev_free': (C.c_int, [C.c_int, _vp]),
     'rr_dev_upload': (C.c_int, [C.c_int, _vp, _vp, _i64]),

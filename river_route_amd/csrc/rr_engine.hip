@@ -40,6 +40,10 @@ int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 constexpr int kBlock = 256;
 constexpr int kSampleGroup = 16;   // routing-tick launches per HIP-event bracket
+// lag[] carries two flag bits for the boundary reaches of a partitioned network
+constexpr int32_t kGhostBit = 1 << 30;    // value prescribed from the ghost series (an upstream reach owned by another GPU)
+constexpr int32_t kExportBit = 1 << 29;   // value also copied to the export series (feeds another GPU)
+constexpr int32_t kLagMask = kExportBit - 1;
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -54,6 +58,10 @@ struct TickArgs {
     const double *xb;          // values written two ticks ago
     double *xc;                // this tick's values
     double *isum;              // running sum over the sub-steps of one output row (nsub > 1 only)
+    const int32_t *bidx;       // [n] ghost / export slot, read by flagged lanes only
+    const double *ghost;       // [total_substeps, n_ghost] prescribed series
+    double *exports;           // [total_substeps, n_export] recorded series
+    int32_t n_ghost, n_export;
     const double *in;          // lateral rows, engine order (NULL for channel-only)
     double *out;               // discharge rows, engine order
     int64_t in_ld, out_ld;
@@ -72,8 +80,13 @@ __global__ __launch_bounds__(kBlock) void k_tick(const TickArgs a)
 {
     const int32_t p = a.p_lo + (int32_t)(blockIdx.x * kBlock + threadIdx.x);
     if (p >= a.p_hi) return;
-    const int64_t ts = a.tau - (int64_t)a.lag[p];
+    const int32_t lag_bits = a.lag[p];
+    const int64_t ts = a.tau - (int64_t)(lag_bits & kLagMask);
     if (ts < 0 || ts >= a.total_substeps) return;
+    if (lag_bits & kGhostBit) {   // boundary inflow: the value another GPU computed for this sub-step
+        a.xc[p] = a.ghost[ts * a.n_ghost + a.bidx[p]];
+        return;
+    }
     uint32_t t, s;
     if (SINGLE_SUBSTEP) { t = (uint32_t)ts; s = 0; }
     else { t = (uint32_t)((uint64_t)ts / a.nsub); s = (uint32_t)((uint64_t)ts - (uint64_t)t * a.nsub); }
@@ -84,6 +97,7 @@ __global__ __launch_bounds__(kBlock) void k_tick(const TickArgs a)
     const double c2 = a.c2[p];
     for (int32_t u = u0; u < u1; ++u) r += c2 * a.xb[u];
     for (int32_t u = u0; u < u1; ++u) r += a.w[u] * a.xa[u];
+    if (lag_bits & kExportBit) a.exports[ts * a.n_export + a.bidx[p]] = r;
     a.xc[p] = r;
 
     if (SINGLE_SUBSTEP) {
@@ -114,7 +128,7 @@ __global__ __launch_bounds__(kBlock) void k_tick_unit(const UnitTickArgs ua)
     const TickArgs &a = ua.t;
     const int32_t p = a.p_lo + (int32_t)(blockIdx.x * kBlock + threadIdx.x);
     if (p >= a.p_hi) return;
-    const int64_t ts = a.tau - (int64_t)a.lag[p];
+    const int64_t ts = a.tau - (int64_t)(a.lag[p] & kLagMask);
     if (ts < 0 || ts >= a.total_substeps) return;
     uint32_t t, s;
     if (SINGLE_SUBSTEP) { t = (uint32_t)ts; s = 0; }
@@ -244,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void k_state_out(double *q_t, const double 
     const int32_t i = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
     if (i >= n) return;
     const int32_t p = inv[i];
-    const int64_t last = (int64_t)lag[p] + total_substeps - 1;
+    const int64_t last = (int64_t)(lag[p] & kLagMask) + total_substeps - 1;
     q_t[i] = x[(last % 3) * n64 + p];
 }
 
@@ -268,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void k_unit_state_out(double *q_ch, double 
     const int32_t k = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
     if (k >= n_inner) return;
     const int32_t p = inner_pos[k];
-    const int64_t last = (int64_t)lag[p] + total_substeps - 1;
+    const int64_t last = (int64_t)(lag[p] & kLagMask) + total_substeps - 1;
     q_full[k] = x[(last % 3) * n64 + p];
     q_ch[k] = qch[p];
 }
@@ -337,6 +351,38 @@ inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)
 // plan object
 // ------------------------------------------------------------------------------------------------
 
+enum class Mode { Rapid, Muskingum, Unit };
+
+// Where the (time, reach) rows in params order come from / go to.
+struct Rows {
+    const double *dev_in = nullptr;   // device array, rows_in rows
+    const double *host_in = nullptr;  // host array, T rows
+    int64_t rows_in = 0;
+    double *dev_out = nullptr;
+    double *host_out = nullptr;
+    int64_t rows_out = 0;
+};
+
+// One routing call in flight: rows enter (permutation in), ticks run, finished rows leave (permutation out).
+// route_core() runs a session start to finish; the rr_stream_* entry points keep it open between calls so the
+// lag pipeline is never drained while forcing or boundary series arrive in chunks (multi-GPU).
+struct Session {
+    bool open = false;
+    Mode mode = Mode::Rapid;
+    int64_t T = 0, nsub = 1, total = 0, total_ticks = 0;
+    Rows io;
+    hipStream_t stream = nullptr;
+    bool direct = false, has_in = true;
+    int64_t ring_rows = 0;
+    int64_t rows_loaded = 0, rows_stored = 0, tau = 0;
+    const double *ghost_series = nullptr;
+    double *export_series = nullptr;
+    TickArgs a{};
+    bool bracket_open = false;
+    int64_t bracket_reaches = 0;
+    size_t max_samples = 0;
+};
+
 struct rr_plan {
     rr::HostPlan h;
     int device = RR_DEVICE_NONE;
@@ -344,6 +390,7 @@ struct rr_plan {
     int64_t chunk_rows = 16, sample_every = 0;
 
     int32_t *d_child_ptr = nullptr, *d_lag = nullptr, *d_perm = nullptr, *d_inv = nullptr, *d_inner_pos = nullptr;
+    int32_t *d_bidx = nullptr;   // ghost / export slot of flagged positions
     uint16_t *d_hwc = nullptr;
     double *d_w = nullptr, *d_c2 = nullptr, *d_c3 = nullptr, *d_c4 = nullptr;
     double *d_x = nullptr, *d_isum = nullptr, *d_qch = nullptr;
@@ -357,6 +404,13 @@ struct rr_plan {
     uint16_t *d_slot_a[2] = {nullptr, nullptr}, *d_slot_b[2] = {nullptr, nullptr};
     int32_t *d_m_index[2] = {nullptr, nullptr};
     int64_t perm_rows_per_block = 2;
+
+    // boundary reaches of a partitioned network
+    int64_t n_ghost = 0, n_export = 0;
+    int64_t ghost_min_lag = 0, export_max_lag = 0;
+    std::vector<int32_t> ghost_pos;   // engine positions of the ghosts, in the caller's ghost order
+
+    Session ses;
 
     // profile of the last route call
     std::vector<hipEvent_t> ev;
@@ -397,220 +451,257 @@ int need_device(const rr_plan *plan)
     return RR_OK;
 }
 
-int ensure_ring(rr_plan *P, int64_t doubles)
+template <typename T>
+int ensure_cap(T **buf, int64_t *cap, int64_t count)
 {
-    if (P->ring_cap >= doubles) return RR_OK;
-    if (P->d_ring) { (void)hipFree(P->d_ring); P->d_ring = nullptr; P->ring_cap = 0; }
-    int rc = dev_alloc(&P->d_ring, doubles);
+    if (*cap >= count) return RR_OK;
+    if (*buf) { (void)hipFree(*buf); *buf = nullptr; *cap = 0; }
+    int rc = dev_alloc(buf, count);
     if (rc) return rc;
-    P->ring_cap = doubles;
+    *cap = count;
     return RR_OK;
 }
 
-int ensure_stage(rr_plan *P, int64_t doubles)
-{
-    if (P->stage_cap >= doubles) return RR_OK;
-    if (P->d_stage) { (void)hipFree(P->d_stage); P->d_stage = nullptr; P->stage_cap = 0; }
-    int rc = dev_alloc(&P->d_stage, doubles);
-    if (rc) return rc;
-    P->stage_cap = doubles;
-    return RR_OK;
-}
+// ---- session -------------------------------------------------------------------------------------
 
-int ensure_mrows(rr_plan *P, int64_t doubles)
-{
-    if (P->mrows_cap >= doubles) return RR_OK;
-    if (P->d_mrows) { (void)hipFree(P->d_mrows); P->d_mrows = nullptr; P->mrows_cap = 0; }
-    int rc = dev_alloc(&P->d_mrows, doubles);
-    if (rc) return rc;
-    P->mrows_cap = doubles;
-    return RR_OK;
-}
-
-enum class Mode { Rapid, Muskingum, Unit };
-
-// Where the (time, reach) rows in params order come from / go to.
-struct Rows {
-    const double *dev_in = nullptr;   // device array, rows_in rows
-    const double *host_in = nullptr;  // host array, T rows
-    int64_t rows_in = 0;
-    double *dev_out = nullptr;
-    double *host_out = nullptr;
-    int64_t rows_out = 0;
-};
-
-// The streaming executor shared by the three routers.  Enqueues everything on `stream`.
-int route_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io, hipStream_t stream)
+int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io, hipStream_t stream,
+                  const double *ghost_series, double *export_series)
 {
     const rr::HostPlan &H = P->h;
     const int64_t n = H.n;
-    const int64_t total = T * nsub;
+    Session &S = P->ses;
+    if (S.open) return fail(RR_E_STATE, "a routing call is already open on this plan (rr_stream_end it first)");
+    S = Session();
+    S.mode = mode; S.T = T; S.nsub = nsub; S.total = T * nsub; S.io = io; S.stream = stream;
+    S.ghost_series = ghost_series; S.export_series = export_series;
     const int64_t dmax = H.depth - 1;
-    const bool has_in = mode != Mode::Muskingum;
+    S.total_ticks = S.total + dmax;
+    S.has_in = mode != Mode::Muskingum;
     const bool host_io = io.host_out != nullptr || io.host_in != nullptr;
-    const bool direct = H.identity && !host_io;   // engine order == params order: stream the caller's arrays
+    S.direct = H.identity && !host_io;   // engine order == params order: stream the caller's arrays
     const int64_t C = std::max<int64_t>(1, P->chunk_rows);
 
     P->prof_launches = P->prof_samples = 0;
-    P->prof_reach_steps = n * total;
+    P->prof_reach_steps = n * S.total;
     P->ev_reaches.clear();
     P->last_stream = stream;
-    if (n == 0 || total == 0) return RR_OK;
+    S.open = true;
+    if (n == 0 || S.total == 0) return RR_OK;
+    if (P->n_ghost > 0 && !ghost_series) { S.open = false; return fail(RR_E_INVALID, "plan has ghost reaches but no ghost series was given"); }
+    if (P->n_export > 0 && !export_series) { S.open = false; return fail(RR_E_INVALID, "plan has export reaches but no export series was given"); }
 
-    // ---- work ring in engine order: lateral rows come in, discharge rows overwrite them in place ----
+    // work ring in engine order: lateral rows come in, discharge rows overwrite them in place
     const int64_t lag_rows = (dmax + nsub - 1) / nsub;
-    const int64_t ring_rows = direct ? 0 : std::min<int64_t>(T, lag_rows + 2 * C + 2);
-    if (ring_rows > 0xFFFFFFFFLL || T > 0x7FFFFFFFLL) return fail(RR_E_INVALID, "route: too many time rows");
-    if (!direct) {
-        int rc = ensure_ring(P, ring_rows * n);
-        if (rc) return rc;
-    }
-    if (host_io) {
-        int rc = ensure_stage(P, C * n);
-        if (rc) return rc;
-    }
+    S.ring_rows = S.direct ? 0 : std::min<int64_t>(T, lag_rows + 2 * C + 2);
+    if (S.ring_rows > 0xFFFFFFFFLL || T > 0x7FFFFFFFLL) { S.open = false; return fail(RR_E_INVALID, "route: too many time rows"); }
+    int rc = RR_OK;
+    if (!S.direct) rc = ensure_cap(&P->d_ring, &P->ring_cap, S.ring_rows * n);
+    if (!rc && !S.direct) rc = ensure_cap(&P->d_mrows, &P->mrows_cap, C * n);
+    if (!rc && host_io) rc = ensure_cap(&P->d_stage, &P->stage_cap, C * n);
+    if (rc) { S.open = false; return rc; }
 
-    TickArgs a{};
+    TickArgs &a = S.a;
     a.child_ptr = P->d_child_ptr; a.lag = P->d_lag; a.w = P->d_w; a.c2 = P->d_c2; a.c3 = P->d_c3; a.c4 = P->d_c4;
-    a.isum = P->d_isum;
-    a.total_substeps = total; a.nsub = (uint32_t)nsub; a.inv_nsub = 1.0 / (double)nsub;
-    if (direct) {
+    a.isum = P->d_isum; a.bidx = P->d_bidx;
+    a.ghost = ghost_series; a.exports = export_series; a.n_ghost = (int32_t)P->n_ghost; a.n_export = (int32_t)P->n_export;
+    a.total_substeps = S.total; a.nsub = (uint32_t)nsub; a.inv_nsub = 1.0 / (double)nsub;
+    if (S.direct) {
         a.in = io.dev_in; a.in_ld = n; a.in_rows = (uint32_t)std::max<int64_t>(1, io.rows_in);
         a.out = io.dev_out; a.out_ld = n; a.out_rows = (uint32_t)io.rows_out;
     } else {
-        a.in = has_in ? P->d_ring : nullptr; a.in_ld = n; a.in_rows = (uint32_t)ring_rows;
-        a.out = P->d_ring; a.out_ld = n; a.out_rows = (uint32_t)ring_rows;
+        a.in = S.has_in ? P->d_ring : nullptr; a.in_ld = n; a.in_rows = (uint32_t)S.ring_rows;
+        a.out = P->d_ring; a.out_ld = n; a.out_rows = (uint32_t)S.ring_rows;
     }
-    UnitTickArgs ua{};
-    ua.hw_children = P->d_hwc; ua.qch = P->d_qch;
 
-    // params order <-> engine order through the two-phase tiled permutation (k_perm_a / k_perm_b)
-    constexpr int E = kPermE;
-    const int64_t tile = (int64_t)E * kPermThreads;
-    const unsigned n_tiles = (unsigned)((n + tile - 1) / tile);
-    const int rpb = (int)std::max<int64_t>(1, P->perm_rows_per_block);
-    const size_t lds_bytes = (size_t)tile * sizeof(double);
-    if (!direct) {
-        int rc = ensure_mrows(P, C * n);
-        if (rc) return rc;
-    }
-    auto permute = [&](int which, const RowView &src, const RowView &dst, int64_t t0, int nrows) {
-        dim3 g(n_tiles, (unsigned)((nrows + rpb - 1) / rpb));
-        hipLaunchKernelGGL(k_perm_a<E>, g, dim3(kPermThreads), lds_bytes, stream, src, P->d_mrows, n,
-                           (const uint16_t *)P->d_slot_a[which], (const int32_t *)P->d_m_index[which], t0, nrows, rpb);
-        hipLaunchKernelGGL(k_perm_b<E>, g, dim3(kPermThreads), lds_bytes, stream, dst, (const double *)P->d_mrows, n,
-                           (const uint16_t *)P->d_slot_b[which], t0, nrows, rpb);
-    };
-    const RowView ring_view{P->d_ring, n, 0, (uint32_t)std::max<int64_t>(1, ring_rows)};
-    auto load_rows = [&](int64_t r0, int64_t r1) -> int {   // params order -> ring
-        if (direct || !has_in) return RR_OK;
-        const int nrows = (int)(r1 - r0);
-        if (io.host_in) {
-            HIPCHK(hipMemcpyAsync(P->d_stage, io.host_in + r0 * n, (size_t)nrows * n * sizeof(double),
-                                  hipMemcpyHostToDevice, stream));
-            permute(0, RowView{P->d_stage, n, r0, (uint32_t)C}, ring_view, r0, nrows);
-            HIPCHK(hipStreamSynchronize(stream));   // the stage is reused by the next chunk
-        } else {
-            permute(0, RowView{const_cast<double *>(io.dev_in), n, 0, (uint32_t)io.rows_in}, ring_view, r0, nrows);
-        }
-        return RR_OK;
-    };
-    auto store_rows = [&](int64_t r0, int64_t r1) -> int {   // ring -> params order
-        if (direct) return RR_OK;
-        for (int64_t b0 = r0; b0 < r1; b0 += C) {
-            const int nrows = (int)std::min<int64_t>(C, r1 - b0);
-            if (io.host_out) {
-                permute(1, ring_view, RowView{P->d_stage, n, b0, (uint32_t)C}, b0, nrows);
-                HIPCHK(hipMemcpyAsync(io.host_out + b0 * n, P->d_stage, (size_t)nrows * n * sizeof(double),
-                                      hipMemcpyDeviceToHost, stream));
-                HIPCHK(hipStreamSynchronize(stream));
-            } else {
-                permute(1, ring_view, RowView{io.dev_out, n, 0, (uint32_t)io.rows_out}, b0, nrows);
-            }
-        }
-        return RR_OK;
-    };
-
-    const int64_t total_ticks = total + dmax;
-    const size_t max_samples = P->sample_every > 0 ? (size_t)std::min<int64_t>(4096, total_ticks / P->sample_every + 1) : 0;
-    while (P->ev.size() < 2 * max_samples) {
+    S.max_samples = P->sample_every >= kSampleGroup ? (size_t)std::min<int64_t>(4096, S.total_ticks / P->sample_every + 1) : 0;
+    while (P->ev.size() < 2 * S.max_samples) {
         hipEvent_t e;
         HIPCHK(hipEventCreate(&e));
         P->ev.push_back(e);
     }
     if (!P->ev_first) { HIPCHK(hipEventCreate(&P->ev_first)); HIPCHK(hipEventCreate(&P->ev_last)); }
-
-    bool bracket_open = false;
-    int64_t bracket_reaches = 0;
-    auto launch_tick = [&](int64_t tau) -> int {
-        // active lags: tau - total < lag <= tau
-        const int64_t lag_lo = std::max<int64_t>(0, tau - total + 1), lag_hi = std::min<int64_t>(tau, dmax);
-        const int64_t p_lo = H.lag_start[lag_lo], p_hi = H.lag_start[lag_hi + 1];
-        if (p_hi <= p_lo) return RR_OK;
-        a.p_lo = (int32_t)p_lo; a.p_hi = (int32_t)p_hi; a.tau = tau;
-        a.xc = P->d_x + (tau % 3) * n;
-        a.xa = P->d_x + ((tau + 2) % 3) * n;
-        a.xb = P->d_x + ((tau + 1) % 3) * n;
-        // sampling: every sample_every-th launch opens a bracket of kSampleGroup consecutive launches, so the
-        // event overhead (~5 us per pair) is amortised and the figure is comparable with rocprofv3's per-kernel time
-        const int64_t phase = P->sample_every > 0 ? P->prof_launches % P->sample_every : -1;
-        const bool open_bracket = phase == 0 && (size_t)(P->prof_samples / kSampleGroup) < max_samples &&
-                                  P->sample_every >= kSampleGroup;
-        if (open_bracket) { HIPCHK(hipEventRecord(P->ev[2 * (P->prof_samples / kSampleGroup)], stream)); bracket_open = true; }
-        const dim3 g = grid1(p_hi - p_lo);
-        if (mode == Mode::Unit) {
-            ua.t = a;
-            if (nsub == 1) hipLaunchKernelGGL(k_tick_unit<true>, g, dim3(kBlock), 0, stream, ua);
-            else hipLaunchKernelGGL(k_tick_unit<false>, g, dim3(kBlock), 0, stream, ua);
-        } else if (mode == Mode::Rapid) {
-            if (nsub == 1) hipLaunchKernelGGL((k_tick<true, true>), g, dim3(kBlock), 0, stream, a);
-            else hipLaunchKernelGGL((k_tick<true, false>), g, dim3(kBlock), 0, stream, a);
-        } else {
-            if (nsub == 1) hipLaunchKernelGGL((k_tick<false, true>), g, dim3(kBlock), 0, stream, a);
-            else hipLaunchKernelGGL((k_tick<false, false>), g, dim3(kBlock), 0, stream, a);
-        }
-        if (bracket_open) {
-            bracket_reaches += p_hi - p_lo;
-            ++P->prof_samples;
-            if (P->prof_samples % kSampleGroup == 0) {
-                HIPCHK(hipEventRecord(P->ev[2 * (P->prof_samples / kSampleGroup) - 1], stream));
-                P->ev_reaches.push_back(bracket_reaches);
-                bracket_reaches = 0;
-                bracket_open = false;
-            }
-        }
-        ++P->prof_launches;
-        return RR_OK;
-    };
-
-    int64_t rows_loaded = 0, rows_stored = 0, tau = 0;
     HIPCHK(hipEventRecord(P->ev_first, stream));
-    while (rows_stored < T) {
-        if (rows_loaded < T) {
-            const int64_t r1 = std::min(T, rows_loaded + C);
-            int rc = load_rows(rows_loaded, r1);
-            if (rc) return rc;
-            rows_loaded = r1;
-        }
-        const int64_t tau_end = rows_loaded < T ? rows_loaded * nsub : total_ticks;
-        for (; tau < tau_end; ++tau) {
-            int rc = launch_tick(tau);
-            if (rc) return rc;
-        }
-        // row t is final once the outlet-most reaches passed it: tick (t+1)*nsub - 1 + dmax
-        int64_t done = tau >= total_ticks ? T : (tau - dmax) / nsub;
-        if (tau - dmax < 0) done = 0;
-        done = std::min(done, T);
-        if (done > rows_stored) {
-            int rc = store_rows(rows_stored, done);
-            if (rc) return rc;
-            rows_stored = done;
+    return RR_OK;
+}
+
+// params order <-> engine order through the two-phase tiled permutation (k_perm_a / k_perm_b)
+void permute_rows(rr_plan *P, int which, const RowView &src, const RowView &dst, int64_t t0, int nrows)
+{
+    const int64_t n = P->h.n;
+    constexpr int E = kPermE;
+    const int64_t tile = (int64_t)E * kPermThreads;
+    const int rpb = (int)std::max<int64_t>(1, P->perm_rows_per_block);
+    dim3 g((unsigned)((n + tile - 1) / tile), (unsigned)((nrows + rpb - 1) / rpb));
+    const size_t lds_bytes = (size_t)tile * sizeof(double);
+    hipStream_t stream = P->ses.stream;
+    hipLaunchKernelGGL(k_perm_a<E>, g, dim3(kPermThreads), lds_bytes, stream, src, P->d_mrows, n,
+                       (const uint16_t *)P->d_slot_a[which], (const int32_t *)P->d_m_index[which], t0, nrows, rpb);
+    hipLaunchKernelGGL(k_perm_b<E>, g, dim3(kPermThreads), lds_bytes, stream, dst, (const double *)P->d_mrows, n,
+                       (const uint16_t *)P->d_slot_b[which], t0, nrows, rpb);
+}
+
+int session_load_rows(rr_plan *P, int64_t r0, int64_t r1)   // params order -> ring
+{
+    Session &S = P->ses;
+    if (S.direct || !S.has_in) return RR_OK;
+    const int64_t n = P->h.n, C = std::max<int64_t>(1, P->chunk_rows);
+    const int nrows = (int)(r1 - r0);
+    const RowView ring_view{P->d_ring, n, 0, (uint32_t)std::max<int64_t>(1, S.ring_rows)};
+    if (S.io.host_in) {
+        HIPCHK(hipMemcpyAsync(P->d_stage, S.io.host_in + r0 * n, (size_t)nrows * n * sizeof(double),
+                              hipMemcpyHostToDevice, S.stream));
+        permute_rows(P, 0, RowView{P->d_stage, n, r0, (uint32_t)C}, ring_view, r0, nrows);
+        HIPCHK(hipStreamSynchronize(S.stream));   // the stage is reused by the next chunk
+    } else {
+        permute_rows(P, 0, RowView{const_cast<double *>(S.io.dev_in), n, 0, (uint32_t)S.io.rows_in}, ring_view, r0, nrows);
+    }
+    return RR_OK;
+}
+
+int session_store_rows(rr_plan *P, int64_t r0, int64_t r1)   // ring -> params order
+{
+    Session &S = P->ses;
+    if (S.direct) return RR_OK;
+    const int64_t n = P->h.n, C = std::max<int64_t>(1, P->chunk_rows);
+    const RowView ring_view{P->d_ring, n, 0, (uint32_t)std::max<int64_t>(1, S.ring_rows)};
+    for (int64_t b0 = r0; b0 < r1; b0 += C) {
+        const int nrows = (int)std::min<int64_t>(C, r1 - b0);
+        if (S.io.host_out) {
+            permute_rows(P, 1, ring_view, RowView{P->d_stage, n, b0, (uint32_t)C}, b0, nrows);
+            HIPCHK(hipMemcpyAsync(S.io.host_out + b0 * n, P->d_stage, (size_t)nrows * n * sizeof(double),
+                                  hipMemcpyDeviceToHost, S.stream));
+            HIPCHK(hipStreamSynchronize(S.stream));
+        } else {
+            permute_rows(P, 1, ring_view, RowView{S.io.dev_out, n, 0, (uint32_t)S.io.rows_out}, b0, nrows);
         }
     }
-    if (bracket_open) P->prof_samples -= P->prof_samples % kSampleGroup;   // incomplete bracket: not counted
-    HIPCHK(hipEventRecord(P->ev_last, stream));
+    return RR_OK;
+}
+
+int session_launch_tick(rr_plan *P, int64_t tau)
+{
+    Session &S = P->ses;
+    const rr::HostPlan &H = P->h;
+    const int64_t n = H.n, dmax = H.depth - 1;
+    // active lags: tau - total < lag <= tau
+    const int64_t lag_lo = std::max<int64_t>(0, tau - S.total + 1), lag_hi = std::min<int64_t>(tau, dmax);
+    const int64_t p_lo = H.lag_start[lag_lo], p_hi = H.lag_start[lag_hi + 1];
+    if (p_hi <= p_lo) return RR_OK;
+    TickArgs &a = S.a;
+    a.p_lo = (int32_t)p_lo; a.p_hi = (int32_t)p_hi; a.tau = tau;
+    a.xc = P->d_x + (tau % 3) * n;
+    a.xa = P->d_x + ((tau + 2) % 3) * n;
+    a.xb = P->d_x + ((tau + 1) % 3) * n;
+    // sampling: every sample_every-th launch opens a bracket of kSampleGroup consecutive launches, so the
+    // event overhead (~5 us per pair) is amortised and the figure is comparable with rocprofv3's per-kernel time
+    const int64_t phase = S.max_samples > 0 ? P->prof_launches % P->sample_every : -1;
+    if (phase == 0 && !S.bracket_open && (size_t)(P->prof_samples / kSampleGroup) < S.max_samples) {
+        HIPCHK(hipEventRecord(P->ev[2 * (P->prof_samples / kSampleGroup)], S.stream));
+        S.bracket_open = true;
+    }
+    const dim3 g = grid1(p_hi - p_lo);
+    const bool one = S.nsub == 1;
+    if (S.mode == Mode::Unit) {
+        UnitTickArgs ua{};
+        ua.t = a; ua.hw_children = P->d_hwc; ua.qch = P->d_qch;
+        if (one) hipLaunchKernelGGL(k_tick_unit<true>, g, dim3(kBlock), 0, S.stream, ua);
+        else hipLaunchKernelGGL(k_tick_unit<false>, g, dim3(kBlock), 0, S.stream, ua);
+    } else if (S.mode == Mode::Rapid) {
+        if (one) hipLaunchKernelGGL((k_tick<true, true>), g, dim3(kBlock), 0, S.stream, a);
+        else hipLaunchKernelGGL((k_tick<true, false>), g, dim3(kBlock), 0, S.stream, a);
+    } else {
+        if (one) hipLaunchKernelGGL((k_tick<false, true>), g, dim3(kBlock), 0, S.stream, a);
+        else hipLaunchKernelGGL((k_tick<false, false>), g, dim3(kBlock), 0, S.stream, a);
+    }
+    if (S.bracket_open) {
+        S.bracket_reaches += p_hi - p_lo;
+        ++P->prof_samples;
+        if (P->prof_samples % kSampleGroup == 0) {
+            HIPCHK(hipEventRecord(P->ev[2 * (P->prof_samples / kSampleGroup) - 1], S.stream));
+            P->ev_reaches.push_back(S.bracket_reaches);
+            S.bracket_reaches = 0;
+            S.bracket_open = false;
+        }
+    }
+    ++P->prof_launches;
+    return RR_OK;
+}
+
+// Runs every tick whose inputs are present: lateral rows [0, rows_ready) and ghost sub-steps [0, ghost_ready).
+// On return *export_ready = number of leading sub-steps of the export series that are final.
+int session_advance(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, int64_t *export_ready)
+{
+    Session &S = P->ses;
+    if (!S.open) return fail(RR_E_STATE, "no routing call is open on this plan");
+    const int64_t n = P->h.n, dmax = P->h.depth - 1, C = std::max<int64_t>(1, P->chunk_rows);
+    if (export_ready) *export_ready = 0;
+    if (n == 0 || S.total == 0) { if (export_ready) *export_ready = S.total; return RR_OK; }
+    rows_ready = std::min(rows_ready, S.T);
+    ghost_ready = std::min(ghost_ready, S.total);
+    // a ghost at lag L is read at tick tau for sub-step tau - L: ticks below ghost_ready + min lag are safe
+    const int64_t ghost_limit = (P->n_ghost == 0 || ghost_ready >= S.total) ? S.total_ticks
+                                                                            : ghost_ready + P->ghost_min_lag;
+    for (;;) {
+        bool progressed = false;
+        if (S.has_in && S.rows_loaded < rows_ready) {
+            const int64_t r1 = std::min(rows_ready, S.rows_loaded + C);
+            int rc = session_load_rows(P, S.rows_loaded, r1);
+            if (rc) return rc;
+            S.rows_loaded = r1;
+            progressed = true;
+        }
+        const int64_t have_rows = S.has_in ? S.rows_loaded : rows_ready;
+        const int64_t lat_limit = have_rows < S.T ? have_rows * S.nsub : S.total_ticks;
+        // without lateral rows to pace the loop, run the ticks in chunk-sized batches so finished rows leave the ring
+        const int64_t batch_limit = S.has_in ? S.total_ticks : S.tau + C * S.nsub;
+        const int64_t tau_end = std::min(std::min(lat_limit, ghost_limit), std::min(batch_limit, S.total_ticks));
+        for (; S.tau < tau_end; ++S.tau) {
+            int rc = session_launch_tick(P, S.tau);
+            if (rc) return rc;
+            progressed = true;
+        }
+        // row t is final once the outlet-most reaches passed it: tick (t+1)*nsub - 1 + dmax
+        int64_t done = S.tau >= S.total_ticks ? S.T : (S.tau - dmax < 0 ? 0 : (S.tau - dmax) / S.nsub);
+        done = std::min(done, S.T);
+        if (done > S.rows_stored) {
+            int rc = session_store_rows(P, S.rows_stored, done);
+            if (rc) return rc;
+            S.rows_stored = done;
+            progressed = true;
+        }
+        if (!progressed) break;
+    }
+    if (export_ready) {
+        const int64_t e = S.tau >= S.total_ticks ? S.total : S.tau - P->export_max_lag;
+        *export_ready = std::max<int64_t>(0, std::min(e, S.total));
+    }
+    return RR_OK;
+}
+
+int session_end(rr_plan *P)
+{
+    Session &S = P->ses;
+    if (!S.open) return fail(RR_E_STATE, "no routing call is open on this plan");
+    const bool complete = P->h.n == 0 || S.total == 0 || (S.tau >= S.total_ticks && S.rows_stored >= S.T);
+    S.open = false;
+    if (!complete) return fail(RR_E_STATE, "routing call closed before all of its time steps were routed");
+    if (P->h.n == 0 || S.total == 0) return RR_OK;
+    if (S.bracket_open) P->prof_samples -= P->prof_samples % kSampleGroup;   // incomplete bracket: not counted
+    HIPCHK(hipEventRecord(P->ev_last, S.stream));
     HIPCHK(hipGetLastError());
     return RR_OK;
+}
+
+// The whole call at once: what the reference's kernel boundary does.
+int route_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io, hipStream_t stream)
+{
+    if (P->n_ghost > 0 || P->n_export > 0)
+        return fail(RR_E_STATE, "plan has boundary reaches: use rr_stream_begin / rr_stream_advance / rr_stream_end");
+    int rc = session_begin(P, mode, T, nsub, io, stream, nullptr, nullptr);
+    if (rc) return rc;
+    rc = session_advance(P, T, T * nsub, nullptr);
+    if (rc) { P->ses.open = false; return rc; }
+    return session_end(P);
 }
 
 int check_route_args(rr_plan *P, bool need_c4, int64_t T, int64_t nsub)
@@ -622,6 +713,20 @@ int check_route_args(rr_plan *P, bool need_c4, int64_t T, int64_t nsub)
     if (T < 0 || nsub < 1) return fail(RR_E_INVALID, "route: need num steps >= 0 and sub-steps >= 1");
     if (nsub > 0x7FFFFFFF) return fail(RR_E_INVALID, "route: too many sub-steps");
     return RR_OK;
+}
+
+void launch_state_in(rr_plan *P, const double *d_q, hipStream_t stream)
+{
+    const int64_t n = P->h.n;
+    hipLaunchKernelGGL(k_state_in, grid1(n), dim3(kBlock), 0, stream, P->d_x, P->d_x + n, P->d_x + 2 * n, d_q,
+                       P->d_perm, (int32_t)n);
+}
+
+void launch_state_out(rr_plan *P, double *d_q, int64_t total, hipStream_t stream)
+{
+    const int64_t n = P->h.n;
+    hipLaunchKernelGGL(k_state_out, grid1(n), dim3(kBlock), 0, stream, d_q, (const double *)P->d_x, n,
+                       P->d_lag, P->d_inv, (int32_t)n, total);
 }
 
 int rapid_like(rr_plan *P, Mode mode, double *q_t, const Rows &io, int64_t T, int64_t nsub, hipStream_t stream,
@@ -638,12 +743,10 @@ int rapid_like(rr_plan *P, Mode mode, double *q_t, const Rows &io, int64_t T, in
         hipError_t e = hipMemcpyAsync(d_q, q_t, n * sizeof(double), hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) { (void)hipFree(tmp); return fail(RR_E_HIP, hipGetErrorString(e)); }
     }
-    hipLaunchKernelGGL(k_state_in, grid1(n), dim3(kBlock), 0, stream, P->d_x, P->d_x + n, P->d_x + 2 * n,
-                       (const double *)d_q, P->d_perm, (int32_t)n);
+    launch_state_in(P, d_q, stream);
     int rc = route_core(P, mode, T, nsub, io, stream);
     if (rc == RR_OK) {
-        hipLaunchKernelGGL(k_state_out, grid1(n), dim3(kBlock), 0, stream, d_q, (const double *)P->d_x, n,
-                           P->d_lag, P->d_inv, (int32_t)n, T * nsub);
+        launch_state_out(P, d_q, T * nsub, stream);
         if (q_on_host) {
             hipError_t e = hipMemcpyAsync(q_t, d_q, n * sizeof(double), hipMemcpyDeviceToHost, stream);
             if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -736,7 +839,7 @@ void rr_plan_destroy(rr_plan *P)
 {
     if (!P) return;
     if (P->device >= 0 && hipSetDevice(P->device) == hipSuccess) {
-        void *ptrs[] = {P->d_child_ptr, P->d_lag, P->d_perm, P->d_inv, P->d_inner_pos, P->d_hwc, P->d_w, P->d_c2,
+        void *ptrs[] = {P->d_child_ptr, P->d_lag, P->d_perm, P->d_inv, P->d_inner_pos, P->d_bidx, P->d_hwc, P->d_w, P->d_c2,
                         P->d_c3, P->d_c4, P->d_x, P->d_isum, P->d_qch, P->d_ring, P->d_stage, P->d_mrows,
                         P->d_slot_a[0], P->d_slot_a[1], P->d_slot_b[0], P->d_slot_b[1], P->d_m_index[0], P->d_m_index[1]};
         for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -776,6 +879,7 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         if (!rc) rc = dev_alloc(&P->d_inv, n);
         if (!rc) rc = dev_alloc(&P->d_inner_pos, ni);
         if (!rc) rc = dev_alloc(&P->d_hwc, n);
+        if (!rc) rc = dev_alloc(&P->d_bidx, n);
         if (!rc) rc = dev_alloc(&P->d_w, n);
         if (!rc) rc = dev_alloc(&P->d_c2, n);
         if (!rc) rc = dev_alloc(&P->d_c3, n);
@@ -881,6 +985,102 @@ int rr_plan_profile(rr_plan *P, double prof[8])
     }
     prof[1] = (double)P->prof_samples; prof[2] = sum; prof[3] = P->prof_samples ? mn : 0.0; prof[4] = mx;
     prof[5] = reaches;
+    return RR_OK;
+}
+
+// ---- partitioned networks: boundary reaches + streaming calls ----
+
+int rr_plan_set_boundary(rr_plan *P, int64_t n_ghost, const int64_t *ghost_reaches, int64_t n_export,
+                         const int64_t *export_reaches)
+{
+    int rc = need_device(P);
+    if (rc) return rc;
+    const rr::HostPlan &H = P->h;
+    const int64_t n = H.n;
+    if (n_ghost < 0 || n_export < 0 || (n_ghost > 0 && !ghost_reaches) || (n_export > 0 && !export_reaches))
+        return fail(RR_E_INVALID, "rr_plan_set_boundary: bad argument");
+    if (P->ses.open) return fail(RR_E_STATE, "rr_plan_set_boundary: a routing call is open");
+    std::vector<int32_t> lag(H.lag), bidx(n, 0);
+    P->ghost_pos.assign(n_ghost, 0);
+    int64_t gmin = H.depth, emax = 0;
+    for (int64_t g = 0; g < n_ghost; ++g) {
+        const int64_t i = ghost_reaches[g];
+        if (i < 0 || i >= n) return fail(RR_E_INVALID, "rr_plan_set_boundary: ghost reach out of range");
+        const int32_t p = H.inv[i];
+        if (H.child_ptr[p + 1] != H.child_ptr[p] || (lag[p] & kGhostBit))
+            return fail(RR_E_INVALID, "rr_plan_set_boundary: a ghost reach must be a headwater of this part, listed once");
+        lag[p] |= kGhostBit;
+        bidx[p] = (int32_t)g;
+        P->ghost_pos[g] = p;
+        gmin = std::min<int64_t>(gmin, H.lag[p]);
+    }
+    for (int64_t e = 0; e < n_export; ++e) {
+        const int64_t i = export_reaches[e];
+        if (i < 0 || i >= n) return fail(RR_E_INVALID, "rr_plan_set_boundary: export reach out of range");
+        const int32_t p = H.inv[i];
+        if (lag[p] & (kGhostBit | kExportBit))
+            return fail(RR_E_INVALID, "rr_plan_set_boundary: an export reach must be a real reach, listed once");
+        lag[p] |= kExportBit;
+        bidx[p] = (int32_t)e;
+        emax = std::max<int64_t>(emax, H.lag[p]);
+    }
+    rc = dev_upload(P->d_lag, lag);
+    if (!rc) rc = dev_upload(P->d_bidx, bidx);
+    if (rc) return rc;
+    P->n_ghost = n_ghost; P->n_export = n_export;
+    P->ghost_min_lag = n_ghost ? gmin : 0;
+    P->export_max_lag = n_export ? emax : 0;
+    return RR_OK;
+}
+
+int rr_stream_begin(rr_plan *P, int has_lateral, const double *q_t, const double *lateral, int64_t lat_rows,
+                    double *discharge, int64_t out_rows, int64_t T, int64_t nsub, const double *ghost_series,
+                    double *export_series, void *stream)
+{
+    int rc = check_route_args(P, has_lateral != 0, T, nsub);
+    if (rc) return rc;
+    if (P->h.n > 0 && T > 0 && (!q_t || !discharge || out_rows < 1 || (has_lateral && (!lateral || lat_rows < 1))))
+        return fail(RR_E_INVALID, "rr_stream_begin: null array or empty row count");
+    Rows io; io.dev_in = has_lateral ? lateral : nullptr; io.rows_in = lat_rows; io.dev_out = discharge; io.rows_out = out_rows;
+    rc = session_begin(P, has_lateral ? Mode::Rapid : Mode::Muskingum, T, nsub, io, (hipStream_t)stream, ghost_series,
+                       export_series);
+    if (rc) return rc;
+    if (P->h.n > 0 && T > 0) launch_state_in(P, q_t, (hipStream_t)stream);
+    return RR_OK;
+}
+
+int rr_stream_advance(rr_plan *P, int64_t lateral_rows_ready, int64_t ghost_substeps_ready, int64_t *export_substeps_ready)
+{
+    int rc = need_device(P);
+    if (rc) return rc;
+    return session_advance(P, lateral_rows_ready, ghost_substeps_ready, export_substeps_ready);
+}
+
+int rr_stream_end(rr_plan *P, double *q_t)
+{
+    int rc = need_device(P);
+    if (rc) return rc;
+    const int64_t total = P->ses.total;
+    hipStream_t stream = P->ses.stream;
+    rc = session_end(P);
+    if (rc) return rc;
+    if (P->h.n > 0 && total > 0 && q_t) launch_state_out(P, q_t, total, stream);
+    return RR_OK;
+}
+
+int rr_partition_forest(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indices, int32_t n_parts,
+                        int32_t *part_of, int64_t *part_sizes)
+{
+    if (!part_of || n_parts < 1) return fail(RR_E_INVALID, "rr_partition_forest: bad argument");
+    rr::HostPlan H;
+    std::string err;
+    int rc = rr::build_host_plan(n, csc_indptr, csc_indices, H, err);
+    if (rc) return fail(rc, err);
+    std::vector<int32_t> down(n, -1);
+    for (int64_t i = 0; i < n; ++i) if (H.edge_of[i] >= 0) down[i] = csc_indices[H.edge_of[i]];
+    std::vector<int64_t> sizes;
+    rr::partition_forest(down, n_parts, part_of, sizes);
+    if (part_sizes) for (int32_t k = 0; k < n_parts; ++k) part_sizes[k] = k < (int32_t)sizes.size() ? sizes[k] : 0;
     return RR_OK;
 }
 

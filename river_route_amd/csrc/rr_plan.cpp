@@ -39,6 +39,107 @@ void build_tiled_permutation(const int32_t *pi, int64_t n, int32_t tile, TiledPe
     for (int64_t i = 0; i < n; ++i) T.slot_b[g_of[i]] = (uint16_t)(q_of[i] % tile);
 }
 
+namespace {
+
+struct Pieces {
+    std::vector<uint8_t> cut;        // edge below reach i is cut
+    std::vector<int32_t> root_of;    // piece root (reach whose downstream edge is cut, or an outlet)
+    std::vector<int32_t> roots;      // all piece roots
+    std::vector<int64_t> size;       // by root reach index
+    std::vector<int32_t> depth;      // cuts between the piece and its outlet, by root reach index
+};
+
+// Bottom-up greedy: a reach keeps its upstream residuals while they fit under `cap`, cutting the heaviest first.
+void cut_forest(const std::vector<int32_t> &down, const std::vector<int32_t> &up_ptr, const std::vector<int32_t> &up_idx,
+                int64_t cap, Pieces &P)
+{
+    const int64_t n = (int64_t)down.size();
+    P.cut.assign(n, 0);
+    std::vector<int64_t> res(n, 0);
+    std::vector<std::pair<int64_t, int32_t>> kids;
+    for (int64_t v = 0; v < n; ++v) {
+        int64_t total = 1;
+        kids.clear();
+        for (int32_t e = up_ptr[v]; e < up_ptr[v + 1]; ++e) { kids.emplace_back(res[up_idx[e]], up_idx[e]); total += res[up_idx[e]]; }
+        if (total > cap) {
+            std::sort(kids.begin(), kids.end(), [](const auto &a, const auto &b) { return a.first > b.first; });
+            for (const auto &k : kids) {
+                if (total <= cap) break;
+                P.cut[k.second] = 1;
+                total -= k.first;
+            }
+        }
+        res[v] = total;
+    }
+    P.root_of.assign(n, -1); P.size.assign(n, 0); P.depth.assign(n, 0); P.roots.clear();
+    for (int64_t v = n - 1; v >= 0; --v) {
+        if (down[v] < 0 || P.cut[v]) {
+            P.root_of[v] = (int32_t)v;
+            P.depth[v] = down[v] < 0 ? 0 : P.depth[P.root_of[down[v]]] + 1;
+            P.roots.push_back((int32_t)v);
+        } else {
+            P.root_of[v] = P.root_of[down[v]];
+        }
+        ++P.size[P.root_of[v]];
+    }
+}
+
+// First-fit-decreasing packing of the pieces of each depth class into bins of capacity cap.
+// Returns the number of bins; bin_of[root] receives the bin.
+int64_t pack_pieces(const Pieces &P, int64_t cap, std::vector<int32_t> &bin_of, std::vector<int64_t> &bin_size,
+                    std::vector<int32_t> &bin_depth)
+{
+    std::vector<int32_t> order(P.roots);
+    std::sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+        if (P.depth[a] != P.depth[b]) return P.depth[a] > P.depth[b];
+        if (P.size[a] != P.size[b]) return P.size[a] > P.size[b];
+        return a < b;
+    });
+    bin_of.assign(P.size.size(), -1);
+    bin_size.clear(); bin_depth.clear();
+    size_t class_begin = 0;
+    int32_t cur_depth = -1;
+    for (int32_t r : order) {
+        if (P.depth[r] != cur_depth) { cur_depth = P.depth[r]; class_begin = bin_size.size(); }
+        size_t b = class_begin;
+        for (; b < bin_size.size(); ++b) if (bin_size[b] + P.size[r] <= cap) break;
+        if (b == bin_size.size()) { bin_size.push_back(0); bin_depth.push_back(cur_depth); }
+        bin_size[b] += P.size[r];
+        bin_of[r] = (int32_t)b;
+    }
+    return (int64_t)bin_size.size();
+}
+
+}  // namespace
+
+void partition_forest(const std::vector<int32_t> &down, int32_t n_parts, int32_t *part_of, std::vector<int64_t> &sizes)
+{
+    const int64_t n = (int64_t)down.size();
+    sizes.clear();
+    if (n == 0) return;
+    std::vector<int32_t> up_ptr(n + 1, 0);
+    for (int64_t c = 0; c < n; ++c) if (down[c] >= 0) ++up_ptr[down[c] + 1];
+    for (int64_t i = 0; i < n; ++i) up_ptr[i + 1] += up_ptr[i];
+    std::vector<int32_t> up_idx(up_ptr[n]), fill(up_ptr.begin(), up_ptr.end() - 1);
+    for (int64_t c = 0; c < n; ++c) if (down[c] >= 0) up_idx[fill[down[c]]++] = (int32_t)c;
+
+    Pieces P;
+    std::vector<int32_t> bin_of, bin_depth;
+    std::vector<int64_t> bin_size;
+    int64_t lo = (n + n_parts - 1) / n_parts, hi = n;   // smallest feasible cap in [lo, hi]; hi is always feasible
+    while (lo < hi) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        cut_forest(down, up_ptr, up_idx, mid, P);
+        if (pack_pieces(P, mid, bin_of, bin_size, bin_depth) <= n_parts) hi = mid; else lo = mid + 1;
+    }
+    cut_forest(down, up_ptr, up_idx, lo, P);
+    const int64_t nb = pack_pieces(P, lo, bin_of, bin_size, bin_depth);
+    // bins come out deepest class first = upstream-first, which is the numbering the callers want
+    sizes.assign(bin_size.begin(), bin_size.end());
+    (void)nb;
+    for (int64_t v = 0; v < n; ++v) part_of[v] = bin_of[P.root_of[v]];
+}
+
 int build_host_plan(int64_t n, const int32_t *indptr, const int32_t *indices, HostPlan &P, std::string &err)
 {
     if (n < 0 || (n > 0 && (!indptr))) { err = "rr_plan_create: null csc_indptr or negative n"; return RR_E_INVALID; }

@@ -50,6 +50,12 @@ struct TiledPermutation {
 };
 void build_tiled_permutation(const int32_t *pi, int64_t n, int32_t tile, TiledPermutation &out);
 
+// Cuts a forest (down[i] = downstream reach or -1, upstream reaches have smaller indices) into at most n_parts
+// parts so that the largest part is as small as the greedy allows and the part graph stays acyclic: every
+// piece between cuts is connected, and only pieces the same number of cuts away from their outlet share a part.
+// Parts are numbered upstream-first.  part_of[n], sizes[parts].
+void partition_forest(const std::vector<int32_t> &down, int32_t n_parts, int32_t *part_of, std::vector<int64_t> &sizes);
+
 // Returns 0 or an RR_E_* code with a message in err.
 int build_host_plan(int64_t n, const int32_t *indptr, const int32_t *indices, HostPlan &plan, std::string &err);
 

@@ -11,7 +11,7 @@ import numpy as np
 from . import _lib
 from ._lib import RRError, check, ptr
 
-__all__ = ['Plan', 'RRError', 'uh_convolve', 'uh_convolve_dev', 'DeviceBuffer']
+__all__ = ['Plan', 'RRError', 'uh_convolve', 'uh_convolve_dev', 'DeviceBuffer', 'partition_forest', 'synchronize']
 
 
 def _f64(a, name):
@@ -142,6 +142,41 @@ class Plan:
                        stream=None) -> None:
         check(_lib.lib().rr_unit_route_dev(self._h, ptr(q_ch), ptr(q_full), ptr(convolved), int(conv_rows),
                                            ptr(discharge), int(out_rows), int(T), int(num_substeps), stream))
+
+
+    # -- partitioned networks: boundary reaches + streaming calls (include/rr_hip.h) --
+    def set_boundary(self, ghost_reaches, export_reaches) -> None:
+        g = np.ascontiguousarray(ghost_reaches, dtype=np.int64)
+        e = np.ascontiguousarray(export_reaches, dtype=np.int64)
+        check(_lib.lib().rr_plan_set_boundary(self._h, g.size, ptr(g) if g.size else None, e.size,
+                                              ptr(e) if e.size else None))
+        self.n_ghost, self.n_export = int(g.size), int(e.size)
+
+    def stream_begin(self, q_t, lateral, lat_rows, discharge, out_rows, T, num_substeps, ghost_series=None,
+                     export_series=None, stream=None) -> None:
+        check(_lib.lib().rr_stream_begin(self._h, 0 if lateral is None else 1, ptr(q_t), ptr(lateral), int(lat_rows),
+                                         ptr(discharge), int(out_rows), int(T), int(num_substeps), ptr(ghost_series),
+                                         ptr(export_series), stream))
+
+    def stream_advance(self, lateral_rows_ready: int, ghost_substeps_ready: int) -> int:
+        ready = C.c_int64(0)
+        check(_lib.lib().rr_stream_advance(self._h, int(lateral_rows_ready), int(ghost_substeps_ready), C.byref(ready)))
+        return int(ready.value)
+
+    def stream_end(self, q_t=None) -> None:
+        check(_lib.lib().rr_stream_end(self._h, ptr(q_t)))
+
+
+def partition_forest(csc_indptr, csc_indices, n_parts: int):
+    """(part_of int32[n], part_sizes int64[n_parts]) -- rr_partition_forest; host-only."""
+    indptr = np.ascontiguousarray(csc_indptr, dtype=np.int32)
+    indices = np.ascontiguousarray(csc_indices, dtype=np.int32)
+    n = indptr.shape[0] - 1
+    part_of = np.empty(n, dtype=np.int32)
+    sizes = np.zeros(n_parts, dtype=np.int64)
+    check(_lib.lib().rr_partition_forest(n, ptr(indptr), ptr(indices) if indices.size else None, int(n_parts),
+                                         ptr(part_of), ptr(sizes)))
+    return part_of, sizes
 
 
 def uh_convolve(kernel, state, lateral, device: int = 0) -> np.ndarray:

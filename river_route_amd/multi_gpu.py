@@ -1,0 +1,308 @@
+"""
+Graph-partitioned routing across the GPUs of one node (BASELINE config 5).
+
+The river network is cut into connected parts, one per GPU (`rr_partition_forest`: min-max greedy, parts
+numbered upstream-first, the part graph is a forest because discharge only flows downstream).  For every cut
+edge (u -> d) the part that owns `d` carries `u` as a GHOST reach whose discharge series is prescribed, and the
+part that owns `u` records `u`'s discharge after every routing sub-step in its export series
+(`rr_plan_set_boundary`).  The only data-path communication is that series, sent downstream in batches of
+`chunk_rows` runoff steps with point-to-point `torch.distributed` send/recv (RCCL over xGMI on the GPU box,
+gloo in the CPU tests): a few KB per batch, so the exchange is latency-bound and batching hides it.  Each
+GPU keeps its lag pipeline open across batches (`rr_stream_begin/advance/end`), so a downstream part simply
+runs a fixed number of ticks behind its upstream parts and all GPUs compute concurrently.
+
+RapidMuskingum / Muskingum only (UnitMuskingum needs the headwater-as-old-value quirk across the cut and is
+single-GPU for now).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+__all__ = ['PartSpec', 'split_network', 'HipPartEngine', 'part_driver', 'run_distributed', 'run_in_process',
+           'bench_main']
+
+
+@dataclass
+class PartSpec:
+    part: int
+    n_parts: int
+    real_global: np.ndarray          # global params indices of this part's reaches, ascending
+    ghost_global: np.ndarray         # global index of the upstream reach behind each ghost
+    ghost_owner: np.ndarray          # part that owns it
+    export_global: np.ndarray        # global indices of this part's export reaches
+    export_consumer: np.ndarray      # part that consumes each export
+    indptr: np.ndarray               # local CSC (ghosts first, then real reaches), int32
+    indices: np.ndarray
+    down_local: np.ndarray           # local downstream index, -1 at local outlets
+    upstream_parts: list = field(default_factory=list)    # [(part, ghost column slice)]
+    downstream_parts: list = field(default_factory=list)  # [(part, export column slice)]
+
+    @property
+    def n_ghost(self) -> int:
+        return int(self.ghost_global.size)
+
+    @property
+    def n_local(self) -> int:
+        return int(self.ghost_global.size + self.real_global.size)
+
+
+def split_network(down_index: np.ndarray, part_of: np.ndarray, part: int, n_parts: int) -> PartSpec:
+    """Local network of one part.  Local index order: ghosts (grouped by owning part, ascending global index)
+    first, then the part's reaches in ascending global index -- still upstream before downstream."""
+    down_index = np.asarray(down_index, dtype=np.int64)
+    part_of = np.asarray(part_of)
+    real = np.flatnonzero(part_of == part)
+    has_down = down_index >= 0
+    dpart = np.where(has_down, part_of[np.maximum(down_index, 0)], -1)
+    cut_in = np.flatnonzero(has_down & (dpart == part) & (part_of != part))      # upstream ends, owned elsewhere
+    cut_in = cut_in[np.lexsort((cut_in, part_of[cut_in]))]
+    cut_out = np.flatnonzero(has_down & (part_of == part) & (dpart != part))
+    cut_out = cut_out[np.lexsort((cut_out, dpart[cut_out]))]
+    ng = cut_in.size
+    local_of = np.full(down_index.size, -1, dtype=np.int64)
+    local_of[cut_in] = np.arange(ng)
+    local_of[real] = ng + np.arange(real.size)
+    members = np.concatenate([cut_in, real])
+    down_local = np.where(has_down[members], local_of[np.maximum(down_index[members], 0)], -1)
+    down_local[ng:][np.isin(real, cut_out)] = -1          # exports are outlets of the local network
+    has = down_local >= 0
+    indptr = np.concatenate([[0], np.cumsum(has)]).astype(np.int32)
+    indices = down_local[has].astype(np.int32)
+    spec = PartSpec(part, n_parts, real, cut_in, part_of[cut_in].astype(np.int64), cut_out,
+                    dpart[cut_out].astype(np.int64), indptr, indices, down_local)
+    for owners, out in ((spec.ghost_owner, spec.upstream_parts), (spec.export_consumer, spec.downstream_parts)):
+        for p in np.unique(owners):
+            cols = np.flatnonzero(owners == p)
+            out.append((int(p), slice(int(cols[0]), int(cols[-1]) + 1)))
+    return spec
+
+
+class HipPartEngine:
+    """One part on one GPU: plan + coefficients + device-resident forcing, state and boundary series (torch
+    tensors for memory and streams only; all compute is librr_hip.so)."""
+
+    def __init__(self, spec: PartSpec, c1, c2, c3, c4_dt, q0_global, lateral_rows, T, nsub, device, out_rows=None,
+                 sample_every=0):
+        import torch
+        from .engine import Plan
+        self.torch = torch
+        self.spec, self.T, self.nsub = spec, int(T), int(nsub)
+        self.dev = torch.device('cuda', device)
+        ng, members = spec.n_ghost, np.concatenate([spec.ghost_global, spec.real_global])
+        n_loc = members.size
+
+        def local(v, ghost_value=0.0):
+            a = np.asarray(v, dtype=np.float64)[members].copy()
+            a[:ng] = ghost_value
+            return a
+
+        self.plan = Plan(spec.indptr, spec.indices, device=device)
+        c1_loc = np.asarray(c1, dtype=np.float64)[members]
+        # off-diagonal of the edge leaving local reach j is -c1 of its downstream reach; for a ghost that is the
+        # real downstream reach across the cut
+        has = spec.down_local >= 0
+        lhs = -c1_loc[spec.down_local[has]]
+        self.plan.set_coeffs(lhs, local(c2), local(c3), None if c4_dt is None else local(c4_dt))
+        export_local = ng + np.searchsorted(spec.real_global, spec.export_global)
+        self.plan.set_boundary(np.arange(ng), export_local)
+        self.plan.set_options(sample_every=sample_every)
+        # lateral rows: (rows, n_loc) in local order; ghost columns are never read
+        lat = np.zeros((lateral_rows.shape[0], n_loc))
+        lat[:, ng:] = lateral_rows
+        self.lateral = torch.from_numpy(lat).to(self.dev)
+        self.lat_rows = lat.shape[0]
+        self.out_rows = int(out_rows or self.lat_rows)
+        self.discharge = torch.zeros((self.out_rows, n_loc), dtype=torch.float64, device=self.dev)
+        q0 = np.asarray(q0_global, dtype=np.float64)[members]      # ghosts start from their reach's own state
+        self.q0 = torch.from_numpy(q0).to(self.dev)
+        self.q_t = torch.empty_like(self.q0)
+        S = self.T * self.nsub
+        self.ghost_series = torch.zeros((S, max(ng, 1)), dtype=torch.float64, device=self.dev)
+        self.export_series = torch.zeros((S, max(spec.export_global.size, 1)), dtype=torch.float64, device=self.dev)
+
+    def begin(self) -> None:
+        self.q_t.copy_(self.q0)
+        stream = self.torch.cuda.current_stream(self.dev).cuda_stream
+        self.plan.stream_begin(self.q_t, self.lateral, self.lat_rows, self.discharge, self.out_rows, self.T,
+                               self.nsub, self.ghost_series, self.export_series, stream)
+
+    def advance(self, rows_ready: int, ghost_ready: int) -> int:
+        return self.plan.stream_advance(rows_ready, ghost_ready)
+
+    def end(self) -> None:
+        self.plan.stream_end(self.q_t)
+
+    def final_state(self) -> np.ndarray:
+        return self.q_t.cpu().numpy()[self.spec.n_ghost:]
+
+
+def part_driver(engine, spec: PartSpec, T: int, nsub: int, chunk_rows: int):
+    """
+    Generator running one part through one routing call.  It yields requests the runner must serve:
+      ('recv', src_part, tensor_view_setter, r0, r1)   block until rows [r0, r1) of src's export block arrived
+      ('send', dst_part, tensor, r0, r1)               ship rows [r0, r1) of the export block for dst
+    """
+    S = T * nsub
+    kc = chunk_rows * nsub
+    engine.begin()
+    sent = 0
+    n_chunks = (T + chunk_rows - 1) // chunk_rows
+
+    def flush(export_ready, final):
+        nonlocal sent
+        while sent < S and (export_ready - sent >= kc or (final and export_ready > sent) or
+                            (export_ready >= S and sent < S)):
+            r1 = min(sent + kc, export_ready, S)
+            for dst, cols in spec.downstream_parts:
+                yield ('send', dst, engine.export_series[sent:r1, cols], sent, r1)
+            sent = r1
+
+    for k in range(n_chunks):
+        rows1 = min(T, (k + 1) * chunk_rows)
+        s0, s1 = k * kc, rows1 * nsub
+        for src, cols in spec.upstream_parts:
+            yield ('recv', src, engine.ghost_series[s0:s1, cols], s0, s1)
+        ready = engine.advance(rows1, s1 if spec.n_ghost else S)
+        if spec.downstream_parts:
+            yield from flush(ready, False)
+    ready = engine.advance(T, S)
+    if spec.downstream_parts:
+        yield from flush(ready, True)
+    engine.end()
+
+
+def run_distributed(engine, spec: PartSpec, T: int, nsub: int, chunk_rows: int, dist) -> None:
+    """Serve one part's driver with torch.distributed point-to-point ops (nccl = RCCL on the GPU box, gloo on CPU).
+    Rank == part.  Sends are asynchronous; their buffers are kept alive until the call ends."""
+    pending = []
+    for req in part_driver(engine, spec, T, nsub, chunk_rows):
+        kind, peer, view, r0, r1 = req
+        if kind == 'recv':
+            buf = view.new_empty(view.shape)
+            dist.recv(buf, src=peer)
+            view.copy_(buf)
+        else:
+            buf = view.contiguous()
+            pending.append((dist.isend(buf, dst=peer), buf))
+    for work, _ in pending:
+        work.wait()
+
+
+def run_in_process(engines, specs, T: int, nsub: int, chunk_rows: int) -> None:
+    """All parts in one process (one GPU): a cooperative scheduler with mailboxes instead of a network.  Used by
+    the single-GPU tests to exercise exactly the driver and engine paths the distributed run uses."""
+    drivers = [part_driver(e, s, T, nsub, chunk_rows) for e, s in zip(engines, specs)]
+    mail: dict = {}
+    waiting = [None] * len(drivers)
+    alive = set(range(len(drivers)))
+    while alive:
+        progressed = False
+        for p in sorted(alive):
+            while True:
+                req = waiting[p]
+                if req is None:
+                    try:
+                        req = next(drivers[p])
+                    except StopIteration:
+                        alive.discard(p)
+                        progressed = True
+                        break
+                kind, peer, view, r0, r1 = req
+                if kind == 'send':
+                    mail.setdefault((p, peer), []).append((r0, r1, view.clone()))
+                    waiting[p] = None
+                    progressed = True
+                    continue
+                box = mail.get((peer, p), [])
+                if box and box[0][0] == r0 and box[0][1] == r1:
+                    view.copy_(box.pop(0)[2])
+                    waiting[p] = None
+                    progressed = True
+                    continue
+                waiting[p] = req
+                break
+        if not progressed:
+            raise RuntimeError('run_in_process: parts are deadlocked (no message can be delivered)')
+
+
+# ------------------------------------------------------------------------------------------------ bench.py --gpus N
+
+def bench_main(args, rank: int, local_rank: int, world: int) -> None:
+    """N > 1 leg of bench.py: ONE network of args.reaches * N reaches, graph-partitioned over the N GPUs
+    (weak scaling: reaches per GPU fixed), boundary discharge exchanged over RCCL."""
+    import json
+    import time
+    import torch
+    import torch.distributed as dist
+    from . import synth
+    from .engine import partition_forest
+
+    n, T, nsub, dt = args.reaches * world, args.runoff_steps, args.substeps, 900.0
+    net = synth.synth_network(n, order=args.order)
+    has = net.down_index >= 0
+    indptr = np.concatenate([[0], np.cumsum(has)]).astype(np.int32)
+    indices = net.down_index[has].astype(np.int32)
+    part_of, sizes = partition_forest(indptr, indices, world)
+    spec = split_network(net.down_index, part_of, rank, world)
+    r = dt / net.k
+    den = r + 2.0 * (1.0 - net.x)
+    c1, c2, c3 = (r - 2.0 * net.x) / den, (r + 2.0 * net.x) / den, (2.0 * (1.0 - net.x) - r) / den
+    rows = min(args.forcing_rows, T)
+    idx = (np.arange(rows, dtype=np.uint64)[:, None] * np.uint64(n)) + spec.real_global.astype(np.uint64)[None, :]
+    lateral = dt * nsub * synth.u01(synth.FORCING_SEED, idx)
+    eng = HipPartEngine(spec, c1, c2, c3, (c1 + c2) / (dt * nsub), np.zeros(n), lateral, T, nsub, local_rank,
+                        sample_every=args.sample_every)
+    chunk_rows = max(16, args.exchange_rows)
+
+    def one_pass():
+        run_distributed(eng, spec, T, nsub, chunk_rows, dist)
+
+    for _ in range(args.warmup):
+        one_pass()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass()
+    torch.cuda.synchronize()
+    dist.barrier()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=eng.dev)
+    dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    elapsed = float(elapsed.item())
+
+    prof = eng.plan.profile()
+    info = torch.tensor([float(spec.real_global.size), float(spec.n_ghost), float(eng.plan.depth)],
+                        dtype=torch.float64, device=eng.dev)
+    gathered = [torch.zeros_like(info) for _ in range(world)]
+    dist.all_gather(gathered, info)
+    if rank == 0:
+        bytes_per = 72 + 16 / nsub
+        roofline = None
+        if prof['sampled'] > 0 and prof['sampled_ms'] > 0:
+            avg_ms = prof['sampled_ms'] / prof['sampled']
+            avg_reaches = prof['sampled_reaches'] / prof['sampled']
+            ach = bytes_per * avg_reaches / (avg_ms * 1e-3) / 1e9
+            roofline = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                        'frac': round(ach / 8000.0, 4), 'traffic': None, 'kernel': 'k_tick (rank 0 part)',
+                        'avg_launch_us': round(avg_ms * 1e3, 3),
+                        'algorithmic_bytes_per_launch': round(bytes_per * avg_reaches)}
+        line = {
+            'metric': 'reach-steps/sec', 'value': float(n) * T * nsub * args.steps / elapsed,
+            'unit': 'reach-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'RapidMuskingum, ONE {n}-reach synthetic random-topology network graph-partitioned '
+                                   f'over {world} MI355X ({args.reaches} reaches per GPU), {T} runoff steps @ 900 s, '
+                                   f'{nsub} sub-step(s), fp64, boundary discharge exchanged over RCCL every '
+                                   f'{chunk_rows} steps',
+                       'reaches': n, 'runoff_steps': T, 'substeps': nsub, 'params_order': args.order,
+                       'part_reaches': [int(g[0].item()) for g in gathered],
+                       'part_ghosts': [int(g[1].item()) for g in gathered],
+                       'part_depth': [int(g[2].item()) for g in gathered],
+                       'exchange_rows': chunk_rows},
+            'roofline': roofline, 'cpu_baseline': None,
+        }
+        print(json.dumps(line))
+    dist.destroy_process_group()

@@ -1,0 +1,117 @@
+"""
+The partitioned path: forest partitioning, local networks with ghost/export reaches, and the batched one-way
+boundary exchange.  CPU: world_size-2 gloo run with an oracle-backed engine injected (tests/multi_helpers.py)
+against the single-domain oracle.  GPU: the real engine, all parts on one card through the in-process runner
+(the same driver and the same C-ABI streaming calls the RCCL run uses), against the single-plan result.
+"""
+import socket
+
+import numpy as np
+import pytest
+
+from conftest import assert_close
+from multi_helpers import OraclePartEngine, gloo_worker, setup_case
+from river_route_amd import synth
+from river_route_amd.engine import partition_forest
+from river_route_amd.multi_gpu import run_in_process, split_network
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize('n,parts', [(9, 2), (1000, 2), (1000, 8), (50001, 5)])
+def test_partition_and_split_invariants(n, parts):
+    net, indptr, indices, *_ = setup_case(n)
+    part_of, sizes = partition_forest(indptr, indices, parts)
+    assert sizes.sum() == n and np.array_equal(np.bincount(part_of, minlength=parts), sizes)
+    has = net.down_index >= 0
+    # parts are numbered upstream-first: discharge never flows to a lower-numbered part
+    assert np.all(part_of[has] <= part_of[net.down_index[has]])
+    if n >= 1000:
+        assert sizes.max() <= 1.35 * n / parts
+    seen = np.zeros(n, dtype=int)
+    n_ghost = n_export = 0
+    for p in range(parts):
+        spec = split_network(net.down_index, part_of, p, parts)
+        seen[spec.real_global] += 1
+        n_ghost += spec.n_ghost
+        n_export += spec.export_global.size
+        # local order is upstream -> downstream and ghosts are headwaters
+        loc = spec.down_local
+        assert np.all((loc < 0) | (loc > np.arange(loc.size)))
+        assert not np.isin(np.arange(spec.n_ghost), loc).any()
+        assert np.all(part_of[spec.ghost_global] == spec.ghost_owner) and np.all(spec.ghost_owner < p)
+        assert np.all(spec.export_consumer > p)
+    assert np.all(seen == 1) and n_ghost == n_export == int((has & (part_of != part_of[np.maximum(net.down_index, 0)])).sum())
+
+
+def single_domain(n, T):
+    from oracle import oracle
+    net, indptr, indices, c1, c2, c3, q0 = setup_case(n)
+    ql = synth.synth_qlateral(n, 0, T)
+    q, d = q0.copy(), np.zeros((T, n))
+    oracle.rapid_route(indptr, indices, -c1[indices], c2, c3, (c1 + c2) / 900.0, q, ql, d, 1)
+    return q, d
+
+
+def test_two_ranks_gloo_match_single_domain(tmp_path):
+    import torch.multiprocessing as mp
+    n, T, world = 700, 37, 2
+    mp.spawn(gloo_worker, args=(world, free_port(), n, T, 8, str(tmp_path)), nprocs=world, join=True)
+    q_ref, d_ref = single_domain(n, T)
+    q, d = np.zeros(n), np.zeros((T, n))
+    for r in range(world):
+        z = np.load(tmp_path / f'rank{r}.npz')
+        q[z['real']], d[:, z['real']] = z['state'], z['discharge']
+    assert_close(q, q_ref, 'state')
+    assert_close(d, d_ref, 'discharge')
+
+
+def test_in_process_runner_with_oracle_engine_three_parts():
+    n, T, parts = 900, 25, 3
+    net, indptr, indices, c1, c2, c3, q0 = setup_case(n)
+    part_of, _ = partition_forest(indptr, indices, parts)
+    specs = [split_network(net.down_index, part_of, p, parts) for p in range(parts)]
+    ql = synth.synth_qlateral(n, 0, T)
+    engines = [OraclePartEngine(s, c1, c2, c3, (c1 + c2) / 900.0, q0, ql[:, s.real_global], T, 1) for s in specs]
+    run_in_process(engines, specs, T, 1, 4)
+    q_ref, d_ref = single_domain(n, T)
+    q, d = np.zeros(n), np.zeros((T, n))
+    for s, e in zip(specs, engines):
+        q[s.real_global], d[:, s.real_global] = e.final_state(), e.discharge
+    assert_close(q, q_ref, 'state')
+    assert_close(d, d_ref, 'discharge')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,T,nsub,parts,chunk', [(5000, 40, 1, 3, 8), (5000, 21, 3, 4, 5), (200000, 64, 1, 8, 16)])
+def test_hip_parts_on_one_gpu_match_single_plan(n, T, nsub, parts, chunk):
+    """Ghost/export reaches + rr_stream_* + the driver, on the real engine; reference = one plan over the whole
+    network (itself checked against the oracle in test_gpu_kernels.py)."""
+    from river_route_amd.engine import Plan
+    from river_route_amd.multi_gpu import HipPartEngine
+    net, indptr, indices, c1, c2, c3, q0 = setup_case(n)
+    dt = 900.0
+    c4_dt = (c1 + c2) / (dt * nsub)
+    ql = synth.synth_qlateral(n, 0, T, dt=dt * nsub)
+    with Plan(indptr, indices) as plan:
+        plan.set_coeffs(-c1[indices], c2, c3, c4_dt)
+        q_ref, d_ref = q0.copy(), np.zeros((T, n))
+        plan.rapid_route(q_ref, ql, d_ref, nsub)
+    part_of, _ = partition_forest(indptr, indices, parts)
+    specs = [split_network(net.down_index, part_of, p, parts) for p in range(parts)]
+    engines = [HipPartEngine(s, c1, c2, c3, c4_dt, q0, ql[:, s.real_global], T, nsub, 0, out_rows=T) for s in specs]
+    run_in_process(engines, specs, T, nsub, chunk)
+    q, d = np.zeros(n), np.zeros((T, n))
+    for s, e in zip(specs, engines):
+        q[s.real_global] = e.final_state()
+        d[:, s.real_global] = e.discharge.cpu().numpy()[:, s.n_ghost:]
+    assert_close(q, q_ref, 'state')
+    assert_close(d, d_ref, 'discharge')
+    # second pass on the same engines (bench.py reuses them): identical
+    run_in_process(engines, specs, T, nsub, chunk)
+    for s, e in zip(specs, engines):
+        np.testing.assert_array_equal(e.final_state(), q[s.real_global])
