@@ -287,6 +287,157 @@ __global__ __launch_bounds__(kBlock) void k_unit_state_out(double *q_ch, double 
     q_ch[k] = qch[p];
 }
 
+// ---- time-tiled routing: blocks of positions advance K ticks per launch ----
+//
+// k_tick streams ~88 B per reach-step because nothing survives from one tick to the next.  k_wave cuts the
+// engine order into blocks of BS = PPT * 1024 consecutive positions and lets one workgroup advance its block
+// by K ticks: coefficients and state sit in registers, the block's own discharges in LDS (double-buffered, one
+// barrier per tick), so HBM sees only the lateral read and the discharge write of every reach-step, plus
+//   * the block's state and coefficients once per K ticks, and
+//   * the "halo": upstream reaches of a block's first level live in the block(s) to its LEFT (upstream reaches
+//     always have smaller positions), so every block writes the values of its last level to a small history
+//     ring hist[tick % hist_rows][p] and its right neighbour reads them one tick later.
+// Task (block b, tick-chunk c) needs (b-1, c) (halo) and (b, c-1) (own state): all tasks on one anti-diagonal
+// b + c are independent, so there is ONE LAUNCH PER DIAGONAL and still no inter-workgroup synchronisation.
+constexpr int kWaveThreads = 1024;
+
+struct WaveArgs {
+    const int32_t *child_ptr, *lag;
+    const double *c1row, *c2, *c3, *c4;   // c1row: the (uniform) weight of a reach's upstream terms
+    double *sq, *ss, *si;                 // carried state: discharge, sum of upstream discharges one tick back, interval sum
+    double *hist;                         // [hist_rows, n]
+    const double *in;
+    double *out;
+    int64_t in_ld, out_ld;
+    uint32_t in_rows, out_rows;
+    int32_t n, hist_rows, K, b_first;
+    int64_t diag, total;
+    uint32_t nsub;
+    double inv_nsub;
+};
+
+template <int PPT, bool SINGLE_SUBSTEP>
+__global__ __launch_bounds__(kWaveThreads) void k_wave(const WaveArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // [2][BS]
+    constexpr int BS = PPT * kWaveThreads;
+    const int tid = threadIdx.x;
+    const int32_t b = a.b_first + (int32_t)blockIdx.x;
+    const int64_t chunk = a.diag - b;
+    const int32_t b0 = b * BS, b1 = min(a.n, b0 + BS);
+    // positions whose downstream reach lies in a block to the right publish to the history ring
+    const int32_t halo_lo = max(b0, a.child_ptr[b1]);
+    auto position = [&](int k) { return b0 + k * kWaveThreads + tid; };
+
+    int32_t lg[PPT], u0[PPT], u1[PPT];
+    double c1[PPT], c2[PPT], c3[PPT], c4[PPT], q[PPT], s_prev[PPT], isum[SINGLE_SUBSTEP ? 1 : PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int32_t p = position(k);
+        if (p < b1) {
+            lg[k] = a.lag[p] & kLagMask; u0[k] = a.child_ptr[p]; u1[k] = a.child_ptr[p + 1];
+            c1[k] = a.c1row[p]; c2[k] = a.c2[p]; c3[k] = a.c3[p]; c4[k] = a.in ? a.c4[p] : 0.0;
+            q[k] = a.sq[p]; s_prev[k] = a.ss[p];
+            if (!SINGLE_SUBSTEP) isum[k] = a.si[p];
+        } else {
+            lg[k] = -1; u0[k] = u1[k] = 0; c1[k] = c2[k] = c3[k] = c4[k] = q[k] = s_prev[k] = 0.0;   // lg < 0: not a reach
+            if (!SINGLE_SUBSTEP) isum[k] = 0.0;
+        }
+    }
+    const int64_t tau0 = chunk * a.K;
+    {   // the block's discharges one tick back
+        double *buf = lds + (size_t)((tau0 + 1) & 1) * BS;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) buf[k * kWaveThreads + tid] = q[k];
+    }
+    // what tick tau needs from HBM does not depend on tick tau-1: fetch it one tick ahead
+    auto fetch = [&](int64_t tau, double (&lat)[PPT], double (&halo)[PPT]) {
+        const double *hrow = a.hist + (int64_t)((uint64_t)(tau - 1 + a.hist_rows) % (uint32_t)a.hist_rows) * a.n;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            lat[k] = 0.0; halo[k] = 0.0;
+            if (lg[k] < 0) continue;
+            const int64_t ts = tau - lg[k];
+            if (a.in && ts >= 0 && ts < a.total) {
+                const uint32_t t = SINGLE_SUBSTEP ? (uint32_t)ts : (uint32_t)((uint64_t)ts / a.nsub);
+                lat[k] = a.in[(int64_t)(t % a.in_rows) * a.in_ld + position(k)];
+            }
+            const int32_t ue = min(u1[k], b0);
+            for (int32_t u = u0[k]; u < ue; ++u) halo[k] += hrow[u];
+        }
+    };
+    double lat_cur[PPT], halo_cur[PPT], lat_nxt[PPT], halo_nxt[PPT];
+    fetch(tau0, lat_cur, halo_cur);
+    __syncthreads();
+
+    for (int64_t tau = tau0; tau < tau0 + a.K; ++tau) {
+        if (tau + 1 < tau0 + a.K) fetch(tau + 1, lat_nxt, halo_nxt);
+        const double *rd = lds + (size_t)((tau + 1) & 1) * BS;   // values of tick tau-1
+        double *wr = lds + (size_t)(tau & 1) * BS;
+        double *hrow = a.hist + (int64_t)((uint64_t)tau % (uint32_t)a.hist_rows) * a.n;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            if (lg[k] < 0) continue;
+            const int32_t p = position(k);
+            double s_cur = halo_cur[k];
+            for (int32_t u = max(u0[k], b0); u < u1[k]; ++u) s_cur += rd[u - b0];
+            const int64_t ts = tau - lg[k];
+            if (ts >= 0 && ts < a.total) {
+                double r = c3[k] * q[k];
+                r += c4[k] * lat_cur[k];
+                r += c2[k] * s_prev[k];
+                r += c1[k] * s_cur;
+                q[k] = r;
+                if (SINGLE_SUBSTEP) {
+                    a.out[(int64_t)((uint32_t)ts % a.out_rows) * a.out_ld + p] = r > 0.0 ? r : 0.0;
+                } else {
+                    const uint32_t t = (uint32_t)((uint64_t)ts / a.nsub);
+                    const uint32_t sub = (uint32_t)((uint64_t)ts - (uint64_t)t * a.nsub);
+                    const double acc = (sub == 0 ? 0.0 : isum[k]) + r;
+                    if (sub + 1 == a.nsub) {
+                        const double v = acc * a.inv_nsub;
+                        a.out[(int64_t)(t % a.out_rows) * a.out_ld + p] = v > 0.0 ? v : 0.0;
+                    }
+                    isum[k] = acc;
+                }
+            }
+            s_prev[k] = s_cur;
+            wr[k * kWaveThreads + tid] = q[k];
+            if (p >= halo_lo) hrow[p] = q[k];
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) { lat_cur[k] = lat_nxt[k]; halo_cur[k] = halo_nxt[k]; }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        if (lg[k] < 0) continue;
+        const int32_t p = position(k);
+        a.sq[p] = q[k]; a.ss[p] = s_prev[k];
+        if (!SINGLE_SUBSTEP) a.si[p] = isum[k];
+    }
+}
+
+// sq = q0 in engine order, ss = sum of the upstream reaches' q0, every history row = q0
+__global__ __launch_bounds__(kBlock) void k_wave_state_in(double *sq, double *ss, double *hist, int32_t hist_rows,
+                                                          const double *q_t, const int32_t *perm,
+                                                          const int32_t *child_ptr, int32_t n)
+{
+    const int32_t p = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (p >= n) return;
+    const double v = q_t[perm[p]];
+    double s = 0.0;
+    for (int32_t u = child_ptr[p]; u < child_ptr[p + 1]; ++u) s += q_t[perm[u]];
+    sq[p] = v; ss[p] = s;
+    for (int32_t r = 0; r < hist_rows; ++r) hist[(int64_t)r * n + p] = v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_wave_state_out(double *q_t, const double *sq, const int32_t *inv, int32_t n)
+{
+    const int32_t i = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (i < n) q_t[i] = sq[inv[i]];
+}
+
 // Unit-hydrograph convolution, direct form (UnitHydrograph.py:93-107):
 //   out[t, i] = [t < n_ks] state[t, i] + sum_{s=0}^{min(t, n_ks-1)} kernel[s, i] * lateral[t - s, i]
 // One reach per lane, TB consecutive outputs per thread held in registers; per tap one kernel value and one
@@ -378,6 +529,9 @@ struct Session {
     const double *ghost_series = nullptr;
     double *export_series = nullptr;
     TickArgs a{};
+    bool wave = false;            // time-tiled k_wave instead of per-tick k_tick
+    int64_t diag = 0, n_diags = 0, n_chunks = 0;
+    WaveArgs wa{};
     bool bracket_open = false;
     int64_t bracket_reaches = 0;
     size_t max_samples = 0;
@@ -404,6 +558,13 @@ struct rr_plan {
     uint16_t *d_slot_a[2] = {nullptr, nullptr}, *d_slot_b[2] = {nullptr, nullptr};
     int32_t *d_m_index[2] = {nullptr, nullptr};
     int64_t perm_rows_per_block = 2;
+
+    // time-tiled routing (k_wave)
+    bool wave_enabled = true, weights_uniform = false;
+    int wave_ppt = 4;
+    int64_t wave_K = 16, wave_nb = 0, wave_jmax = 0;
+    double *d_c1row = nullptr, *d_sq = nullptr, *d_ss = nullptr, *d_si = nullptr, *d_hist = nullptr;
+    int64_t hist_cap = 0;
 
     // boundary reaches of a partitioned network
     int64_t n_ghost = 0, n_export = 0;
@@ -464,6 +625,15 @@ int ensure_cap(T **buf, int64_t *cap, int64_t count)
 
 // ---- session -------------------------------------------------------------------------------------
 
+bool use_wave(const rr_plan *P, Mode mode)
+{
+    return P->wave_enabled && P->weights_uniform && mode != Mode::Unit && P->n_ghost == 0 && P->n_export == 0 &&
+           P->h.n > 0;
+}
+
+int64_t wave_hist_rows(const rr_plan *P) { return (P->wave_jmax + 2) * P->wave_K; }
+
+
 int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io, hipStream_t stream,
                   const double *ghost_series, double *export_series)
 {
@@ -490,8 +660,15 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
     if (P->n_ghost > 0 && !ghost_series) { S.open = false; return fail(RR_E_INVALID, "plan has ghost reaches but no ghost series was given"); }
     if (P->n_export > 0 && !export_series) { S.open = false; return fail(RR_E_INVALID, "plan has export reaches but no export series was given"); }
 
-    // work ring in engine order: lateral rows come in, discharge rows overwrite them in place
-    const int64_t lag_rows = (dmax + nsub - 1) / nsub;
+    S.wave = use_wave(P, mode);
+    if (S.wave) {
+        S.n_chunks = (S.total_ticks + P->wave_K - 1) / P->wave_K;
+        S.n_diags = S.n_chunks + P->wave_nb - 1;
+    }
+    // work ring in engine order: lateral rows come in, discharge rows overwrite them in place.  Rows stay until
+    // the outlet-most reaches have passed them; the time-tiled schedule adds (blocks - 1) * K ticks of skew.
+    const int64_t skew_ticks = dmax + (S.wave ? P->wave_nb * P->wave_K : 0);
+    const int64_t lag_rows = (skew_ticks + nsub - 1) / nsub;
     S.ring_rows = S.direct ? 0 : std::min<int64_t>(T, lag_rows + 2 * C + 2);
     if (S.ring_rows > 0xFFFFFFFFLL || T > 0x7FFFFFFFLL) { S.open = false; return fail(RR_E_INVALID, "route: too many time rows"); }
     int rc = RR_OK;
@@ -513,6 +690,14 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         a.out = P->d_ring; a.out_ld = n; a.out_rows = (uint32_t)S.ring_rows;
     }
 
+    if (S.wave) {
+        WaveArgs &w = S.wa;
+        w.child_ptr = P->d_child_ptr; w.lag = P->d_lag; w.c1row = P->d_c1row; w.c2 = P->d_c2; w.c3 = P->d_c3; w.c4 = P->d_c4;
+        w.sq = P->d_sq; w.ss = P->d_ss; w.si = P->d_si; w.hist = P->d_hist; w.hist_rows = (int32_t)wave_hist_rows(P);
+        w.in = a.in; w.out = a.out; w.in_ld = a.in_ld; w.out_ld = a.out_ld; w.in_rows = a.in_rows; w.out_rows = a.out_rows;
+        w.n = (int32_t)n; w.K = (int32_t)P->wave_K; w.total = S.total; w.nsub = (uint32_t)nsub; w.inv_nsub = 1.0 / (double)nsub;
+        if (!P->d_hist || P->hist_cap < (int64_t)w.hist_rows * n) { S.open = false; return fail(RR_E_STATE, "time-tiled routing: history ring not initialised"); }
+    }
     S.max_samples = P->sample_every >= kSampleGroup ? (size_t)std::min<int64_t>(4096, S.total_ticks / P->sample_every + 1) : 0;
     while (P->ev.size() < 2 * S.max_samples) {
         hipEvent_t e;
@@ -627,6 +812,96 @@ int session_launch_tick(rr_plan *P, int64_t tau)
     return RR_OK;
 }
 
+// One anti-diagonal of the time-tiled schedule: tasks (block b, chunk diag - b) for every block whose chunk exists.
+int session_launch_diag(rr_plan *P, int64_t d)
+{
+    Session &S = P->ses;
+    const int64_t nb = P->wave_nb, K = P->wave_K, n = P->h.n;
+    const int64_t b_lo = std::max<int64_t>(0, d - (S.n_chunks - 1)), b_hi = std::min<int64_t>(nb - 1, d);
+    if (b_hi < b_lo) return RR_OK;
+    WaveArgs &w = S.wa;
+    w.diag = d; w.b_first = (int32_t)b_lo;
+    // a launch is sampled when every block takes part and every reach is active for all K ticks of its task
+    const int64_t dmax = P->h.depth - 1;
+    const bool full = b_lo == 0 && b_hi == nb - 1 && (d - (nb - 1)) * K >= dmax && (d + 1) * K <= S.total;
+    const bool sample = S.max_samples > 0 && full && (P->prof_launches % 8) == 0 &&
+                        (size_t)(P->prof_samples / K) < S.max_samples;
+    if (sample) HIPCHK(hipEventRecord(P->ev[2 * (P->prof_samples / K)], S.stream));
+    const dim3 g((unsigned)(b_hi - b_lo + 1));
+    const size_t lds_bytes = (size_t)2 * P->wave_ppt * kWaveThreads * sizeof(double);
+    const bool one = S.nsub == 1;
+    const dim3 t(kWaveThreads);
+    switch (P->wave_ppt) {
+        case 1:
+            if (one) hipLaunchKernelGGL((k_wave<1, true>), g, t, lds_bytes, S.stream, w);
+            else hipLaunchKernelGGL((k_wave<1, false>), g, t, lds_bytes, S.stream, w);
+            break;
+        case 2:
+            if (one) hipLaunchKernelGGL((k_wave<2, true>), g, t, lds_bytes, S.stream, w);
+            else hipLaunchKernelGGL((k_wave<2, false>), g, t, lds_bytes, S.stream, w);
+            break;
+        default:
+            if (one) hipLaunchKernelGGL((k_wave<4, true>), g, t, lds_bytes, S.stream, w);
+            else hipLaunchKernelGGL((k_wave<4, false>), g, t, lds_bytes, S.stream, w);
+            break;
+    }
+    if (sample) {
+        HIPCHK(hipEventRecord(P->ev[2 * (P->prof_samples / K) + 1], S.stream));
+        P->ev_reaches.push_back(n * K);
+        P->prof_samples += K;
+    }
+    ++P->prof_launches;
+    return RR_OK;
+}
+
+int session_advance_wave(rr_plan *P, int64_t rows_ready)
+{
+    Session &S = P->ses;
+    const int64_t dmax = P->h.depth - 1, C = std::max<int64_t>(1, P->chunk_rows);
+    const int64_t nb = P->wave_nb, K = P->wave_K;
+    rows_ready = std::min(rows_ready, S.T);
+    for (;;) {
+        bool progressed = false;
+        if (S.has_in && S.rows_loaded < rows_ready) {
+            const int64_t r1 = std::min(rows_ready, S.rows_loaded + C);
+            int rc = session_load_rows(P, S.rows_loaded, r1);
+            if (rc) return rc;
+            S.rows_loaded = r1;
+            progressed = true;
+        }
+        // diagonal d runs chunk d of block 0 (lag 0): ticks below (d+1)*K need rows below ceil((d+1)*K / nsub)
+        const int64_t have_rows = S.has_in ? S.rows_loaded : rows_ready;
+        int64_t launched = 0;
+        const int64_t batch = std::max<int64_t>(1, C * S.nsub / K);
+        while (S.diag < S.n_diags && launched < batch) {
+            const int64_t need_ticks = std::min((S.diag + 1) * K, S.total);
+            if (have_rows < S.T && have_rows * S.nsub < need_ticks) break;
+            int rc = session_launch_diag(P, S.diag);
+            if (rc) return rc;
+            ++S.diag; ++launched;
+            progressed = true;
+        }
+        // the last block has finished chunk diag - nb; every other block is further along
+        const int64_t c_done = S.diag - nb;   // chunks [0, c_done] complete everywhere
+        int64_t done = 0;
+        if (S.diag >= S.n_diags) done = S.T;
+        else if (c_done >= 0) {
+            const int64_t ticks = (c_done + 1) * K;
+            done = ticks - dmax <= 0 ? 0 : (ticks - dmax) / S.nsub;
+        }
+        done = std::min(done, S.T);
+        if (done > S.rows_stored) {
+            int rc = session_store_rows(P, S.rows_stored, done);
+            if (rc) return rc;
+            S.rows_stored = done;
+            progressed = true;
+        }
+        if (!progressed) break;
+    }
+    if (S.diag >= S.n_diags) S.tau = S.total_ticks;
+    return RR_OK;
+}
+
 // Runs every tick whose inputs are present: lateral rows [0, rows_ready) and ghost sub-steps [0, ghost_ready).
 // On return *export_ready = number of leading sub-steps of the export series that are final.
 int session_advance(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, int64_t *export_ready)
@@ -636,6 +911,11 @@ int session_advance(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, int64_t
     const int64_t n = P->h.n, dmax = P->h.depth - 1, C = std::max<int64_t>(1, P->chunk_rows);
     if (export_ready) *export_ready = 0;
     if (n == 0 || S.total == 0) { if (export_ready) *export_ready = S.total; return RR_OK; }
+    if (S.wave) {
+        int rc = session_advance_wave(P, rows_ready);
+        if (export_ready) *export_ready = S.tau >= S.total_ticks ? S.total : 0;
+        return rc;
+    }
     rows_ready = std::min(rows_ready, S.T);
     ghost_ready = std::min(ghost_ready, S.total);
     // a ghost at lag L is read at tick tau for sub-step tau - L: ticks below ghost_ready + min lag are safe
@@ -715,16 +995,30 @@ int check_route_args(rr_plan *P, bool need_c4, int64_t T, int64_t nsub)
     return RR_OK;
 }
 
-void launch_state_in(rr_plan *P, const double *d_q, hipStream_t stream)
+int launch_state_in(rr_plan *P, Mode mode, const double *d_q, hipStream_t stream)
 {
     const int64_t n = P->h.n;
+    if (use_wave(P, mode)) {
+        const int64_t hr = wave_hist_rows(P);
+        int rc = ensure_cap(&P->d_hist, &P->hist_cap, hr * n);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_wave_state_in, grid1(n), dim3(kBlock), 0, stream, P->d_sq, P->d_ss, P->d_hist, (int32_t)hr,
+                           d_q, P->d_perm, P->d_child_ptr, (int32_t)n);
+        return RR_OK;
+    }
     hipLaunchKernelGGL(k_state_in, grid1(n), dim3(kBlock), 0, stream, P->d_x, P->d_x + n, P->d_x + 2 * n, d_q,
                        P->d_perm, (int32_t)n);
+    return RR_OK;
 }
 
-void launch_state_out(rr_plan *P, double *d_q, int64_t total, hipStream_t stream)
+void launch_state_out(rr_plan *P, Mode mode, double *d_q, int64_t total, hipStream_t stream)
 {
     const int64_t n = P->h.n;
+    if (use_wave(P, mode)) {
+        hipLaunchKernelGGL(k_wave_state_out, grid1(n), dim3(kBlock), 0, stream, d_q, (const double *)P->d_sq, P->d_inv,
+                           (int32_t)n);
+        return;
+    }
     hipLaunchKernelGGL(k_state_out, grid1(n), dim3(kBlock), 0, stream, d_q, (const double *)P->d_x, n,
                        P->d_lag, P->d_inv, (int32_t)n, total);
 }
@@ -743,10 +1037,10 @@ int rapid_like(rr_plan *P, Mode mode, double *q_t, const Rows &io, int64_t T, in
         hipError_t e = hipMemcpyAsync(d_q, q_t, n * sizeof(double), hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) { (void)hipFree(tmp); return fail(RR_E_HIP, hipGetErrorString(e)); }
     }
-    launch_state_in(P, d_q, stream);
-    int rc = route_core(P, mode, T, nsub, io, stream);
+    int rc = launch_state_in(P, mode, d_q, stream);
+    if (rc == RR_OK) rc = route_core(P, mode, T, nsub, io, stream);
     if (rc == RR_OK) {
-        launch_state_out(P, d_q, T * nsub, stream);
+        launch_state_out(P, mode, d_q, T * nsub, stream);
         if (q_on_host) {
             hipError_t e = hipMemcpyAsync(q_t, d_q, n * sizeof(double), hipMemcpyDeviceToHost, stream);
             if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -840,6 +1134,7 @@ void rr_plan_destroy(rr_plan *P)
     if (!P) return;
     if (P->device >= 0 && hipSetDevice(P->device) == hipSuccess) {
         void *ptrs[] = {P->d_child_ptr, P->d_lag, P->d_perm, P->d_inv, P->d_inner_pos, P->d_bidx, P->d_hwc, P->d_w, P->d_c2,
+                        P->d_c1row, P->d_sq, P->d_ss, P->d_si, P->d_hist,
                         P->d_c3, P->d_c4, P->d_x, P->d_isum, P->d_qch, P->d_ring, P->d_stage, P->d_mrows,
                         P->d_slot_a[0], P->d_slot_a[1], P->d_slot_b[0], P->d_slot_b[1], P->d_m_index[0], P->d_m_index[1]};
         for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -858,9 +1153,22 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
     if (!P) return fail(RR_E_ALLOC, "rr_plan_create: out of memory");
     if (const char *e = getenv("RR_CHUNK_ROWS")) P->chunk_rows = std::max(1, atoi(e));        // tuning knobs
     if (const char *e = getenv("RR_PERM_ROWS_PER_BLOCK")) P->perm_rows_per_block = std::max(1, atoi(e));
+    if (const char *e = getenv("RR_WAVE")) P->wave_enabled = atoi(e) != 0;
+    if (const char *e = getenv("RR_WAVE_K")) P->wave_K = std::max(1, atoi(e));
     std::string err;
     int rc = rr::build_host_plan(n, csc_indptr, csc_indices, P->h, err);
     if (rc) { delete P; return fail(rc, err); }
+    {   // time-tiled schedule: smallest block (PPT * 1024 positions) that keeps the block count at or below one per CU
+        int ppt = 1;
+        while (ppt < 4 && (n + (int64_t)ppt * kWaveThreads - 1) / ((int64_t)ppt * kWaveThreads) > 256) ppt *= 2;
+        if (const char *e = getenv("RR_WAVE_PPT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) ppt = v; }
+        P->wave_ppt = ppt;
+        const int64_t bs = (int64_t)ppt * kWaveThreads;
+        P->wave_nb = (n + bs - 1) / bs;
+        int64_t jmax = 0;
+        for (int64_t b = 0; b < P->wave_nb; ++b) jmax = std::max(jmax, b - (int64_t)P->h.child_ptr[b * bs] / bs);
+        P->wave_jmax = jmax;
+    }
     if (device != RR_DEVICE_NONE) {
         int count = rr_device_count();
         if (device < 0 || device >= count) {
@@ -880,6 +1188,10 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         if (!rc) rc = dev_alloc(&P->d_inner_pos, ni);
         if (!rc) rc = dev_alloc(&P->d_hwc, n);
         if (!rc) rc = dev_alloc(&P->d_bidx, n);
+        if (!rc) rc = dev_alloc(&P->d_c1row, n);
+        if (!rc) rc = dev_alloc(&P->d_sq, n);
+        if (!rc) rc = dev_alloc(&P->d_ss, n);
+        if (!rc) rc = dev_alloc(&P->d_si, n);
         if (!rc) rc = dev_alloc(&P->d_w, n);
         if (!rc) rc = dev_alloc(&P->d_c2, n);
         if (!rc) rc = dev_alloc(&P->d_c3, n);
@@ -955,7 +1267,18 @@ int rr_plan_set_coeffs(rr_plan *P, const double *lhs_off_data, const double *c2,
         a3[p] = c3[i];
         if (c4_dt) a4[p] = c4_dt[i];
     }
+    // the time-tiled kernel keeps ONE upstream weight per reach; per-edge weights (never produced by the
+    // reference's callers) fall back to the streaming kernel
+    std::vector<double> c1row(n, 0.0);
+    bool uniform = true;
+    for (int64_t p = 0; p < n; ++p) {
+        const int32_t u0 = H.child_ptr[p], u1 = H.child_ptr[p + 1];
+        if (u1 > u0) c1row[p] = w[u0];
+        for (int32_t u = u0 + 1; u < u1; ++u) if (w[u] != w[u0]) uniform = false;
+    }
+    P->weights_uniform = uniform;
     rc = dev_upload(P->d_w, w);
+    if (!rc) rc = dev_upload(P->d_c1row, c1row);
     if (!rc) rc = dev_upload(P->d_c2, a2);
     if (!rc) rc = dev_upload(P->d_c3, a3);
     if (!rc) rc = dev_upload(P->d_c4, a4);
@@ -1042,11 +1365,13 @@ int rr_stream_begin(rr_plan *P, int has_lateral, const double *q_t, const double
     if (P->h.n > 0 && T > 0 && (!q_t || !discharge || out_rows < 1 || (has_lateral && (!lateral || lat_rows < 1))))
         return fail(RR_E_INVALID, "rr_stream_begin: null array or empty row count");
     Rows io; io.dev_in = has_lateral ? lateral : nullptr; io.rows_in = lat_rows; io.dev_out = discharge; io.rows_out = out_rows;
-    rc = session_begin(P, has_lateral ? Mode::Rapid : Mode::Muskingum, T, nsub, io, (hipStream_t)stream, ghost_series,
-                       export_series);
-    if (rc) return rc;
-    if (P->h.n > 0 && T > 0) launch_state_in(P, q_t, (hipStream_t)stream);
-    return RR_OK;
+    const Mode mode = has_lateral ? Mode::Rapid : Mode::Muskingum;
+    if (P->ses.open) return fail(RR_E_STATE, "a routing call is already open on this plan (rr_stream_end it first)");
+    if (P->h.n > 0 && T > 0) {
+        rc = launch_state_in(P, mode, q_t, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return session_begin(P, mode, T, nsub, io, (hipStream_t)stream, ghost_series, export_series);
 }
 
 int rr_stream_advance(rr_plan *P, int64_t lateral_rows_ready, int64_t ghost_substeps_ready, int64_t *export_substeps_ready)
@@ -1064,7 +1389,7 @@ int rr_stream_end(rr_plan *P, double *q_t)
     hipStream_t stream = P->ses.stream;
     rc = session_end(P);
     if (rc) return rc;
-    if (P->h.n > 0 && total > 0 && q_t) launch_state_out(P, q_t, total, stream);
+    if (P->h.n > 0 && total > 0 && q_t) launch_state_out(P, P->ses.mode, q_t, total, stream);
     return RR_OK;
 }
 
