@@ -114,14 +114,20 @@ def main():
 
     if not torch.cuda.is_available() or _lib.device_count() < 1:
         raise SystemExit('bench.py needs a GPU: the HIP engine has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # one rank per GPU; RR_DIST_BACKEND=gloo lets several ranks share one card for a rehearsal on a 1-GPU box
+    backend = os.environ.get('RR_DIST_BACKEND', 'nccl')
+    device_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device_index)
+    dev = torch.device('cuda', device_index)
     if world > 1:
-        dist.init_process_group('nccl', device_id=dev)
-    if world > 1:
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
         from river_route_amd import multi_gpu
-        multi_gpu.bench_main(args, rank, local_rank, world)
+        multi_gpu.bench_main(args, rank, device_index, world)
         return
+    local_rank = device_index
 
     n, T, nsub, dt = args.reaches, args.runoff_steps, args.substeps, 900.0
     net = synth.synth_network(n, order=args.order)

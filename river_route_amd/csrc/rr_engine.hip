@@ -299,7 +299,6 @@ __global__ __launch_bounds__(kBlock) void k_unit_state_out(double *q_ch, double 
 //     ring hist[tick % hist_rows][p] and its right neighbour reads them one tick later.
 // Task (block b, tick-chunk c) needs (b-1, c) (halo) and (b, c-1) (own state): all tasks on one anti-diagonal
 // b + c are independent, so there is ONE LAUNCH PER DIAGONAL and still no inter-workgroup synchronisation.
-constexpr int kWaveThreads = 1024;
 
 struct WaveArgs {
     const int32_t *child_ptr, *lag;
@@ -310,24 +309,31 @@ struct WaveArgs {
     double *out;
     int64_t in_ld, out_ld;
     uint32_t in_rows, out_rows;
-    int32_t n, hist_rows, K, b_first;
+    int32_t n, hist_rows, K, b_first, lh;   // lh: LDS positions per tick buffer (halo capacity + block)
     int64_t diag, total;
     uint32_t nsub;
     double inv_nsub;
 };
 
-template <int PPT, bool SINGLE_SUBSTEP>
-__global__ __launch_bounds__(kWaveThreads) void k_wave(const WaveArgs a)
+// LDS-only workgroup barrier: waits for this wave's LDS traffic, not for its global loads/stores, so the
+// lateral/halo prefetches stay in flight across ticks (__syncthreads() would drain vmcnt every tick).
+__device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// PPT positions per thread; HPT halo values per thread (halo <= HPT * 1024 positions); two ticks of HBM
+// prefetch in flight (stages A/B, the tick loop is unrolled by two so the stage registers are static).
+template <int TH, int PPT, int HPT, bool SINGLE_SUBSTEP>
+__global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];   // [2][BS]
-    constexpr int BS = PPT * kWaveThreads;
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // [2][lh]: positions [h0, b1) of one tick
+    constexpr int BS = PPT * TH;
     const int tid = threadIdx.x;
     const int32_t b = a.b_first + (int32_t)blockIdx.x;
     const int64_t chunk = a.diag - b;
     const int32_t b0 = b * BS, b1 = min(a.n, b0 + BS);
-    // positions whose downstream reach lies in a block to the right publish to the history ring
-    const int32_t halo_lo = max(b0, a.child_ptr[b1]);
-    auto position = [&](int k) { return b0 + k * kWaveThreads + tid; };
+    const int32_t h0 = min(a.child_ptr[b0], b0);          // first halo position (upstream reaches left of the block)
+    const int32_t nh = b0 - h0;
+    const int32_t halo_lo = max(b0, a.child_ptr[b1]);     // own positions read by blocks to the right
+    auto position = [&](int k) { return b0 + k * TH + tid; };
 
     int32_t lg[PPT], u0[PPT], u1[PPT];
     double c1[PPT], c2[PPT], c3[PPT], c4[PPT], q[PPT], s_prev[PPT], isum[SINGLE_SUBSTEP ? 1 : PPT];
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(kWaveThreads) void k_wave(const WaveArgs a)
     for (int k = 0; k < PPT; ++k) {
         const int32_t p = position(k);
         if (p < b1) {
-            lg[k] = a.lag[p] & kLagMask; u0[k] = a.child_ptr[p]; u1[k] = a.child_ptr[p + 1];
+            lg[k] = a.lag[p] & kLagMask; u0[k] = a.child_ptr[p] - h0; u1[k] = a.child_ptr[p + 1] - h0;
             c1[k] = a.c1row[p]; c2[k] = a.c2[p]; c3[k] = a.c3[p]; c4[k] = a.in ? a.c4[p] : 0.0;
             q[k] = a.sq[p]; s_prev[k] = a.ss[p];
             if (!SINGLE_SUBSTEP) isum[k] = a.si[p];
@@ -344,49 +350,53 @@ __global__ __launch_bounds__(kWaveThreads) void k_wave(const WaveArgs a)
             if (!SINGLE_SUBSTEP) isum[k] = 0.0;
         }
     }
-    const int64_t tau0 = chunk * a.K;
-    {   // the block's discharges one tick back
-        double *buf = lds + (size_t)((tau0 + 1) & 1) * BS;
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) buf[k * kWaveThreads + tid] = q[k];
-    }
-    // what tick tau needs from HBM does not depend on tick tau-1: fetch it one tick ahead
-    auto fetch = [&](int64_t tau, double (&lat)[PPT], double (&halo)[PPT]) {
-        const double *hrow = a.hist + (int64_t)((uint64_t)(tau - 1 + a.hist_rows) % (uint32_t)a.hist_rows) * a.n;
+    const int64_t tau0 = chunk * a.K, tau_end = tau0 + a.K;
+
+    // Prefetches are branch-free (addresses are clamped to something valid, the value is ignored where it does
+    // not apply) and nothing touches the loaded registers until the tick that consumes them, so hipcc leaves the
+    // loads in flight across the barriers instead of waiting right behind each one.
+    const double *lat_base = a.in ? a.in : a.sq;     // channel-only routing: any readable array, c4 is zero
+    const uint32_t lat_rows = a.in ? a.in_rows : 1u;
+    const int64_t lat_ld = a.in ? a.in_ld : 0;
+    auto fetch_lat = [&](int64_t tau, double (&lat)[PPT]) {     // lateral of the row each reach is at
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            lat[k] = 0.0; halo[k] = 0.0;
-            if (lg[k] < 0) continue;
-            const int64_t ts = tau - lg[k];
-            if (a.in && ts >= 0 && ts < a.total) {
-                const uint32_t t = SINGLE_SUBSTEP ? (uint32_t)ts : (uint32_t)((uint64_t)ts / a.nsub);
-                lat[k] = a.in[(int64_t)(t % a.in_rows) * a.in_ld + position(k)];
-            }
-            const int32_t ue = min(u1[k], b0);
-            for (int32_t u = u0[k]; u < ue; ++u) halo[k] += hrow[u];
+            int64_t ts = tau - (lg[k] < 0 ? 0 : lg[k]);
+            ts = ts < 0 ? 0 : (ts >= a.total ? a.total - 1 : ts);
+            const uint32_t t = SINGLE_SUBSTEP ? (uint32_t)ts : (uint32_t)((uint64_t)ts / a.nsub);
+            lat[k] = lat_base[(int64_t)(t % lat_rows) * lat_ld + min(position(k), b1 - 1)];
         }
     };
-    double lat_cur[PPT], halo_cur[PPT], lat_nxt[PPT], halo_nxt[PPT];
-    fetch(tau0, lat_cur, halo_cur);
-    __syncthreads();
-
-    for (int64_t tau = tau0; tau < tau0 + a.K; ++tau) {
-        if (tau + 1 < tau0 + a.K) fetch(tau + 1, lat_nxt, halo_nxt);
-        const double *rd = lds + (size_t)((tau + 1) & 1) * BS;   // values of tick tau-1
-        double *wr = lds + (size_t)(tau & 1) * BS;
+    auto fetch_halo = [&](int64_t tau, double (&h)[HPT]) {      // the left neighbours' values of tick tau
+        const double *hrow = a.hist + (int64_t)((uint64_t)(tau + a.hist_rows) % (uint32_t)a.hist_rows) * a.n + h0;
+#pragma unroll
+        for (int j = 0; j < HPT; ++j) {
+            const int32_t i = j * TH + tid;
+            h[j] = hrow[i < nh ? i : 0];
+        }
+    };
+    auto put_halo = [&](double *buf, const double (&h)[HPT]) {
+#pragma unroll
+        for (int j = 0; j < HPT; ++j) {
+            const int32_t i = j * TH + tid;
+            if (i < nh) buf[i] = h[j];
+        }
+    };
+    auto tick = [&](int64_t tau, const double (&lat)[PPT], const double (&h)[HPT]) {
+        const double *rd = lds + (size_t)((tau + 1) & 1) * a.lh;   // values of tick tau-1
+        double *wr = lds + (size_t)(tau & 1) * a.lh;
         double *hrow = a.hist + (int64_t)((uint64_t)tau % (uint32_t)a.hist_rows) * a.n;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             if (lg[k] < 0) continue;
             const int32_t p = position(k);
-            double s_cur = halo_cur[k];
-            for (int32_t u = max(u0[k], b0); u < u1[k]; ++u) s_cur += rd[u - b0];
+            double s_cur = 0.0;
+            for (int32_t u = u0[k]; u < u1[k]; ++u) s_cur += rd[u];
             const int64_t ts = tau - lg[k];
             if (ts >= 0 && ts < a.total) {
-                double r = c3[k] * q[k];
-                r += c4[k] * lat_cur[k];
-                r += c2[k] * s_prev[k];
-                r += c1[k] * s_cur;
+                // explicit fma: the unrolled copies of this tick must round identically (split run == joint run)
+                const double r = __builtin_fma(c1[k], s_cur, __builtin_fma(c2[k], s_prev[k],
+                                 __builtin_fma(c4[k], lat[k], c3[k] * q[k])));
                 q[k] = r;
                 if (SINGLE_SUBSTEP) {
                     a.out[(int64_t)((uint32_t)ts % a.out_rows) * a.out_ld + p] = r > 0.0 ? r : 0.0;
@@ -402,12 +412,40 @@ __global__ __launch_bounds__(kWaveThreads) void k_wave(const WaveArgs a)
                 }
             }
             s_prev[k] = s_cur;
-            wr[k * kWaveThreads + tid] = q[k];
+            wr[nh + k * TH + tid] = q[k];
             if (p >= halo_lo) hrow[p] = q[k];
         }
+        put_halo(wr, h);
+    };
+
+    // Three register stages, each fetched two ticks before it is consumed and BEFORE the tick in between issues
+    // its stores: vmcnt retires in order, so a wait for stage s only has to cover ops older than the two younger
+    // fetches and never the stores of the tick just finished.
+    double lat0[PPT], lat1[PPT], lat2[PPT], h0v[HPT], h1v[HPT], h2v[HPT];
+    {   // tick tau0 reads the buffer of tick tau0 - 1: own discharges + the halo row of that tick
+        double *buf = lds + (size_t)((tau0 + 1) & 1) * a.lh;
+        fetch_halo(tau0 - 1, h0v);
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) { lat_cur[k] = lat_nxt[k]; halo_cur[k] = halo_nxt[k]; }
-        __syncthreads();
+        for (int k = 0; k < PPT; ++k) buf[nh + k * TH + tid] = q[k];
+        put_halo(buf, h0v);
+    }
+    fetch_lat(tau0, lat0); fetch_halo(tau0, h0v);
+    fetch_lat(tau0 + 1, lat1); fetch_halo(tau0 + 1, h1v);     // rows past the chunk are clamped, never used
+    barrier_lds();
+    for (int64_t tau = tau0; tau < tau_end; tau += 3) {
+        fetch_lat(tau + 2, lat2); fetch_halo(tau + 2, h2v);
+        tick(tau, lat0, h0v);
+        barrier_lds();
+        if (tau + 1 < tau_end) {
+            fetch_lat(tau + 3, lat0); fetch_halo(tau + 3, h0v);
+            tick(tau + 1, lat1, h1v);
+        }
+        barrier_lds();
+        if (tau + 2 < tau_end) {
+            fetch_lat(tau + 4, lat1); fetch_halo(tau + 4, h1v);
+            tick(tau + 2, lat2, h2v);
+        }
+        barrier_lds();
     }
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
@@ -561,8 +599,8 @@ struct rr_plan {
 
     // time-tiled routing (k_wave)
     bool wave_enabled = true, weights_uniform = false;
-    int wave_ppt = 4;
-    int64_t wave_K = 16, wave_nb = 0, wave_jmax = 0;
+    int wave_threads = 512, wave_ppt = 4, wave_hpt = 4;
+    int64_t wave_K = 16, wave_nb = 0, wave_jmax = 0, wave_lh = 0;
     double *d_c1row = nullptr, *d_sq = nullptr, *d_ss = nullptr, *d_si = nullptr, *d_hist = nullptr;
     int64_t hist_cap = 0;
 
@@ -577,7 +615,7 @@ struct rr_plan {
     std::vector<hipEvent_t> ev;
     std::vector<int64_t> ev_reaches;
     hipEvent_t ev_first = nullptr, ev_last = nullptr;
-    int64_t prof_launches = 0, prof_samples = 0, prof_reach_steps = 0;
+    int64_t prof_launches = 0, prof_samples = 0, prof_brackets = 0, prof_reach_steps = 0;
     hipStream_t last_stream = nullptr;
 };
 
@@ -651,7 +689,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
     S.direct = H.identity && !host_io;   // engine order == params order: stream the caller's arrays
     const int64_t C = std::max<int64_t>(1, P->chunk_rows);
 
-    P->prof_launches = P->prof_samples = 0;
+    P->prof_launches = P->prof_samples = P->prof_brackets = 0;
     P->prof_reach_steps = n * S.total;
     P->ev_reaches.clear();
     P->last_stream = stream;
@@ -695,6 +733,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         w.child_ptr = P->d_child_ptr; w.lag = P->d_lag; w.c1row = P->d_c1row; w.c2 = P->d_c2; w.c3 = P->d_c3; w.c4 = P->d_c4;
         w.sq = P->d_sq; w.ss = P->d_ss; w.si = P->d_si; w.hist = P->d_hist; w.hist_rows = (int32_t)wave_hist_rows(P);
         w.in = a.in; w.out = a.out; w.in_ld = a.in_ld; w.out_ld = a.out_ld; w.in_rows = a.in_rows; w.out_rows = a.out_rows;
+        w.lh = (int32_t)P->wave_lh;
         w.n = (int32_t)n; w.K = (int32_t)P->wave_K; w.total = S.total; w.nsub = (uint32_t)nsub; w.inv_nsub = 1.0 / (double)nsub;
         if (!P->d_hist || P->hist_cap < (int64_t)w.hist_rows * n) { S.open = false; return fail(RR_E_STATE, "time-tiled routing: history ring not initialised"); }
     }
@@ -780,8 +819,8 @@ int session_launch_tick(rr_plan *P, int64_t tau)
     // sampling: every sample_every-th launch opens a bracket of kSampleGroup consecutive launches, so the
     // event overhead (~5 us per pair) is amortised and the figure is comparable with rocprofv3's per-kernel time
     const int64_t phase = S.max_samples > 0 ? P->prof_launches % P->sample_every : -1;
-    if (phase == 0 && !S.bracket_open && (size_t)(P->prof_samples / kSampleGroup) < S.max_samples) {
-        HIPCHK(hipEventRecord(P->ev[2 * (P->prof_samples / kSampleGroup)], S.stream));
+    if (phase == 0 && !S.bracket_open && (size_t)P->prof_brackets < S.max_samples) {
+        HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets], S.stream));
         S.bracket_open = true;
     }
     const dim3 g = grid1(p_hi - p_lo);
@@ -802,7 +841,8 @@ int session_launch_tick(rr_plan *P, int64_t tau)
         S.bracket_reaches += p_hi - p_lo;
         ++P->prof_samples;
         if (P->prof_samples % kSampleGroup == 0) {
-            HIPCHK(hipEventRecord(P->ev[2 * (P->prof_samples / kSampleGroup) - 1], S.stream));
+            HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));
+            ++P->prof_brackets;
             P->ev_reaches.push_back(S.bracket_reaches);
             S.bracket_reaches = 0;
             S.bracket_open = false;
@@ -810,6 +850,23 @@ int session_launch_tick(rr_plan *P, int64_t tau)
     }
     ++P->prof_launches;
     return RR_OK;
+}
+
+typedef void (*wave_kernel_t)(const WaveArgs);
+
+// Block = threads * ppt positions, halo capacity = threads * hpt.  Two shapes are built:
+//   1024 threads x {1,2} positions (16 waves, latency hidden by occupancy) and
+//    512 threads x {2,4} positions (8 waves, up to 256 VGPRs: latency hidden by the prefetch stages).
+wave_kernel_t wave_kernel(int threads, int ppt, int hpt, bool one)
+{
+#define RR_WAVE_PICK(T_, P_, H_) (one ? (wave_kernel_t)k_wave<T_, P_, H_, true> : (wave_kernel_t)k_wave<T_, P_, H_, false>)
+    if (threads == 1024) {
+        if (hpt <= 2) return ppt == 1 ? RR_WAVE_PICK(1024, 1, 2) : RR_WAVE_PICK(1024, 2, 2);
+        return ppt == 1 ? RR_WAVE_PICK(1024, 1, 4) : RR_WAVE_PICK(1024, 2, 4);
+    }
+    if (hpt <= 4) return ppt == 2 ? RR_WAVE_PICK(512, 2, 4) : RR_WAVE_PICK(512, 4, 4);
+    return ppt == 2 ? RR_WAVE_PICK(512, 2, 8) : RR_WAVE_PICK(512, 4, 8);
+#undef RR_WAVE_PICK
 }
 
 // One anti-diagonal of the time-tiled schedule: tasks (block b, chunk diag - b) for every block whose chunk exists.
@@ -824,31 +881,18 @@ int session_launch_diag(rr_plan *P, int64_t d)
     // a launch is sampled when every block takes part and every reach is active for all K ticks of its task
     const int64_t dmax = P->h.depth - 1;
     const bool full = b_lo == 0 && b_hi == nb - 1 && (d - (nb - 1)) * K >= dmax && (d + 1) * K <= S.total;
-    const bool sample = S.max_samples > 0 && full && (P->prof_launches % 8) == 0 &&
-                        (size_t)(P->prof_samples / K) < S.max_samples;
-    if (sample) HIPCHK(hipEventRecord(P->ev[2 * (P->prof_samples / K)], S.stream));
+    const bool sample = S.max_samples > 0 && full && (P->prof_launches % 8) == 0 && (size_t)P->prof_brackets < S.max_samples;
+    if (sample) HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets], S.stream));
     const dim3 g((unsigned)(b_hi - b_lo + 1));
-    const size_t lds_bytes = (size_t)2 * P->wave_ppt * kWaveThreads * sizeof(double);
-    const bool one = S.nsub == 1;
-    const dim3 t(kWaveThreads);
-    switch (P->wave_ppt) {
-        case 1:
-            if (one) hipLaunchKernelGGL((k_wave<1, true>), g, t, lds_bytes, S.stream, w);
-            else hipLaunchKernelGGL((k_wave<1, false>), g, t, lds_bytes, S.stream, w);
-            break;
-        case 2:
-            if (one) hipLaunchKernelGGL((k_wave<2, true>), g, t, lds_bytes, S.stream, w);
-            else hipLaunchKernelGGL((k_wave<2, false>), g, t, lds_bytes, S.stream, w);
-            break;
-        default:
-            if (one) hipLaunchKernelGGL((k_wave<4, true>), g, t, lds_bytes, S.stream, w);
-            else hipLaunchKernelGGL((k_wave<4, false>), g, t, lds_bytes, S.stream, w);
-            break;
-    }
+    const size_t lds_bytes = (size_t)2 * P->wave_lh * sizeof(double);
+    const dim3 t((unsigned)P->wave_threads);
+    wave_kernel_t fn = wave_kernel(P->wave_threads, P->wave_ppt, P->wave_hpt, S.nsub == 1);
+    hipLaunchKernelGGL(fn, g, t, lds_bytes, S.stream, w);
     if (sample) {
-        HIPCHK(hipEventRecord(P->ev[2 * (P->prof_samples / K) + 1], S.stream));
+        HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));
         P->ev_reaches.push_back(n * K);
         P->prof_samples += K;
+        ++P->prof_brackets;
     }
     ++P->prof_launches;
     return RR_OK;
@@ -1158,16 +1202,31 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
     std::string err;
     int rc = rr::build_host_plan(n, csc_indptr, csc_indices, P->h, err);
     if (rc) { delete P; return fail(rc, err); }
-    {   // time-tiled schedule: smallest block (PPT * 1024 positions) that keeps the block count at or below one per CU
-        int ppt = 1;
-        while (ppt < 4 && (n + (int64_t)ppt * kWaveThreads - 1) / ((int64_t)ppt * kWaveThreads) > 256) ppt *= 2;
-        if (const char *e = getenv("RR_WAVE_PPT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) ppt = v; }
+    {   // time-tiled schedule: 2,048-position blocks (1,024 for small networks), see wave_kernel()
+        int threads = 1024;
+        if (const char *e = getenv("RR_WAVE_THREADS")) threads = atoi(e) == 512 ? 512 : 1024;
+        int ppt = threads == 1024 ? 2 : 4;
+        if (n <= 256 * 1024) ppt /= 2;
+        if (const char *e = getenv("RR_WAVE_PPT")) {
+            const int v = atoi(e);
+            if ((threads == 1024 && (v == 1 || v == 2)) || (threads == 512 && (v == 2 || v == 4))) ppt = v;
+        }
+        P->wave_threads = threads;
         P->wave_ppt = ppt;
-        const int64_t bs = (int64_t)ppt * kWaveThreads;
+        const int64_t bs = (int64_t)ppt * threads;
         P->wave_nb = (n + bs - 1) / bs;
-        int64_t jmax = 0;
-        for (int64_t b = 0; b < P->wave_nb; ++b) jmax = std::max(jmax, b - (int64_t)P->h.child_ptr[b * bs] / bs);
+        int64_t jmax = 0, halo_max = 0;
+        for (int64_t b = 0; b < P->wave_nb; ++b) {
+            const int64_t first_up = std::min<int64_t>(P->h.child_ptr[b * bs], b * bs);
+            jmax = std::max(jmax, b - first_up / bs);
+            halo_max = std::max(halo_max, b * bs - first_up);
+        }
         P->wave_jmax = jmax;
+        const int small = threads == 1024 ? 2 : 4;     // halo registers per thread: 2,048 or 4,096 positions
+        P->wave_hpt = halo_max <= (int64_t)small * threads ? small : 2 * small;
+        P->wave_lh = bs + (int64_t)P->wave_hpt * threads;
+        if (halo_max > (int64_t)2 * small * threads) P->wave_enabled = false;   // a level wider than the LDS halo: stream with k_tick
+        if (P->wave_K % 2) ++P->wave_K;
     }
     if (device != RR_DEVICE_NONE) {
         int count = rr_device_count();
@@ -1179,6 +1238,12 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) { delete P; return fail(RR_E_HIP, hipGetErrorString(e)); }
         P->device = device;
+        for (int one = 0; one < 2; ++one) {   // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
+            hipError_t ea = hipFuncSetAttribute((const void *)wave_kernel(P->wave_threads, P->wave_ppt, P->wave_hpt, one != 0),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)(2 * P->wave_lh * sizeof(double)));
+            if (ea != hipSuccess) P->wave_enabled = false;
+        }
         const rr::HostPlan &H = P->h;
         const int64_t ni = (int64_t)H.inner_pos.size();
         rc = dev_alloc(&P->d_child_ptr, n + 1);
@@ -1301,9 +1366,10 @@ int rr_plan_profile(rr_plan *P, double prof[8])
     HIPCHK(hipEventElapsedTime(&ms, P->ev_first, P->ev_last));
     prof[6] = ms;
     double sum = 0, mn = 1e300, mx = 0, reaches = 0;
-    for (int64_t k = 0; k < P->prof_samples / kSampleGroup; ++k) {
+    const double per = P->prof_brackets ? (double)P->prof_samples / (double)P->prof_brackets : 1.0;   // ticks per bracket
+    for (int64_t k = 0; k < P->prof_brackets; ++k) {
         HIPCHK(hipEventElapsedTime(&ms, P->ev[2 * k], P->ev[2 * k + 1]));
-        sum += ms; mn = std::min<double>(mn, ms / kSampleGroup); mx = std::max<double>(mx, ms / kSampleGroup);
+        sum += ms; mn = std::min<double>(mn, ms / per); mx = std::max<double>(mx, ms / per);
         reaches += (double)P->ev_reaches[k];
     }
     prof[1] = (double)P->prof_samples; prof[2] = sum; prof[3] = P->prof_samples ? mn : 0.0; prof[4] = mx;

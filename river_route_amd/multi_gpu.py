@@ -177,14 +177,15 @@ def run_distributed(engine, spec: PartSpec, T: int, nsub: int, chunk_rows: int, 
     """Serve one part's driver with torch.distributed point-to-point ops (nccl = RCCL on the GPU box, gloo on CPU).
     Rank == part.  Sends are asynchronous; their buffers are kept alive until the call ends."""
     pending = []
+    via_host = dist.get_backend() != 'nccl'     # gloo moves host memory: stage device tensors through the CPU
     for req in part_driver(engine, spec, T, nsub, chunk_rows):
         kind, peer, view, r0, r1 = req
         if kind == 'recv':
-            buf = view.new_empty(view.shape)
+            buf = view.new_empty(view.shape, device='cpu') if via_host else view.new_empty(view.shape)
             dist.recv(buf, src=peer)
             view.copy_(buf)
         else:
-            buf = view.contiguous()
+            buf = view.cpu().contiguous() if via_host else view.contiguous()
             pending.append((dist.isend(buf, dst=peer), buf))
     for work, _ in pending:
         work.wait()
@@ -268,13 +269,14 @@ def bench_main(args, rank: int, local_rank: int, world: int) -> None:
         one_pass()
     torch.cuda.synchronize()
     dist.barrier()
-    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=eng.dev)
+    cdev = eng.dev if dist.get_backend() == 'nccl' else torch.device('cpu')
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
 
     prof = eng.plan.profile()
     info = torch.tensor([float(spec.real_global.size), float(spec.n_ghost), float(eng.plan.depth)],
-                        dtype=torch.float64, device=eng.dev)
+                        dtype=torch.float64, device=cdev)
     gathered = [torch.zeros_like(info) for _ in range(world)]
     dist.all_gather(gathered, info)
     if rank == 0:

@@ -1,0 +1,80 @@
+"""The engine has three routing kernels behind one C ABI: the per-tick streaming kernel (k_tick), the time-tiled
+kernel (k_wave, default) and its 512-thread shape.  All must agree with the oracle; the choice is an
+RR_WAVE* environment knob read at plan creation."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_close
+from oracle import oracle
+from river_route_amd import synth
+from river_route_amd.engine import Plan
+
+pytestmark = pytest.mark.gpu
+
+
+def csc_from_down(down_index):
+    has = down_index >= 0
+    indptr = np.concatenate([[0], np.cumsum(has)]).astype(np.int32)
+    return indptr, down_index[has].astype(np.int32)
+
+
+@pytest.mark.parametrize('env', [{'RR_WAVE': '0'}, {'RR_WAVE_K': '4'}, {'RR_WAVE_K': '16', 'RR_WAVE_PPT': '1'},
+                                 {'RR_WAVE_THREADS': '512', 'RR_WAVE_K': '6'},
+                                 {'RR_WAVE_THREADS': '512', 'RR_WAVE_PPT': '2', 'RR_WAVE_K': '32'}])
+@pytest.mark.parametrize('n,T,nsub,has_lateral', [(60000, 70, 1, True), (60000, 23, 3, True), (60000, 31, 2, False)])
+def test_every_kernel_shape_matches_the_oracle(monkeypatch, env, n, T, nsub, has_lateral):
+    for k in ('RR_WAVE', 'RR_WAVE_K', 'RR_WAVE_PPT', 'RR_WAVE_THREADS'):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    net = synth.synth_network(n, seed=21)
+    indptr, indices = csc_from_down(net.down_index)
+    dt = 900.0
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, dt)
+    lhs = -c1[indices]
+    q0 = 5.0 * synth.u01(99, np.arange(n))
+    with Plan(indptr, indices) as plan:
+        if has_lateral:
+            c4_dt = (c1 + c2) / (dt * nsub)
+            ql = synth.synth_qlateral(n, 0, T, dt=dt * nsub)
+            plan.set_coeffs(lhs, c2, c3, c4_dt)
+            q_ref, d_ref = q0.copy(), np.zeros((T, n))
+            oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql, d_ref, nsub)
+            q, d = q0.copy(), np.zeros((T, n))
+            plan.rapid_route(q, ql, d, nsub)
+            # a second call continues from the state of the first (state hand-off between files)
+            q2_ref, d2_ref = q_ref.copy(), np.zeros((T, n))
+            oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q2_ref, ql, d2_ref, nsub)
+            q2, d2 = q.copy(), np.zeros((T, n))
+            plan.rapid_route(q2, ql, d2, nsub)
+            assert_close(q2, q2_ref, 'second call q_t')
+            assert_close(d2, d2_ref, 'second call discharge')
+        else:
+            plan.set_coeffs(lhs, c2, c3, None)
+            q_ref, d_ref = q0.copy(), np.zeros((T, n))
+            oracle.muskingum_route(indptr, indices, lhs, c2, c3, q_ref, d_ref, T, nsub)
+            q, d = q0.copy(), np.zeros((T, n))
+            plan.muskingum_route(q, d, T, nsub)
+        assert_close(q, q_ref, 'q_t')
+        assert_close(d, d_ref, 'discharge')
+
+
+def test_per_edge_weights_fall_back_to_the_streaming_kernel():
+    """lhs_off_data is per CSC entry in the reference's signature; non-uniform weights into one reach are honoured."""
+    n, T = 3000, 20
+    net = synth.synth_network(n, seed=2)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0)
+    lhs = -c1[indices] * (1.0 + 0.1 * synth.u01(5, np.arange(indices.size)))
+    c4_dt = (c1 + c2) / 900.0
+    ql = synth.synth_qlateral(n, 0, T)
+    q_ref, d_ref = np.zeros(n), np.zeros((T, n))
+    oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql, d_ref, 1)
+    with Plan(indptr, indices) as plan:
+        plan.set_coeffs(lhs, c2, c3, c4_dt)
+        q, d = np.zeros(n), np.zeros((T, n))
+        plan.rapid_route(q, ql, d, 1)
+    assert_close(q, q_ref, 'q_t')
+    assert_close(d, d_ref, 'discharge')
