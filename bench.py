@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0)
     ap.add_argument('--exchange-rows', type=int, default=128,
                     help='N>1: runoff steps per boundary-series message')
+    ap.add_argument('--workload', default='rapid', choices=['rapid', 'unit'],
+                    help="'unit' = BASELINE config 4 (UnitMuskingum + 48-step UH kernel); secondary line, not the headline")
+    ap.add_argument('--uh-steps', type=int, default=48)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--traffic-bytes-per-launch', type=float, default=None,
                     help='HBM bytes per routing-tick launch from a separate rocprofv3 --pmc run (profiles/)')
@@ -97,6 +100,90 @@ def cpu_baseline(net, indptr, indices, c1, c2, c3, dt, nsub, steps, seconds):
             'check_row': check_row}
 
 
+def bench_unit(args, device_index):
+    """BASELINE config 4: UnitMuskingum, 1M reaches, 48-step UH kernel.  One bench step = convolve + route one
+    block of runoff depths (default 3,504 steps = 1/10 year; the (T, n) depth block must be resident for the
+    convolution, 28 GB at 1M reaches)."""
+    import torch
+    from river_route_amd import synth
+    from river_route_amd.engine import Plan, uh_convolve_dev
+    n, nsub, dt, n_ks = args.reaches, args.substeps, 900.0, args.uh_steps
+    T = args.runoff_steps if args.runoff_steps != 35_040 else 3_504
+    dev = torch.device('cuda', device_index)
+    net = synth.synth_network(n, order=args.order)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = muskingum_coefficients(net.k, net.x, dt / nsub)
+    plan = Plan(indptr, indices, device=device_index)
+    plan.set_coeffs(-c1[indices], c2, c3, None)
+    plan.set_options(rows_per_chunk=args.chunk_rows, sample_every=args.sample_every)
+    kern_h = synth.synth_uh_kernel(n, n_ks, tr=dt)
+    kern = torch.from_numpy(kern_h).to(dev)
+    state = torch.zeros_like(kern)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    depth = torch.rand((T, n), dtype=torch.float64, device=dev, generator=g) * 1e-3
+    conv = torch.empty_like(depth)
+    out_rows = 96
+    out = torch.zeros((out_rows, n), dtype=torch.float64, device=dev)
+    n_inner = plan.n_inner
+    q_ch = torch.zeros(n_inner, dtype=torch.float64, device=dev)
+    q_full = torch.zeros(n_inner, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def one_pass():
+        state.zero_(); q_ch.zero_(); q_full.zero_()
+        uh_convolve_dev(kern, state, depth, conv, T, n_ks, n, device=device_index, stream=stream)
+        plan.unit_route_dev(q_ch, q_full, conv, T, out, out_rows, T, nsub, stream)
+
+    base = None
+    if not args.no_cpu_baseline:
+        from oracle import oracle
+        import tempfile
+        out_dir = tempfile.mkdtemp(prefix='rr_oracle_')
+        oracle.build(fast=True, out_dir=out_dir)
+        Tc = 64
+        d_h = depth[:Tc].cpu().numpy()
+        from tests_support import unit_split_arrays
+        hw_idx, inner_idx, A_in, A_hw = unit_split_arrays(indptr, indices, n)
+        c1i, c2i, c3i = c1[inner_idx], c2[inner_idx], c3[inner_idx]
+        uh = oracle.UnitHydrograph(kern_h)
+        t0 = time.perf_counter()
+        conv_h = uh.convolve(d_h)
+        qc, qf, dd = np.zeros(inner_idx.size), np.zeros(inner_idx.size), np.zeros((Tc, n))
+        oracle.unit_route(A_in.indptr, A_in.indices, -c1i[A_in.indices], A_in.indptr, A_in.indices, A_in.data,
+                          A_hw.indptr, A_hw.indices, A_hw.data, c1i, c2i, c3i, hw_idx, inner_idx, qc, qf, conv_h, dd,
+                          nsub, fast=True, out_dir=out_dir)
+        dt_s = time.perf_counter() - t0
+        base = {'value': n * Tc * nsub / dt_s, 'unit': 'reach-steps/s', 'cores': 1, 'kind': 'port',
+                'sample': f'{n} reaches x {Tc} runoff steps, direct-form convolution + unit_route, {dt_s:.2f} s, 1 thread'}
+        chk = torch.zeros((Tc, n), dtype=torch.float64, device=dev)
+        state.zero_(); q_ch.zero_(); q_full.zero_()
+        conv_c = torch.empty((Tc, n), dtype=torch.float64, device=dev)
+        uh_convolve_dev(kern, state, depth[:Tc].contiguous(), conv_c, Tc, n_ks, n, device=device_index, stream=stream)
+        plan.unit_route_dev(q_ch, q_full, conv_c, Tc, chk, Tc, Tc, nsub, stream)
+        torch.cuda.synchronize()
+        got = chk.cpu().numpy()
+        if not np.allclose(got, dd, rtol=1e-10, atol=1e-10 * np.abs(dd).max()):
+            raise SystemExit('bench.py: GPU UnitMuskingum result differs from the oracle; refusing to report a number')
+
+    for _ in range(args.warmup):
+        one_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    line = {'metric': 'reach-steps/sec', 'value': float(n) * T * nsub * args.steps / elapsed, 'unit': 'reach-steps/s',
+            'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'UnitMuskingum, {n}-reach synthetic network + {n_ks}-step UH kernel, {T} runoff steps, '
+                                   f'{nsub} sub-step(s), fp64, 1xMI355X (BASELINE config 4; convolution + routing)',
+                       'reaches': n, 'runoff_steps': T, 'uh_steps': n_ks, 'headwaters': plan.n_headwaters},
+            'roofline': None, 'cpu_baseline': base}
+    print(json.dumps(line))
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get('RANK', '0'))
@@ -129,6 +216,9 @@ def main():
         return
     local_rank = device_index
 
+    if args.workload == 'unit':
+        bench_unit(args, device_index)
+        return
     n, T, nsub, dt = args.reaches, args.runoff_steps, args.substeps, 900.0
     net = synth.synth_network(n, order=args.order)
     indptr, indices = csc_from_down(net.down_index)
@@ -174,19 +264,33 @@ def main():
     prof = plan.profile()      # HIP events of the last timed pass, on the engine's stream
     reach_steps = float(n) * T * nsub * args.steps
     bytes_per_reach_tick = BYTES_PER_REACH_SUBSTEP + BYTES_PER_REACH_ROW / nsub
+    # roofline of the dominant kernel: the routing kernel (k_wave: one launch = `ticks_per_launch` routing ticks over
+    # all reaches).  `achieved` prices the launch at the ALGORITHMIC bytes of SURVEY section 8(d) (streaming model,
+    # 88 B per reach-step at nsub=1), which a time-tiled kernel legitimately undercuts; `traffic` is what it
+    # really moved (separate rocprofv3 --pmc passes, profiles/r01_pmc_traffic.json; default shape at 1M reaches).
+    traffic = args.traffic_bytes_per_launch
+    if traffic is None and n == 1_000_000 and nsub == 1 and not any(k.startswith('RR_WAVE') for k in os.environ):
+        try:
+            with open(os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')) as f:
+                traffic = json.load(f)['kernels']['k_wave']['hbm_bytes']
+        except (OSError, KeyError, ValueError):
+            traffic = None
     roofline = None
     if prof['sampled'] > 0 and prof['sampled_ms'] > 0:
-        avg_ms = prof['sampled_ms'] / prof['sampled']
-        avg_reaches = prof['sampled_reaches'] / prof['sampled']
-        achieved = bytes_per_reach_tick * avg_reaches / (avg_ms * 1e-3) / 1e9
+        tpl = max(1, prof['ticks_per_launch'])
+        launches = prof['sampled'] / tpl                       # launches inside HIP-event brackets
+        avg_ms = prof['sampled_ms'] / launches
+        reach_ticks = prof['sampled_reaches'] / launches       # reach-steps one launch advances
+        alg_bytes = bytes_per_reach_tick * reach_ticks
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
         roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(achieved / HBM_PEAK_GBS, 4),
-                    'traffic': args.traffic_bytes_per_launch,
-                    'kernel': 'k_tick<lateral, 1 sub-step>' if nsub == 1 else 'k_tick<lateral, sub-steps>',
-                    'avg_launch_us': round(avg_ms * 1e3, 3), 'min_launch_us': round(prof['min_ms'] * 1e3, 3),
-                    'max_launch_us': round(prof['max_ms'] * 1e3, 3),
-                    'algorithmic_bytes_per_launch': round(bytes_per_reach_tick * avg_reaches),
-                    'launches_per_pass': prof['launches'], 'launches_sampled': prof['sampled'],
+                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                    'kernel': 'k_wave (time-tiled routing)' if tpl > 1 else 'k_tick (streaming routing)',
+                    'ticks_per_launch': tpl, 'avg_launch_us': round(avg_ms * 1e3, 3),
+                    'algorithmic_bytes_per_launch': round(alg_bytes),
+                    'compulsory_bytes_per_launch': round(16.0 / nsub * reach_ticks),
+                    'measured_hbm_gbps': None if traffic is None else round(traffic / (avg_ms * 1e-3) / 1e9, 1),
+                    'launches_per_pass': prof['launches'], 'launches_sampled': int(launches),
                     'pass_region_ms': round(prof['region_ms'], 3)}
     line = {
         'metric': 'reach-steps/sec', 'value': reach_steps / elapsed, 'unit': 'reach-steps/s',

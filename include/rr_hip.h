@@ -88,12 +88,13 @@ int rr_plan_set_coeffs(rr_plan *plan, const double *lhs_off_data, const double *
  * consecutive routing-tick launches on the call's stream (0 switches sampling off). */
 int rr_plan_set_options(rr_plan *plan, int64_t rows_per_chunk, int64_t sample_every);
 
-/* prof[0]=routing-tick launches of the last route call, [1]=launches inside brackets, [2]=sum of the bracket
+/* prof[0]=routing launches of the last route call, [1]=routing ticks inside brackets, [2]=sum of the bracket
  * durations (ms), [3]/[4]=smallest/largest per-launch mean of a bracket (ms), [5]=reaches updated by the
  * bracketed launches,
  * [6]=ms between the first and the last routing-step launch of the call (permutation passes included),
- * [7]=reach-steps of the call.  Synchronises the plan's last stream. */
-int rr_plan_profile(rr_plan *plan, double prof[8]);
+ * [7]=reach-steps of the call, [8]=number of brackets, [9]=routing ticks per launch (K of the time-tiled
+ * kernel, 1 for the streaming kernel).  Synchronises the plan's last stream. */
+int rr_plan_profile(rr_plan *plan, double prof[10]);
 
 /* ---- routing, host pointers (the reference's kernel boundary) ---- */
 

@@ -511,6 +511,46 @@ __global__ __launch_bounds__(kBlock) void k_uh_convolve(const double *__restrict
         if (t0 + j < T) out[(t0 + j) * n + i] = acc[j];
 }
 
+// Long-series form of the same convolution: one reach per lane walks its whole time segment once.  The kernel
+// column sits in registers (static indices: the tap loop is unrolled over the padded length NK), the last NK
+// lateral values in an LDS ring [slot][lane] (conflict-free), so HBM sees each lateral row and each output row
+// exactly once and the kernel taps once per segment -- k_uh_convolve re-reads the taps for every 8 rows.
+constexpr int kUhThreads = 128;
+
+template <int NK>   // power of two >= n_ks
+__global__ __launch_bounds__(kUhThreads) void k_uh_convolve_ring(const double *__restrict__ kernel,
+                                                                const double *__restrict__ state,
+                                                                const double *__restrict__ lateral,
+                                                                double *__restrict__ out, int64_t T, int32_t n_ks,
+                                                                int64_t n, int64_t seg_rows)
+{
+    extern __shared__ __attribute__((aligned(16))) double win[];   // [NK][kUhThreads]
+    const int tid = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kUhThreads + tid;
+    const int64_t t0 = (int64_t)blockIdx.y * seg_rows, t1 = min(T, t0 + seg_rows);
+    const bool live = i < n;
+    double kv[NK];
+#pragma unroll
+    for (int s = 0; s < NK; ++s) kv[s] = (live && s < n_ks) ? kernel[(int64_t)s * n + i] : 0.0;
+    // slot of lateral[t] is t & (NK - 1); preload the NK - 1 rows before the segment
+#pragma unroll
+    for (int s = 1; s < NK; ++s) {
+        const int64_t t = t0 - s;
+        win[(size_t)((uint64_t)t & (NK - 1)) * kUhThreads + tid] = (live && t >= 0 && s < n_ks) ? lateral[t * n + i] : 0.0;
+    }
+    double nxt = (live && t0 < t1) ? lateral[t0 * n + i] : 0.0;
+    for (int64_t t = t0; t < t1; ++t) {
+        const double cur = nxt;
+        if (t + 1 < t1 && live) nxt = lateral[(t + 1) * n + i];          // one row ahead
+        win[(size_t)((uint64_t)t & (NK - 1)) * kUhThreads + tid] = cur;
+        double acc = (live && t < n_ks) ? state[t * n + i] : 0.0;
+#pragma unroll
+        for (int s = 0; s < NK; ++s)
+            acc = __builtin_fma(kv[s], win[(size_t)((uint64_t)(t - s) & (NK - 1)) * kUhThreads + tid], acc);
+        if (live) out[t * n + i] = acc;
+    }
+}
+
 // Carry-over tail: new_state[s, i] = buf[T + s, i] for s < n_ks - 1, 0 for s = n_ks - 1 (lines 103-105), where
 // buf[m] = sum_{s'} kernel[s'] lateral[m - s'] (+ state[m] when m < n_ks).
 __global__ __launch_bounds__(kBlock) void k_uh_tail(const double *__restrict__ kernel,
@@ -1140,9 +1180,30 @@ int uh_convolve_core(const double *d_kernel, double *d_state, const double *d_la
     double *d_tail = nullptr;
     int rc = dev_alloc(&d_tail, n_ks * n);
     if (rc) return rc;
-    dim3 g((unsigned)((n + kBlock - 1) / kBlock), (unsigned)((T + TB - 1) / TB));
-    hipLaunchKernelGGL(k_uh_convolve<TB>, g, dim3(kBlock), 0, stream, d_kernel, (const double *)d_state, d_lateral,
-                       d_out, T, (int32_t)n_ks, n);
+    if (n_ks <= 64 && T >= 64) {
+        // long series: register-resident taps + LDS window; split time only as far as needed to fill the chip
+        const int64_t blocks_x = (n + kUhThreads - 1) / kUhThreads;
+        int64_t segs = std::max<int64_t>(1, std::min<int64_t>(T / 256, (2048 + blocks_x - 1) / blocks_x));
+        const int64_t seg_rows = (T + segs - 1) / segs;
+        segs = (T + seg_rows - 1) / seg_rows;
+        dim3 g((unsigned)blocks_x, (unsigned)segs);
+#define RR_UH_LAUNCH(NK_)                                                                                          \
+        do {                                                                                                       \
+            const size_t lds = (size_t)NK_ * kUhThreads * sizeof(double);                                          \
+            (void)hipFuncSetAttribute((const void *)k_uh_convolve_ring<NK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL(k_uh_convolve_ring<NK_>, g, dim3(kUhThreads), lds, stream, d_kernel, (const double *)d_state,       \
+                               d_lateral, d_out, T, (int32_t)n_ks, n, seg_rows);                                   \
+        } while (0)
+        if (n_ks <= 8) RR_UH_LAUNCH(8);
+        else if (n_ks <= 16) RR_UH_LAUNCH(16);
+        else if (n_ks <= 32) RR_UH_LAUNCH(32);
+        else RR_UH_LAUNCH(64);
+#undef RR_UH_LAUNCH
+    } else {
+        dim3 g((unsigned)((n + kBlock - 1) / kBlock), (unsigned)((T + TB - 1) / TB));
+        hipLaunchKernelGGL(k_uh_convolve<TB>, g, dim3(kBlock), 0, stream, d_kernel, (const double *)d_state, d_lateral,
+                           d_out, T, (int32_t)n_ks, n);
+    }
     dim3 gt((unsigned)((n + kBlock - 1) / kBlock), (unsigned)n_ks);
     hipLaunchKernelGGL(k_uh_tail, gt, dim3(kBlock), 0, stream, d_kernel, (const double *)d_state, d_lateral, d_tail,
                        T, (int32_t)n_ks, n);
@@ -1353,11 +1414,13 @@ int rr_plan_set_coeffs(rr_plan *P, const double *lhs_off_data, const double *c2,
     return RR_OK;
 }
 
-int rr_plan_profile(rr_plan *P, double prof[8])
+int rr_plan_profile(rr_plan *P, double prof[10])
 {
     if (!P || !prof) return fail(RR_E_INVALID, "rr_plan_profile: null argument");
-    for (int k = 0; k < 8; ++k) prof[k] = 0.0;
+    for (int k = 0; k < 10; ++k) prof[k] = 0.0;
     prof[0] = (double)P->prof_launches;
+    prof[8] = (double)P->prof_brackets;
+    prof[9] = P->ses.wave ? (double)P->wave_K : 1.0;
     prof[7] = (double)P->prof_reach_steps;
     if (P->device < 0 || !P->ev_first || P->prof_launches == 0) return RR_OK;
     HIPCHK(hipSetDevice(P->device));

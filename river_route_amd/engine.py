@@ -83,10 +83,11 @@ class Plan:
         check(_lib.lib().rr_plan_set_options(self._h, int(rows_per_chunk), int(sample_every)))
 
     def profile(self) -> dict:
-        p = np.zeros(8, dtype=np.float64)
+        p = np.zeros(10, dtype=np.float64)
         check(_lib.lib().rr_plan_profile(self._h, ptr(p)))
         return dict(launches=int(p[0]), sampled=int(p[1]), sampled_ms=float(p[2]), min_ms=float(p[3]),
-                    max_ms=float(p[4]), sampled_reaches=float(p[5]), region_ms=float(p[6]), reach_steps=float(p[7]))
+                    max_ms=float(p[4]), sampled_reaches=float(p[5]), region_ms=float(p[6]), reach_steps=float(p[7]),
+                    brackets=int(p[8]), ticks_per_launch=int(p[9]))
 
     # -- coefficients --
     def set_coeffs(self, lhs_off_data, c2, c3, c4_dt=None) -> None:

@@ -246,3 +246,49 @@ def test_initial_state_decays():
     assert diff[-1] < 1e-6
     assert np.abs(d_b - d_a).max(axis=1)[0] > 1.0
     plan.close()
+
+
+@pytest.mark.parametrize('n,T,n_ks', [(3000, 300, 48), (700, 1000, 5), (129, 64, 64), (5000, 200, 17), (40, 70, 33)])
+def test_long_series_convolution_vs_oracle(n, T, n_ks):
+    """The register/LDS-window kernel (T >= 64, n_ks <= 64), several time segments, carried state in and out."""
+    kern = synth.synth_uh_kernel(n, n_ks)
+    depth = synth.synth_runoff_depth(n, 0, T)
+    uh = oracle.UnitHydrograph(kern)
+    uh.state = 0.3 * kern[::-1].copy()
+    st = uh.state.copy()
+    ref_a = uh.convolve(depth[:T // 2])
+    ref_b = uh.convolve(depth[T // 2:])
+    got_a = uh_convolve(kern, st, depth[:T // 2])
+    got_b = uh_convolve(kern, st, depth[T // 2:])
+    assert_close(got_a, ref_a, 'first half')
+    assert_close(got_b, ref_b, 'second half (carried state)')
+    assert_close(st, uh.state, 'state')
+
+
+def test_unit_muskingum_1m_properties():
+    """BASELINE config 4 size: 1M reaches, 48-step kernel.  Headwater discharge equals the convolved lateral exactly
+    (_numba_kernels.py:122-123), outputs non-negative on inner reaches, first rows match the oracle."""
+    from conftest import unit_split
+    n, T, n_ks = 1_000_000, 12, 48
+    net = synth.synth_network(n)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = coeffs(net, 900.0)
+    kern = synth.synth_uh_kernel(n, n_ks)
+    depth = synth.synth_runoff_depth(n, 0, T)
+    st = np.zeros_like(kern)
+    conv = uh_convolve(kern, st, depth)
+    with Plan(indptr, indices) as plan:
+        plan.set_coeffs(-c1[indices], c2, c3, None)
+        q_ch, q_full, d = np.zeros(plan.n_inner), np.zeros(plan.n_inner), np.zeros((T, n))
+        plan.unit_route(q_ch, q_full, conv, d, 1)
+    hw_idx, inner_idx, A_in, A_hw = unit_split(indptr, indices, n)
+    np.testing.assert_array_equal(d[:, hw_idx], conv[:, hw_idx])
+    assert d[:, inner_idx].min() >= 0.0
+    c1i, c2i, c3i = c1[inner_idx], c2[inner_idx], c3[inner_idx]
+    uh = oracle.UnitHydrograph(kern)
+    conv_ref = uh.convolve(depth[:3])
+    qc, qf, d_ref = np.zeros(inner_idx.size), np.zeros(inner_idx.size), np.zeros((3, n))
+    oracle.unit_route(A_in.indptr, A_in.indices, -c1i[A_in.indices], A_in.indptr, A_in.indices, A_in.data,
+                      A_hw.indptr, A_hw.indices, A_hw.data, c1i, c2i, c3i, hw_idx, inner_idx, qc, qf, conv_ref, d_ref, 1)
+    assert_close(conv[:3], conv_ref, 'convolved')
+    assert_close(d[:3], d_ref, 'discharge')
