@@ -517,7 +517,7 @@ __global__ __launch_bounds__(kBlock) void k_uh_convolve(const double *__restrict
 // exactly once and the kernel taps once per segment -- k_uh_convolve re-reads the taps for every 8 rows.
 constexpr int kUhThreads = 128;
 
-template <int NK>   // power of two >= n_ks
+template <int NK>   // power of two >= n_ks + 3
 __global__ __launch_bounds__(kUhThreads) void k_uh_convolve_ring(const double *__restrict__ kernel,
                                                                 const double *__restrict__ state,
                                                                 const double *__restrict__ lateral,
@@ -525,29 +525,46 @@ __global__ __launch_bounds__(kUhThreads) void k_uh_convolve_ring(const double *_
                                                                 int64_t n, int64_t seg_rows)
 {
     extern __shared__ __attribute__((aligned(16))) double win[];   // [NK][kUhThreads]
+    constexpr int R = 4;                 // outputs per pass: every window value read from LDS feeds R accumulators
+    constexpr int NT = NK - (R - 1);     // taps held in registers
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * kUhThreads + tid;
     const int64_t t0 = (int64_t)blockIdx.y * seg_rows, t1 = min(T, t0 + seg_rows);
     const bool live = i < n;
-    double kv[NK];
+    const int64_t col = live ? i : 0;
+    double kv[NT];
 #pragma unroll
-    for (int s = 0; s < NK; ++s) kv[s] = (live && s < n_ks) ? kernel[(int64_t)s * n + i] : 0.0;
-    // slot of lateral[t] is t & (NK - 1); preload the NK - 1 rows before the segment
+    for (int s = 0; s < NT; ++s) kv[s] = (live && s < n_ks) ? kernel[(int64_t)s * n + col] : 0.0;
+    // slot of lateral[t] is t & (NK - 1); preload the rows before the segment
 #pragma unroll
-    for (int s = 1; s < NK; ++s) {
+    for (int s = 1; s < NT; ++s) {
         const int64_t t = t0 - s;
-        win[(size_t)((uint64_t)t & (NK - 1)) * kUhThreads + tid] = (live && t >= 0 && s < n_ks) ? lateral[t * n + i] : 0.0;
+        win[(size_t)((uint64_t)t & (NK - 1)) * kUhThreads + tid] = (t >= 0 && s < n_ks) ? lateral[t * n + col] : 0.0;
     }
-    double nxt = (live && t0 < t1) ? lateral[t0 * n + i] : 0.0;
-    for (int64_t t = t0; t < t1; ++t) {
-        const double cur = nxt;
-        if (t + 1 < t1 && live) nxt = lateral[(t + 1) * n + i];          // one row ahead
-        win[(size_t)((uint64_t)t & (NK - 1)) * kUhThreads + tid] = cur;
-        double acc = (live && t < n_ks) ? state[t * n + i] : 0.0;
+    double nxt[R];
 #pragma unroll
-        for (int s = 0; s < NK; ++s)
-            acc = __builtin_fma(kv[s], win[(size_t)((uint64_t)(t - s) & (NK - 1)) * kUhThreads + tid], acc);
-        if (live) out[t * n + i] = acc;
+    for (int j = 0; j < R; ++j) nxt[j] = lateral[min(t0 + j, T - 1) * n + col];
+    for (int64_t t = t0; t < t1; t += R) {
+        double acc[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            win[(size_t)((uint64_t)(t + j) & (NK - 1)) * kUhThreads + tid] = nxt[j];
+            acc[j] = (t + j < n_ks && t + j < T) ? state[(t + j) * n + col] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) nxt[j] = lateral[min(t + R + j, T - 1) * n + col];     // next pass, in flight
+        // window value m = t + R - 1 - d is tap (j + d - (R - 1)) of output t + j
+#pragma unroll
+        for (int d = 0; d < NT + R - 1; ++d) {
+            const double v = win[(size_t)((uint64_t)(t + (R - 1) - d) & (NK - 1)) * kUhThreads + tid];
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const int sidx = j + d - (R - 1);
+                if (sidx >= 0 && sidx < NT) acc[j] = __builtin_fma(kv[sidx], v, acc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) if (live && t + j < t1) out[(t + j) * n + i] = acc[j];
     }
 }
 
@@ -1180,7 +1197,7 @@ int uh_convolve_core(const double *d_kernel, double *d_state, const double *d_la
     double *d_tail = nullptr;
     int rc = dev_alloc(&d_tail, n_ks * n);
     if (rc) return rc;
-    if (n_ks <= 64 && T >= 64) {
+    if (n_ks <= 61 && T >= 64) {
         // long series: register-resident taps + LDS window; split time only as far as needed to fill the chip
         const int64_t blocks_x = (n + kUhThreads - 1) / kUhThreads;
         int64_t segs = std::max<int64_t>(1, std::min<int64_t>(T / 256, (2048 + blocks_x - 1) / blocks_x));
@@ -1194,9 +1211,9 @@ int uh_convolve_core(const double *d_kernel, double *d_state, const double *d_la
             hipLaunchKernelGGL(k_uh_convolve_ring<NK_>, g, dim3(kUhThreads), lds, stream, d_kernel, (const double *)d_state,       \
                                d_lateral, d_out, T, (int32_t)n_ks, n, seg_rows);                                   \
         } while (0)
-        if (n_ks <= 8) RR_UH_LAUNCH(8);
-        else if (n_ks <= 16) RR_UH_LAUNCH(16);
-        else if (n_ks <= 32) RR_UH_LAUNCH(32);
+        if (n_ks <= 5) RR_UH_LAUNCH(8);            // NK >= n_ks + 3 window slots
+        else if (n_ks <= 13) RR_UH_LAUNCH(16);
+        else if (n_ks <= 29) RR_UH_LAUNCH(32);
         else RR_UH_LAUNCH(64);
 #undef RR_UH_LAUNCH
     } else {
