@@ -275,23 +275,8 @@ def main():
                 traffic = json.load(f)['kernels']['k_wave']['hbm_bytes']
         except (OSError, KeyError, ValueError):
             traffic = None
-    roofline = None
-    if prof['sampled'] > 0 and prof['sampled_ms'] > 0:
-        tpl = max(1, prof['ticks_per_launch'])
-        launches = prof['sampled'] / tpl                       # launches inside HIP-event brackets
-        avg_ms = prof['sampled_ms'] / launches
-        reach_ticks = prof['sampled_reaches'] / launches       # reach-steps one launch advances
-        alg_bytes = bytes_per_reach_tick * reach_ticks
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        roofline = {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                    'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                    'kernel': 'k_wave (time-tiled routing)' if tpl > 1 else 'k_tick (streaming routing)',
-                    'ticks_per_launch': tpl, 'avg_launch_us': round(avg_ms * 1e3, 3),
-                    'algorithmic_bytes_per_launch': round(alg_bytes),
-                    'compulsory_bytes_per_launch': round(16.0 / nsub * reach_ticks),
-                    'measured_hbm_gbps': None if traffic is None else round(traffic / (avg_ms * 1e-3) / 1e9, 1),
-                    'launches_per_pass': prof['launches'], 'launches_sampled': int(launches),
-                    'pass_region_ms': round(prof['region_ms'], 3)}
+    from river_route_amd.multi_gpu import roofline_from_profile
+    roofline = roofline_from_profile(prof, nsub, traffic, HBM_PEAK_GBS)
     line = {
         'metric': 'reach-steps/sec', 'value': reach_steps / elapsed, 'unit': 'reach-steps/s',
         'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,

@@ -305,6 +305,10 @@ struct WaveArgs {
     const double *c1row, *c2, *c3, *c4;   // c1row: the (uniform) weight of a reach's upstream terms
     double *sq, *ss, *si;                 // carried state: discharge, sum of upstream discharges one tick back, interval sum
     double *hist;                         // [hist_rows, n]
+    const int32_t *bidx;                  // ghost / export slots (flag bits live in lag[])
+    const double *ghost;
+    double *exports;
+    int32_t n_ghost, n_export;
     const double *in;
     double *out;
     int64_t in_ld, out_ld;
@@ -335,13 +339,16 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
     const int32_t halo_lo = max(b0, a.child_ptr[b1]);     // own positions read by blocks to the right
     auto position = [&](int k) { return b0 + k * TH + tid; };
 
-    int32_t lg[PPT], u0[PPT], u1[PPT];
+    // lg keeps the ghost / export flag bits of lag[]; slot is the column of a flagged reach in its boundary series
+    int32_t lg[PPT], u0[PPT], u1[PPT], slot[PPT];
     double c1[PPT], c2[PPT], c3[PPT], c4[PPT], q[PPT], s_prev[PPT], isum[SINGLE_SUBSTEP ? 1 : PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int32_t p = position(k);
+        slot[k] = 0;
         if (p < b1) {
-            lg[k] = a.lag[p] & kLagMask; u0[k] = a.child_ptr[p] - h0; u1[k] = a.child_ptr[p + 1] - h0;
+            lg[k] = a.lag[p]; u0[k] = a.child_ptr[p] - h0; u1[k] = a.child_ptr[p + 1] - h0;
+            if (lg[k] & (kGhostBit | kExportBit)) slot[k] = a.bidx[p];
             c1[k] = a.c1row[p]; c2[k] = a.c2[p]; c3[k] = a.c3[p]; c4[k] = a.in ? a.c4[p] : 0.0;
             q[k] = a.sq[p]; s_prev[k] = a.ss[p];
             if (!SINGLE_SUBSTEP) isum[k] = a.si[p];
@@ -361,10 +368,12 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
     auto fetch_lat = [&](int64_t tau, double (&lat)[PPT]) {     // lateral of the row each reach is at
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            int64_t ts = tau - (lg[k] < 0 ? 0 : lg[k]);
+            int64_t ts = tau - (lg[k] < 0 ? 0 : (lg[k] & kLagMask));
             ts = ts < 0 ? 0 : (ts >= a.total ? a.total - 1 : ts);
             const uint32_t t = SINGLE_SUBSTEP ? (uint32_t)ts : (uint32_t)((uint64_t)ts / a.nsub);
-            lat[k] = lat_base[(int64_t)(t % lat_rows) * lat_ld + min(position(k), b1 - 1)];
+            const double *src = lat_base + (int64_t)(t % lat_rows) * lat_ld + min(position(k), b1 - 1);
+            if (lg[k] >= 0 && (lg[k] & kGhostBit)) src = a.ghost + ts * a.n_ghost + slot[k];   // prescribed boundary inflow
+            lat[k] = *src;
         }
     };
     auto fetch_halo = [&](int64_t tau, double (&h)[HPT]) {      // the left neighbours' values of tick tau
@@ -392,12 +401,15 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
             const int32_t p = position(k);
             double s_cur = 0.0;
             for (int32_t u = u0[k]; u < u1[k]; ++u) s_cur += rd[u];
-            const int64_t ts = tau - lg[k];
-            if (ts >= 0 && ts < a.total) {
+            const int64_t ts = tau - (lg[k] & kLagMask);
+            if (ts >= 0 && ts < a.total && (lg[k] & kGhostBit)) {
+                q[k] = lat[k];      // a ghost only republishes what its owner computed
+            } else if (ts >= 0 && ts < a.total) {
                 // explicit fma: the unrolled copies of this tick must round identically (split run == joint run)
                 const double r = __builtin_fma(c1[k], s_cur, __builtin_fma(c2[k], s_prev[k],
                                  __builtin_fma(c4[k], lat[k], c3[k] * q[k])));
                 q[k] = r;
+                if (lg[k] & kExportBit) a.exports[ts * a.n_export + slot[k]] = r;
                 if (SINGLE_SUBSTEP) {
                     a.out[(int64_t)((uint32_t)ts % a.out_rows) * a.out_ld + p] = r > 0.0 ? r : 0.0;
                 } else {
@@ -664,6 +676,7 @@ struct rr_plan {
     // boundary reaches of a partitioned network
     int64_t n_ghost = 0, n_export = 0;
     int64_t ghost_min_lag = 0, export_max_lag = 0;
+    int64_t wave_ghost_slack = 0, wave_export_skew = 0;   // the same bounds in the time-tiled schedule (block skew included)
     std::vector<int32_t> ghost_pos;   // engine positions of the ghosts, in the caller's ghost order
 
     Session ses;
@@ -722,8 +735,7 @@ int ensure_cap(T **buf, int64_t *cap, int64_t count)
 
 bool use_wave(const rr_plan *P, Mode mode)
 {
-    return P->wave_enabled && P->weights_uniform && mode != Mode::Unit && P->n_ghost == 0 && P->n_export == 0 &&
-           P->h.n > 0;
+    return P->wave_enabled && P->weights_uniform && mode != Mode::Unit && P->h.n > 0;
 }
 
 int64_t wave_hist_rows(const rr_plan *P) { return (P->wave_jmax + 2) * P->wave_K; }
@@ -789,6 +801,8 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         WaveArgs &w = S.wa;
         w.child_ptr = P->d_child_ptr; w.lag = P->d_lag; w.c1row = P->d_c1row; w.c2 = P->d_c2; w.c3 = P->d_c3; w.c4 = P->d_c4;
         w.sq = P->d_sq; w.ss = P->d_ss; w.si = P->d_si; w.hist = P->d_hist; w.hist_rows = (int32_t)wave_hist_rows(P);
+        w.bidx = P->d_bidx; w.ghost = ghost_series; w.exports = export_series;
+        w.n_ghost = (int32_t)P->n_ghost; w.n_export = (int32_t)P->n_export;
         w.in = a.in; w.out = a.out; w.in_ld = a.in_ld; w.out_ld = a.out_ld; w.in_rows = a.in_rows; w.out_rows = a.out_rows;
         w.lh = (int32_t)P->wave_lh;
         w.n = (int32_t)n; w.K = (int32_t)P->wave_K; w.total = S.total; w.nsub = (uint32_t)nsub; w.inv_nsub = 1.0 / (double)nsub;
@@ -955,7 +969,7 @@ int session_launch_diag(rr_plan *P, int64_t d)
     return RR_OK;
 }
 
-int session_advance_wave(rr_plan *P, int64_t rows_ready)
+int session_advance_wave(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, int64_t *export_ready)
 {
     Session &S = P->ses;
     const int64_t dmax = P->h.depth - 1, C = std::max<int64_t>(1, P->chunk_rows);
@@ -977,6 +991,9 @@ int session_advance_wave(rr_plan *P, int64_t rows_ready)
         while (S.diag < S.n_diags && launched < batch) {
             const int64_t need_ticks = std::min((S.diag + 1) * K, S.total);
             if (have_rows < S.T && have_rows * S.nsub < need_ticks) break;
+            // a ghost in block b at lag L is read for sub-steps below (diag - b + 1) * K - L
+            if (P->n_ghost > 0 && ghost_ready < S.total &&
+                ghost_ready < std::min((S.diag + 1) * K - P->wave_ghost_slack, S.total)) break;
             int rc = session_launch_diag(P, S.diag);
             if (rc) return rc;
             ++S.diag; ++launched;
@@ -1000,6 +1017,10 @@ int session_advance_wave(rr_plan *P, int64_t rows_ready)
         if (!progressed) break;
     }
     if (S.diag >= S.n_diags) S.tau = S.total_ticks;
+    if (export_ready) {   // an export reach in block b at lag L has produced sub-steps below (diag - b) * K - L
+        const int64_t e = S.diag >= S.n_diags ? S.total : S.diag * K - P->wave_export_skew;
+        *export_ready = std::max<int64_t>(0, std::min(e, S.total));
+    }
     return RR_OK;
 }
 
@@ -1012,11 +1033,7 @@ int session_advance(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, int64_t
     const int64_t n = P->h.n, dmax = P->h.depth - 1, C = std::max<int64_t>(1, P->chunk_rows);
     if (export_ready) *export_ready = 0;
     if (n == 0 || S.total == 0) { if (export_ready) *export_ready = S.total; return RR_OK; }
-    if (S.wave) {
-        int rc = session_advance_wave(P, rows_ready);
-        if (export_ready) *export_ready = S.tau >= S.total_ticks ? S.total : 0;
-        return rc;
-    }
+    if (S.wave) return session_advance_wave(P, rows_ready, std::min(ghost_ready, S.total), export_ready);
     rows_ready = std::min(rows_ready, S.T);
     ghost_ready = std::min(ghost_ready, S.total);
     // a ghost at lag L is read at tick tau for sub-step tau - L: ticks below ghost_ready + min lag are safe
@@ -1499,6 +1516,14 @@ int rr_plan_set_boundary(rr_plan *P, int64_t n_ghost, const int64_t *ghost_reach
     P->n_ghost = n_ghost; P->n_export = n_export;
     P->ghost_min_lag = n_ghost ? gmin : 0;
     P->export_max_lag = n_export ? emax : 0;
+    {
+        const int64_t bs = (int64_t)P->wave_ppt * P->wave_threads, K = P->wave_K;
+        int64_t slack = (int64_t)H.depth + P->wave_nb * K, skew = 0;
+        for (int64_t g = 0; g < n_ghost; ++g) { const int64_t p = H.inv[ghost_reaches[g]]; slack = std::min(slack, (p / bs) * K + H.lag[p]); }
+        for (int64_t e = 0; e < n_export; ++e) { const int64_t p = H.inv[export_reaches[e]]; skew = std::max(skew, (p / bs) * K + H.lag[p]); }
+        P->wave_ghost_slack = n_ghost ? slack : 0;
+        P->wave_export_skew = n_export ? skew : 0;
+    }
     return RR_OK;
 }
 

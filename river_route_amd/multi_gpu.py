@@ -228,6 +228,29 @@ def run_in_process(engines, specs, T: int, nsub: int, chunk_rows: int) -> None:
             raise RuntimeError('run_in_process: parts are deadlocked (no message can be delivered)')
 
 
+def roofline_from_profile(prof: dict, nsub: int, traffic, peak_gbs: float = 8000.0):
+    """`roofline` object of bench.py from Plan.profile(): algorithmic bytes of SURVEY section 8(d) (72 B per reach
+    sub-step + 16 B per reach row) over the HIP-event time of the bracketed routing launches."""
+    if prof['sampled'] <= 0 or prof['sampled_ms'] <= 0:
+        return None
+    bytes_per_reach_tick = 72.0 + 16.0 / nsub
+    tpl = max(1, prof['ticks_per_launch'])
+    launches = prof['sampled'] / tpl
+    avg_ms = prof['sampled_ms'] / launches
+    reach_ticks = prof['sampled_reaches'] / launches
+    alg_bytes = bytes_per_reach_tick * reach_ticks
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    return {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': peak_gbs, 'unit': 'GB/s',
+            'frac': round(achieved / peak_gbs, 4), 'traffic': traffic,
+            'kernel': 'k_wave (time-tiled routing)' if tpl > 1 else 'k_tick (streaming routing)',
+            'ticks_per_launch': tpl, 'avg_launch_us': round(avg_ms * 1e3, 3),
+            'algorithmic_bytes_per_launch': round(alg_bytes),
+            'compulsory_bytes_per_launch': round(16.0 / nsub * reach_ticks),
+            'measured_hbm_gbps': None if traffic is None else round(traffic / (avg_ms * 1e-3) / 1e9, 1),
+            'launches_per_pass': prof['launches'], 'launches_sampled': int(launches),
+            'pass_region_ms': round(prof['region_ms'], 3)}
+
+
 # ------------------------------------------------------------------------------------------------ bench.py --gpus N
 
 def bench_main(args, rank: int, local_rank: int, world: int) -> None:
@@ -280,16 +303,7 @@ def bench_main(args, rank: int, local_rank: int, world: int) -> None:
     gathered = [torch.zeros_like(info) for _ in range(world)]
     dist.all_gather(gathered, info)
     if rank == 0:
-        bytes_per = 72 + 16 / nsub
-        roofline = None
-        if prof['sampled'] > 0 and prof['sampled_ms'] > 0:
-            avg_ms = prof['sampled_ms'] / prof['sampled']
-            avg_reaches = prof['sampled_reaches'] / prof['sampled']
-            ach = bytes_per * avg_reaches / (avg_ms * 1e-3) / 1e9
-            roofline = {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': 8000.0, 'unit': 'GB/s',
-                        'frac': round(ach / 8000.0, 4), 'traffic': None, 'kernel': 'k_tick (rank 0 part)',
-                        'avg_launch_us': round(avg_ms * 1e3, 3),
-                        'algorithmic_bytes_per_launch': round(bytes_per * avg_reaches)}
+        roofline = roofline_from_profile(prof, nsub, None)
         line = {
             'metric': 'reach-steps/sec', 'value': float(n) * T * nsub * args.steps / elapsed,
             'unit': 'reach-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
