@@ -164,6 +164,12 @@ int rr_stream_end(rr_plan *plan, double *q_t);
 int rr_partition_forest(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indices, int32_t n_parts,
                         int32_t *part_of, int64_t *part_sizes);
 
+/* ---- router post-processing on the device (river_route/routers/TransformMuskingum.py:128-142) ----
+ * out[o, i] = (float) mean_{j < factor} discharge[o * factor + j, i]; num_rows must be a multiple of factor.
+ * Halves (or better) the bytes that leave the GPU: the reference's routers hand float32 to their writer. */
+int rr_resample_cast_dev(int device, const double *discharge, int64_t num_rows, int64_t n, int64_t factor, float *out,
+                         void *stream);
+
 /* ---- small device helpers so a host language needs no HIP binding of its own ---- */
 int rr_dev_malloc(int device, int64_t bytes, void **out);
 int rr_dev_free(int device, void *ptr);

@@ -91,6 +91,7 @@ _SIGNATURES = {
     'rr_stream_advance': (C.c_int, [_vp, _i64, _i64, C.POINTER(_i64)]),
     'rr_stream_end': (C.c_int, [_vp, _vp]),
     'rr_partition_forest': (C.c_int, [_i64, _vp, _vp, C.c_int32, _vp, _vp]),
+    'rr_resample_cast_dev': (C.c_int, [C.c_int, _vp, _i64, _i64, _i64, _vp, _vp]),
     'rr_dev_malloc': (C.c_int, [C.c_int, _i64, C.POINTER(_vp)]),
     'rr_dev_free': (C.c_int, [C.c_int, _vp]),
     'rr_dev_upload': (C.c_int, [C.c_int, _vp, _vp, _i64]),
@@ -136,6 +137,8 @@ def ptr(a) -> int | None:
         if not a.flags['C_CONTIGUOUS']:
             raise ValueError('array must be C-contiguous')
         return a.ctypes.data
+    if hasattr(a, 'address'):        # engine.DeviceBuffer
+        return int(a.address)
     if hasattr(a, 'data_ptr'):
         if not a.is_contiguous():
             raise ValueError('tensor must be contiguous')

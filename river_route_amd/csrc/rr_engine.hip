@@ -601,6 +601,20 @@ __global__ __launch_bounds__(kBlock) void k_uh_tail(const double *__restrict__ k
     new_state[(int64_t)s * n + i] = acc;
 }
 
+// Router post-processing on the device (TransformMuskingum.py:128-142): mean over `factor` consecutive rows
+// (sequential sum then one division, as numpy's reduction over a strided axis does) and the float32 cast.
+__global__ __launch_bounds__(kBlock) void k_resample_cast(const double *__restrict__ src, float *__restrict__ dst,
+                                                          int64_t n, int64_t out_rows, int32_t factor)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t o = blockIdx.y;
+    if (i >= n || o >= out_rows) return;
+    const double *p = src + o * factor * n + i;
+    double acc = p[0];
+    for (int32_t j = 1; j < factor; ++j) acc += p[(int64_t)j * n];
+    dst[o * n + i] = (float)(factor > 1 ? acc / (double)factor : acc);
+}
+
 inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
 }  // namespace
@@ -1690,6 +1704,32 @@ int rr_uh_convolve(int device, const double *kernel, double *state, const double
     }
     for (double *p : {d_k, d_s, d_l, d_o}) if (p) (void)hipFree(p);
     return rc;
+}
+
+int rr_resample_cast_dev(int device, const double *discharge, int64_t num_rows, int64_t n, int64_t factor, float *out,
+                         void *stream)
+{
+    if (device < 0 || device >= rr_device_count()) return fail(RR_E_NO_DEVICE, "rr_resample_cast_dev: no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    if (num_rows < 0 || n < 0 || factor < 1 || factor > 0x7FFFFFFF || (factor > 0 && num_rows % factor != 0))
+        return fail(RR_E_INVALID, "rr_resample_cast_dev: rows must be a multiple of factor >= 1");
+    const int64_t out_rows = num_rows / factor;
+    if (out_rows == 0 || n == 0) return RR_OK;
+    if (!discharge || !out) return fail(RR_E_INVALID, "rr_resample_cast_dev: null array");
+    if (out_rows > 65535) {   // grid.y limit: go in slabs
+        for (int64_t o0 = 0; o0 < out_rows; o0 += 65535) {
+            const int64_t rows = std::min<int64_t>(65535, out_rows - o0);
+            dim3 g((unsigned)((n + kBlock - 1) / kBlock), (unsigned)rows);
+            hipLaunchKernelGGL(k_resample_cast, g, dim3(kBlock), 0, (hipStream_t)stream, discharge + o0 * factor * n,
+                               out + o0 * n, n, rows, (int32_t)factor);
+        }
+    } else {
+        dim3 g((unsigned)((n + kBlock - 1) / kBlock), (unsigned)out_rows);
+        hipLaunchKernelGGL(k_resample_cast, g, dim3(kBlock), 0, (hipStream_t)stream, discharge, out, n, out_rows,
+                           (int32_t)factor);
+    }
+    HIPCHK(hipGetLastError());
+    return RR_OK;
 }
 
 // ---- device helpers ----

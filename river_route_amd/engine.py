@@ -11,7 +11,8 @@ import numpy as np
 from . import _lib
 from ._lib import RRError, check, ptr
 
-__all__ = ['Plan', 'RRError', 'uh_convolve', 'uh_convolve_dev', 'DeviceBuffer', 'partition_forest', 'synchronize']
+__all__ = ['Plan', 'RRError', 'uh_convolve', 'uh_convolve_dev', 'DeviceBuffer', 'partition_forest', 'synchronize',
+           'resample_cast_dev']
 
 
 def _f64(a, name):
@@ -197,6 +198,11 @@ def uh_convolve(kernel, state, lateral, device: int = 0) -> np.ndarray:
 def uh_convolve_dev(kernel, state, lateral, out, T, n_ks, n, device: int = 0, stream=None) -> None:
     check(_lib.lib().rr_uh_convolve_dev(int(device), ptr(kernel), ptr(state), ptr(lateral), ptr(out), int(T),
                                         int(n_ks), int(n), stream))
+
+
+def resample_cast_dev(discharge, num_rows, n, factor, out, device: int = 0, stream=None) -> None:
+    """Device-side mean over `factor` rows + float32 cast (rr_resample_cast_dev)."""
+    check(_lib.lib().rr_resample_cast_dev(int(device), ptr(discharge), int(num_rows), int(n), int(factor), ptr(out), stream))
 
 
 class DeviceBuffer:

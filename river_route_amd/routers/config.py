@@ -140,5 +140,74 @@ class Configs:
             if val and not os.path.isdir(val):
                 raise NotADirectoryError(f'Output directory not found: {val}')
 
+    def deep_validate(self) -> 'Configs':
+        """Content checks of the files the configs point at (river_route/routers/Config.py:185-280); like the
+        reference's, this is an explicit extra step -- the routers never call it.  Raises ValueError with the
+        reference's messages; returns self."""
+        import numpy as np
+        import pandas as pd
+
+        def need(ok, message):
+            if not ok:
+                raise ValueError(message)
+
+        pf = self.params_file
+        try:
+            params = pd.read_parquet(pf)
+        except Exception as e:
+            raise ValueError('Error reading params file. Must be valid parquet file') from e
+        for col in ('river_id', 'downstream_river_id', 'k', 'x'):
+            need(col in params.columns, f'{pf} missing {col} column')
+        for col in ('river_id', 'downstream_river_id'):
+            need(not np.any(params[col].isnull()), f'{pf} {col} column contains null values')
+            need(pd.api.types.is_integer_dtype(params[col]), f'{pf} {col} column must be integer type')
+            if col == 'river_id':
+                need(params[col].is_unique, f'{pf} river_id column must be unique')
+        need(not np.any(params['downstream_river_id'] < -1), f'{pf} downstream_river_id column must be -1 or positive integers')
+        river_ids = set(params['river_id'].unique())
+        need(set(params['downstream_river_id'].unique()).issubset(river_ids | {-1}),
+             f'{pf} downstream_river_id values must exist in river_id (except -1)')
+        need(not np.any(params['k'] <= 0), f'{pf} k column must be positive')
+        need(not (np.any(params['x'] < 0) or np.any(params['x'] > 0.5)), f'{pf} x column must be in the range [0, 0.5]')
+        rid = params['river_id'].to_numpy()
+        did = params['downstream_river_id'].to_numpy()
+        order = np.argsort(rid, kind='stable')
+        has = did >= 0
+        down_idx = order[np.searchsorted(rid[order], did[has])]
+        need(np.all(down_idx > np.flatnonzero(has)), f'{pf} is not topologically sorted (upstream to downstream)')
+
+        if self.grid_weights_file:
+            try:
+                import xarray as xr
+                ds = xr.load_dataset(self.grid_weights_file)
+            except Exception as e:
+                raise ValueError('Error reading grid weights file. Must be valid netCDF file') from e
+            names = ('river_id', 'x_index', 'y_index', 'x', 'y', 'area_sqm', 'proportion')
+            for v in names:
+                need(v in ds, f'Grid weights file missing {v} variable')
+            need(not np.any(ds['river_id'].isnull()), 'Grid weights river_id variable contains null values')
+            need(pd.api.types.is_integer_dtype(ds['river_id'].dtype), 'Grid weights river_id variable must be integer type')
+            need(set(ds['river_id'].values).issubset(river_ids), 'Grid weights river_id values must exist in params river_id')
+            for v in names[1:]:
+                need(not np.any(ds[v].isnull()), f'Grid weights {v} variable contains null values')
+                need(pd.api.types.is_numeric_dtype(ds[v].dtype), f'Grid weights {v} variable must be numeric type')
+            need(not np.any(ds['area_sqm'] <= 0), 'Grid weights area_sqm variable must be positive')
+            need(not (np.any(ds['proportion'] <= 0) or np.any(ds['proportion'] > 1)),
+                 'Grid weights proportion variable must be in the range (0, 1]')
+            need(np.allclose(ds['proportion'].groupby(ds['river_id']).sum().values, 1.0),
+                 'Grid weights proportion variable must sum to 1 for each river_id')
+
+        if self.channel_state_init_file:
+            try:
+                state = pd.read_parquet(self.channel_state_init_file)
+            except Exception as e:
+                raise ValueError('Error reading initial state file. Must be valid parquet file') from e
+            need('Q' in state.columns, 'Initial state file missing Q column')
+            need(not np.any(state['Q'].isnull()), 'Initial state file Q column contains null values')
+            need(pd.api.types.is_numeric_dtype(state['Q']), 'Initial state file Q column must be numeric type')
+            need(not np.any(state['Q'] < 0), 'Initial state file Q column must be non-negative')
+            need(state.shape[0] == params.shape[0], f'Initial state file must have the same number of rows as {pf}')
+        return self
+
     def as_dict(self) -> dict[str, Any]:
         return {f.name: getattr(self, f.name) for f in fields(self)}

@@ -17,6 +17,7 @@ __all__ = ['TransformMuskingum']
 class TransformMuskingum(Muskingum, ABC):
     _ROUTER_REQUIRED_CONFIGS: tuple[str, ...] = ()
     _as_volumes: bool = False
+    _device_postprocess: bool = True   # keep each file on the GPU from lateral upload to float32 discharge
 
     def _qlateral_generator(self):
         """Yields (dates datetime64[s], lateral float64 (T, n), input file, output file) per input file."""
@@ -83,20 +84,24 @@ class TransformMuskingum(Muskingum, ABC):
             self.logger.info(f'Routing qlateral: {runoff_file}')
             self._set_network_and_time_dependent_vectors(dates)
             self.logger.debug('Starting routing computation')
-            q_t, q_array = self._router(qlateral)
+            per = int(self.dt_discharge / self.dt_runoff) if self.dt_discharge > self.dt_runoff else 1
+            if self._device_postprocess and hasattr(self._plan, 'rapid_route_dev'):
+                # device-resident file: lateral in once, resample-mean + float32 cast on the GPU, float32 out
+                q_t, q_array = self._router_device(qlateral, per)
+            else:
+                q_t, q_array = self._router(qlateral)
+                if per > 1:
+                    q_array = q_array.reshape((int(self.dt_total / self.dt_discharge), per, self.A.shape[0])).mean(axis=1)
+                q_array = q_array.astype(np.float32, copy=False)
             if self.cfg.runoff_processing_mode == 'sequential':
                 self.channel_state = q_t
             elif self.cfg.runoff_processing_mode == 'ensemble':
                 self._ensemble_member_states.append(q_t.copy())
-
-            if self.dt_discharge > self.dt_runoff:
+            if per > 1:
                 self.logger.debug('Resampling dates and discharges to specified timestep')
-                per = int(self.dt_discharge / self.dt_runoff)
-                q_array = q_array.reshape((int(self.dt_total / self.dt_discharge), per, self.A.shape[0])).mean(axis=1)
                 dates = dates[::self.num_runoff_steps_per_discharge]
 
             self.logger.debug('Writing Discharge Array to File')
-            q_array = q_array.astype(np.float32, copy=False)
             self._write_discharges(dates, q_array, discharge_file, runoff_file)
 
         if self.cfg.runoff_processing_mode == 'ensemble':
@@ -105,4 +110,15 @@ class TransformMuskingum(Muskingum, ABC):
 
     @abstractmethod
     def _router(self, qlateral: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
-        ...
+        """(final state float64[n], discharge float64[T, n]) for one input file, host arrays."""
+
+    @abstractmethod
+    def _router_device(self, qlateral: np.ndarray, rows_per_output: int) -> tuple[np.ndarray, np.ndarray]:
+        """(final state float64[n], discharge float32[T / rows_per_output, n]) with the whole file on the device."""
+
+    def _check_lateral(self, qlateral: np.ndarray) -> np.ndarray:
+        ql = np.ascontiguousarray(qlateral, dtype=np.float64)
+        if ql.shape != (self.num_runoff_steps, self.A.shape[0]):
+            raise ValueError(f'lateral inflow has shape {ql.shape}, expected '
+                             f'({self.num_runoff_steps}, {self.A.shape[0]}) from the time options')
+        return ql

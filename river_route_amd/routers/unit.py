@@ -45,6 +45,37 @@ class UnitMuskingum(TransformMuskingum):
         q_final[self.inner_idx] = q_full
         return q_final, discharge_array
 
+    def _router_device(self, qlateral: np.ndarray, rows_per_output: int) -> tuple[np.ndarray, np.ndarray]:
+        from ..engine import DeviceBuffer, resample_cast_dev, uh_convolve_dev
+        depth = self._check_lateral(qlateral)
+        T, n = depth.shape
+        dev = self.cfg.device
+        n_ks = self._uh.kernel.shape[0]
+        self._upload_coefficients(None, ('unit',))
+        bufs = []
+        try:
+            d_depth = DeviceBuffer(depth.nbytes, dev).upload(depth); bufs.append(d_depth)
+            d_kern = DeviceBuffer(self._uh.kernel.nbytes, dev).upload(self._uh.kernel); bufs.append(d_kern)
+            d_state = DeviceBuffer(self._uh.kernel.nbytes, dev).upload(np.ascontiguousarray(self._uh.state)); bufs.append(d_state)
+            d_conv = DeviceBuffer(depth.nbytes, dev); bufs.append(d_conv)
+            uh_convolve_dev(d_kern, d_state, d_depth, d_conv, T, n_ks, n, device=dev)
+            self._uh.state = d_state.download(np.float64, self._uh.kernel.shape)
+            d_depth.free()
+            q_ch = np.array(self.channel_state[self.inner_idx], dtype=np.float64, order='C')
+            d_qch = DeviceBuffer(max(q_ch.nbytes, 8), dev).upload(q_ch); bufs.append(d_qch)
+            d_qfull = DeviceBuffer(max(q_ch.nbytes, 8), dev).upload(q_ch); bufs.append(d_qfull)
+            d_out = DeviceBuffer(depth.nbytes, dev); bufs.append(d_out)
+            d_f32 = DeviceBuffer((T // rows_per_output) * n * 4, dev); bufs.append(d_f32)
+            self._plan.unit_route_dev(d_qch, d_qfull, d_conv, T, d_out, T, T, self.num_routing_steps_per_runoff)
+            resample_cast_dev(d_out, T, n, rows_per_output, d_f32, dev)
+            q_array = d_f32.download(np.float32, (T // rows_per_output, n))
+            q_final = d_conv.download(np.float64, (n,), offset=(T - 1) * n * 8)    # headwaters keep the last lateral row
+            q_final[self.inner_idx] = d_qfull.download(np.float64, q_ch.shape)
+        finally:
+            for b in bufs:
+                b.free()
+        return q_final, q_array
+
     def _write_final_state(self) -> None:
         super()._write_final_state()
         if self.cfg.uh_state_final_file and self._uh is not None:

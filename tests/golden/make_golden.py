@@ -192,6 +192,15 @@ def main():
     except ValueError as e:
         out['coeff_fail/message'] = np.array(str(e))
 
+    # (vii) SCS kernel builders (uhkernels/_SCSBase.py:36-76) -- what produces a realistic uh_kernel_file
+    scs_mod = importlib.import_module('river_route.uhkernels')
+    tc = np.array([7200.0, 14400.0, 3600.0, 900.0, 40000.0])
+    area = np.array([1e6, 5e6, 2e5, 3.3e7, 1.0e8])
+    for tr in (3600.0, 900.0):
+        out[f'scs/tr{int(tr)}/triangular'] = scs_mod.SCSTriangular(tr=tr, tc=tc, area=area).kernel
+        out[f'scs/tr{int(tr)}/curvilinear'] = scs_mod.SCSCurvilinear(tr=tr, tc=tc, area=area).kernel
+    out['scs/tc'], out['scs/area'] = tc, area
+
     np.savez_compressed(os.path.join(HERE, 'kernels.npz'), **out)
     print('wrote kernels.npz with', len(out), 'arrays')
 

@@ -314,3 +314,123 @@ def test_engine_order_is_a_valid_topological_order():
     from river_route_amd.engine import Plan
     with Plan(A.indptr, A.indices, device=_lib.RR_DEVICE_NONE) as plan:
         assert plan.identity_order
+
+
+@pytest.mark.gpu
+def test_device_file_path_equals_host_path(case, monkeypatch):
+    """The routers keep each file on the GPU (lateral in, resample-mean + float32 cast on the device, float32 out);
+    the reference-shaped host path (_router + numpy post-processing) must give the same arrays."""
+    from river_route_amd.routers.transform import TransformMuskingum
+    g = case['g']
+    kp, us = _unit_files(case)
+    runs = {}
+    for flag in (True, False):
+        monkeypatch.setattr(TransformMuskingum, '_device_postprocess', flag)
+        r1, got1 = drive(rr.RapidMuskingum, case, [g['vol0'], g['vol1']], channel_state_init_file=case['init'],
+                         dt_routing=1800, dt_discharge=3 * 3600)
+        r2, got2 = drive(rr.UnitMuskingum, case, [g['depth0'], g['depth1']], channel_state_init_file=case['init'],
+                         dt_routing=1200, uh_kernel_file=kp, uh_state_init_file=us, dt_discharge=2 * 3600)
+        runs[flag] = (r1.channel_state, [q for _, q, _, _ in got1], r2.channel_state, [q for _, q, _, _ in got2],
+                      r2._uh.state)
+    for a, b in zip(runs[True], runs[False]):
+        if isinstance(a, list):
+            for x, y in zip(a, b):
+                assert x.dtype == np.float32 and x.shape == y.shape
+                np.testing.assert_array_equal(x, y)
+        else:
+            np.testing.assert_array_equal(a, b)
+
+
+def test_scs_kernel_builders(golden_kernels):
+    """uhkernels/_SCSBase.py: kernels equal the reference's, conserve volume (tests/test_uhkernels.py:19-42)."""
+    from river_route_amd.uhkernels import SCSCurvilinear, SCSTriangular
+    g = golden_kernels
+    tc, area = g['scs/tc'], g['scs/area']
+    for tr in (3600.0, 900.0):
+        for name, cls in (('triangular', SCSTriangular), ('curvilinear', SCSCurvilinear)):
+            uh = cls(tr=tr, tc=tc, area=area)
+            want = g[f'scs/tr{int(tr)}/{name}']
+            assert uh.kernel.shape == want.shape and uh.kernel.ndim == 2
+            np.testing.assert_allclose(uh.kernel, want, rtol=1e-12, atol=1e-12 * want.max())
+            np.testing.assert_allclose(uh.kernel.sum(axis=0) * tr, area, rtol=1e-6)
+    with pytest.raises(ValueError, match='tr must be > 0'):
+        SCSTriangular(tr=0.0, tc=tc, area=area)
+    with pytest.raises(ValueError, match='same length'):
+        SCSTriangular(tr=900.0, tc=tc, area=area[:2])
+
+
+def test_scs_kernel_file_round_trip(tmp_path):
+    from river_route_amd.uhkernels import SCSTriangular, UnitHydrograph
+    uh = SCSTriangular(tr=900.0, tc=np.array([2000.0, 9000.0]), area=np.array([1e6, 4e6]))
+    path = tmp_path / 'k.npz'
+    uh.save(path)
+    loaded = scipy.sparse.load_npz(path).toarray()
+    np.testing.assert_array_equal(loaded, uh.kernel)
+
+
+def test_deep_validate(tmp_path, golden_routers):
+    """Config.py:185-280 -- explicit content validation with the reference's messages."""
+    g = golden_routers
+    good = tmp_path / 'p.parquet'
+    df = pd.DataFrame({'river_id': g['river_ids'], 'downstream_river_id': g['downstream_ids'], 'k': g['k'], 'x': g['x']})
+    df.to_parquet(good)
+    st = tmp_path / 's.parquet'
+    pd.DataFrame({'Q': g['q0']}).to_parquet(st)
+    cfg = rr.Configs(params_file=str(good), discharge_dir=str(tmp_path), channel_state_init_file=str(st))
+    assert cfg.deep_validate() is cfg
+
+    def broken(mutate, match, state=None):
+        bad = tmp_path / 'bad.parquet'
+        d = df.copy()
+        mutate(d)
+        d.to_parquet(bad)
+        c = rr.Configs(params_file=str(bad), discharge_dir=str(tmp_path), channel_state_init_file=state)
+        with pytest.raises(ValueError, match=match):
+            c.deep_validate()
+
+    broken(lambda d: d.drop(columns=['k'], inplace=True), 'missing k column')
+    broken(lambda d: d.__setitem__('k', -d['k']), 'k column must be positive')
+    broken(lambda d: d.__setitem__('x', d['x'] + 1.0), r'x column must be in the range \[0, 0.5\]')
+    broken(lambda d: d.__setitem__('river_id', d['river_id'].iloc[0]), 'river_id column must be unique')
+    broken(lambda d: d.__setitem__('downstream_river_id', d['downstream_river_id'].where(d.index != 3, 99999999)),
+           'must exist in river_id')
+    broken(lambda d: d.__setitem__('downstream_river_id', d['downstream_river_id'].astype(float)), 'must be integer type')
+
+    def reverse(d):
+        d.iloc[:] = d.iloc[::-1].to_numpy()
+        for c in ('river_id', 'downstream_river_id'):
+            d[c] = d[c].astype(np.int64)
+    broken(reverse, 'not topologically sorted')
+    short = tmp_path / 'short.parquet'
+    pd.DataFrame({'Q': g['q0'][:-1]}).to_parquet(short)
+    broken(lambda d: None, 'same number of rows', state=str(short))
+    neg = tmp_path / 'neg.parquet'
+    pd.DataFrame({'Q': -g['q0']}).to_parquet(neg)
+    broken(lambda d: None, 'non-negative', state=str(neg))
+
+
+def test_cli_dispatch(backend, case, capsys):
+    """river_route/_cli.py: `rr RapidMuskingum cfg` and `rr route --router X cfg` run Router(cfg).route()."""
+    import yaml
+    from scipy.io import netcdf_file
+    from river_route_amd import _cli
+    g, tmp = case['g'], case['tmp']
+    for i in range(2):
+        with netcdf_file(case['files'][i], 'w', version=2) as ds:
+            T, n = g[f'vol{i}'].shape
+            ds.createDimension('time', T)
+            ds.createDimension('river_id', n)
+            tv = ds.createVariable('time', 'f8', ('time',))
+            tv.units = 'seconds since 1970-01-01 00:00:00'
+            tv[:] = g[f'dates{i}'].astype(np.float64)
+            ds.createVariable('qlateral', 'f8', ('time', 'river_id'))[:] = g[f'vol{i}']
+    cfg = tmp / 'c.yaml'
+    cfg.write_text(yaml.safe_dump(dict(params_file=case['params'], qlateral_files=case['files'],
+                                       discharge_dir=str(tmp), log=False, progress_bar=False)))
+    _cli.main(['RapidMuskingum', str(cfg)])
+    assert (tmp / 'discharge_ql0.nc').exists() and (tmp / 'discharge_ql1.nc').exists()
+    (tmp / 'discharge_ql0.nc').unlink()
+    _cli.main(['route', '--router', 'RapidMuskingum', str(cfg)])
+    assert (tmp / 'discharge_ql0.nc').exists()
+    _cli.main([])
+    assert 'usage' in capsys.readouterr().out.lower()
