@@ -304,6 +304,8 @@ struct WaveArgs {
     const int32_t *child_ptr, *lag;
     const double *c1row, *c2, *c3, *c4;   // c1row: the (uniform) weight of a reach's upstream terms
     double *sq, *ss, *si;                 // carried state: discharge, sum of upstream discharges one tick back, interval sum
+    double *sqch;                         // UnitMuskingum: channel-only discharge of inner reaches
+    const uint16_t *hw_children;          // UnitMuskingum: headwater tributaries come first in a reach's upstream range
     double *hist;                         // [hist_rows, n]
     const int32_t *bidx;                  // ghost / export slots (flag bits live in lag[])
     const double *ghost;
@@ -325,7 +327,7 @@ __device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(
 
 // PPT positions per thread; HPT halo values per thread (halo <= HPT * 1024 positions); two ticks of HBM
 // prefetch in flight (stages A/B, the tick loop is unrolled by two so the stage registers are static).
-template <int TH, int PPT, int HPT, bool SINGLE_SUBSTEP>
+template <int TH, int PPT, int HPT, bool SINGLE_SUBSTEP, bool UNIT>
 __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];   // [2][lh]: positions [h0, b1) of one tick
@@ -340,14 +342,18 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
     auto position = [&](int k) { return b0 + k * TH + tid; };
 
     // lg keeps the ghost / export flag bits of lag[]; slot is the column of a flagged reach in its boundary series
-    int32_t lg[PPT], u0[PPT], u1[PPT], slot[PPT];
-    double c1[PPT], c2[PPT], c3[PPT], c4[PPT], q[PPT], s_prev[PPT], isum[SINGLE_SUBSTEP ? 1 : PPT];
+    // UNIT (UnitMuskingum, _numba_kernels.py:113-171): q is what a reach publishes (q_full, or the lateral itself for a
+    // headwater), qch the channel-only discharge; uh splits the upstream range into headwater and inner tributaries.
+    int32_t lg[PPT], u0[PPT], u1[PPT], slot[PPT], uh[UNIT ? PPT : 1];
+    double c1[PPT], c2[PPT], c3[PPT], c4[PPT], q[PPT], s_prev[PPT], isum[SINGLE_SUBSTEP ? 1 : PPT], qch[UNIT ? PPT : 1];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int32_t p = position(k);
         slot[k] = 0;
+        if (UNIT) { uh[k] = 0; qch[k] = 0.0; }
         if (p < b1) {
             lg[k] = a.lag[p]; u0[k] = a.child_ptr[p] - h0; u1[k] = a.child_ptr[p + 1] - h0;
+            if (UNIT) { uh[k] = u0[k] + (int32_t)a.hw_children[p]; qch[k] = a.sqch[p]; }
             if (lg[k] & (kGhostBit | kExportBit)) slot[k] = a.bidx[p];
             c1[k] = a.c1row[p]; c2[k] = a.c2[p]; c3[k] = a.c3[p]; c4[k] = a.in ? a.c4[p] : 0.0;
             q[k] = a.sq[p]; s_prev[k] = a.ss[p];
@@ -399,12 +405,38 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
         for (int k = 0; k < PPT; ++k) {
             if (lg[k] < 0) continue;
             const int32_t p = position(k);
-            double s_cur = 0.0;
-            for (int32_t u = u0[k]; u < u1[k]; ++u) s_cur += rd[u];
+            double s_cur = 0.0, s_hw = 0.0;
+            if (UNIT) {
+                for (int32_t u = u0[k]; u < uh[k]; ++u) s_hw += rd[u];       // headwater tributaries: "old" value is l_t too
+                for (int32_t u = uh[k]; u < u1[k]; ++u) s_cur += rd[u];
+            } else {
+                for (int32_t u = u0[k]; u < u1[k]; ++u) s_cur += rd[u];
+            }
             const int64_t ts = tau - (lg[k] & kLagMask);
-            if (ts >= 0 && ts < a.total && (lg[k] & kGhostBit)) {
+            const bool active = ts >= 0 && ts < a.total;
+            if (UNIT && active) {
+                const uint32_t t = SINGLE_SUBSTEP ? (uint32_t)ts : (uint32_t)((uint64_t)ts / a.nsub);
+                const uint32_t sub = SINGLE_SUBSTEP ? 0u : (uint32_t)((uint64_t)ts - (uint64_t)t * a.nsub);
+                double *orow = a.out + (int64_t)(t % a.out_rows) * a.out_ld;
+                if (u0[k] == u1[k]) {   // headwater: discharge is the lateral inflow, unclamped and un-averaged
+                    q[k] = lat[k];
+                    if (sub == 0) orow[p] = lat[k];
+                } else {
+                    const double r = __builtin_fma(c1[k], s_hw + s_cur, __builtin_fma(c2[k], s_hw + s_prev[k], c3[k] * qch[k]));
+                    qch[k] = r;
+                    const double qfull = r + lat[k];
+                    q[k] = qfull;
+                    if (SINGLE_SUBSTEP) {
+                        orow[p] = qfull > 0.0 ? qfull : 0.0;
+                    } else {
+                        const double acc = (sub == 0 ? 0.0 : isum[k]) + qfull;
+                        if (sub + 1 == a.nsub) { const double v = acc * a.inv_nsub; orow[p] = v > 0.0 ? v : 0.0; }
+                        isum[k] = acc;
+                    }
+                }
+            } else if (active && (lg[k] & kGhostBit)) {
                 q[k] = lat[k];      // a ghost only republishes what its owner computed
-            } else if (ts >= 0 && ts < a.total) {
+            } else if (active) {
                 // explicit fma: the unrolled copies of this tick must round identically (split run == joint run)
                 const double r = __builtin_fma(c1[k], s_cur, __builtin_fma(c2[k], s_prev[k],
                                  __builtin_fma(c4[k], lat[k], c3[k] * q[k])));
@@ -465,6 +497,7 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
         const int32_t p = position(k);
         a.sq[p] = q[k]; a.ss[p] = s_prev[k];
         if (!SINGLE_SUBSTEP) a.si[p] = isum[k];
+        if (UNIT) a.sqch[p] = qch[k];
     }
 }
 
@@ -480,6 +513,34 @@ __global__ __launch_bounds__(kBlock) void k_wave_state_in(double *sq, double *ss
     for (int32_t u = child_ptr[p]; u < child_ptr[p + 1]; ++u) s += q_t[perm[u]];
     sq[p] = v; ss[p] = s;
     for (int32_t r = 0; r < hist_rows; ++r) hist[(int64_t)r * n + p] = v;
+}
+
+// UnitMuskingum state for the time-tiled kernel: published discharge = q_full on inner reaches (0 on headwaters until
+// their first tick), ss = sum over the INNER tributaries only, qch = channel discharge; history rows = published values.
+__global__ __launch_bounds__(kBlock) void k_wave_unit_state_in(double *sq, double *ss, double *qch, double *hist,
+                                                               int32_t hist_rows, const double *x0,
+                                                               const int32_t *child_ptr, int32_t n)
+{
+    const int32_t p = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (p >= n) return;
+    const double v = x0[p];     // x0: q_full scattered to engine positions, zeros on headwaters (k_unit_state_in)
+    double s = 0.0;
+    for (int32_t u = child_ptr[p]; u < child_ptr[p + 1]; ++u)
+        if (child_ptr[u + 1] > child_ptr[u]) s += x0[u];
+    sq[p] = v; ss[p] = s;
+    for (int32_t r = 0; r < hist_rows; ++r) hist[(int64_t)r * n + p] = v;
+    (void)qch;
+}
+
+__global__ __launch_bounds__(kBlock) void k_wave_unit_state_out(double *q_ch, double *q_full, const double *sq,
+                                                                const double *qch, const int32_t *inner_pos,
+                                                                int32_t n_inner)
+{
+    const int32_t k = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (k >= n_inner) return;
+    const int32_t p = inner_pos[k];
+    q_full[k] = sq[p];
+    q_ch[k] = qch[p];
 }
 
 __global__ __launch_bounds__(kBlock) void k_wave_state_out(double *q_t, const double *sq, const int32_t *inv, int32_t n)
@@ -749,7 +810,8 @@ int ensure_cap(T **buf, int64_t *cap, int64_t count)
 
 bool use_wave(const rr_plan *P, Mode mode)
 {
-    return P->wave_enabled && P->weights_uniform && mode != Mode::Unit && P->h.n > 0;
+    return P->wave_enabled && P->weights_uniform && P->h.n > 0 &&
+           (mode != Mode::Unit || (P->n_ghost == 0 && P->n_export == 0));
 }
 
 int64_t wave_hist_rows(const rr_plan *P) { return (P->wave_jmax + 2) * P->wave_K; }
@@ -814,7 +876,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
     if (S.wave) {
         WaveArgs &w = S.wa;
         w.child_ptr = P->d_child_ptr; w.lag = P->d_lag; w.c1row = P->d_c1row; w.c2 = P->d_c2; w.c3 = P->d_c3; w.c4 = P->d_c4;
-        w.sq = P->d_sq; w.ss = P->d_ss; w.si = P->d_si; w.hist = P->d_hist; w.hist_rows = (int32_t)wave_hist_rows(P);
+        w.sq = P->d_sq; w.ss = P->d_ss; w.si = P->d_si; w.sqch = P->d_qch; w.hw_children = P->d_hwc; w.hist = P->d_hist; w.hist_rows = (int32_t)wave_hist_rows(P);
         w.bidx = P->d_bidx; w.ghost = ghost_series; w.exports = export_series;
         w.n_ghost = (int32_t)P->n_ghost; w.n_export = (int32_t)P->n_export;
         w.in = a.in; w.out = a.out; w.in_ld = a.in_ld; w.out_ld = a.out_ld; w.in_rows = a.in_rows; w.out_rows = a.out_rows;
@@ -942,9 +1004,11 @@ typedef void (*wave_kernel_t)(const WaveArgs);
 // Block = threads * ppt positions, halo capacity = threads * hpt.  Two shapes are built:
 //   1024 threads x {1,2} positions (16 waves, latency hidden by occupancy) and
 //    512 threads x {2,4} positions (8 waves, up to 256 VGPRs: latency hidden by the prefetch stages).
-wave_kernel_t wave_kernel(int threads, int ppt, int hpt, bool one)
+wave_kernel_t wave_kernel(int threads, int ppt, int hpt, bool one, bool unit)
 {
-#define RR_WAVE_PICK(T_, P_, H_) (one ? (wave_kernel_t)k_wave<T_, P_, H_, true> : (wave_kernel_t)k_wave<T_, P_, H_, false>)
+#define RR_WAVE_PICK(T_, P_, H_)                                                                                    \
+    (unit ? (one ? (wave_kernel_t)k_wave<T_, P_, H_, true, true> : (wave_kernel_t)k_wave<T_, P_, H_, false, true>)   \
+          : (one ? (wave_kernel_t)k_wave<T_, P_, H_, true, false> : (wave_kernel_t)k_wave<T_, P_, H_, false, false>))
     if (threads == 1024) {
         if (hpt <= 2) return ppt == 1 ? RR_WAVE_PICK(1024, 1, 2) : RR_WAVE_PICK(1024, 2, 2);
         return ppt == 1 ? RR_WAVE_PICK(1024, 1, 4) : RR_WAVE_PICK(1024, 2, 4);
@@ -971,7 +1035,7 @@ int session_launch_diag(rr_plan *P, int64_t d)
     const dim3 g((unsigned)(b_hi - b_lo + 1));
     const size_t lds_bytes = (size_t)2 * P->wave_lh * sizeof(double);
     const dim3 t((unsigned)P->wave_threads);
-    wave_kernel_t fn = wave_kernel(P->wave_threads, P->wave_ppt, P->wave_hpt, S.nsub == 1);
+    wave_kernel_t fn = wave_kernel(P->wave_threads, P->wave_ppt, P->wave_hpt, S.nsub == 1, S.mode == Mode::Unit);
     hipLaunchKernelGGL(fn, g, t, lds_bytes, S.stream, w);
     if (sample) {
         HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));
@@ -1202,8 +1266,21 @@ int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io, int64_t 
     if (ni > 0)
         hipLaunchKernelGGL(k_unit_state_in, grid1(ni), dim3(kBlock), 0, stream, P->d_x, P->d_x + n, P->d_x + 2 * n,
                            P->d_qch, (const double *)d_qch, (const double *)d_qfull, P->d_inner_pos, (int32_t)ni);
-    int rc = route_core(P, Mode::Unit, T, nsub, io, stream);
+    const bool wave = use_wave(P, Mode::Unit);
+    int rc = RR_OK;
+    if (wave) {   // d_x[0] now holds q_full in engine order, d_qch the channel discharge
+        const int64_t hr = wave_hist_rows(P);
+        rc = ensure_cap(&P->d_hist, &P->hist_cap, hr * n);
+        if (rc == RR_OK)
+            hipLaunchKernelGGL(k_wave_unit_state_in, grid1(n), dim3(kBlock), 0, stream, P->d_sq, P->d_ss, P->d_qch,
+                               P->d_hist, (int32_t)hr, (const double *)P->d_x, P->d_child_ptr, (int32_t)n);
+    }
+    if (rc == RR_OK) rc = route_core(P, Mode::Unit, T, nsub, io, stream);
     if (rc == RR_OK && ni > 0) {
+        if (wave)
+            hipLaunchKernelGGL(k_wave_unit_state_out, grid1(ni), dim3(kBlock), 0, stream, d_qch, d_qfull,
+                               (const double *)P->d_sq, (const double *)P->d_qch, P->d_inner_pos, (int32_t)ni);
+        else
         hipLaunchKernelGGL(k_unit_state_out, grid1(ni), dim3(kBlock), 0, stream, d_qch, d_qfull,
                            (const double *)P->d_x, n, (const double *)P->d_qch, P->d_lag, P->d_inner_pos,
                            (int32_t)ni, T * nsub);
@@ -1347,8 +1424,19 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) { delete P; return fail(RR_E_HIP, hipGetErrorString(e)); }
         P->device = device;
-        for (int one = 0; one < 2; ++one) {   // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
-            hipError_t ea = hipFuncSetAttribute((const void *)wave_kernel(P->wave_threads, P->wave_ppt, P->wave_hpt, one != 0),
+        if (!getenv("RR_WAVE_K") && n > 0) {
+            // The time-tiled schedule keeps (depth + blocks * K) rows of the work ring alive.  Keep that under a
+            // third of the card's memory: shrink K, and below K = 4 stream with k_tick (ring = depth rows only).
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
+                const int64_t budget_rows = (int64_t)(total_b / 3) / (n * (int64_t)sizeof(double));
+                int64_t k = (budget_rows - P->h.depth - 64) / std::max<int64_t>(1, P->wave_nb);
+                k = std::min<int64_t>(P->wave_K, k) & ~(int64_t)1;
+                if (k < 4) P->wave_enabled = false; else P->wave_K = k;
+            }
+        }
+        for (int v = 0; v < 4; ++v) {   // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
+            hipError_t ea = hipFuncSetAttribute((const void *)wave_kernel(P->wave_threads, P->wave_ppt, P->wave_hpt, (v & 1) != 0, (v & 2) != 0),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 (int)(2 * P->wave_lh * sizeof(double)));
             if (ea != hipSuccess) P->wave_enabled = false;

@@ -78,3 +78,45 @@ def test_per_edge_weights_fall_back_to_the_streaming_kernel():
         plan.rapid_route(q, ql, d, 1)
     assert_close(q, q_ref, 'q_t')
     assert_close(d, d_ref, 'discharge')
+
+
+@pytest.mark.parametrize('env', [{'RR_WAVE': '0'}, {}, {'RR_WAVE_K': '4'}, {'RR_WAVE_THREADS': '512', 'RR_WAVE_K': '10'}])
+@pytest.mark.parametrize('n,T,nsub,n_ks', [(40000, 50, 1, 48), (40000, 17, 3, 5)])
+def test_unit_route_every_kernel_shape(monkeypatch, env, n, T, nsub, n_ks):
+    """UnitMuskingum through the streaming kernel (k_tick_unit) and the time-tiled kernel (k_wave, UNIT) vs the oracle,
+    two consecutive files with state hand-off as UnitMuskingum._router does it."""
+    from conftest import unit_split
+    from river_route_amd.engine import uh_convolve
+    for k in ('RR_WAVE', 'RR_WAVE_K', 'RR_WAVE_PPT', 'RR_WAVE_THREADS'):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    net = synth.synth_network(n, seed=31)
+    indptr, indices = csc_from_down(net.down_index)
+    hw_idx, inner_idx, A_in, A_hw = unit_split(indptr, indices, n)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0 / nsub)
+    c1i, c2i, c3i = c1[inner_idx], c2[inner_idx], c3[inner_idx]
+    args = (A_in.indptr, A_in.indices, -c1i[A_in.indices], A_in.indptr, A_in.indices, A_in.data,
+            A_hw.indptr, A_hw.indices, A_hw.data, c1i, c2i, c3i, hw_idx, inner_idx)
+    kern = synth.synth_uh_kernel(n, n_ks)
+    uh = oracle.UnitHydrograph(kern)
+    st = np.zeros_like(kern)
+    state_ref = 3.0 * synth.u01(7, np.arange(n))
+    state = state_ref.copy()
+    with Plan(indptr, indices) as plan:
+        plan.set_coeffs(-c1[indices], c2, c3, None)
+        for f in range(2):
+            depth = synth.synth_runoff_depth(n, f * T, (f + 1) * T)
+            conv_ref = uh.convolve(depth)
+            conv = uh_convolve(kern, st, depth)
+            assert_close(conv, conv_ref, f'file {f} convolved')
+            qc_ref, qf_ref, d_ref = state_ref[inner_idx].copy(), state_ref[inner_idx].copy(), np.zeros((T, n))
+            oracle.unit_route(*args, qc_ref, qf_ref, conv_ref, d_ref, nsub)
+            state_ref[hw_idx], state_ref[inner_idx] = conv_ref[-1][hw_idx], qf_ref
+            qc, qf, d = state[inner_idx].copy(), state[inner_idx].copy(), np.zeros((T, n))
+            plan.unit_route(qc, qf, conv_ref, d, nsub)
+            state[hw_idx], state[inner_idx] = conv_ref[-1][hw_idx], qf
+            assert_close(qc, qc_ref, f'file {f} q_ch')
+            assert_close(qf, qf_ref, f'file {f} q_full')
+            assert_close(d, d_ref, f'file {f} discharge')
+            np.testing.assert_array_equal(d[:, hw_idx], conv_ref[:, hw_idx])
