@@ -120,3 +120,46 @@ def test_unit_route_every_kernel_shape(monkeypatch, env, n, T, nsub, n_ks):
             assert_close(qf, qf_ref, f'file {f} q_full')
             assert_close(d, d_ref, f'file {f} discharge')
             np.testing.assert_array_equal(d[:, hw_idx], conv_ref[:, hw_idx])
+
+
+def _route_vs_oracle(down, T=25, nsub=1, seed=3):
+    n = down.shape[0]
+    indptr, indices = csc_from_down(down)
+    k = 900.0 + 6300.0 * synth.u01(seed, np.arange(n))
+    x = 0.05 + 0.4 * synth.u01(seed + 1, np.arange(n))
+    c1, c2, c3 = oracle.muskingum_coefficients(k, x, 900.0)
+    lhs = -c1[indices]
+    c4_dt = (c1 + c2) / (900.0 * nsub)
+    ql = synth.synth_qlateral(n, 0, T, dt=900.0 * nsub)
+    q0 = 2.0 * synth.u01(seed + 2, np.arange(n))
+    q_ref, d_ref = q0.copy(), np.zeros((T, n))
+    oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql, d_ref, nsub)
+    with Plan(indptr, indices) as plan:
+        plan.set_coeffs(lhs, c2, c3, c4_dt)
+        q, d = q0.copy(), np.zeros((T, n))
+        plan.rapid_route(q, ql, d, nsub)
+        depth, widest = plan.depth, plan.widest_level
+    assert_close(q, q_ref, 'q_t')
+    assert_close(d, d_ref, 'discharge')
+    return depth, widest
+
+
+@pytest.mark.parametrize('wave', ['0', '1'])
+def test_degenerate_network_shapes(monkeypatch, wave):
+    """Extremes of the lag pipeline: a single chain (depth = n, every level one reach wide), a star (one level of
+    5,000 tributaries into one outlet: in-degree 5,000, wider than the time-tiled kernel's LDS halo, so it streams),
+    unconnected reaches only, and a comb (a main stem with one tributary per reach)."""
+    monkeypatch.setenv('RR_WAVE', wave)
+    n = 3000
+    chain = np.arange(1, n + 1, dtype=np.int64)
+    chain[-1] = -1
+    assert _route_vs_oracle(chain, T=12) == (n, 1)
+    star = np.full(5001, 5000, dtype=np.int64)
+    star[-1] = -1
+    assert _route_vs_oracle(star, T=9, nsub=2) == (2, 5000)
+    lone = np.full(777, -1, dtype=np.int64)
+    assert _route_vs_oracle(lone, T=5) == (1, 777)
+    m = 1500   # comb: reaches 0..m-1 are tributaries, m..2m-1 the stem
+    comb = np.concatenate([m + np.arange(m), m + 1 + np.arange(m)]).astype(np.int64)
+    comb[-1] = -1
+    assert _route_vs_oracle(comb, T=14)[0] == m + 1
