@@ -315,6 +315,8 @@ struct WaveArgs {
     double *out;
     int64_t in_ld, out_ld;
     uint32_t in_rows, out_rows;
+    double *rec;                          // record ring [rec_chunks][n][16] (record mode)
+    int32_t rec_chunks;
     int32_t n, hist_rows, K, b_first, lh;   // lh: LDS positions per tick buffer (halo capacity + block)
     int64_t diag, total;
     uint32_t nsub;
@@ -501,6 +503,157 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
     }
 }
 
+// ---- record mode ----
+// With one sub-step per row, a task (block, chunk of kRec = 16 ticks) consumes for every position exactly the 16
+// consecutive rows t = tick - lag.  The work ring is therefore kept as RECORDS indexed by tick:
+//     rec[(tick / 16) % chunks][position][tick % 16]        (128 bytes per position and chunk)
+// A task reads its block's records as one contiguous 128 B * BS stream into registers, routes 16 ticks with the
+// lateral values (already scaled by c4dt) taken from and the discharges written back to those registers, and
+// stores the records in place.  The permutation to and from params order becomes ONE pass each way that moves
+// whole 128-byte records (k_rec_in / k_rec_out) instead of two tiled passes over rows.
+constexpr int kRec = 16;
+
+template <int TH, int PPT, int HPT, bool UNIT>
+__global__ __launch_bounds__(TH) void k_wave_rec(const WaveArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];   // [2][lh]
+    constexpr int BS = PPT * TH;
+    const int tid = threadIdx.x;
+    const int32_t b = a.b_first + (int32_t)blockIdx.x;
+    const int64_t chunk = a.diag - b;
+    const int32_t b0 = b * BS, b1 = min(a.n, b0 + BS);
+    const int32_t h0 = min(a.child_ptr[b0], b0);
+    const int32_t nh = b0 - h0;
+    const int32_t halo_lo = max(b0, a.child_ptr[b1]);
+    auto position = [&](int k) { return b0 + k * TH + tid; };
+    const int64_t tau0 = chunk * kRec;
+    double *rbase = a.rec + (int64_t)((uint64_t)chunk % (uint32_t)a.rec_chunks) * a.n * kRec;
+
+    int32_t lg[PPT], u0[PPT], u1[PPT], uh[UNIT ? PPT : 1];
+    double c1[PPT], c2[PPT], c3[PPT], q[PPT], s_prev[PPT], qch[UNIT ? PPT : 1];
+    double rec[PPT][kRec];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int32_t p = position(k);
+        if (UNIT) { uh[k] = 0; qch[k] = 0.0; }
+        if (p < b1) {
+            lg[k] = a.lag[p]; u0[k] = a.child_ptr[p] - h0; u1[k] = a.child_ptr[p + 1] - h0;
+            if (UNIT) { uh[k] = u0[k] + (int32_t)a.hw_children[p]; qch[k] = a.sqch[p]; }
+            c1[k] = a.c1row[p]; c2[k] = a.c2[p]; c3[k] = a.c3[p];
+            q[k] = a.sq[p]; s_prev[k] = a.ss[p];
+            const double2 *r2 = reinterpret_cast<const double2 *>(rbase + (int64_t)p * kRec);
+            // the whole 128-byte record back to back: the eight 16-byte requests of a lane hit one line while it is hot
+            // (spreading them over the ticks re-fetches the line: measured 1.9x slower)
+#pragma unroll
+            for (int j = 0; j < kRec / 2; ++j) { const double2 v = r2[j]; rec[k][2 * j] = v.x; rec[k][2 * j + 1] = v.y; }
+            if (lg[k] & kGhostBit) {   // boundary inflow: this chunk of the ghost series instead of the ring
+                const int32_t g = a.bidx[p];
+#pragma unroll
+                for (int j = 0; j < kRec; ++j) {
+                    int64_t ts = tau0 + j - (lg[k] & kLagMask);
+                    ts = ts < 0 ? 0 : (ts >= a.total ? a.total - 1 : ts);
+                    rec[k][j] = a.ghost[ts * a.n_ghost + g];
+                }
+            }
+        } else {
+            lg[k] = -1; u0[k] = u1[k] = 0; c1[k] = c2[k] = c3[k] = q[k] = s_prev[k] = 0.0;
+#pragma unroll
+            for (int j = 0; j < kRec; ++j) rec[k][j] = 0.0;
+        }
+    }
+    const bool has_lat = a.in != nullptr;   // channel-only routing: the records only carry discharge
+
+    auto fetch_halo = [&](int64_t tau, double (&h)[HPT]) {
+        const double *hrow = a.hist + (int64_t)((uint64_t)(tau + a.hist_rows) % (uint32_t)a.hist_rows) * a.n + h0;
+#pragma unroll
+        for (int j = 0; j < HPT; ++j) {
+            const int32_t i = j * TH + tid;
+            h[j] = hrow[i < nh ? i : 0];
+        }
+    };
+    auto put_halo = [&](double *buf, const double (&h)[HPT]) {
+#pragma unroll
+        for (int j = 0; j < HPT; ++j) {
+            const int32_t i = j * TH + tid;
+            if (i < nh) buf[i] = h[j];
+        }
+    };
+    double hs[3][HPT];
+    {
+        double *buf = lds + (size_t)((tau0 + 1) & 1) * a.lh;
+        fetch_halo(tau0 - 1, hs[2]);
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) buf[nh + k * TH + tid] = q[k];
+        put_halo(buf, hs[2]);
+    }
+    fetch_halo(tau0, hs[0]);
+    fetch_halo(tau0 + 1, hs[1]);
+    barrier_lds();
+#pragma unroll
+    for (int s = 0; s < kRec; ++s) {
+        const int64_t tau = tau0 + s;
+        fetch_halo(tau + 2, hs[(s + 2) % 3]);
+        const double *rd = lds + (size_t)((tau + 1) & 1) * a.lh;
+        double *wr = lds + (size_t)(tau & 1) * a.lh;
+        double *hrow = a.hist + (int64_t)((uint64_t)tau % (uint32_t)a.hist_rows) * a.n;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            if (lg[k] < 0) continue;
+            const int32_t p = position(k);
+            double s_cur = 0.0, s_hw = 0.0;
+            if (UNIT) {
+                for (int32_t u = u0[k]; u < uh[k]; ++u) s_hw += rd[u];
+                for (int32_t u = uh[k]; u < u1[k]; ++u) s_cur += rd[u];
+            } else {
+                for (int32_t u = u0[k]; u < u1[k]; ++u) s_cur += rd[u];
+            }
+            const int64_t ts = tau - (lg[k] & kLagMask);
+            if (ts >= 0 && ts < a.total) {
+                const double lat = has_lat ? rec[k][s] : 0.0;
+                if (UNIT) {
+                    if (u0[k] == u1[k]) {
+                        q[k] = lat;        // headwater: discharge = lateral, the record slot already holds it
+                    } else {
+                        const double r = __builtin_fma(c1[k], s_hw + s_cur, __builtin_fma(c2[k], s_hw + s_prev[k], c3[k] * qch[k]));
+                        qch[k] = r;
+                        const double qfull = r + lat;
+                        q[k] = qfull;
+                        rec[k][s] = qfull > 0.0 ? qfull : 0.0;
+                    }
+                } else if (lg[k] & kGhostBit) {
+                    q[k] = rec[k][s];
+                } else {
+                    const double r = __builtin_fma(c1[k], s_cur, __builtin_fma(c2[k], s_prev[k], __builtin_fma(c3[k], q[k], lat)));
+                    q[k] = r;
+                    if (lg[k] & kExportBit) a.exports[ts * a.n_export + a.bidx[p]] = r;
+                    rec[k][s] = r > 0.0 ? r : 0.0;
+                }
+            }
+            s_prev[k] = s_cur;
+            wr[nh + k * TH + tid] = q[k];
+            if (p >= halo_lo) hrow[p] = q[k];
+        }
+        put_halo(wr, hs[s % 3]);
+        if ((s & 7) == 7) {   // eight slots are final: write that whole 64-byte sector of every record now
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                if (lg[k] < 0 || (lg[k] & kGhostBit)) continue;
+                double2 *r2 = reinterpret_cast<double2 *>(rbase + (int64_t)position(k) * kRec) + (s >> 3) * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r2[j] = make_double2(rec[k][s - 7 + 2 * j], rec[k][s - 6 + 2 * j]);
+            }
+        }
+        barrier_lds();
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        if (lg[k] < 0) continue;
+        const int32_t p = position(k);
+        a.sq[p] = q[k]; a.ss[p] = s_prev[k];
+        if (UNIT) a.sqch[p] = qch[k];
+    }
+}
+
 // sq = q0 in engine order, ss = sum of the upstream reaches' q0, every history row = q0
 __global__ __launch_bounds__(kBlock) void k_wave_state_in(double *sq, double *ss, double *hist, int32_t hist_rows,
                                                           const double *q_t, const int32_t *perm,
@@ -662,6 +815,117 @@ __global__ __launch_bounds__(kBlock) void k_uh_tail(const double *__restrict__ k
     new_state[(int64_t)s * n + i] = acc;
 }
 
+// ---- record-mode permutation (one pass each way), see k_wave_rec ----
+// Column i of the params-order rows is engine position p = inv[i] with lag L = 16 * sh + o.  Row t of that column
+// is slot (t + L) % 16 of record (t + L) / 16, so the 64 rows [64 j - o, 64 j + 64 - o) are exactly the four
+// records 4 j + sh .. 4 j + sh + 3.  k_rec_in reads the 79 rows [64 j - 15, 64 j + 64) of a 64-column tile
+// coalesced into LDS and writes four whole 128-byte records per column (8 lanes x 16 B per record); k_rec_out
+// reads five records per column the same way and writes the 64 rows [64 j, 64 j + 64) of the tile coalesced.
+constexpr int kRecCols = 64, kRecBatch = 4, kRecThreads = 256;
+
+struct RecPermArgs {
+    double *rec;
+    int32_t rec_chunks;
+    int64_t n, T, batch;
+    const int2 *colmeta;      // per params column: {engine position, lag}
+    const double *scale;      // c4dt in PARAMS order (RapidMuskingum: the ring holds c4dt * lateral) or NULL
+    RowView rows;             // params-order rows (source of k_rec_in, destination of k_rec_out)
+};
+
+__global__ __launch_bounds__(kRecThreads) void k_rec_in(const RecPermArgs a)
+{
+    constexpr int R = 16 * kRecBatch + 15;
+    __shared__ double tile[R][kRecCols + 1];
+    const int tid = threadIdx.x;
+    const int64_t col0 = (int64_t)blockIdx.x * kRecCols;
+    const int64_t row_first = 64 * a.batch - 15;
+    {   // all row loads in flight first (branch-free: out-of-range rows/columns are clamped and zeroed afterwards)
+        constexpr int RPT = (R + kRecThreads / kRecCols - 1) / (kRecThreads / kRecCols);
+        const int c = tid % kRecCols, r0 = tid / kRecCols;
+        const int64_t i = min(col0 + c, a.n - 1);
+        double v[RPT];
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int64_t t = row_first + r0 + q * (kRecThreads / kRecCols);
+            v[q] = a.rows.row(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t))[i];
+        }
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int r = r0 + q * (kRecThreads / kRecCols);
+            const int64_t t = row_first + r;
+            if (r < R) tile[r][c] = (t >= 0 && t < a.T && col0 + c < a.n) ? v[q] : 0.0;
+        }
+    }
+    __syncthreads();
+    constexpr int IT = kRecCols * kRecBatch * 8 / kRecThreads;
+    int2 meta[IT];
+    double f[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {     // all metadata loads first: they are independent
+        const int64_t i = col0 + ((it * kRecThreads + tid) >> 5);
+        meta[it] = i < a.n ? a.colmeta[i] : make_int2(-1, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int64_t i = col0 + ((it * kRecThreads + tid) >> 5);
+        f[it] = (a.scale && i < a.n) ? a.scale[i] : 1.0;
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int piece = it * kRecThreads + tid;       // (column, record, 16-byte part): 8 consecutive lanes = one record
+        const int c = piece >> 5, k = (piece >> 3) & 3, part = piece & 7;
+        const int32_t p = meta[it].x;
+        if (p < 0) continue;
+        const int32_t lag = meta[it].y;
+        const int o = lag & 15;
+        const int64_t chunk = 4 * a.batch + (lag >> 4) + k;
+        const int r = 15 - o + 16 * k + 2 * part;
+        const double v0 = tile[r][c] * f[it], v1 = tile[r + 1][c] * f[it];
+        double2 *dst = reinterpret_cast<double2 *>(a.rec + ((int64_t)((uint64_t)chunk % (uint32_t)a.rec_chunks) * a.n + p) * kRec) + part;
+        *dst = make_double2(v0, v1);
+    }
+}
+
+__global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
+{
+    constexpr int S = 16 * (kRecBatch + 1);
+    __shared__ double recs[kRecCols][S + 1];
+    const int tid = threadIdx.x;
+    const int64_t col0 = (int64_t)blockIdx.x * kRecCols;
+    constexpr int IT = kRecCols * (kRecBatch + 1) * 8 / kRecThreads;
+    int2 meta[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int64_t i = col0 + (it * kRecThreads + tid) / ((kRecBatch + 1) * 8);
+        meta[it] = i < a.n ? a.colmeta[i] : make_int2(-1, 0);
+    }
+    double2 v[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {     // all record reads in flight before the first LDS write
+        const int piece = it * kRecThreads + tid;
+        const int k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
+        const int32_t p = meta[it].x < 0 ? 0 : meta[it].x;
+        const int64_t chunk = 4 * a.batch + (meta[it].y >> 4) + k;
+        v[it] = *(reinterpret_cast<const double2 *>(a.rec + ((int64_t)((uint64_t)chunk % (uint32_t)a.rec_chunks) * a.n + p) * kRec) + part);
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int piece = it * kRecThreads + tid;
+        const int c = piece / ((kRecBatch + 1) * 8), k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
+        recs[c][16 * k + 2 * part] = v[it].x;
+        recs[c][16 * k + 2 * part + 1] = v[it].y;
+    }
+    __syncthreads();
+    const int c = tid % kRecCols;
+    const int64_t i = col0 + c;
+    if (i >= a.n) return;
+    const int o = a.colmeta[i].y & 15;
+    for (int r = tid / kRecCols; r < 16 * kRecBatch; r += kRecThreads / kRecCols) {
+        const int64_t t = 64 * a.batch + r;
+        if (t < a.T) a.rows.row(t)[i] = recs[c][o + r];
+    }
+}
+
 // Router post-processing on the device (TransformMuskingum.py:128-142): mean over `factor` consecutive rows
 // (sequential sum then one division, as numpy's reduction over a strided axis does) and the float32 cast.
 __global__ __launch_bounds__(kBlock) void k_resample_cast(const double *__restrict__ src, float *__restrict__ dst,
@@ -712,6 +976,8 @@ struct Session {
     double *export_series = nullptr;
     TickArgs a{};
     bool wave = false;            // time-tiled k_wave instead of per-tick k_tick
+    bool rec = false;             // record-mode ring + one-pass permutation (k_wave_rec, k_rec_in, k_rec_out)
+    int64_t rec_chunks = 0, in_batches = 0, n_in_batches = 0, out_batches = 0, n_out_batches = 0;
     int64_t diag = 0, n_diags = 0, n_chunks = 0;
     WaveArgs wa{};
     bool bracket_open = false;
@@ -747,6 +1013,10 @@ struct rr_plan {
     int64_t wave_K = 16, wave_nb = 0, wave_jmax = 0, wave_lh = 0;
     double *d_c1row = nullptr, *d_sq = nullptr, *d_ss = nullptr, *d_si = nullptr, *d_hist = nullptr;
     int64_t hist_cap = 0;
+    int2 *d_colmeta = nullptr;   // per params column {engine position, lag}
+    double *d_c4_params = nullptr;   // c4dt in params order (scale of the record-mode permutation)
+    bool rec_enabled = true;     // record mode where it applies (one sub-step, K = 16, permuted order, device rows)
+    size_t dev_total_bytes = 0;
 
     // boundary reaches of a partitioned network
     int64_t n_ghost = 0, n_export = 0;
@@ -852,13 +1122,27 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
     // the outlet-most reaches have passed them; the time-tiled schedule adds (blocks - 1) * K ticks of skew.
     const int64_t skew_ticks = dmax + (S.wave ? P->wave_nb * P->wave_K : 0);
     const int64_t lag_rows = (skew_ticks + nsub - 1) / nsub;
-    S.ring_rows = S.direct ? 0 : std::min<int64_t>(T, lag_rows + 2 * C + 2);
+    S.rec = S.wave && P->rec_enabled && nsub == 1 && P->wave_K == kRec && !S.direct && !host_io &&
+            (P->wave_threads == 512 || P->wave_hpt == 2);    // the 1024-thread shape with a 4,096-wide halo would spill
+    if (S.rec) {
+        // records are indexed by tick = row + lag: the live rows span (skew + depth) ticks
+        // no wrap-around needed when every chunk the call can touch fits: batches * 4 + deepest lag + the look-ahead record
+        const int64_t all_chunks = kRecBatch * ((T + 14) / (16 * kRecBatch) + 2) + (dmax >> 4) + 2;
+        S.rec_chunks = std::min<int64_t>(all_chunks, (skew_ticks + dmax) / kRec + 32);
+        const int64_t bytes = S.rec_chunks * kRec * n * (int64_t)sizeof(double);
+        if (P->dev_total_bytes > 0 && bytes > (int64_t)(P->dev_total_bytes / 2)) S.rec = false;
+    }
+    S.ring_rows = S.direct ? 0 : (S.rec ? S.rec_chunks * kRec : std::min<int64_t>(T, lag_rows + 2 * C + 2));
     if (S.ring_rows > 0xFFFFFFFFLL || T > 0x7FFFFFFFLL) { S.open = false; return fail(RR_E_INVALID, "route: too many time rows"); }
     int rc = RR_OK;
     if (!S.direct) rc = ensure_cap(&P->d_ring, &P->ring_cap, S.ring_rows * n);
-    if (!rc && !S.direct) rc = ensure_cap(&P->d_mrows, &P->mrows_cap, C * n);
+    if (!rc && !S.direct && !S.rec) rc = ensure_cap(&P->d_mrows, &P->mrows_cap, C * n);
     if (!rc && host_io) rc = ensure_cap(&P->d_stage, &P->stage_cap, C * n);
     if (rc) { S.open = false; return rc; }
+    if (S.rec) {
+        S.n_in_batches = S.has_in ? (T + 14) / (16 * kRecBatch) + 1 : 0;
+        S.n_out_batches = (T + 16 * kRecBatch - 1) / (16 * kRecBatch);
+    }
 
     TickArgs &a = S.a;
     a.child_ptr = P->d_child_ptr; a.lag = P->d_lag; a.w = P->d_w; a.c2 = P->d_c2; a.c3 = P->d_c3; a.c4 = P->d_c4;
@@ -881,6 +1165,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         w.n_ghost = (int32_t)P->n_ghost; w.n_export = (int32_t)P->n_export;
         w.in = a.in; w.out = a.out; w.in_ld = a.in_ld; w.out_ld = a.out_ld; w.in_rows = a.in_rows; w.out_rows = a.out_rows;
         w.lh = (int32_t)P->wave_lh;
+        w.rec = S.rec ? P->d_ring : nullptr; w.rec_chunks = (int32_t)S.rec_chunks;
         w.n = (int32_t)n; w.K = (int32_t)P->wave_K; w.total = S.total; w.nsub = (uint32_t)nsub; w.inv_nsub = 1.0 / (double)nsub;
         if (!P->d_hist || P->hist_cap < (int64_t)w.hist_rows * n) { S.open = false; return fail(RR_E_STATE, "time-tiled routing: history ring not initialised"); }
     }
@@ -1018,6 +1303,18 @@ wave_kernel_t wave_kernel(int threads, int ppt, int hpt, bool one, bool unit)
 #undef RR_WAVE_PICK
 }
 
+wave_kernel_t wave_rec_kernel(int threads, int ppt, int hpt, bool unit)
+{
+#define RR_REC_PICK(T_, P_, H_) (unit ? (wave_kernel_t)k_wave_rec<T_, P_, H_, true> : (wave_kernel_t)k_wave_rec<T_, P_, H_, false>)
+    if (threads == 1024) {
+        if (hpt <= 2) return ppt == 1 ? RR_REC_PICK(1024, 1, 2) : RR_REC_PICK(1024, 2, 2);
+        return ppt == 1 ? RR_REC_PICK(1024, 1, 4) : RR_REC_PICK(1024, 2, 4);
+    }
+    if (hpt <= 4) return ppt == 2 ? RR_REC_PICK(512, 2, 4) : RR_REC_PICK(512, 4, 4);
+    return ppt == 2 ? RR_REC_PICK(512, 2, 8) : RR_REC_PICK(512, 4, 8);
+#undef RR_REC_PICK
+}
+
 // One anti-diagonal of the time-tiled schedule: tasks (block b, chunk diag - b) for every block whose chunk exists.
 int session_launch_diag(rr_plan *P, int64_t d)
 {
@@ -1035,7 +1332,8 @@ int session_launch_diag(rr_plan *P, int64_t d)
     const dim3 g((unsigned)(b_hi - b_lo + 1));
     const size_t lds_bytes = (size_t)2 * P->wave_lh * sizeof(double);
     const dim3 t((unsigned)P->wave_threads);
-    wave_kernel_t fn = wave_kernel(P->wave_threads, P->wave_ppt, P->wave_hpt, S.nsub == 1, S.mode == Mode::Unit);
+    wave_kernel_t fn = S.rec ? wave_rec_kernel(P->wave_threads, P->wave_ppt, P->wave_hpt, S.mode == Mode::Unit)
+                             : wave_kernel(P->wave_threads, P->wave_ppt, P->wave_hpt, S.nsub == 1, S.mode == Mode::Unit);
     hipLaunchKernelGGL(fn, g, t, lds_bytes, S.stream, w);
     if (sample) {
         HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));
@@ -1047,25 +1345,60 @@ int session_launch_diag(rr_plan *P, int64_t d)
     return RR_OK;
 }
 
+void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
+{
+    Session &S = P->ses;
+    const int64_t n = P->h.n;
+    RecPermArgs ra{};
+    ra.rec = P->d_ring; ra.rec_chunks = (int32_t)S.rec_chunks; ra.n = n; ra.T = S.T; ra.batch = batch;
+    ra.colmeta = P->d_colmeta;
+    ra.scale = (in && S.mode == Mode::Rapid) ? P->d_c4_params : nullptr;
+    ra.rows = in ? RowView{const_cast<double *>(S.io.dev_in), n, 0, (uint32_t)S.io.rows_in}
+                 : RowView{S.io.dev_out, n, 0, (uint32_t)S.io.rows_out};
+    const dim3 g((unsigned)((n + kRecCols - 1) / kRecCols));
+    if (in) hipLaunchKernelGGL(k_rec_in, g, dim3(kRecThreads), 0, S.stream, ra);
+    else hipLaunchKernelGGL(k_rec_out, g, dim3(kRecThreads), 0, S.stream, ra);
+}
+
 int session_advance_wave(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, int64_t *export_ready)
 {
     Session &S = P->ses;
     const int64_t dmax = P->h.depth - 1, C = std::max<int64_t>(1, P->chunk_rows);
     const int64_t nb = P->wave_nb, K = P->wave_K;
+    const int64_t rows_per_batch = 16 * kRecBatch;
     rows_ready = std::min(rows_ready, S.T);
     for (;;) {
         bool progressed = false;
-        if (S.has_in && S.rows_loaded < rows_ready) {
-            const int64_t r1 = std::min(rows_ready, S.rows_loaded + C);
-            int rc = session_load_rows(P, S.rows_loaded, r1);
-            if (rc) return rc;
-            S.rows_loaded = r1;
-            progressed = true;
+        int64_t have_rows;
+        if (S.rec) {
+            // one batch of 64 rows -> records; a record slot is recycled only after every row it can hold has left
+            if (S.in_batches < S.n_in_batches) {
+                const int64_t j = S.in_batches;
+                const int64_t hi = kRecBatch * j + (dmax >> 4) + kRecBatch - 1;
+                const bool rows_here = rows_ready >= std::min(rows_per_batch * (j + 1), S.T);
+                const bool slot_free = hi < S.rec_chunks || S.rows_stored >= std::min(S.T, kRec * (hi - S.rec_chunks + 1));
+                if (rows_here && slot_free) {
+                    launch_rec_permute(P, true, j);
+                    ++S.in_batches;
+                    progressed = true;
+                }
+            }
+            const int64_t loaded = S.in_batches >= S.n_in_batches ? S.T : std::max<int64_t>(0, rows_per_batch * S.in_batches - 15);
+            S.rows_loaded = loaded;
+            have_rows = S.has_in ? loaded : rows_ready;
+        } else {
+            if (S.has_in && S.rows_loaded < rows_ready) {
+                const int64_t r1 = std::min(rows_ready, S.rows_loaded + C);
+                int rc = session_load_rows(P, S.rows_loaded, r1);
+                if (rc) return rc;
+                S.rows_loaded = r1;
+                progressed = true;
+            }
+            have_rows = S.has_in ? S.rows_loaded : rows_ready;
         }
         // diagonal d runs chunk d of block 0 (lag 0): ticks below (d+1)*K need rows below ceil((d+1)*K / nsub)
-        const int64_t have_rows = S.has_in ? S.rows_loaded : rows_ready;
         int64_t launched = 0;
-        const int64_t batch = std::max<int64_t>(1, C * S.nsub / K);
+        const int64_t batch = std::max<int64_t>(1, (S.rec ? rows_per_batch : C) * S.nsub / K);
         while (S.diag < S.n_diags && launched < batch) {
             const int64_t need_ticks = std::min((S.diag + 1) * K, S.total);
             if (have_rows < S.T && have_rows * S.nsub < need_ticks) break;
@@ -1086,7 +1419,14 @@ int session_advance_wave(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
             done = ticks - dmax <= 0 ? 0 : (ticks - dmax) / S.nsub;
         }
         done = std::min(done, S.T);
-        if (done > S.rows_stored) {
+        if (S.rec) {
+            while (S.out_batches < S.n_out_batches && done >= std::min(rows_per_batch * (S.out_batches + 1), S.T)) {
+                launch_rec_permute(P, false, S.out_batches);
+                ++S.out_batches;
+                S.rows_stored = std::min(S.T, rows_per_batch * S.out_batches);
+                progressed = true;
+            }
+        } else if (done > S.rows_stored) {
             int rc = session_store_rows(P, S.rows_stored, done);
             if (rc) return rc;
             S.rows_stored = done;
@@ -1364,7 +1704,7 @@ void rr_plan_destroy(rr_plan *P)
     if (!P) return;
     if (P->device >= 0 && hipSetDevice(P->device) == hipSuccess) {
         void *ptrs[] = {P->d_child_ptr, P->d_lag, P->d_perm, P->d_inv, P->d_inner_pos, P->d_bidx, P->d_hwc, P->d_w, P->d_c2,
-                        P->d_c1row, P->d_sq, P->d_ss, P->d_si, P->d_hist,
+                        P->d_c1row, P->d_sq, P->d_ss, P->d_si, P->d_hist, P->d_colmeta, P->d_c4_params,
                         P->d_c3, P->d_c4, P->d_x, P->d_isum, P->d_qch, P->d_ring, P->d_stage, P->d_mrows,
                         P->d_slot_a[0], P->d_slot_a[1], P->d_slot_b[0], P->d_slot_b[1], P->d_m_index[0], P->d_m_index[1]};
         for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1384,6 +1724,7 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
     if (const char *e = getenv("RR_CHUNK_ROWS")) P->chunk_rows = std::max(1, atoi(e));        // tuning knobs
     if (const char *e = getenv("RR_PERM_ROWS_PER_BLOCK")) P->perm_rows_per_block = std::max(1, atoi(e));
     if (const char *e = getenv("RR_WAVE")) P->wave_enabled = atoi(e) != 0;
+    if (const char *e = getenv("RR_REC")) P->rec_enabled = atoi(e) != 0;
     if (const char *e = getenv("RR_WAVE_K")) P->wave_K = std::max(1, atoi(e));
     std::string err;
     int rc = rr::build_host_plan(n, csc_indptr, csc_indices, P->h, err);
@@ -1429,6 +1770,7 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
             // third of the card's memory: shrink K, and below K = 4 stream with k_tick (ring = depth rows only).
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
+                P->dev_total_bytes = total_b;
                 const int64_t budget_rows = (int64_t)(total_b / 3) / (n * (int64_t)sizeof(double));
                 int64_t k = (budget_rows - P->h.depth - 64) / std::max<int64_t>(1, P->wave_nb);
                 k = std::min<int64_t>(P->wave_K, k) & ~(int64_t)1;
@@ -1441,6 +1783,9 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
                                                 (int)(2 * P->wave_lh * sizeof(double)));
             if (ea != hipSuccess) P->wave_enabled = false;
         }
+        for (int v = 0; v < 2; ++v)
+            (void)hipFuncSetAttribute((const void *)wave_rec_kernel(P->wave_threads, P->wave_ppt, P->wave_hpt, v != 0),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * P->wave_lh * sizeof(double)));
         const rr::HostPlan &H = P->h;
         const int64_t ni = (int64_t)H.inner_pos.size();
         rc = dev_alloc(&P->d_child_ptr, n + 1);
@@ -1450,6 +1795,13 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         if (!rc) rc = dev_alloc(&P->d_inner_pos, ni);
         if (!rc) rc = dev_alloc(&P->d_hwc, n);
         if (!rc) rc = dev_alloc(&P->d_bidx, n);
+        if (!rc) rc = dev_alloc(&P->d_c4_params, n);
+        if (!rc) rc = dev_alloc(&P->d_colmeta, n);
+        if (!rc) {
+            std::vector<int2> cm(n);
+            for (int64_t i = 0; i < n; ++i) cm[i] = make_int2(H.inv[i], H.lag[H.inv[i]]);
+            rc = dev_upload(P->d_colmeta, cm);
+        }
         if (!rc) rc = dev_alloc(&P->d_c1row, n);
         if (!rc) rc = dev_alloc(&P->d_sq, n);
         if (!rc) rc = dev_alloc(&P->d_ss, n);
@@ -1544,6 +1896,10 @@ int rr_plan_set_coeffs(rr_plan *P, const double *lhs_off_data, const double *c2,
     if (!rc) rc = dev_upload(P->d_c2, a2);
     if (!rc) rc = dev_upload(P->d_c3, a3);
     if (!rc) rc = dev_upload(P->d_c4, a4);
+    if (!rc && c4_dt && n > 0) {
+        hipError_t e = hipMemcpy(P->d_c4_params, c4_dt, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) rc = fail(RR_E_HIP, hipGetErrorString(e));
+    }
     if (rc) return rc;
     P->coeffs_set = true;
     P->has_c4 = c4_dt != nullptr;

@@ -163,3 +163,49 @@ def test_degenerate_network_shapes(monkeypatch, wave):
     comb = np.concatenate([m + np.arange(m), m + 1 + np.arange(m)]).astype(np.int64)
     comb[-1] = -1
     assert _route_vs_oracle(comb, T=14)[0] == m + 1
+
+
+def _device_route(plan, q0, ql, T, nsub, out_rows=None):
+    from river_route_amd.engine import DeviceBuffer
+    n = q0.shape[0]
+    out_rows = out_rows or T
+    d_q = DeviceBuffer(n * 8).upload(q0)
+    d_ql = DeviceBuffer(ql.nbytes).upload(ql)
+    d_out = DeviceBuffer(out_rows * n * 8)
+    plan.rapid_route_dev(d_q, d_ql, ql.shape[0], d_out, out_rows, T, nsub)
+    q = d_q.download(np.float64, (n,))
+    d = d_out.download(np.float64, (out_rows, n))
+    for b in (d_q, d_ql, d_out):
+        b.free()
+    return q, d
+
+
+@pytest.mark.parametrize('env', [{}, {'RR_REC': '0'}, {'RR_WAVE': '0'}, {'RR_WAVE_THREADS': '512'}])
+@pytest.mark.parametrize('n,T,ql_rows', [(60000, 100, 100), (60000, 7, 7), (3000, 6000, 48), (60000, 5000, 96)])
+def test_device_resident_route_record_mode(monkeypatch, env, n, T, ql_rows):
+    """Device arrays in params order (the bench path): record-mode ring + one-pass permutation (default), the
+    row-mode tiled permutation (RR_REC=0) and the streaming kernel, incl. cyclic forcing and ring wrap-around."""
+    for k in ('RR_WAVE', 'RR_WAVE_K', 'RR_WAVE_PPT', 'RR_WAVE_THREADS', 'RR_REC'):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    net = synth.synth_network(n, seed=13)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0)
+    lhs, c4_dt = -c1[indices], (c1 + c2) / 900.0
+    ql = synth.synth_qlateral(n, 0, ql_rows)
+    q0 = 4.0 * synth.u01(1, np.arange(n))
+    ql_full = np.ascontiguousarray(np.tile(ql, (T // ql_rows + 1, 1))[:T])
+    q_ref, d_ref = q0.copy(), np.zeros((T, n))
+    oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql_full, d_ref, 1)
+    with Plan(indptr, indices) as plan:
+        plan.set_coeffs(lhs, c2, c3, c4_dt)
+        q, d = _device_route(plan, q0, ql, T, 1)
+        assert_close(q, q_ref, 'q_t')
+        assert_close(d, d_ref, 'discharge')
+        # again on the same plan, into a cyclic sink: only the last rows survive
+        sink = min(T, 32)
+        q2, d2 = _device_route(plan, q0, ql, T, 1, out_rows=sink)
+        np.testing.assert_array_equal(q2, q)
+        last = np.arange(T - sink, T)
+        np.testing.assert_array_equal(d2[last % sink], d[last])
