@@ -1008,7 +1008,7 @@ struct rr_plan {
     int64_t perm_rows_per_block = 2;
 
     // time-tiled routing (k_wave)
-    bool wave_enabled = true, weights_uniform = false;
+    bool wave_enabled = true, wave_forced = false, wave_now = false, weights_uniform = false;
     int wave_threads = 512, wave_ppt = 4, wave_hpt = 4;
     int64_t wave_K = 16, wave_nb = 0, wave_jmax = 0, wave_lh = 0;
     double *d_c1row = nullptr, *d_sq = nullptr, *d_ss = nullptr, *d_si = nullptr, *d_hist = nullptr;
@@ -1078,11 +1078,22 @@ int ensure_cap(T **buf, int64_t *cap, int64_t count)
 
 // ---- session -------------------------------------------------------------------------------------
 
-bool use_wave(const rr_plan *P, Mode mode)
+// Which routing kernel a call of `total` sub-steps uses.  The time-tiled schedule pays (blocks * K) extra ticks of
+// fill/drain per call but runs a full tick ~2.8x faster than the streaming kernel, and its partly filled launches are
+// cheap; measured at 1M reaches (blocks * K = 7,824): 744 steps 35 vs 29 ms, 2,976 steps 73 vs 96 ms, break-even
+// near 1,200 steps.  RR_WAVE=1 forces it, RR_WAVE=0 forbids it.
+bool decide_wave(rr_plan *P, Mode mode, int64_t total)
 {
-    return P->wave_enabled && P->weights_uniform && P->h.n > 0 &&
-           (mode != Mode::Unit || (P->n_ghost == 0 && P->n_export == 0));
+    bool ok = P->wave_enabled && P->weights_uniform && P->h.n > 0 &&
+              (mode != Mode::Unit || (P->n_ghost == 0 && P->n_export == 0));
+    if (ok && !P->wave_forced) {
+        ok = 6 * total >= P->wave_nb * P->wave_K;
+    }
+    P->wave_now = ok;
+    return ok;
 }
+
+bool use_wave(const rr_plan *P, Mode) { return P->wave_now; }
 
 int64_t wave_hist_rows(const rr_plan *P) { return (P->wave_jmax + 2) * P->wave_K; }
 
@@ -1564,6 +1575,7 @@ int rapid_like(rr_plan *P, Mode mode, double *q_t, const Rows &io, int64_t T, in
 {
     const int64_t n = P->h.n;
     if (n == 0 || T == 0) return RR_OK;
+    decide_wave(P, mode, T * nsub);
     double *d_q = q_t;
     double *tmp = nullptr;
     if (q_on_host) {
@@ -1592,6 +1604,7 @@ int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io, int64_t 
 {
     const int64_t n = P->h.n, ni = (int64_t)P->h.inner_pos.size();
     if (n == 0 || T == 0) return RR_OK;
+    decide_wave(P, Mode::Unit, T * nsub);
     double *d_qch = q_ch, *d_qfull = q_full, *tmp = nullptr;
     if (q_on_host) {
         int rc = dev_alloc(&tmp, 2 * std::max<int64_t>(ni, 1));
@@ -1723,7 +1736,7 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
     if (!P) return fail(RR_E_ALLOC, "rr_plan_create: out of memory");
     if (const char *e = getenv("RR_CHUNK_ROWS")) P->chunk_rows = std::max(1, atoi(e));        // tuning knobs
     if (const char *e = getenv("RR_PERM_ROWS_PER_BLOCK")) P->perm_rows_per_block = std::max(1, atoi(e));
-    if (const char *e = getenv("RR_WAVE")) P->wave_enabled = atoi(e) != 0;
+    if (const char *e = getenv("RR_WAVE")) { P->wave_enabled = atoi(e) != 0; P->wave_forced = atoi(e) == 1; }
     if (const char *e = getenv("RR_REC")) P->rec_enabled = atoi(e) != 0;
     if (const char *e = getenv("RR_WAVE_K")) P->wave_K = std::max(1, atoi(e));
     std::string err;
@@ -1996,6 +2009,7 @@ int rr_stream_begin(rr_plan *P, int has_lateral, const double *q_t, const double
     Rows io; io.dev_in = has_lateral ? lateral : nullptr; io.rows_in = lat_rows; io.dev_out = discharge; io.rows_out = out_rows;
     const Mode mode = has_lateral ? Mode::Rapid : Mode::Muskingum;
     if (P->ses.open) return fail(RR_E_STATE, "a routing call is already open on this plan (rr_stream_end it first)");
+    decide_wave(P, mode, T * nsub);
     if (P->h.n > 0 && T > 0) {
         rc = launch_state_in(P, mode, q_t, (hipStream_t)stream);
         if (rc) return rc;

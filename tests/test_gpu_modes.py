@@ -20,9 +20,9 @@ def csc_from_down(down_index):
     return indptr, down_index[has].astype(np.int32)
 
 
-@pytest.mark.parametrize('env', [{'RR_WAVE': '0'}, {'RR_WAVE_K': '4'}, {'RR_WAVE_K': '16', 'RR_WAVE_PPT': '1'},
-                                 {'RR_WAVE_THREADS': '512', 'RR_WAVE_K': '6'},
-                                 {'RR_WAVE_THREADS': '512', 'RR_WAVE_PPT': '2', 'RR_WAVE_K': '32'}])
+@pytest.mark.parametrize('env', [{'RR_WAVE': '0'}, {'RR_WAVE': '1', 'RR_WAVE_K': '4'}, {'RR_WAVE': '1', 'RR_WAVE_K': '16', 'RR_WAVE_PPT': '1'},
+                                 {'RR_WAVE': '1', 'RR_WAVE_THREADS': '512', 'RR_WAVE_K': '6'},
+                                 {'RR_WAVE': '1', 'RR_WAVE_THREADS': '512', 'RR_WAVE_PPT': '2', 'RR_WAVE_K': '32'}])
 @pytest.mark.parametrize('n,T,nsub,has_lateral', [(60000, 70, 1, True), (60000, 23, 3, True), (60000, 31, 2, False)])
 def test_every_kernel_shape_matches_the_oracle(monkeypatch, env, n, T, nsub, has_lateral):
     for k in ('RR_WAVE', 'RR_WAVE_K', 'RR_WAVE_PPT', 'RR_WAVE_THREADS'):
@@ -80,7 +80,7 @@ def test_per_edge_weights_fall_back_to_the_streaming_kernel():
     assert_close(d, d_ref, 'discharge')
 
 
-@pytest.mark.parametrize('env', [{'RR_WAVE': '0'}, {}, {'RR_WAVE_K': '4'}, {'RR_WAVE_THREADS': '512', 'RR_WAVE_K': '10'}])
+@pytest.mark.parametrize('env', [{'RR_WAVE': '0'}, {'RR_WAVE': '1'}, {}, {'RR_WAVE': '1', 'RR_WAVE_K': '4'}, {'RR_WAVE': '1', 'RR_WAVE_THREADS': '512', 'RR_WAVE_K': '10'}])
 @pytest.mark.parametrize('n,T,nsub,n_ks', [(40000, 50, 1, 48), (40000, 17, 3, 5)])
 def test_unit_route_every_kernel_shape(monkeypatch, env, n, T, nsub, n_ks):
     """UnitMuskingum through the streaming kernel (k_tick_unit) and the time-tiled kernel (k_wave, UNIT) vs the oracle,
@@ -180,7 +180,8 @@ def _device_route(plan, q0, ql, T, nsub, out_rows=None):
     return q, d
 
 
-@pytest.mark.parametrize('env', [{}, {'RR_REC': '0'}, {'RR_WAVE': '0'}, {'RR_WAVE_THREADS': '512'}])
+@pytest.mark.parametrize('env', [{'RR_WAVE': '1'}, {}, {'RR_WAVE': '1', 'RR_REC': '0'}, {'RR_WAVE': '0'},
+                                 {'RR_WAVE': '1', 'RR_WAVE_THREADS': '512'}])
 @pytest.mark.parametrize('n,T,ql_rows', [(60000, 100, 100), (60000, 7, 7), (3000, 6000, 48), (60000, 5000, 96)])
 def test_device_resident_route_record_mode(monkeypatch, env, n, T, ql_rows):
     """Device arrays in params order (the bench path): record-mode ring + one-pass permutation (default), the
