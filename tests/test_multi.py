@@ -87,7 +87,7 @@ def test_in_process_runner_with_oracle_engine_three_parts():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('wave', ['0', '1'])
+@pytest.mark.parametrize('wave', ['0', '1', 'rec'])
 @pytest.mark.parametrize('n,T,nsub,parts,chunk', [(5000, 40, 1, 3, 8), (5000, 21, 3, 4, 5), (200000, 64, 1, 8, 16),
                                                   (200000, 300, 1, 4, 32)])
 def test_hip_parts_on_one_gpu_match_single_plan(monkeypatch, wave, n, T, nsub, parts, chunk):
@@ -95,8 +95,13 @@ def test_hip_parts_on_one_gpu_match_single_plan(monkeypatch, wave, n, T, nsub, p
     network (itself checked against the oracle in test_gpu_kernels.py)."""
     from river_route_amd.engine import Plan
     from river_route_amd.multi_gpu import HipPartEngine
-    monkeypatch.setenv('RR_WAVE', wave)      # streaming kernel (k_tick) and time-tiled kernel (k_wave) boundary paths
-    monkeypatch.setenv('RR_WAVE_K', '8')
+    # boundary reaches in the streaming kernel (k_tick), the time-tiled kernel in row mode (k_wave, K = 8) and in
+    # record mode (k_wave_rec, K = 16; one sub-step per row only)
+    monkeypatch.setenv('RR_WAVE', '0' if wave == '0' else '1')
+    if wave == '1':
+        monkeypatch.setenv('RR_WAVE_K', '8')
+    else:
+        monkeypatch.delenv('RR_WAVE_K', raising=False)
     net, indptr, indices, c1, c2, c3, q0 = setup_case(n)
     dt = 900.0
     c4_dt = (c1 + c2) / (dt * nsub)
