@@ -83,7 +83,7 @@ int rr_plan_layout(const rr_plan *plan, int32_t *perm, int32_t *lag, int32_t *ch
 int rr_plan_set_coeffs(rr_plan *plan, const double *lhs_off_data, const double *c2, const double *c3,
                        const double *c4_dt);
 
-/* Tuning / measurement.  rows_per_chunk: time rows moved per permutation launch (default 32).
+/* Tuning / measurement.  rows_per_chunk: time rows moved per row-mode permutation launch (default 16).
  * sample_every >= 16: every sample_every-th routing-tick launch opens a HIP-event bracket around 16
  * consecutive routing-tick launches on the call's stream (0 switches sampling off). */
 int rr_plan_set_options(rr_plan *plan, int64_t rows_per_chunk, int64_t sample_every);
