@@ -342,7 +342,6 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
     const int32_t nh = b0 - h0;
     const int32_t halo_lo = max(b0, a.child_ptr[b1]);     // own positions read by blocks to the right
     auto position = [&](int k) { return b0 + k * TH + tid; };
-
     // lg keeps the ghost / export flag bits of lag[]; slot is the column of a flagged reach in its boundary series
     // UNIT (UnitMuskingum, _numba_kernels.py:113-171): q is what a reach publishes (q_full, or the lateral itself for a
     // headwater), qch the channel-only discharge; uh splits the upstream range into headwater and inner tributaries.
@@ -527,6 +526,7 @@ __global__ __launch_bounds__(TH) void k_wave_rec(const WaveArgs a)
     const int32_t halo_lo = max(b0, a.child_ptr[b1]);
     auto position = [&](int k) { return b0 + k * TH + tid; };
     const int64_t tau0 = chunk * kRec;
+
     double *rbase = a.rec + (int64_t)((uint64_t)chunk % (uint32_t)a.rec_chunks) * a.n * kRec;
 
     int32_t lg[PPT], u0[PPT], u1[PPT], uh[UNIT ? PPT : 1];
@@ -1331,8 +1331,14 @@ int session_launch_diag(rr_plan *P, int64_t d)
 {
     Session &S = P->ses;
     const int64_t nb = P->wave_nb, K = P->wave_K, n = P->h.n;
-    const int64_t b_lo = std::max<int64_t>(0, d - (S.n_chunks - 1)), b_hi = std::min<int64_t>(nb - 1, d);
-    if (b_hi < b_lo) return RR_OK;
+    int64_t b_lo = std::max<int64_t>(0, d - (S.n_chunks - 1)), b_hi = std::min<int64_t>(nb - 1, d);
+    // fill / drain: a block none of whose reaches is active during its chunk has nothing to do (lag is sorted, so the
+    // idle blocks are a suffix while the pipeline fills and a prefix while it drains; history rows they leave
+    // untouched are only ever read by reaches that are inactive themselves)
+    const int64_t bs = (int64_t)P->wave_ppt * P->wave_threads;
+    while (b_hi >= b_lo && (d - b_hi + 1) * K <= P->h.lag[b_hi * bs]) --b_hi;
+    while (b_lo <= b_hi && (d - b_lo) * K >= (int64_t)P->h.lag[std::min(n, (b_lo + 1) * bs) - 1] + S.total) ++b_lo;
+    if (b_hi < b_lo) { ++P->prof_launches; return RR_OK; }
     WaveArgs &w = S.wa;
     w.diag = d; w.b_first = (int32_t)b_lo;
     // a launch is sampled when every block takes part and every reach is active for all K ticks of its task
