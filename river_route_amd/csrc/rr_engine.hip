@@ -49,6 +49,26 @@ constexpr int32_t kLagMask = kExportBit - 1;
 // kernels
 // ------------------------------------------------------------------------------------------------
 
+// Index arithmetic: every tick, row and chunk index of a call is below 2^31 (checked in session_begin), and the
+// hardware has no integer divide -- a 64-bit `%` is a ~100-instruction emulation.  Division by a run-time constant
+// goes through a host-computed double reciprocal instead: floor(x * (1/d)) is exact or one too small (only when d
+// divides x), which the single fix-up repairs.
+struct Div32 {
+    uint32_t d;
+    double inv;
+    Div32() = default;
+    __host__ __device__ explicit Div32(uint32_t d_) : d(d_ ? d_ : 1u), inv(1.0 / (double)(d_ ? d_ : 1u)) {}
+    __device__ __forceinline__ uint32_t div(uint32_t x, uint32_t &rem) const
+    {
+        uint32_t q = (uint32_t)((double)x * inv);
+        uint32_t r = x - q * d;
+        if (r >= d) { r -= d; ++q; }
+        rem = r;
+        return q;
+    }
+    __device__ __forceinline__ uint32_t mod(uint32_t x) const { uint32_t r; div(x, r); return r; }
+};
+
 struct TickArgs {
     const int32_t *child_ptr;  // [n+1]
     const int32_t *lag;        // [n]
@@ -65,11 +85,11 @@ struct TickArgs {
     const double *in;          // lateral rows, engine order (NULL for channel-only)
     double *out;               // discharge rows, engine order
     int64_t in_ld, out_ld;
-    uint32_t in_rows, out_rows;
+    Div32 in_rows, out_rows;
     int32_t p_lo, p_hi;        // active engine positions
     int64_t tau;               // tick
     int64_t total_substeps;    // T * nsub
-    uint32_t nsub;
+    Div32 nsub;
     double inv_nsub;
 };
 
@@ -81,32 +101,32 @@ __global__ __launch_bounds__(kBlock) void k_tick(const TickArgs a)
     const int32_t p = a.p_lo + (int32_t)(blockIdx.x * kBlock + threadIdx.x);
     if (p >= a.p_hi) return;
     const int32_t lag_bits = a.lag[p];
-    const int64_t ts = a.tau - (int64_t)(lag_bits & kLagMask);
-    if (ts < 0 || ts >= a.total_substeps) return;
+    const int32_t ts = (int32_t)a.tau - (lag_bits & kLagMask);
+    if (ts < 0 || ts >= (int32_t)a.total_substeps) return;
     if (lag_bits & kGhostBit) {   // boundary inflow: the value another GPU computed for this sub-step
-        a.xc[p] = a.ghost[ts * a.n_ghost + a.bidx[p]];
+        a.xc[p] = a.ghost[(int64_t)ts * a.n_ghost + a.bidx[p]];
         return;
     }
     uint32_t t, s;
     if (SINGLE_SUBSTEP) { t = (uint32_t)ts; s = 0; }
-    else { t = (uint32_t)((uint64_t)ts / a.nsub); s = (uint32_t)((uint64_t)ts - (uint64_t)t * a.nsub); }
+    else t = a.nsub.div((uint32_t)ts, s);
 
     const int32_t u0 = a.child_ptr[p], u1 = a.child_ptr[p + 1];
     double r = a.c3[p] * a.xa[p];
-    if (HAS_LATERAL) r += a.c4[p] * a.in[(int64_t)(t % a.in_rows) * a.in_ld + p];
+    if (HAS_LATERAL) r += a.c4[p] * a.in[(int64_t)a.in_rows.mod(t) * a.in_ld + p];
     const double c2 = a.c2[p];
     for (int32_t u = u0; u < u1; ++u) r += c2 * a.xb[u];
     for (int32_t u = u0; u < u1; ++u) r += a.w[u] * a.xa[u];
-    if (lag_bits & kExportBit) a.exports[ts * a.n_export + a.bidx[p]] = r;
+    if (lag_bits & kExportBit) a.exports[(int64_t)ts * a.n_export + a.bidx[p]] = r;
     a.xc[p] = r;
 
     if (SINGLE_SUBSTEP) {
-        a.out[(int64_t)(t % a.out_rows) * a.out_ld + p] = r > 0.0 ? r : 0.0;
+        a.out[(int64_t)a.out_rows.mod(t) * a.out_ld + p] = r > 0.0 ? r : 0.0;
     } else {
         const double acc = (s == 0 ? 0.0 : a.isum[p]) + r;
-        if (s + 1 == a.nsub) {
+        if (s + 1 == a.nsub.d) {
             const double v = acc * a.inv_nsub;
-            a.out[(int64_t)(t % a.out_rows) * a.out_ld + p] = v > 0.0 ? v : 0.0;
+            a.out[(int64_t)a.out_rows.mod(t) * a.out_ld + p] = v > 0.0 ? v : 0.0;
         } else {
             a.isum[p] = acc;
         }
@@ -128,17 +148,17 @@ __global__ __launch_bounds__(kBlock) void k_tick_unit(const UnitTickArgs ua)
     const TickArgs &a = ua.t;
     const int32_t p = a.p_lo + (int32_t)(blockIdx.x * kBlock + threadIdx.x);
     if (p >= a.p_hi) return;
-    const int64_t ts = a.tau - (int64_t)(a.lag[p] & kLagMask);
-    if (ts < 0 || ts >= a.total_substeps) return;
+    const int32_t ts = (int32_t)a.tau - (a.lag[p] & kLagMask);
+    if (ts < 0 || ts >= (int32_t)a.total_substeps) return;
     uint32_t t, s;
     if (SINGLE_SUBSTEP) { t = (uint32_t)ts; s = 0; }
-    else { t = (uint32_t)((uint64_t)ts / a.nsub); s = (uint32_t)((uint64_t)ts - (uint64_t)t * a.nsub); }
+    else t = a.nsub.div((uint32_t)ts, s);
 
-    const double lat = a.in[(int64_t)(t % a.in_rows) * a.in_ld + p];
+    const double lat = a.in[(int64_t)a.in_rows.mod(t) * a.in_ld + p];
     const int32_t u0 = a.child_ptr[p], u1 = a.child_ptr[p + 1];
     if (u0 == u1) {  // headwater: discharge is the lateral inflow, unclamped and un-averaged (lines 122-123)
         a.xc[p] = lat;
-        if (s == 0) a.out[(int64_t)(t % a.out_rows) * a.out_ld + p] = lat;
+        if (s == 0) a.out[(int64_t)a.out_rows.mod(t) * a.out_ld + p] = lat;
         return;
     }
     const int32_t uh = u0 + (int32_t)ua.hw_children[p];
@@ -152,12 +172,12 @@ __global__ __launch_bounds__(kBlock) void k_tick_unit(const UnitTickArgs ua)
     a.xc[p] = qfull;
 
     if (SINGLE_SUBSTEP) {
-        a.out[(int64_t)(t % a.out_rows) * a.out_ld + p] = qfull > 0.0 ? qfull : 0.0;
+        a.out[(int64_t)a.out_rows.mod(t) * a.out_ld + p] = qfull > 0.0 ? qfull : 0.0;
     } else {
         const double acc = (s == 0 ? 0.0 : a.isum[p]) + qfull;
-        if (s + 1 == a.nsub) {
+        if (s + 1 == a.nsub.d) {
             const double v = acc * a.inv_nsub;
-            a.out[(int64_t)(t % a.out_rows) * a.out_ld + p] = v > 0.0 ? v : 0.0;
+            a.out[(int64_t)a.out_rows.mod(t) * a.out_ld + p] = v > 0.0 ? v : 0.0;
         } else {
             a.isum[p] = acc;
         }
@@ -173,8 +193,10 @@ struct RowView {
     double *base;
     int64_t ld;
     int64_t t0;
-    uint32_t rows;
-    __device__ __forceinline__ double *row(int64_t t) const { return base + (int64_t)((uint64_t)(t - t0) % rows) * ld; }
+    Div32 rows;
+    RowView() = default;
+    RowView(double *base_, int64_t ld_, int64_t t0_, uint32_t rows_) : base(base_), ld(ld_), t0(t0_), rows(rows_) {}
+    __device__ __forceinline__ double *row(int64_t t) const { return base + (int64_t)rows.mod((uint32_t)(t - t0)) * ld; }
 };
 
 // Phase A: source tile -> LDS (sorted by destination tile) -> runs of the intermediate rows M[r, :].
@@ -314,12 +336,15 @@ struct WaveArgs {
     const double *in;
     double *out;
     int64_t in_ld, out_ld;
-    uint32_t in_rows, out_rows;
+    Div32 in_rows, out_rows;
     double *rec;                          // record ring [rec_chunks][n][16] (record mode)
-    int32_t rec_chunks;
+    Div32 rec_chunks;
+#ifdef RR_WAVE_TRACE
+    long long *trace; int64_t trace_diag;   // development build: per-block timestamps of one diagonal (profiles/microbench/wave_dbg.py)
+#endif
     int32_t n, hist_rows, K, b_first, lh;   // lh: LDS positions per tick buffer (halo capacity + block)
     int64_t diag, total;
-    uint32_t nsub;
+    Div32 nsub;
     double inv_nsub;
 };
 
@@ -364,27 +389,33 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
             if (!SINGLE_SUBSTEP) isum[k] = 0.0;
         }
     }
-    const int64_t tau0 = chunk * a.K, tau_end = tau0 + a.K;
+    const int32_t tau0 = (int32_t)chunk * a.K, tau_end = tau0 + a.K, total = (int32_t)a.total;
 
     // Prefetches are branch-free (addresses are clamped to something valid, the value is ignored where it does
     // not apply) and nothing touches the loaded registers until the tick that consumes them, so hipcc leaves the
     // loads in flight across the barriers instead of waiting right behind each one.
     const double *lat_base = a.in ? a.in : a.sq;     // channel-only routing: any readable array, c4 is zero
-    const uint32_t lat_rows = a.in ? a.in_rows : 1u;
+    const Div32 lat_rows = a.in ? a.in_rows : Div32(1u);
     const int64_t lat_ld = a.in ? a.in_ld : 0;
-    auto fetch_lat = [&](int64_t tau, double (&lat)[PPT]) {     // lateral of the row each reach is at
+    auto fetch_lat = [&](int32_t tau, double (&lat)[PPT]) {     // lateral of the row each reach is at
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            int64_t ts = tau - (lg[k] < 0 ? 0 : (lg[k] & kLagMask));
-            ts = ts < 0 ? 0 : (ts >= a.total ? a.total - 1 : ts);
-            const uint32_t t = SINGLE_SUBSTEP ? (uint32_t)ts : (uint32_t)((uint64_t)ts / a.nsub);
-            const double *src = lat_base + (int64_t)(t % lat_rows) * lat_ld + min(position(k), b1 - 1);
-            if (lg[k] >= 0 && (lg[k] & kGhostBit)) src = a.ghost + ts * a.n_ghost + slot[k];   // prescribed boundary inflow
+            int32_t ts = tau - (lg[k] < 0 ? 0 : (lg[k] & kLagMask));
+            ts = ts < 0 ? 0 : (ts >= total ? total - 1 : ts);
+            uint32_t sub;
+            const uint32_t t = SINGLE_SUBSTEP ? (uint32_t)ts : a.nsub.div((uint32_t)ts, sub);
+            const double *src = lat_base + (int64_t)lat_rows.mod(t) * lat_ld + min(position(k), b1 - 1);
+            if (lg[k] >= 0 && (lg[k] & kGhostBit)) src = a.ghost + (int64_t)ts * a.n_ghost + slot[k];   // prescribed boundary inflow
             lat[k] = *src;
         }
     };
-    auto fetch_halo = [&](int64_t tau, double (&h)[HPT]) {      // the left neighbours' values of tick tau
-        const double *hrow = a.hist + (int64_t)((uint64_t)(tau + a.hist_rows) % (uint32_t)a.hist_rows) * a.n + h0;
+    // the history ring is walked one row per tick: rows of the next halo fetch and of the next tick's own writes
+    const uint32_t hrows = (uint32_t)a.hist_rows;
+    auto next_row = [&](uint32_t r) { return r + 1 == hrows ? 0u : r + 1; };
+    uint32_t hr_fetch = Div32(hrows).mod((uint32_t)tau0 + hrows - 1), hr_tick = next_row(hr_fetch);
+    auto fetch_halo = [&](double (&h)[HPT]) {      // the left neighbours' values of the next tick in sequence
+        const double *hrow = a.hist + (int64_t)hr_fetch * a.n + h0;
+        hr_fetch = next_row(hr_fetch);
 #pragma unroll
         for (int j = 0; j < HPT; ++j) {
             const int32_t i = j * TH + tid;
@@ -398,10 +429,11 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
             if (i < nh) buf[i] = h[j];
         }
     };
-    auto tick = [&](int64_t tau, const double (&lat)[PPT], const double (&h)[HPT]) {
+    auto tick = [&](int32_t tau, const double (&lat)[PPT], const double (&h)[HPT]) {
         const double *rd = lds + (size_t)((tau + 1) & 1) * a.lh;   // values of tick tau-1
         double *wr = lds + (size_t)(tau & 1) * a.lh;
-        double *hrow = a.hist + (int64_t)((uint64_t)tau % (uint32_t)a.hist_rows) * a.n;
+        double *hrow = a.hist + (int64_t)hr_tick * a.n;
+        hr_tick = next_row(hr_tick);
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
             if (lg[k] < 0) continue;
@@ -413,12 +445,12 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
             } else {
                 for (int32_t u = u0[k]; u < u1[k]; ++u) s_cur += rd[u];
             }
-            const int64_t ts = tau - (lg[k] & kLagMask);
-            const bool active = ts >= 0 && ts < a.total;
+            const int32_t ts = tau - (lg[k] & kLagMask);
+            const bool active = ts >= 0 && ts < total;
             if (UNIT && active) {
-                const uint32_t t = SINGLE_SUBSTEP ? (uint32_t)ts : (uint32_t)((uint64_t)ts / a.nsub);
-                const uint32_t sub = SINGLE_SUBSTEP ? 0u : (uint32_t)((uint64_t)ts - (uint64_t)t * a.nsub);
-                double *orow = a.out + (int64_t)(t % a.out_rows) * a.out_ld;
+                uint32_t sub = 0u;
+                const uint32_t t = SINGLE_SUBSTEP ? (uint32_t)ts : a.nsub.div((uint32_t)ts, sub);
+                double *orow = a.out + (int64_t)a.out_rows.mod(t) * a.out_ld;
                 if (u0[k] == u1[k]) {   // headwater: discharge is the lateral inflow, unclamped and un-averaged
                     q[k] = lat[k];
                     if (sub == 0) orow[p] = lat[k];
@@ -431,7 +463,7 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
                         orow[p] = qfull > 0.0 ? qfull : 0.0;
                     } else {
                         const double acc = (sub == 0 ? 0.0 : isum[k]) + qfull;
-                        if (sub + 1 == a.nsub) { const double v = acc * a.inv_nsub; orow[p] = v > 0.0 ? v : 0.0; }
+                        if (sub + 1 == a.nsub.d) { const double v = acc * a.inv_nsub; orow[p] = v > 0.0 ? v : 0.0; }
                         isum[k] = acc;
                     }
                 }
@@ -442,16 +474,16 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
                 const double r = __builtin_fma(c1[k], s_cur, __builtin_fma(c2[k], s_prev[k],
                                  __builtin_fma(c4[k], lat[k], c3[k] * q[k])));
                 q[k] = r;
-                if (lg[k] & kExportBit) a.exports[ts * a.n_export + slot[k]] = r;
+                if (lg[k] & kExportBit) a.exports[(int64_t)ts * a.n_export + slot[k]] = r;
                 if (SINGLE_SUBSTEP) {
-                    a.out[(int64_t)((uint32_t)ts % a.out_rows) * a.out_ld + p] = r > 0.0 ? r : 0.0;
+                    a.out[(int64_t)a.out_rows.mod((uint32_t)ts) * a.out_ld + p] = r > 0.0 ? r : 0.0;
                 } else {
-                    const uint32_t t = (uint32_t)((uint64_t)ts / a.nsub);
-                    const uint32_t sub = (uint32_t)((uint64_t)ts - (uint64_t)t * a.nsub);
+                    uint32_t sub;
+                    const uint32_t t = a.nsub.div((uint32_t)ts, sub);
                     const double acc = (sub == 0 ? 0.0 : isum[k]) + r;
-                    if (sub + 1 == a.nsub) {
+                    if (sub + 1 == a.nsub.d) {
                         const double v = acc * a.inv_nsub;
-                        a.out[(int64_t)(t % a.out_rows) * a.out_ld + p] = v > 0.0 ? v : 0.0;
+                        a.out[(int64_t)a.out_rows.mod(t) * a.out_ld + p] = v > 0.0 ? v : 0.0;
                     }
                     isum[k] = acc;
                 }
@@ -469,25 +501,25 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
     double lat0[PPT], lat1[PPT], lat2[PPT], h0v[HPT], h1v[HPT], h2v[HPT];
     {   // tick tau0 reads the buffer of tick tau0 - 1: own discharges + the halo row of that tick
         double *buf = lds + (size_t)((tau0 + 1) & 1) * a.lh;
-        fetch_halo(tau0 - 1, h0v);
+        fetch_halo(h0v);                                      // tick tau0 - 1
 #pragma unroll
         for (int k = 0; k < PPT; ++k) buf[nh + k * TH + tid] = q[k];
         put_halo(buf, h0v);
     }
-    fetch_lat(tau0, lat0); fetch_halo(tau0, h0v);
-    fetch_lat(tau0 + 1, lat1); fetch_halo(tau0 + 1, h1v);     // rows past the chunk are clamped, never used
+    fetch_lat(tau0, lat0); fetch_halo(h0v);
+    fetch_lat(tau0 + 1, lat1); fetch_halo(h1v);               // rows past the chunk are clamped, never used
     barrier_lds();
-    for (int64_t tau = tau0; tau < tau_end; tau += 3) {
-        fetch_lat(tau + 2, lat2); fetch_halo(tau + 2, h2v);
+    for (int32_t tau = tau0; tau < tau_end; tau += 3) {
+        fetch_lat(tau + 2, lat2); fetch_halo(h2v);
         tick(tau, lat0, h0v);
         barrier_lds();
         if (tau + 1 < tau_end) {
-            fetch_lat(tau + 3, lat0); fetch_halo(tau + 3, h0v);
+            fetch_lat(tau + 3, lat0); fetch_halo(h0v);
             tick(tau + 1, lat1, h1v);
         }
         barrier_lds();
         if (tau + 2 < tau_end) {
-            fetch_lat(tau + 4, lat1); fetch_halo(tau + 4, h1v);
+            fetch_lat(tau + 4, lat1); fetch_halo(h1v);
             tick(tau + 2, lat2, h2v);
         }
         barrier_lds();
@@ -502,6 +534,31 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
     }
 }
 
+// Predicated global stores without a branch: a raw buffer store whose byte offset is pushed past the end of the
+// buffer is dropped by the bounds check.  Unlike `if (cond) *ptr = v` the instruction is always issued, so hipcc can
+// count it in vmcnt and the in-order wait for an older prefetch does not have to assume the worst (which drained the
+// younger prefetches too and tied every tick to a full store round trip).
+constexpr uint32_t kBufferFlags = 0x00020000;      // gfx9 raw buffer, 32-bit data format
+constexpr uint32_t kDropStore = 0xFFFFFFF0u;       // offset outside any buffer this file creates (< 4 GiB - 16)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, (int)kBufferFlags);
+}
+__device__ __forceinline__ void store_f64(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, double v)
+{
+    u32x2 bits;
+    __builtin_memcpy(&bits, &v, sizeof bits);
+    __builtin_amdgcn_raw_buffer_store_b64(bits, r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ void store_f64x2(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, double2 v)
+{
+    u32x4 bits;
+    __builtin_memcpy(&bits, &v, sizeof bits);
+    __builtin_amdgcn_raw_buffer_store_b128(bits, r, (int)byte_off, 0, 0);
+}
+
 // ---- record mode ----
 // With one sub-step per row, a task (block, chunk of kRec = 16 ticks) consumes for every position exactly the 16
 // consecutive rows t = tick - lag.  The work ring is therefore kept as RECORDS indexed by tick:
@@ -511,11 +568,24 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
 // stores the records in place.  The permutation to and from params order becomes ONE pass each way that moves
 // whole 128-byte records (k_rec_in / k_rec_out) instead of two tiled passes over rows.
 constexpr int kRec = 16;
+// Record stores go through a per-wave LDS transpose: a lane owns a position (its record lives in registers), but a
+// store instruction in which every lane writes 16 bytes of a different record costs L2 one request per lane.  After
+// the transpose four neighbouring lanes write the 64 contiguous bytes of one half record: a quarter of the requests.
+constexpr int kStageStride = 10;   // doubles per position in the staging area: 64 bytes + 16 of padding (bank spread, skip flag)
+// Lanes of one wave exchange data through its staging area without a workgroup barrier: a wave's LDS instructions
+// execute in order.  The compiler still has to be told that other lanes wrote (it would reuse earlier reads).
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+constexpr int kStageLanes = 32;    // positions transposed at a time (half a wave: keeps the area at 2.5 KiB per wave)
+// LDS of k_wave_rec, in doubles: X[2][lh] | c1[BS] | c2[BS] | c3[BS] | stage[waves][kStageLanes * kStageStride]
+constexpr size_t wave_rec_lds_bytes(int64_t lh, int threads, int ppt)
+{
+    return (size_t)(2 * lh + 3 * (int64_t)ppt * threads + (threads / 64) * kStageLanes * kStageStride) * sizeof(double);
+}
 
 template <int TH, int PPT, int HPT, bool UNIT>
 __global__ __launch_bounds__(TH) void k_wave_rec(const WaveArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) double lds[];   // [2][lh]
+    extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int BS = PPT * TH;
     const int tid = threadIdx.x;
     const int32_t b = a.b_first + (int32_t)blockIdx.x;
@@ -525,46 +595,97 @@ __global__ __launch_bounds__(TH) void k_wave_rec(const WaveArgs a)
     const int32_t nh = b0 - h0;
     const int32_t halo_lo = max(b0, a.child_ptr[b1]);
     auto position = [&](int k) { return b0 + k * TH + tid; };
-    const int64_t tau0 = chunk * kRec;
+    const int32_t tau0 = (int32_t)chunk * kRec, total = (int32_t)a.total;
+    const int lane = tid & 63;
+    // the coefficients are read once per tick: they live in LDS, the registers go to the records
+    double *cc1 = lds + 2 * (size_t)a.lh, *cc2 = cc1 + BS, *cc3 = cc2 + BS;
+    double *stage = cc3 + BS + (size_t)(tid >> 6) * (kStageLanes * kStageStride);   // this wave's transpose area
+#ifdef RR_WAVE_TRACE
+    const bool trace = a.trace && a.diag == a.trace_diag && tid == 0;
+    long long *tq = a.trace + (int64_t)b * 8;
+#define RR_TRACE(i) do { if (trace) tq[i] = wall_clock64(); } while (0)
+#else
+#define RR_TRACE(i) do { } while (0)
+#endif
+    RR_TRACE(0);
 
-    double *rbase = a.rec + (int64_t)((uint64_t)chunk % (uint32_t)a.rec_chunks) * a.n * kRec;
+    double *rbase = a.rec + (int64_t)a.rec_chunks.mod((uint32_t)chunk) * a.n * kRec;
+    const __amdgpu_buffer_rsrc_t rec_chunk = make_rsrc(rbase, (uint32_t)a.n * 128u);   // n < 2^25 in record mode (session_begin)
 
+    // A slot past the end of the network keeps lag -1: no upstream range, never active, publishes 0.0 to nobody.
     int32_t lg[PPT], u0[PPT], u1[PPT], uh[UNIT ? PPT : 1];
-    double c1[PPT], c2[PPT], c3[PPT], q[PPT], s_prev[PPT], qch[UNIT ? PPT : 1];
+    double s_prev[PPT], qch[UNIT ? PPT : 1];
     double rec[PPT][kRec];
+    {
+        double *buf = lds + (size_t)((tau0 + 1) & 1) * a.lh;     // tick tau0 reads the buffer of tick tau0 - 1
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        const int32_t p = position(k);
-        if (UNIT) { uh[k] = 0; qch[k] = 0.0; }
-        if (p < b1) {
-            lg[k] = a.lag[p]; u0[k] = a.child_ptr[p] - h0; u1[k] = a.child_ptr[p + 1] - h0;
-            if (UNIT) { uh[k] = u0[k] + (int32_t)a.hw_children[p]; qch[k] = a.sqch[p]; }
-            c1[k] = a.c1row[p]; c2[k] = a.c2[p]; c3[k] = a.c3[p];
-            q[k] = a.sq[p]; s_prev[k] = a.ss[p];
-            const double2 *r2 = reinterpret_cast<const double2 *>(rbase + (int64_t)p * kRec);
-            // the whole 128-byte record back to back: the eight 16-byte requests of a lane hit one line while it is hot
-            // (spreading them over the ticks re-fetches the line: measured 1.9x slower)
-#pragma unroll
-            for (int j = 0; j < kRec / 2; ++j) { const double2 v = r2[j]; rec[k][2 * j] = v.x; rec[k][2 * j + 1] = v.y; }
-            if (lg[k] & kGhostBit) {   // boundary inflow: this chunk of the ghost series instead of the ring
-                const int32_t g = a.bidx[p];
-#pragma unroll
-                for (int j = 0; j < kRec; ++j) {
-                    int64_t ts = tau0 + j - (lg[k] & kLagMask);
-                    ts = ts < 0 ? 0 : (ts >= a.total ? a.total - 1 : ts);
-                    rec[k][j] = a.ghost[ts * a.n_ghost + g];
-                }
+        for (int k = 0; k < PPT; ++k) {
+            const int32_t p = position(k);
+            if (UNIT) { uh[k] = 0; qch[k] = 0.0; }
+            if (p < b1) {
+                lg[k] = a.lag[p]; u0[k] = a.child_ptr[p] - h0; u1[k] = a.child_ptr[p + 1] - h0;
+                if (UNIT) { uh[k] = u0[k] + (int32_t)a.hw_children[p]; qch[k] = a.sqch[p]; }
+                cc1[k * TH + tid] = a.c1row[p]; cc2[k * TH + tid] = a.c2[p]; cc3[k * TH + tid] = a.c3[p];
+                buf[nh + k * TH + tid] = a.sq[p]; s_prev[k] = a.ss[p];
+            } else {
+                lg[k] = -1; u0[k] = u1[k] = 0; s_prev[k] = 0.0;
+                cc1[k * TH + tid] = cc2[k * TH + tid] = cc3[k * TH + tid] = 0.0;
+                buf[nh + k * TH + tid] = 0.0;
             }
-        } else {
-            lg[k] = -1; u0[k] = u1[k] = 0; c1[k] = c2[k] = c3[k] = q[k] = s_prev[k] = 0.0;
+        }
+        // Records: like the stores, the loads are issued four lanes per 64-byte sector (a quarter of the L2 requests
+        // of one record per lane), all of them back to back, and then handed to the owning lanes through the staging area.
+        constexpr int HW = 64 / kStageLanes, MS = kStageLanes / 16, ROUNDS = PPT * 2 * HW;   // round = (k, half, h)
+        double raw_x[ROUNDS * MS], raw_y[ROUNDS * MS];
 #pragma unroll
-            for (int j = 0; j < kRec; ++j) rec[k][j] = 0.0;
+        for (int i = 0; i < ROUNDS * MS; ++i) {
+            const int k = i / (2 * HW * MS), half = i / (HW * MS) % 2, h = i / MS % HW, m = i % MS;
+            const int32_t pos = min(b0 + k * TH + (tid - lane) + h * kStageLanes + 16 * m + (lane >> 2), b1 - 1);
+            const double2 v = reinterpret_cast<const double2 *>(rbase + (int64_t)pos * kRec)[half * 4 + (lane & 3)];
+            raw_x[i] = v.x; raw_y[i] = v.y;
+        }
+#pragma unroll
+        for (int r = 0; r < ROUNDS; ++r) {
+            const int k = r / (2 * HW), half = r / HW % 2, h = r % HW;
+#pragma unroll
+            for (int m = 0; m < MS; ++m)
+                reinterpret_cast<double2 *>(stage + (16 * m + (lane >> 2)) * kStageStride)[lane & 3] = make_double2(raw_x[r * MS + m], raw_y[r * MS + m]);
+            wave_lds_fence();
+            if (lane / kStageLanes == h) {
+                const double2 *mine = reinterpret_cast<const double2 *>(stage + (lane % kStageLanes) * kStageStride);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const double2 v = mine[j]; rec[k][8 * half + 2 * j] = v.x; rec[k][8 * half + 2 * j + 1] = v.y; }
+            }
+            wave_lds_fence();
+        }
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            const int32_t p = position(k);
+            if (p < b1) {
+                if (lg[k] & kGhostBit) {   // boundary inflow: this chunk of the ghost series instead of the ring
+                    const int32_t g = a.bidx[p];
+#pragma unroll
+                    for (int j = 0; j < kRec; ++j) {
+                        int32_t ts = tau0 + j - (lg[k] & kLagMask);
+                        ts = ts < 0 ? 0 : (ts >= total ? total - 1 : ts);
+                        rec[k][j] = a.ghost[(int64_t)ts * a.n_ghost + g];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < kRec; ++j) rec[k][j] = 0.0;
+            }
         }
     }
     const bool has_lat = a.in != nullptr;   // channel-only routing: the records only carry discharge
 
-    auto fetch_halo = [&](int64_t tau, double (&h)[HPT]) {
-        const double *hrow = a.hist + (int64_t)((uint64_t)(tau + a.hist_rows) % (uint32_t)a.hist_rows) * a.n + h0;
+    // the history ring is walked one row per tick: rows of the next halo fetch and of the next tick's own writes
+    const uint32_t hrows = (uint32_t)a.hist_rows;
+    auto next_row = [&](uint32_t r) { return r + 1 == hrows ? 0u : r + 1; };
+    uint32_t hr_fetch = Div32(hrows).mod((uint32_t)tau0 + hrows - 1), hr_tick = next_row(hr_fetch);
+    auto fetch_halo = [&](double (&h)[HPT]) {      // one history row per call, starting at tick tau0 - 1
+        const double *hrow = a.hist + (int64_t)hr_fetch * a.n + h0;
+        hr_fetch = next_row(hr_fetch);
 #pragma unroll
         for (int j = 0; j < HPT; ++j) {
             const int32_t i = j * TH + tid;
@@ -578,28 +699,53 @@ __global__ __launch_bounds__(TH) void k_wave_rec(const WaveArgs a)
             if (i < nh) buf[i] = h[j];
         }
     };
-    double hs[3][HPT];
-    {
-        double *buf = lds + (size_t)((tau0 + 1) & 1) * a.lh;
-        fetch_halo(tau0 - 1, hs[2]);
+    // Eight slots of every record are final: write that 64-byte sector.  Half a wave at a time parks its sectors in
+    // the wave's staging area, then all 64 lanes store them, four lanes per sector.
+    auto store_half_records = [&](int k, int half) {
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) buf[nh + k * TH + tid] = q[k];
-        put_halo(buf, hs[2]);
-    }
-    fetch_halo(tau0, hs[0]);
-    fetch_halo(tau0 + 1, hs[1]);
+        for (int h = 0; h < 64 / kStageLanes; ++h) {
+            if (lane / kStageLanes == h) {
+                double2 *mine = reinterpret_cast<double2 *>(stage + (lane % kStageLanes) * kStageStride);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mine[j] = make_double2(rec[k][8 * half + 2 * j], rec[k][8 * half + 2 * j + 1]);
+                reinterpret_cast<int32_t *>(mine + 4)[0] = (lg[k] < 0 || (lg[k] & kGhostBit)) ? 1 : 0;   // not this block's to write
+            }
+            wave_lds_fence();
+            const uint32_t first = (uint32_t)(b0 + k * TH + (tid - lane) + h * kStageLanes) * 128u + (uint32_t)half * 64u;
+#pragma unroll
+            for (int m = 0; m < kStageLanes / 16; ++m) {       // lanes 4i .. 4i+3: the four 16-byte pieces of position 16 m + i
+                const int pm = 16 * m + (lane >> 2), piece = lane & 3;
+                const double2 *theirs = reinterpret_cast<const double2 *>(stage + pm * kStageStride);
+                const double2 v = theirs[piece];
+                const bool skip = reinterpret_cast<const int32_t *>(theirs + 4)[0] != 0;
+                store_f64x2(rec_chunk, skip ? kDropStore : first + (uint32_t)pm * 128u + (uint32_t)piece * 16u, v);
+            }
+            wave_lds_fence();
+        }
+    };
+
+    double hs[3][HPT];
+    fetch_halo(hs[2]);
+    put_halo(lds + (size_t)((tau0 + 1) & 1) * a.lh, hs[2]);
+    fetch_halo(hs[0]);
+    fetch_halo(hs[1]);
     barrier_lds();
+    RR_TRACE(1);
 #pragma unroll
     for (int s = 0; s < kRec; ++s) {
-        const int64_t tau = tau0 + s;
-        fetch_halo(tau + 2, hs[(s + 2) % 3]);
+        const int32_t tau = tau0 + s;
+        if (s == 1) RR_TRACE(2);
+        if (s == 8) RR_TRACE(3);
+        fetch_halo(hs[(s + 2) % 3]);
         const double *rd = lds + (size_t)((tau + 1) & 1) * a.lh;
         double *wr = lds + (size_t)(tau & 1) * a.lh;
-        double *hrow = a.hist + (int64_t)((uint64_t)tau % (uint32_t)a.hist_rows) * a.n;
+        const __amdgpu_buffer_rsrc_t hist_row = make_rsrc(a.hist + (int64_t)hr_tick * a.n, (uint32_t)a.n * 8u);
+        hr_tick = next_row(hr_tick);
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            if (lg[k] < 0) continue;
             const int32_t p = position(k);
+            double qk = rd[nh + k * TH + tid];       // own discharge one tick back
+            const double c1 = cc1[k * TH + tid], c2 = cc2[k * TH + tid], c3 = cc3[k * TH + tid];
             double s_cur = 0.0, s_hw = 0.0;
             if (UNIT) {
                 for (int32_t u = u0[k]; u < uh[k]; ++u) s_hw += rd[u];
@@ -607,51 +753,48 @@ __global__ __launch_bounds__(TH) void k_wave_rec(const WaveArgs a)
             } else {
                 for (int32_t u = u0[k]; u < u1[k]; ++u) s_cur += rd[u];
             }
-            const int64_t ts = tau - (lg[k] & kLagMask);
-            if (ts >= 0 && ts < a.total) {
+            const int32_t ts = tau - (lg[k] & kLagMask);
+            if (ts >= 0 && ts < total) {
                 const double lat = has_lat ? rec[k][s] : 0.0;
                 if (UNIT) {
                     if (u0[k] == u1[k]) {
-                        q[k] = lat;        // headwater: discharge = lateral, the record slot already holds it
+                        qk = lat;        // headwater: discharge = lateral, the record slot already holds it
                     } else {
-                        const double r = __builtin_fma(c1[k], s_hw + s_cur, __builtin_fma(c2[k], s_hw + s_prev[k], c3[k] * qch[k]));
+                        const double r = __builtin_fma(c1, s_hw + s_cur, __builtin_fma(c2, s_hw + s_prev[k], c3 * qch[k]));
                         qch[k] = r;
-                        const double qfull = r + lat;
-                        q[k] = qfull;
-                        rec[k][s] = qfull > 0.0 ? qfull : 0.0;
+                        qk = r + lat;
+                        rec[k][s] = qk > 0.0 ? qk : 0.0;
                     }
                 } else if (lg[k] & kGhostBit) {
-                    q[k] = rec[k][s];
+                    qk = rec[k][s];
                 } else {
-                    const double r = __builtin_fma(c1[k], s_cur, __builtin_fma(c2[k], s_prev[k], __builtin_fma(c3[k], q[k], lat)));
-                    q[k] = r;
-                    if (lg[k] & kExportBit) a.exports[ts * a.n_export + a.bidx[p]] = r;
-                    rec[k][s] = r > 0.0 ? r : 0.0;
+                    // explicit fma: every copy of this tick must round identically (split run == joint run)
+                    qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev[k], __builtin_fma(c3, qk, lat)));
+                    if (lg[k] & kExportBit) a.exports[(int64_t)ts * a.n_export + a.bidx[p]] = qk;
+                    rec[k][s] = qk > 0.0 ? qk : 0.0;
                 }
             }
             s_prev[k] = s_cur;
-            wr[nh + k * TH + tid] = q[k];
-            if (p >= halo_lo) hrow[p] = q[k];
+            wr[nh + k * TH + tid] = qk;
+            store_f64(hist_row, p >= halo_lo ? (uint32_t)p * 8u : kDropStore, qk);   // positions >= n fall off the row
         }
         put_halo(wr, hs[s % 3]);
-        if ((s & 7) == 7) {   // eight slots are final: write that whole 64-byte sector of every record now
+        if ((s & 7) == 7) {
 #pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                if (lg[k] < 0 || (lg[k] & kGhostBit)) continue;
-                double2 *r2 = reinterpret_cast<double2 *>(rbase + (int64_t)position(k) * kRec) + (s >> 3) * 4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) r2[j] = make_double2(rec[k][s - 7 + 2 * j], rec[k][s - 6 + 2 * j]);
-            }
+            for (int k = 0; k < PPT; ++k) store_half_records(k, s >> 3);
         }
         barrier_lds();
     }
+    const double *last = lds + (size_t)((tau0 + kRec - 1) & 1) * a.lh;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         if (lg[k] < 0) continue;
         const int32_t p = position(k);
-        a.sq[p] = q[k]; a.ss[p] = s_prev[k];
+        a.sq[p] = last[nh + k * TH + tid]; a.ss[p] = s_prev[k];
         if (UNIT) a.sqch[p] = qch[k];
     }
+    RR_TRACE(4);
+#undef RR_TRACE
 }
 
 // sq = q0 in engine order, ss = sum of the upstream reaches' q0, every history row = q0
@@ -825,7 +968,7 @@ constexpr int kRecCols = 64, kRecBatch = 4, kRecThreads = 256;
 
 struct RecPermArgs {
     double *rec;
-    int32_t rec_chunks;
+    Div32 rec_chunks;
     int64_t n, T, batch;
     const int2 *colmeta;      // per params column: {engine position, lag}
     const double *scale;      // c4dt in PARAMS order (RapidMuskingum: the ring holds c4dt * lateral) or NULL
@@ -878,10 +1021,10 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_in(const RecPermArgs a)
         if (p < 0) continue;
         const int32_t lag = meta[it].y;
         const int o = lag & 15;
-        const int64_t chunk = 4 * a.batch + (lag >> 4) + k;
+        const uint32_t chunk = 4u * (uint32_t)a.batch + (uint32_t)(lag >> 4) + k;
         const int r = 15 - o + 16 * k + 2 * part;
         const double v0 = tile[r][c] * f[it], v1 = tile[r + 1][c] * f[it];
-        double2 *dst = reinterpret_cast<double2 *>(a.rec + ((int64_t)((uint64_t)chunk % (uint32_t)a.rec_chunks) * a.n + p) * kRec) + part;
+        double2 *dst = reinterpret_cast<double2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.n + p) * kRec) + part;
         *dst = make_double2(v0, v1);
     }
 }
@@ -905,8 +1048,8 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
         const int piece = it * kRecThreads + tid;
         const int k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
         const int32_t p = meta[it].x < 0 ? 0 : meta[it].x;
-        const int64_t chunk = 4 * a.batch + (meta[it].y >> 4) + k;
-        v[it] = *(reinterpret_cast<const double2 *>(a.rec + ((int64_t)((uint64_t)chunk % (uint32_t)a.rec_chunks) * a.n + p) * kRec) + part);
+        const uint32_t chunk = 4u * (uint32_t)a.batch + (uint32_t)(meta[it].y >> 4) + k;
+        v[it] = *(reinterpret_cast<const double2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.n + p) * kRec) + part);
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -1110,6 +1253,9 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
     S.ghost_series = ghost_series; S.export_series = export_series;
     const int64_t dmax = H.depth - 1;
     S.total_ticks = S.total + dmax;
+    // the kernels index ticks, rows and chunks in 32 bits (Div32)
+    if (S.total_ticks >= (int64_t{1} << 31) - (int64_t{1} << 20) || io.rows_in >= (int64_t{1} << 31) || io.rows_out >= (int64_t{1} << 31))
+        return fail(RR_E_UNSUPPORTED, "more than 2^31 routing ticks or rows in one call: split it into several calls");
     S.has_in = mode != Mode::Muskingum;
     const bool host_io = io.host_out != nullptr || io.host_in != nullptr;
     S.direct = H.identity && !host_io;   // engine order == params order: stream the caller's arrays
@@ -1133,7 +1279,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
     // the outlet-most reaches have passed them; the time-tiled schedule adds (blocks - 1) * K ticks of skew.
     const int64_t skew_ticks = dmax + (S.wave ? P->wave_nb * P->wave_K : 0);
     const int64_t lag_rows = (skew_ticks + nsub - 1) / nsub;
-    S.rec = S.wave && P->rec_enabled && nsub == 1 && P->wave_K == kRec && !S.direct && !host_io &&
+    S.rec = S.wave && P->rec_enabled && nsub == 1 && P->wave_K == kRec && !S.direct && !host_io && n < (int64_t{1} << 25) &&
             (P->wave_threads == 512 || P->wave_hpt == 2);    // the 1024-thread shape with a 4,096-wide halo would spill
     if (S.rec) {
         // records are indexed by tick = row + lag: the live rows span (skew + depth) ticks
@@ -1159,13 +1305,13 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
     a.child_ptr = P->d_child_ptr; a.lag = P->d_lag; a.w = P->d_w; a.c2 = P->d_c2; a.c3 = P->d_c3; a.c4 = P->d_c4;
     a.isum = P->d_isum; a.bidx = P->d_bidx;
     a.ghost = ghost_series; a.exports = export_series; a.n_ghost = (int32_t)P->n_ghost; a.n_export = (int32_t)P->n_export;
-    a.total_substeps = S.total; a.nsub = (uint32_t)nsub; a.inv_nsub = 1.0 / (double)nsub;
+    a.total_substeps = S.total; a.nsub = Div32((uint32_t)nsub); a.inv_nsub = 1.0 / (double)nsub;
     if (S.direct) {
-        a.in = io.dev_in; a.in_ld = n; a.in_rows = (uint32_t)std::max<int64_t>(1, io.rows_in);
-        a.out = io.dev_out; a.out_ld = n; a.out_rows = (uint32_t)io.rows_out;
+        a.in = io.dev_in; a.in_ld = n; a.in_rows = Div32((uint32_t)std::max<int64_t>(1, io.rows_in));
+        a.out = io.dev_out; a.out_ld = n; a.out_rows = Div32((uint32_t)io.rows_out);
     } else {
-        a.in = S.has_in ? P->d_ring : nullptr; a.in_ld = n; a.in_rows = (uint32_t)S.ring_rows;
-        a.out = P->d_ring; a.out_ld = n; a.out_rows = (uint32_t)S.ring_rows;
+        a.in = S.has_in ? P->d_ring : nullptr; a.in_ld = n; a.in_rows = Div32((uint32_t)S.ring_rows);
+        a.out = P->d_ring; a.out_ld = n; a.out_rows = Div32((uint32_t)S.ring_rows);
     }
 
     if (S.wave) {
@@ -1176,8 +1322,17 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         w.n_ghost = (int32_t)P->n_ghost; w.n_export = (int32_t)P->n_export;
         w.in = a.in; w.out = a.out; w.in_ld = a.in_ld; w.out_ld = a.out_ld; w.in_rows = a.in_rows; w.out_rows = a.out_rows;
         w.lh = (int32_t)P->wave_lh;
-        w.rec = S.rec ? P->d_ring : nullptr; w.rec_chunks = (int32_t)S.rec_chunks;
-        w.n = (int32_t)n; w.K = (int32_t)P->wave_K; w.total = S.total; w.nsub = (uint32_t)nsub; w.inv_nsub = 1.0 / (double)nsub;
+#ifdef RR_WAVE_TRACE
+        w.trace = nullptr; w.trace_diag = -1;
+        if (getenv("RR_WAVE_TRACE_DIAG")) {
+            static long long *tbuf = nullptr;
+            if (!tbuf) (void)hipMalloc(&tbuf, 8 * 8 * 4096);
+            (void)hipMemset(tbuf, 0, 8 * 8 * 4096);
+            w.trace = tbuf; w.trace_diag = atoll(getenv("RR_WAVE_TRACE_DIAG"));
+        }
+#endif
+        w.rec = S.rec ? P->d_ring : nullptr; w.rec_chunks = Div32((uint32_t)S.rec_chunks);
+        w.n = (int32_t)n; w.K = (int32_t)P->wave_K; w.total = S.total; w.nsub = Div32((uint32_t)nsub); w.inv_nsub = 1.0 / (double)nsub;
         if (!P->d_hist || P->hist_cap < (int64_t)w.hist_rows * n) { S.open = false; return fail(RR_E_STATE, "time-tiled routing: history ring not initialised"); }
     }
     S.max_samples = P->sample_every >= kSampleGroup ? (size_t)std::min<int64_t>(4096, S.total_ticks / P->sample_every + 1) : 0;
@@ -1347,7 +1502,7 @@ int session_launch_diag(rr_plan *P, int64_t d)
     const bool sample = S.max_samples > 0 && full && (P->prof_launches % 8) == 0 && (size_t)P->prof_brackets < S.max_samples;
     if (sample) HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets], S.stream));
     const dim3 g((unsigned)(b_hi - b_lo + 1));
-    const size_t lds_bytes = (size_t)2 * P->wave_lh * sizeof(double);
+    const size_t lds_bytes = S.rec ? wave_rec_lds_bytes(P->wave_lh, P->wave_threads, P->wave_ppt) : (size_t)2 * P->wave_lh * sizeof(double);
     const dim3 t((unsigned)P->wave_threads);
     wave_kernel_t fn = S.rec ? wave_rec_kernel(P->wave_threads, P->wave_ppt, P->wave_hpt, S.mode == Mode::Unit)
                              : wave_kernel(P->wave_threads, P->wave_ppt, P->wave_hpt, S.nsub == 1, S.mode == Mode::Unit);
@@ -1367,7 +1522,7 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
     Session &S = P->ses;
     const int64_t n = P->h.n;
     RecPermArgs ra{};
-    ra.rec = P->d_ring; ra.rec_chunks = (int32_t)S.rec_chunks; ra.n = n; ra.T = S.T; ra.batch = batch;
+    ra.rec = P->d_ring; ra.rec_chunks = Div32((uint32_t)S.rec_chunks); ra.n = n; ra.T = S.T; ra.batch = batch;
     ra.colmeta = P->d_colmeta;
     ra.scale = (in && S.mode == Mode::Rapid) ? P->d_c4_params : nullptr;
     ra.rows = in ? RowView{const_cast<double *>(S.io.dev_in), n, 0, (uint32_t)S.io.rows_in}
@@ -1522,6 +1677,18 @@ int session_end(rr_plan *P)
     if (S.bracket_open) P->prof_samples -= P->prof_samples % kSampleGroup;   // incomplete bracket: not counted
     HIPCHK(hipEventRecord(P->ev_last, S.stream));
     HIPCHK(hipGetLastError());
+#ifdef RR_WAVE_TRACE
+    if (S.wave && S.wa.trace) {
+        std::vector<long long> hbuf(8 * 4096);
+        (void)hipStreamSynchronize(S.stream);
+        (void)hipMemcpy(hbuf.data(), S.wa.trace, hbuf.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE *f = fopen(getenv("RR_WAVE_TRACE_FILE") ? getenv("RR_WAVE_TRACE_FILE") : "/tmp/wave_trace.txt", "w")) {
+            for (int b = 0; b < 4096; ++b)
+                if (hbuf[8 * b]) fprintf(f, "%d %lld %lld %lld %lld %lld\n", b, hbuf[8 * b], hbuf[8 * b + 1], hbuf[8 * b + 2], hbuf[8 * b + 3], hbuf[8 * b + 4]);
+            fclose(f);
+        }
+    }
+#endif
     return RR_OK;
 }
 
@@ -1804,7 +1971,7 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         }
         for (int v = 0; v < 2; ++v)
             (void)hipFuncSetAttribute((const void *)wave_rec_kernel(P->wave_threads, P->wave_ppt, P->wave_hpt, v != 0),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * P->wave_lh * sizeof(double)));
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wave_rec_lds_bytes(P->wave_lh, P->wave_threads, P->wave_ppt));
         const rr::HostPlan &H = P->h;
         const int64_t ni = (int64_t)H.inner_pos.size();
         rc = dev_alloc(&P->d_child_ptr, n + 1);
