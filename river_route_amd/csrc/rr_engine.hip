@@ -559,6 +559,19 @@ __device__ __forceinline__ void store_f64x2(__amdgpu_buffer_rsrc_t r, uint32_t b
     __builtin_amdgcn_raw_buffer_store_b128(bits, r, (int)byte_off, 0, 0);
 }
 
+__device__ __forceinline__ void load_f64x2(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, double &x, double &y)
+{
+    const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);   // one 16-byte request per lane
+    double2 v;
+    __builtin_memcpy(&v, &bits, sizeof v);
+    x = v.x; y = v.y;
+}
+
+// The tick loops are fully unrolled (the record slots are registers), so anything derived from a per-position constant
+// is "loop invariant" and hipcc keeps every such derivative in a VGPR for the whole task.  fresh() hands the constant
+// back as an opaque value: the two-instruction unpacking is redone each tick and the registers stay free.
+__device__ __forceinline__ int32_t fresh(int32_t v) { asm volatile("" : "+v"(v)); return v; }
+
 // ---- record mode ----
 // With one sub-step per row, a task (block, chunk of kRec = 16 ticks) consumes for every position exactly the 16
 // consecutive rows t = tick - lag.  The work ring is therefore kept as RECORDS indexed by tick:
@@ -576,7 +589,8 @@ constexpr int kStageStride = 10;   // doubles per position in the staging area: 
 // execute in order.  The compiler still has to be told that other lanes wrote (it would reuse earlier reads).
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 constexpr int kStageLanes = 32;    // positions transposed at a time (half a wave: keeps the area at 2.5 KiB per wave)
-// LDS of k_wave_rec, in doubles: X[2][lh] | c1[BS] | c2[BS] | c3[BS] | stage[waves][kStageLanes * kStageStride]
+// LDS in doubles: X[2][lh] | c1[BS] | c2[BS] | c3[BS] | stage[waves][kStageLanes * kStageStride].  The three
+// coefficients and the own discharge are read from LDS once per tick: the registers go to the records.
 constexpr size_t wave_rec_lds_bytes(int64_t lh, int threads, int ppt)
 {
     return (size_t)(2 * lh + 3 * (int64_t)ppt * threads + (threads / 64) * kStageLanes * kStageStride) * sizeof(double);
@@ -587,6 +601,7 @@ __global__ __launch_bounds__(TH) void k_wave_rec(const WaveArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int BS = PPT * TH;
+    constexpr int NS = 3;                  // history rows in flight (register stages)
     const int tid = threadIdx.x;
     const int32_t b = a.b_first + (int32_t)blockIdx.x;
     const int64_t chunk = a.diag - b;
@@ -597,7 +612,6 @@ __global__ __launch_bounds__(TH) void k_wave_rec(const WaveArgs a)
     auto position = [&](int k) { return b0 + k * TH + tid; };
     const int32_t tau0 = (int32_t)chunk * kRec, total = (int32_t)a.total;
     const int lane = tid & 63;
-    // the coefficients are read once per tick: they live in LDS, the registers go to the records
     double *cc1 = lds + 2 * (size_t)a.lh, *cc2 = cc1 + BS, *cc3 = cc2 + BS;
     double *stage = cc3 + BS + (size_t)(tid >> 6) * (kStageLanes * kStageStride);   // this wave's transpose area
 #ifdef RR_WAVE_TRACE
@@ -611,38 +625,40 @@ __global__ __launch_bounds__(TH) void k_wave_rec(const WaveArgs a)
 
     double *rbase = a.rec + (int64_t)a.rec_chunks.mod((uint32_t)chunk) * a.n * kRec;
     const __amdgpu_buffer_rsrc_t rec_chunk = make_rsrc(rbase, (uint32_t)a.n * 128u);   // n < 2^25 in record mode (session_begin)
+    double *first_buf = lds + (size_t)((tau0 + 1) & 1) * a.lh;     // tick tau0 reads the buffer of tick tau0 - 1
 
     // A slot past the end of the network keeps lag -1: no upstream range, never active, publishes 0.0 to nobody.
-    int32_t lg[PPT], u0[PPT], u1[PPT], uh[UNIT ? PPT : 1];
+    // up[k]: LDS slot of the first upstream value (low 16 bits) and the number of upstream reaches (high 16 bits)
+    int32_t lg[PPT], up[PPT], uh[UNIT ? PPT : 1];
     double s_prev[PPT], qch[UNIT ? PPT : 1];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        const int32_t p = position(k);
+        if (UNIT) { uh[k] = 0; qch[k] = 0.0; }
+        if (p < b1) {
+            const int32_t first_up = a.child_ptr[p];
+            lg[k] = a.lag[p]; up[k] = (first_up - h0) | ((a.child_ptr[p + 1] - first_up) << 16);
+            if (UNIT) { uh[k] = (first_up - h0) + (int32_t)a.hw_children[p]; qch[k] = a.sqch[p]; }
+            s_prev[k] = a.ss[p];
+            first_buf[nh + k * TH + tid] = a.sq[p];
+            cc1[k * TH + tid] = a.c1row[p]; cc2[k * TH + tid] = a.c2[p]; cc3[k * TH + tid] = a.c3[p];
+        } else {
+            lg[k] = -1; up[k] = 0; s_prev[k] = 0.0;
+            first_buf[nh + k * TH + tid] = 0.0;
+            cc1[k * TH + tid] = cc2[k * TH + tid] = cc3[k * TH + tid] = 0.0;
+        }
+    }
+    // Records: like the stores, the loads are issued four lanes per 64-byte sector (a quarter of the L2 requests of
+    // one record per lane), all of them back to back, and then handed to the owning lanes through the staging area.
     double rec[PPT][kRec];
     {
-        double *buf = lds + (size_t)((tau0 + 1) & 1) * a.lh;     // tick tau0 reads the buffer of tick tau0 - 1
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int32_t p = position(k);
-            if (UNIT) { uh[k] = 0; qch[k] = 0.0; }
-            if (p < b1) {
-                lg[k] = a.lag[p]; u0[k] = a.child_ptr[p] - h0; u1[k] = a.child_ptr[p + 1] - h0;
-                if (UNIT) { uh[k] = u0[k] + (int32_t)a.hw_children[p]; qch[k] = a.sqch[p]; }
-                cc1[k * TH + tid] = a.c1row[p]; cc2[k * TH + tid] = a.c2[p]; cc3[k * TH + tid] = a.c3[p];
-                buf[nh + k * TH + tid] = a.sq[p]; s_prev[k] = a.ss[p];
-            } else {
-                lg[k] = -1; u0[k] = u1[k] = 0; s_prev[k] = 0.0;
-                cc1[k * TH + tid] = cc2[k * TH + tid] = cc3[k * TH + tid] = 0.0;
-                buf[nh + k * TH + tid] = 0.0;
-            }
-        }
-        // Records: like the stores, the loads are issued four lanes per 64-byte sector (a quarter of the L2 requests
-        // of one record per lane), all of them back to back, and then handed to the owning lanes through the staging area.
         constexpr int HW = 64 / kStageLanes, MS = kStageLanes / 16, ROUNDS = PPT * 2 * HW;   // round = (k, half, h)
-        double raw_x[ROUNDS * MS], raw_y[ROUNDS * MS];
+        double raw_x[ROUNDS * MS], raw_y[ROUNDS * MS];      // (an array of double2 is not promoted to registers)
 #pragma unroll
         for (int i = 0; i < ROUNDS * MS; ++i) {
             const int k = i / (2 * HW * MS), half = i / (HW * MS) % 2, h = i / MS % HW, m = i % MS;
             const int32_t pos = min(b0 + k * TH + (tid - lane) + h * kStageLanes + 16 * m + (lane >> 2), b1 - 1);
-            const double2 v = reinterpret_cast<const double2 *>(rbase + (int64_t)pos * kRec)[half * 4 + (lane & 3)];
-            raw_x[i] = v.x; raw_y[i] = v.y;
+            load_f64x2(rec_chunk, (uint32_t)pos * 128u + (uint32_t)(half * 64 + (lane & 3) * 16), raw_x[i], raw_y[i]);
         }
 #pragma unroll
         for (int r = 0; r < ROUNDS; ++r) {
@@ -658,22 +674,19 @@ __global__ __launch_bounds__(TH) void k_wave_rec(const WaveArgs a)
             }
             wave_lds_fence();
         }
+    }
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int32_t p = position(k);
-            if (p < b1) {
-                if (lg[k] & kGhostBit) {   // boundary inflow: this chunk of the ghost series instead of the ring
-                    const int32_t g = a.bidx[p];
+    for (int k = 0; k < PPT; ++k) {
+        if (lg[k] < 0) {
 #pragma unroll
-                    for (int j = 0; j < kRec; ++j) {
-                        int32_t ts = tau0 + j - (lg[k] & kLagMask);
-                        ts = ts < 0 ? 0 : (ts >= total ? total - 1 : ts);
-                        rec[k][j] = a.ghost[(int64_t)ts * a.n_ghost + g];
-                    }
-                }
-            } else {
+            for (int j = 0; j < kRec; ++j) rec[k][j] = 0.0;
+        } else if (lg[k] & kGhostBit) {   // boundary inflow: this chunk of the ghost series instead of the ring
+            const int32_t g = a.bidx[position(k)];
 #pragma unroll
-                for (int j = 0; j < kRec; ++j) rec[k][j] = 0.0;
+            for (int j = 0; j < kRec; ++j) {
+                int32_t ts = tau0 + j - (lg[k] & kLagMask);
+                ts = ts < 0 ? 0 : (ts >= total ? total - 1 : ts);
+                rec[k][j] = a.ghost[(int64_t)ts * a.n_ghost + g];
             }
         }
     }
@@ -686,16 +699,18 @@ __global__ __launch_bounds__(TH) void k_wave_rec(const WaveArgs a)
     auto fetch_halo = [&](double (&h)[HPT]) {      // one history row per call, starting at tick tau0 - 1
         const double *hrow = a.hist + (int64_t)hr_fetch * a.n + h0;
         hr_fetch = next_row(hr_fetch);
+        const int32_t t = fresh(tid);
 #pragma unroll
         for (int j = 0; j < HPT; ++j) {
-            const int32_t i = j * TH + tid;
+            const int32_t i = j * TH + t;
             h[j] = hrow[i < nh ? i : 0];
         }
     };
     auto put_halo = [&](double *buf, const double (&h)[HPT]) {
+        const int32_t t = fresh(tid);
 #pragma unroll
         for (int j = 0; j < HPT; ++j) {
-            const int32_t i = j * TH + tid;
+            const int32_t i = j * TH + t;
             if (i < nh) buf[i] = h[j];
         }
     };
@@ -724,11 +739,11 @@ __global__ __launch_bounds__(TH) void k_wave_rec(const WaveArgs a)
         }
     };
 
-    double hs[3][HPT];
-    fetch_halo(hs[2]);
-    put_halo(lds + (size_t)((tau0 + 1) & 1) * a.lh, hs[2]);
-    fetch_halo(hs[0]);
-    fetch_halo(hs[1]);
+    double hs[NS][HPT];
+    fetch_halo(hs[NS - 1]);
+    put_halo(first_buf, hs[NS - 1]);
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i) fetch_halo(hs[i]);
     barrier_lds();
     RR_TRACE(1);
 #pragma unroll
@@ -736,28 +751,30 @@ __global__ __launch_bounds__(TH) void k_wave_rec(const WaveArgs a)
         const int32_t tau = tau0 + s;
         if (s == 1) RR_TRACE(2);
         if (s == 8) RR_TRACE(3);
-        fetch_halo(hs[(s + 2) % 3]);
+        fetch_halo(hs[(s + NS - 1) % NS]);
         const double *rd = lds + (size_t)((tau + 1) & 1) * a.lh;
         double *wr = lds + (size_t)(tau & 1) * a.lh;
         const __amdgpu_buffer_rsrc_t hist_row = make_rsrc(a.hist + (int64_t)hr_tick * a.n, (uint32_t)a.n * 8u);
         hr_tick = next_row(hr_tick);
+        const int32_t t = fresh(tid);       // slot and offset arithmetic is redone per tick, not held in registers
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            const int32_t p = position(k);
-            double qk = rd[nh + k * TH + tid];       // own discharge one tick back
-            const double c1 = cc1[k * TH + tid], c2 = cc2[k * TH + tid], c3 = cc3[k * TH + tid];
+            const int32_t p = b0 + k * TH + t, lgk = fresh(lg[k]), upk = fresh(up[k]);
+            const int32_t u0 = upk & 0xFFFF, u1 = u0 + (upk >> 16);
+            double qk = rd[nh + k * TH + t];       // own discharge one tick back
+            const double c1 = cc1[k * TH + t], c2 = cc2[k * TH + t], c3 = cc3[k * TH + t];
             double s_cur = 0.0, s_hw = 0.0;
-            if (UNIT) {
-                for (int32_t u = u0[k]; u < uh[k]; ++u) s_hw += rd[u];
-                for (int32_t u = uh[k]; u < u1[k]; ++u) s_cur += rd[u];
+            if (UNIT) {   // headwater tributaries come first in the upstream range
+                for (int32_t u = u0; u < uh[k]; ++u) s_hw += rd[u];
+                for (int32_t u = uh[k]; u < u1; ++u) s_cur += rd[u];
             } else {
-                for (int32_t u = u0[k]; u < u1[k]; ++u) s_cur += rd[u];
+                for (int32_t u = u0; u < u1; ++u) s_cur += rd[u];
             }
-            const int32_t ts = tau - (lg[k] & kLagMask);
+            const int32_t ts = tau - (lgk & kLagMask);
             if (ts >= 0 && ts < total) {
                 const double lat = has_lat ? rec[k][s] : 0.0;
                 if (UNIT) {
-                    if (u0[k] == u1[k]) {
+                    if (u0 == u1) {
                         qk = lat;        // headwater: discharge = lateral, the record slot already holds it
                     } else {
                         const double r = __builtin_fma(c1, s_hw + s_cur, __builtin_fma(c2, s_hw + s_prev[k], c3 * qch[k]));
@@ -765,20 +782,20 @@ __global__ __launch_bounds__(TH) void k_wave_rec(const WaveArgs a)
                         qk = r + lat;
                         rec[k][s] = qk > 0.0 ? qk : 0.0;
                     }
-                } else if (lg[k] & kGhostBit) {
+                } else if (lgk & kGhostBit) {
                     qk = rec[k][s];
                 } else {
                     // explicit fma: every copy of this tick must round identically (split run == joint run)
                     qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev[k], __builtin_fma(c3, qk, lat)));
-                    if (lg[k] & kExportBit) a.exports[(int64_t)ts * a.n_export + a.bidx[p]] = qk;
+                    if (lgk & kExportBit) a.exports[(int64_t)ts * a.n_export + a.bidx[p]] = qk;
                     rec[k][s] = qk > 0.0 ? qk : 0.0;
                 }
             }
             s_prev[k] = s_cur;
-            wr[nh + k * TH + tid] = qk;
+            wr[nh + k * TH + t] = qk;
             store_f64(hist_row, p >= halo_lo ? (uint32_t)p * 8u : kDropStore, qk);   // positions >= n fall off the row
         }
-        put_halo(wr, hs[s % 3]);
+        put_halo(wr, hs[s % NS]);
         if ((s & 7) == 7) {
 #pragma unroll
             for (int k = 0; k < PPT; ++k) store_half_records(k, s >> 3);
