@@ -981,7 +981,15 @@ __global__ __launch_bounds__(kBlock) void k_uh_tail(const double *__restrict__ k
 // records 4 j + sh .. 4 j + sh + 3.  k_rec_in reads the 79 rows [64 j - 15, 64 j + 64) of a 64-column tile
 // coalesced into LDS and writes four whole 128-byte records per column (8 lanes x 16 B per record); k_rec_out
 // reads five records per column the same way and writes the 64 rows [64 j, 64 j + 64) of the tile coalesced.
-constexpr int kRecCols = 64, kRecBatch = 4, kRecThreads = 256;
+#ifndef RR_REC_BATCH
+#define RR_REC_BATCH 8
+#define RR_REC_COLS 32
+#endif
+#ifndef RR_REC_THREADS
+#define RR_REC_THREADS 256
+#endif
+constexpr int kRecCols = RR_REC_COLS, kRecBatch = RR_REC_BATCH, kRecThreads = RR_REC_THREADS;
+constexpr int kRecRows = 16 * kRecBatch;    // rows of one batch
 
 struct RecPermArgs {
     double *rec;
@@ -998,7 +1006,7 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_in(const RecPermArgs a)
     __shared__ double tile[R][kRecCols + 1];
     const int tid = threadIdx.x;
     const int64_t col0 = (int64_t)blockIdx.x * kRecCols;
-    const int64_t row_first = 64 * a.batch - 15;
+    const int64_t row_first = kRecRows * a.batch - 15;
     {   // all row loads in flight first (branch-free: out-of-range rows/columns are clamped and zeroed afterwards)
         constexpr int RPT = (R + kRecThreads / kRecCols - 1) / (kRecThreads / kRecCols);
         const int c = tid % kRecCols, r0 = tid / kRecCols;
@@ -1022,23 +1030,23 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_in(const RecPermArgs a)
     double f[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {     // all metadata loads first: they are independent
-        const int64_t i = col0 + ((it * kRecThreads + tid) >> 5);
+        const int64_t i = col0 + (it * kRecThreads + tid) / (8 * kRecBatch);
         meta[it] = i < a.n ? a.colmeta[i] : make_int2(-1, 0);
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-        const int64_t i = col0 + ((it * kRecThreads + tid) >> 5);
+        const int64_t i = col0 + (it * kRecThreads + tid) / (8 * kRecBatch);
         f[it] = (a.scale && i < a.n) ? a.scale[i] : 1.0;
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int piece = it * kRecThreads + tid;       // (column, record, 16-byte part): 8 consecutive lanes = one record
-        const int c = piece >> 5, k = (piece >> 3) & 3, part = piece & 7;
+        const int c = piece / (8 * kRecBatch), k = (piece >> 3) % kRecBatch, part = piece & 7;
         const int32_t p = meta[it].x;
         if (p < 0) continue;
         const int32_t lag = meta[it].y;
         const int o = lag & 15;
-        const uint32_t chunk = 4u * (uint32_t)a.batch + (uint32_t)(lag >> 4) + k;
+        const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)(lag >> 4) + k;
         const int r = 15 - o + 16 * k + 2 * part;
         const double v0 = tile[r][c] * f[it], v1 = tile[r + 1][c] * f[it];
         double2 *dst = reinterpret_cast<double2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.n + p) * kRec) + part;
@@ -1065,7 +1073,7 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
         const int piece = it * kRecThreads + tid;
         const int k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
         const int32_t p = meta[it].x < 0 ? 0 : meta[it].x;
-        const uint32_t chunk = 4u * (uint32_t)a.batch + (uint32_t)(meta[it].y >> 4) + k;
+        const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)(meta[it].y >> 4) + k;
         v[it] = *(reinterpret_cast<const double2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.n + p) * kRec) + part);
     }
 #pragma unroll
@@ -1081,7 +1089,7 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
     if (i >= a.n) return;
     const int o = a.colmeta[i].y & 15;
     for (int r = tid / kRecCols; r < 16 * kRecBatch; r += kRecThreads / kRecCols) {
-        const int64_t t = 64 * a.batch + r;
+        const int64_t t = kRecRows * a.batch + r;
         if (t < a.T) a.rows.row(t)[i] = recs[c][o + r];
     }
 }
