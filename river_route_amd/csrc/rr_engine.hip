@@ -901,9 +901,19 @@ __global__ __launch_bounds__(kBlock) void k_uh_convolve(const double *__restrict
 // column sits in registers (static indices: the tap loop is unrolled over the padded length NK), the last NK
 // lateral values in an LDS ring [slot][lane] (conflict-free), so HBM sees each lateral row and each output row
 // exactly once and the kernel taps once per segment -- k_uh_convolve re-reads the taps for every 8 rows.
-constexpr int kUhThreads = 128;
+#ifndef RR_UH_THREADS
+#define RR_UH_THREADS 128
+#endif
+#ifndef RR_UH48
+#define RR_UH48 64, 48, 8, 3
+#endif
+constexpr int kUhThreads = RR_UH_THREADS;
 
-template <int NK>   // power of two >= n_ks + 3
+// NK window slots (power of two), R outputs per pass (every window value read from LDS feeds R accumulators),
+// D passes of lateral rows in flight.  The window costs NK * 8 B of LDS per thread, which caps the kernel at about
+// one wave per SIMD: latency is hidden by depth instead (R * D rows per lane in flight; registers are free at
+// that occupancy).
+template <int NK, int NT, int R, int D>    // NT taps held in registers (n_ks <= NT <= NK - (R - 1))
 __global__ __launch_bounds__(kUhThreads) void k_uh_convolve_ring(const double *__restrict__ kernel,
                                                                 const double *__restrict__ state,
                                                                 const double *__restrict__ lateral,
@@ -911,8 +921,7 @@ __global__ __launch_bounds__(kUhThreads) void k_uh_convolve_ring(const double *_
                                                                 int64_t n, int64_t seg_rows)
 {
     extern __shared__ __attribute__((aligned(16))) double win[];   // [NK][kUhThreads]
-    constexpr int R = 4;                 // outputs per pass: every window value read from LDS feeds R accumulators
-    constexpr int NT = NK - (R - 1);     // taps held in registers
+    static_assert(NT + R - 1 <= NK, "window ring too small");
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * kUhThreads + tid;
     const int64_t t0 = (int64_t)blockIdx.y * seg_rows, t1 = min(T, t0 + seg_rows);
@@ -927,30 +936,52 @@ __global__ __launch_bounds__(kUhThreads) void k_uh_convolve_ring(const double *_
         const int64_t t = t0 - s;
         win[(size_t)((uint64_t)t & (NK - 1)) * kUhThreads + tid] = (t >= 0 && s < n_ks) ? lateral[t * n + col] : 0.0;
     }
-    double nxt[R];
+    double nxt[D][R];
 #pragma unroll
-    for (int j = 0; j < R; ++j) nxt[j] = lateral[min(t0 + j, T - 1) * n + col];
-    for (int64_t t = t0; t < t1; t += R) {
-        double acc[R];
+    for (int dd = 0; dd < D; ++dd)
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            win[(size_t)((uint64_t)(t + j) & (NK - 1)) * kUhThreads + tid] = nxt[j];
-            acc[j] = (t + j < n_ks && t + j < T) ? state[(t + j) * n + col] : 0.0;
-        }
+        for (int j = 0; j < R; ++j) nxt[dd][j] = lateral[min(t0 + dd * R + j, T - 1) * n + col];
+    for (int64_t tb = t0; tb < t1; tb += R * D) {
 #pragma unroll
-        for (int j = 0; j < R; ++j) nxt[j] = lateral[min(t + R + j, T - 1) * n + col];     // next pass, in flight
-        // window value m = t + R - 1 - d is tap (j + d - (R - 1)) of output t + j
-#pragma unroll
-        for (int d = 0; d < NT + R - 1; ++d) {
-            const double v = win[(size_t)((uint64_t)(t + (R - 1) - d) & (NK - 1)) * kUhThreads + tid];
+        for (int dd = 0; dd < D; ++dd) {
+            const int64_t t = tb + dd * R;
+            if (t >= t1) break;
+            double acc[R];
 #pragma unroll
             for (int j = 0; j < R; ++j) {
-                const int sidx = j + d - (R - 1);
-                if (sidx >= 0 && sidx < NT) acc[j] = __builtin_fma(kv[sidx], v, acc[j]);
+                win[(size_t)((uint64_t)(t + j) & (NK - 1)) * kUhThreads + tid] = nxt[dd][j];
+                acc[j] = (t + j < n_ks && t + j < T) ? state[(t + j) * n + col] : 0.0;
             }
-        }
 #pragma unroll
-        for (int j = 0; j < R; ++j) if (live && t + j < t1) out[(t + j) * n + i] = acc[j];
+            for (int j = 0; j < R; ++j) nxt[dd][j] = lateral[min(t + R * D + j, T - 1) * n + col];     // D passes ahead
+            // window value m = t + R - 1 - d is tap (j + d - (R - 1)) of output t + j.  With one wave per SIMD nothing
+            // else hides the LDS latency: the window is read CH values at a time, one chunk ahead of the FMAs.
+            constexpr int CH = 8, ND = NT + R - 1, NCH = (ND + CH - 1) / CH;
+            double wv[2][CH];
+            auto read_chunk = [&](int c, double (&v)[CH]) {
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    const int d = c * CH + e;
+                    if (d < ND) v[e] = win[(size_t)((uint64_t)(t + (R - 1) - d) & (NK - 1)) * kUhThreads + tid];
+                }
+            };
+            read_chunk(0, wv[0]);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (c + 1 < NCH) read_chunk(c + 1, wv[(c + 1) & 1]);
+#pragma unroll
+                for (int e = 0; e < CH; ++e) {
+                    const int d = c * CH + e;
+#pragma unroll
+                    for (int j = 0; j < R; ++j) {
+                        const int sidx = j + d - (R - 1);
+                        if (d < ND && sidx >= 0 && sidx < NT) acc[j] = __builtin_fma(kv[sidx], wv[c & 1][e], acc[j]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < R; ++j) if (live && t + j < t1) out[(t + j) * n + i] = acc[j];
+        }
     }
 }
 
@@ -1856,25 +1887,29 @@ int uh_convolve_core(const double *d_kernel, double *d_state, const double *d_la
     double *d_tail = nullptr;
     int rc = dev_alloc(&d_tail, n_ks * n);
     if (rc) return rc;
-    if (n_ks <= 61 && T >= 64) {
+    if (n_ks <= 57 && T >= 64) {
         // long series: register-resident taps + LDS window; split time only as far as needed to fill the chip
         const int64_t blocks_x = (n + kUhThreads - 1) / kUhThreads;
         int64_t segs = std::max<int64_t>(1, std::min<int64_t>(T / 256, (2048 + blocks_x - 1) / blocks_x));
         const int64_t seg_rows = (T + segs - 1) / segs;
         segs = (T + seg_rows - 1) / seg_rows;
         dim3 g((unsigned)blocks_x, (unsigned)segs);
-#define RR_UH_LAUNCH(NK_)                                                                                          \
+#define RR_UH_LAUNCH(NK_, NT_, R_, D_)                                                                             \
         do {                                                                                                       \
             const size_t lds = (size_t)NK_ * kUhThreads * sizeof(double);                                          \
-            (void)hipFuncSetAttribute((const void *)k_uh_convolve_ring<NK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL(k_uh_convolve_ring<NK_>, g, dim3(kUhThreads), lds, stream, d_kernel, (const double *)d_state,       \
+            (void)hipFuncSetAttribute((const void *)k_uh_convolve_ring<NK_, NT_, R_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_uh_convolve_ring<NK_, NT_, R_, D_>), g, dim3(kUhThreads), lds, stream, d_kernel, (const double *)d_state,     \
                                d_lateral, d_out, T, (int32_t)n_ks, n, seg_rows);                                   \
         } while (0)
-        if (n_ks <= 5) RR_UH_LAUNCH(8);            // NK >= n_ks + 3 window slots
-        else if (n_ks <= 13) RR_UH_LAUNCH(16);
-        else if (n_ks <= 29) RR_UH_LAUNCH(32);
-        else RR_UH_LAUNCH(64);
+#define RR_UH_LAUNCH_X(...) RR_UH_LAUNCH(__VA_ARGS__)
+        if (n_ks <= 5) RR_UH_LAUNCH(8, 5, 4, 2);            // NK >= NT + R - 1 window slots
+        else if (n_ks <= 13) RR_UH_LAUNCH(16, 13, 4, 2);
+        else if (n_ks <= 24) RR_UH_LAUNCH(32, 24, 8, 2);
+        else if (n_ks <= 29) RR_UH_LAUNCH(32, 29, 4, 3);
+        else if (n_ks <= 48) RR_UH_LAUNCH_X(RR_UH48);
+        else RR_UH_LAUNCH(64, 57, 8, 3);
 #undef RR_UH_LAUNCH
+#undef RR_UH_LAUNCH_X
     } else {
         dim3 g((unsigned)((n + kBlock - 1) / kBlock), (unsigned)((T + TB - 1) / TB));
         hipLaunchKernelGGL(k_uh_convolve<TB>, g, dim3(kBlock), 0, stream, d_kernel, (const double *)d_state, d_lateral,
