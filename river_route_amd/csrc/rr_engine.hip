@@ -905,7 +905,7 @@ __global__ __launch_bounds__(kBlock) void k_uh_convolve(const double *__restrict
 #define RR_UH_THREADS 128
 #endif
 #ifndef RR_UH48
-#define RR_UH48 64, 48, 8, 3
+#define RR_UH48 64, 48, 8, 2
 #endif
 constexpr int kUhThreads = RR_UH_THREADS;
 
@@ -941,46 +941,100 @@ __global__ __launch_bounds__(kUhThreads) void k_uh_convolve_ring(const double *_
     for (int dd = 0; dd < D; ++dd)
 #pragma unroll
         for (int j = 0; j < R; ++j) nxt[dd][j] = lateral[min(t0 + dd * R + j, T - 1) * n + col];
-    for (int64_t tb = t0; tb < t1; tb += R * D) {
+    // window value m = t + R - 1 - d is tap (j + d - (R - 1)) of output t + j.  With one wave per SIMD nothing else
+    // hides the LDS latency: the window is read CH values at a time, one chunk ahead of the FMAs.
+    constexpr int CH = 8, ND = NT + R - 1, NCH = (ND + CH - 1) / CH;
+    constexpr int PASSES = NK / R;        // passes per group of NK rows
+    constexpr bool STATIC_GROUPS = PASSES % D == 0;
+    // Rows are handled in groups of NK (segments start at multiples of NK, rr_uh_convolve_dev).  A group that needs
+    // no carried-in state, no clamped prefetch and no partial store runs with every window slot a compile-time
+    // constant (the LDS offsets become immediates); the slot and row arithmetic of the general pass was two thirds
+    // of its instructions, and with one wave per SIMD every instruction is on the critical path.
+    for (int64_t tb = t0; tb < t1; tb += NK) {
+        const bool fast = STATIC_GROUPS && tb >= n_ks && tb + NK <= t1 && tb + NK + R * D <= T;
+        if (fast) {
+            const double *lat_g = lateral + tb * n + col;     // row tb of this column
+            double *out_g = out + tb * n + col;
 #pragma unroll
-        for (int dd = 0; dd < D; ++dd) {
-            const int64_t t = tb + dd * R;
-            if (t >= t1) break;
-            double acc[R];
+            for (int pp = 0; pp < PASSES; ++pp) {
+                constexpr int mask = NK - 1;
+                const int dd = pp % D;
+                double acc[R];
 #pragma unroll
-            for (int j = 0; j < R; ++j) {
-                win[(size_t)((uint64_t)(t + j) & (NK - 1)) * kUhThreads + tid] = nxt[dd][j];
-                acc[j] = (t + j < n_ks && t + j < T) ? state[(t + j) * n + col] : 0.0;
-            }
-#pragma unroll
-            for (int j = 0; j < R; ++j) nxt[dd][j] = lateral[min(t + R * D + j, T - 1) * n + col];     // D passes ahead
-            // window value m = t + R - 1 - d is tap (j + d - (R - 1)) of output t + j.  With one wave per SIMD nothing
-            // else hides the LDS latency: the window is read CH values at a time, one chunk ahead of the FMAs.
-            constexpr int CH = 8, ND = NT + R - 1, NCH = (ND + CH - 1) / CH;
-            double wv[2][CH];
-            auto read_chunk = [&](int c, double (&v)[CH]) {
-#pragma unroll
-                for (int e = 0; e < CH; ++e) {
-                    const int d = c * CH + e;
-                    if (d < ND) v[e] = win[(size_t)((uint64_t)(t + (R - 1) - d) & (NK - 1)) * kUhThreads + tid];
+                for (int j = 0; j < R; ++j) {
+                    win[(size_t)((pp * R + j) & mask) * kUhThreads + tid] = nxt[dd][j];
+                    acc[j] = 0.0;
                 }
-            };
-            read_chunk(0, wv[0]);
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                if (c + 1 < NCH) read_chunk(c + 1, wv[(c + 1) & 1]);
+                for (int j = 0; j < R; ++j) nxt[dd][j] = lat_g[(int64_t)(pp * R + R * D + j) * n];
+                double wv[2][CH];
+                auto read_chunk = [&](int c, double (&v)[CH]) {
 #pragma unroll
-                for (int e = 0; e < CH; ++e) {
-                    const int d = c * CH + e;
+                    for (int e = 0; e < CH; ++e) {
+                        const int d = c * CH + e;
+                        if (d < ND) v[e] = win[(size_t)((pp * R + (R - 1) - d) & mask) * kUhThreads + tid];
+                    }
+                };
+                read_chunk(0, wv[0]);
 #pragma unroll
-                    for (int j = 0; j < R; ++j) {
-                        const int sidx = j + d - (R - 1);
-                        if (d < ND && sidx >= 0 && sidx < NT) acc[j] = __builtin_fma(kv[sidx], wv[c & 1][e], acc[j]);
+                for (int c = 0; c < NCH; ++c) {
+                    if (c + 1 < NCH) read_chunk(c + 1, wv[(c + 1) & 1]);
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) {
+                        const int d = c * CH + e;
+#pragma unroll
+                        for (int j = 0; j < R; ++j) {
+                            const int sidx = j + d - (R - 1);
+                            if (d < ND && sidx >= 0 && sidx < NT) acc[j] = __builtin_fma(kv[sidx], wv[c & 1][e], acc[j]);
+                        }
                     }
                 }
-            }
+                if (live) {
 #pragma unroll
-            for (int j = 0; j < R; ++j) if (live && t + j < t1) out[(t + j) * n + i] = acc[j];
+                    for (int j = 0; j < R; ++j) out_g[(int64_t)(pp * R + j) * n] = acc[j];
+                }
+            }
+            continue;
+        }
+        const int64_t tg_end = min(t1, tb + NK);
+        for (int64_t tg = tb; tg < tg_end; tg += R * D) {
+#pragma unroll
+            for (int dd = 0; dd < D; ++dd) {
+                const int64_t t = tg + dd * R;
+                if (t >= tg_end) break;
+                double acc[R];
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    win[(size_t)((uint64_t)(t + j) & (NK - 1)) * kUhThreads + tid] = nxt[dd][j];
+                    acc[j] = (t + j < n_ks && t + j < T) ? state[(t + j) * n + col] : 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < R; ++j) nxt[dd][j] = lateral[min(t + R * D + j, T - 1) * n + col];     // D passes ahead
+                double wv[2][CH];
+                auto read_chunk = [&](int c, double (&v)[CH]) {
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) {
+                        const int d = c * CH + e;
+                        if (d < ND) v[e] = win[(size_t)((uint64_t)(t + (R - 1) - d) & (NK - 1)) * kUhThreads + tid];
+                    }
+                };
+                read_chunk(0, wv[0]);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (c + 1 < NCH) read_chunk(c + 1, wv[(c + 1) & 1]);
+#pragma unroll
+                    for (int e = 0; e < CH; ++e) {
+                        const int d = c * CH + e;
+#pragma unroll
+                        for (int j = 0; j < R; ++j) {
+                            const int sidx = j + d - (R - 1);
+                            if (d < ND && sidx >= 0 && sidx < NT) acc[j] = __builtin_fma(kv[sidx], wv[c & 1][e], acc[j]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < R; ++j) if (live && t + j < t1) out[(t + j) * n + i] = acc[j];
+            }
         }
     }
 }
@@ -1891,7 +1945,7 @@ int uh_convolve_core(const double *d_kernel, double *d_state, const double *d_la
         // long series: register-resident taps + LDS window; split time only as far as needed to fill the chip
         const int64_t blocks_x = (n + kUhThreads - 1) / kUhThreads;
         int64_t segs = std::max<int64_t>(1, std::min<int64_t>(T / 256, (2048 + blocks_x - 1) / blocks_x));
-        const int64_t seg_rows = (T + segs - 1) / segs;
+        const int64_t seg_rows = ((T + segs - 1) / segs + 63) / 64 * 64;      // segments start at multiples of every NK
         segs = (T + seg_rows - 1) / seg_rows;
         dim3 g((unsigned)blocks_x, (unsigned)segs);
 #define RR_UH_LAUNCH(NK_, NT_, R_, D_)                                                                             \
@@ -1905,9 +1959,9 @@ int uh_convolve_core(const double *d_kernel, double *d_state, const double *d_la
         if (n_ks <= 5) RR_UH_LAUNCH(8, 5, 4, 2);            // NK >= NT + R - 1 window slots
         else if (n_ks <= 13) RR_UH_LAUNCH(16, 13, 4, 2);
         else if (n_ks <= 24) RR_UH_LAUNCH(32, 24, 8, 2);
-        else if (n_ks <= 29) RR_UH_LAUNCH(32, 29, 4, 3);
+        else if (n_ks <= 29) RR_UH_LAUNCH(32, 29, 4, 2);
         else if (n_ks <= 48) RR_UH_LAUNCH_X(RR_UH48);
-        else RR_UH_LAUNCH(64, 57, 8, 3);
+        else RR_UH_LAUNCH(64, 57, 8, 2);
 #undef RR_UH_LAUNCH
 #undef RR_UH_LAUNCH_X
     } else {
