@@ -170,6 +170,26 @@ int rr_partition_forest(int64_t n, const int32_t *csc_indptr, const int32_t *csc
 int rr_resample_cast_dev(int device, const double *discharge, int64_t num_rows, int64_t n, int64_t factor, float *out,
                          void *stream);
 
+/* ---- gridded runoff -> catchment lateral inflow (river_route/runoff.py:288-330) ----
+ * qlateral[t, r] = sum over the CSR row r of weights[k] * runoff(t, indices[k]), then, in the reference's order:
+ * RR_RUNOFF_CUMULATIVE input -> incremental (row t minus row t - 1, row 0 kept), RR_RUNOFF_FORCE_POSITIVE -> clip at 0,
+ * NaN -> 0 (unless RR_RUNOFF_KEEP_NAN: the host resamples irregular time steps before filling), and, when
+ * area != NULL, times area[r] (volumes, the routers' as_volumes=True).  weights = proportion * unit conversion.
+ * runoff element (t, p) is at runoff[t * stride_t + p * stride_p] (float when runoff_is_f32, else double): pass the
+ * block point-major (stride_t = 1, stride_p = T) for contiguous gathers, or as read from the file (stride_p = 1).
+ * The non-uniform-time resampling of the reference (pandas, runoff.py:313-325) stays on the host.
+ * rr_runoff_to_qlateral takes host arrays; the _dev form takes device arrays and only enqueues on `stream`. */
+#define RR_RUNOFF_CUMULATIVE 1
+#define RR_RUNOFF_FORCE_POSITIVE 2
+#define RR_RUNOFF_KEEP_NAN 4
+int rr_runoff_to_qlateral(int device, int64_t n_rivers, int64_t n_points, int64_t T, const int32_t *indptr,
+                          const int32_t *indices, const double *weights, const void *runoff, int runoff_is_f32,
+                          int64_t stride_t, int64_t stride_p, const double *area, int flags, double *qlateral);
+int rr_runoff_to_qlateral_dev(int device, int64_t n_rivers, int64_t n_points, int64_t T, const int32_t *indptr,
+                              const int32_t *indices, const double *weights, const void *runoff, int runoff_is_f32,
+                              int64_t stride_t, int64_t stride_p, const double *area, int flags, double *qlateral,
+                              void *stream);
+
 /* ---- small device helpers so a host language needs no HIP binding of its own ---- */
 int rr_dev_malloc(int device, int64_t bytes, void **out);
 int rr_dev_free(int device, void *ptr);

@@ -158,3 +158,30 @@ class UnitHydrograph:
         out = np.empty((T, n))
         _check(lib().orc_uh_convolve(T, n_ks, n, self.kernel, self.state, lateral, out))
         return out
+
+
+def runoff_to_qlateral_core(weights, runoff_raw, catchment_area=None, cumulative=False, force_positive_runoff=False,
+                            keep_nan=False):
+    """The arithmetic of river_route/runoff.py:296-330 on arrays already extracted from the files: `weights` is the
+    scipy CSR (n_rivers, n_points) of proportion * unit conversion (runoff.py:288-291), `runoff_raw` the (T, n_points)
+    block of the runoff variable (float32 or float64).  numpy/scipy restatement, same statements in the same order:
+    sparse product (296), cumulative -> incremental from the last row down (307-309), clip (310-311), NaN -> 0
+    (327-329), times catchment area for volumes (331-332).  `keep_nan` stops before the fill, where the reference's
+    irregular-time-step branch resamples (313-325).
+
+    PARITY UNPINNED for this function: the reference's own tests of this path (tests/test_runoff.py:50-99) need the
+    downloaded ERA5 / VPU data set and xarray, neither of which is in the image, so there is no reference output to
+    pin it to; it is checked against an independent dense evaluation instead (tests/test_runoff.py)."""
+    q = np.array(np.asarray(weights @ np.asarray(runoff_raw).T).T, dtype=np.float64)      # (time, n_rivers)
+    if cumulative:
+        for i in range(q.shape[0] - 1, 0, -1):
+            q[i] -= q[i - 1]
+    if force_positive_runoff:
+        np.clip(q, 0, None, out=q)
+    if not keep_nan:
+        mask = np.isnan(q)
+        if mask.any():
+            q[mask] = 0.0
+    if catchment_area is not None:
+        q *= np.asarray(catchment_area, dtype=np.float64)[np.newaxis, :]
+    return q

@@ -1,0 +1,38 @@
+"""rr_runoff_to_qlateral_dev at routing scale: 1M catchments, a 500 x 500-cell grid region,
+~3 cells per catchment, one month of hourly float32 runoff (744 steps), device-resident arrays, HIP-event timing on
+the stream the kernel is launched on.  Algorithmic bytes = the (T, n) float64 result written once + each stored
+weight's T float32 values gathered once + the CSR once."""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, '.')
+from river_route_amd import _lib
+
+n, npts, T = 1_000_000, 250_000, 744
+rng = np.random.default_rng(0)
+cnt = rng.integers(1, 6, n)
+indptr = np.zeros(n + 1, np.int32); indptr[1:] = np.cumsum(cnt)
+nnz = int(indptr[-1])
+base = rng.integers(0, npts, n)                       # a catchment's cells are neighbours on the grid
+indices = ((np.repeat(base, cnt) + rng.integers(0, 3, nnz) + 500 * rng.integers(0, 3, nnz)) % npts).astype(np.int32)
+weights = rng.random(nnz)
+dev = torch.device('cuda:0')
+d_ip, d_ix, d_w = torch.from_numpy(indptr).to(dev), torch.from_numpy(indices).to(dev), torch.from_numpy(weights).to(dev)
+area = torch.rand(n, dtype=torch.float64, device=dev) * 1e7
+for layout in ('point-major', 'time-major'):
+    runoff = torch.rand((npts, T) if layout == 'point-major' else (T, npts), dtype=torch.float32, device=dev)
+    st, sp = (1, T) if layout == 'point-major' else (npts, 1)
+    out = torch.empty((T, n), dtype=torch.float64, device=dev)
+    s = torch.cuda.current_stream()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ms = []
+    for rep in range(4):
+        ev[0].record(s)
+        rc = _lib.lib().rr_runoff_to_qlateral_dev(0, n, npts, T, d_ip.data_ptr(), d_ix.data_ptr(), d_w.data_ptr(), runoff.data_ptr(), 1,
+                                                  st, sp, area.data_ptr(), 2, out.data_ptr(), s.cuda_stream)
+        assert rc == 0
+        ev[1].record(s); torch.cuda.synchronize()
+        ms.append(ev[0].elapsed_time(ev[1]))
+    alg = T * n * 8 + nnz * T * 4 + nnz * 12 + n * 12
+    print(f'{layout}: {min(ms):.2f} ms for {n} catchments x {T} steps ({nnz} weights) -> {alg / min(ms) / 1e6:.0f} GB/s algorithmic, '
+          f'{n * T / (min(ms) * 1e-3):.3g} catchment-steps/s')

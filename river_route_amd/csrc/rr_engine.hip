@@ -1193,6 +1193,48 @@ __global__ __launch_bounds__(kBlock) void k_resample_cast(const double *__restri
     dst[o * n + i] = (float)(factor > 1 ? acc / (double)factor : acc);
 }
 
+// ---- gridded runoff -> catchment lateral inflow (river_route/runoff.py:288-330) ----
+// qlateral[t, r] = sum_k weights[k] * runoff[t, point[k]] over the CSR row of river r (scipy's csr @ dense: the terms
+// in stored order, multiply and add rounded separately), then cumulative -> incremental (row t minus row t - 1, row 0
+// kept), clip at zero, NaN -> 0, times the catchment area.  One lane per river and a chunk of kRunoffRows time steps:
+// with the runoff stored point-major (stride_t = 1) every gathered point is one contiguous run of the chunk's rows.
+constexpr int kRunoffRows = 16;
+
+template <typename RT>
+__global__ __launch_bounds__(kBlock) void k_runoff_to_qlateral(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                                               const double *__restrict__ weights, const RT *__restrict__ runoff,
+                                                               int64_t stride_t, int64_t stride_p, const double *__restrict__ area,
+                                                               int flags, double *__restrict__ out, int64_t n_rivers, int64_t T)
+{
+    const int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t t0 = (int64_t)blockIdx.y * kRunoffRows;
+    if (r >= n_rivers) return;
+    const int nt = (int)min((int64_t)kRunoffRows, T - t0);
+    const bool cumulative = flags & RR_RUNOFF_CUMULATIVE, force_positive = flags & RR_RUNOFF_FORCE_POSITIVE,
+               keep_nan = flags & RR_RUNOFF_KEEP_NAN;
+    double acc[kRunoffRows + 1];        // slot 0: row t0 - 1 (cumulative input only)
+#pragma unroll
+    for (int j = 0; j <= kRunoffRows; ++j) acc[j] = 0.0;
+    const bool need_prev = cumulative && t0 > 0;
+    for (int32_t k = indptr[r]; k < indptr[r + 1]; ++k) {
+        const double w = weights[k];
+        const RT *src = runoff + (int64_t)indices[k] * stride_p + (t0 - 1) * stride_t;
+#pragma unroll
+        for (int j = 0; j <= kRunoffRows; ++j) {
+            if (j == 0 ? need_prev : j <= nt) acc[j] = __dadd_rn(acc[j], __dmul_rn(w, (double)src[(int64_t)j * stride_t]));
+        }
+    }
+    const double a = area ? area[r] : 1.0;
+#pragma unroll
+    for (int j = 1; j <= kRunoffRows; ++j) {
+        if (j > nt) break;
+        double v = (cumulative && t0 + j - 1 > 0) ? acc[j] - acc[j - 1] : acc[j];
+        if (force_positive) v = v < 0.0 ? 0.0 : v;      // np.clip leaves NaN alone, as does this comparison
+        if (v != v && !keep_nan) v = 0.0;
+        out[(t0 + j - 1) * n_rivers + r] = area ? v * a : v;
+    }
+}
+
 inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
 }  // namespace
@@ -2475,6 +2517,72 @@ int rr_resample_cast_dev(int device, const double *discharge, int64_t num_rows, 
     }
     HIPCHK(hipGetLastError());
     return RR_OK;
+}
+
+int rr_runoff_to_qlateral_dev(int device, int64_t n_rivers, int64_t n_points, int64_t T, const int32_t *indptr,
+                              const int32_t *indices, const double *weights, const void *runoff, int runoff_is_f32,
+                              int64_t stride_t, int64_t stride_p, const double *area, int flags, double *qlateral, void *stream)
+{
+    if (device < 0 || device >= rr_device_count()) return fail(RR_E_NO_DEVICE, "rr_runoff_to_qlateral_dev: no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    if (n_rivers < 0 || n_points < 0 || T < 0 || n_rivers > 0x7FFFFFFFLL || n_points > 0x7FFFFFFFLL)
+        return fail(RR_E_INVALID, "rr_runoff_to_qlateral_dev: sizes out of range");
+    if (n_rivers == 0 || T == 0) return RR_OK;
+    if (!indptr || !indices || !weights || !runoff || !qlateral) return fail(RR_E_INVALID, "rr_runoff_to_qlateral_dev: null array");
+    const int64_t chunks = (T + kRunoffRows - 1) / kRunoffRows;
+    if (chunks > 65535) return fail(RR_E_UNSUPPORTED, "rr_runoff_to_qlateral_dev: more than 1,048,560 time steps in one call");
+    dim3 g((unsigned)((n_rivers + kBlock - 1) / kBlock), (unsigned)chunks);
+    if (runoff_is_f32)
+        hipLaunchKernelGGL(k_runoff_to_qlateral<float>, g, dim3(kBlock), 0, (hipStream_t)stream, indptr, indices, weights,
+                           (const float *)runoff, stride_t, stride_p, area, flags, qlateral, n_rivers, T);
+    else
+        hipLaunchKernelGGL(k_runoff_to_qlateral<double>, g, dim3(kBlock), 0, (hipStream_t)stream, indptr, indices, weights,
+                           (const double *)runoff, stride_t, stride_p, area, flags, qlateral, n_rivers, T);
+    HIPCHK(hipGetLastError());
+    return RR_OK;
+}
+
+int rr_runoff_to_qlateral(int device, int64_t n_rivers, int64_t n_points, int64_t T, const int32_t *indptr,
+                          const int32_t *indices, const double *weights, const void *runoff, int runoff_is_f32,
+                          int64_t stride_t, int64_t stride_p, const double *area, int flags, double *qlateral)
+{
+    if (device < 0 || device >= rr_device_count()) return fail(RR_E_NO_DEVICE, "rr_runoff_to_qlateral: no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    if (n_rivers < 0 || n_points < 0 || T < 0) return fail(RR_E_INVALID, "rr_runoff_to_qlateral: negative size");
+    if (n_rivers == 0 || T == 0) return RR_OK;
+    if (!indptr || !indices || !weights || !runoff || !qlateral) return fail(RR_E_INVALID, "rr_runoff_to_qlateral: null array");
+    // the runoff block spans max over (t, p) of t * stride_t + p * stride_p elements
+    if (stride_t < 0 || stride_p < 0) return fail(RR_E_INVALID, "rr_runoff_to_qlateral: negative stride");
+    const int64_t nnz = indptr[n_rivers];
+    const int64_t elems = (T - 1) * stride_t + (n_points > 0 ? (n_points - 1) * stride_p : 0) + 1;
+    const size_t esz = runoff_is_f32 ? sizeof(float) : sizeof(double);
+    int32_t *d_indptr = nullptr, *d_indices = nullptr;
+    double *d_w = nullptr, *d_area = nullptr, *d_out = nullptr;
+    void *d_runoff = nullptr;
+    int rc = dev_alloc(&d_indptr, n_rivers + 1);
+    if (!rc) rc = dev_alloc(&d_indices, std::max<int64_t>(1, nnz));
+    if (!rc) rc = dev_alloc(&d_w, std::max<int64_t>(1, nnz));
+    if (!rc && area) rc = dev_alloc(&d_area, n_rivers);
+    if (!rc) rc = dev_alloc(&d_out, T * n_rivers);
+    if (!rc && hipMalloc(&d_runoff, (size_t)elems * esz) != hipSuccess) rc = fail(RR_E_ALLOC, "rr_runoff_to_qlateral: device allocation failed");
+    auto release = [&]() {
+        (void)hipFree(d_indptr); (void)hipFree(d_indices); (void)hipFree(d_w); (void)hipFree(d_area); (void)hipFree(d_out); (void)hipFree(d_runoff);
+    };
+    if (rc) { release(); return rc; }
+    hipError_t e = hipMemcpy(d_indptr, indptr, (size_t)(n_rivers + 1) * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && nnz > 0) e = hipMemcpy(d_indices, indices, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess && nnz > 0) e = hipMemcpy(d_w, weights, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess && area) e = hipMemcpy(d_area, area, (size_t)n_rivers * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_runoff, runoff, (size_t)elems * esz, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { release(); return fail(RR_E_HIP, hipGetErrorString(e)); }
+    rc = rr_runoff_to_qlateral_dev(device, n_rivers, n_points, T, d_indptr, d_indices, d_w, d_runoff, runoff_is_f32, stride_t,
+                                   stride_p, d_area, flags, d_out, nullptr);
+    if (!rc) {
+        e = hipMemcpy(qlateral, d_out, (size_t)(T * n_rivers) * sizeof(double), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(RR_E_HIP, hipGetErrorString(e));
+    }
+    release();
+    return rc;
 }
 
 // ---- device helpers ----

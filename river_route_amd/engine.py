@@ -11,7 +11,7 @@ import numpy as np
 from . import _lib
 from ._lib import RRError, check, ptr
 
-__all__ = ['Plan', 'RRError', 'uh_convolve', 'uh_convolve_dev', 'DeviceBuffer', 'partition_forest', 'synchronize',
+__all__ = ['Plan', 'RRError', 'uh_convolve', 'uh_convolve_dev', 'runoff_to_qlateral', 'DeviceBuffer', 'partition_forest', 'synchronize',
            'resample_cast_dev']
 
 
@@ -198,6 +198,37 @@ def uh_convolve(kernel, state, lateral, device: int = 0) -> np.ndarray:
 def uh_convolve_dev(kernel, state, lateral, out, T, n_ks, n, device: int = 0, stream=None) -> None:
     check(_lib.lib().rr_uh_convolve_dev(int(device), ptr(kernel), ptr(state), ptr(lateral), ptr(out), int(T),
                                         int(n_ks), int(n), stream))
+
+
+RUNOFF_CUMULATIVE, RUNOFF_FORCE_POSITIVE, RUNOFF_KEEP_NAN = 1, 2, 4
+
+
+def runoff_to_qlateral(indptr, indices, weights, runoff_tp, area=None, flags: int = 0, device: int = 0) -> np.ndarray:
+    """rr_runoff_to_qlateral: (T, n_rivers) float64 from a CSR weight matrix (n_rivers x n_points, float64 data,
+    int32 structure) and a (T, n_points) float32/float64 runoff block (river_route/runoff.py:288-330).  The block is
+    handed over point-major so every gathered grid point is one contiguous run of time steps."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    weights = np.ascontiguousarray(weights, dtype=np.float64)
+    runoff_tp = np.asarray(runoff_tp)
+    if runoff_tp.ndim != 2:
+        raise ValueError('runoff must be (time, points)')
+    if runoff_tp.dtype not in (np.float32, np.float64):
+        runoff_tp = runoff_tp.astype(np.float64)
+    T, n_points = runoff_tp.shape
+    n_rivers = indptr.shape[0] - 1
+    if indices.shape[0] and (indices.min() < 0 or indices.max() >= n_points):
+        raise ValueError('weight matrix refers to grid points outside the runoff block')
+    point_major = np.ascontiguousarray(runoff_tp.T)          # (n_points, T): stride_t = 1, stride_p = T
+    out = np.empty((T, n_rivers), dtype=np.float64)
+    if area is not None:
+        area = np.ascontiguousarray(area, dtype=np.float64)
+        if area.shape != (n_rivers,):
+            raise ValueError('area must have one value per river')
+    check(_lib.lib().rr_runoff_to_qlateral(int(device), n_rivers, n_points, T, ptr(indptr), ptr(indices), ptr(weights),
+                                           ptr(point_major), int(point_major.dtype == np.float32), 1, T,
+                                           ptr(area) if area is not None else None, int(flags), ptr(out)))
+    return out
 
 
 def resample_cast_dev(discharge, num_rows, n, factor, out, device: int = 0, stream=None) -> None:

@@ -9,7 +9,7 @@ import re
 
 import numpy as np
 
-__all__ = ['read_qlateral', 'write_discharge']
+__all__ = ['read_qlateral', 'write_discharge', 'read_variables']
 
 _UNIT_SECONDS = {'second': 1, 'seconds': 1, 'sec': 1, 'secs': 1, 's': 1, 'minute': 60, 'minutes': 60, 'min': 60,
                  'hour': 3600, 'hours': 3600, 'h': 3600, 'hr': 3600, 'day': 86400, 'days': 86400, 'd': 86400}
@@ -47,6 +47,35 @@ def read_qlateral(path, var_t: str = 'time', var: str = 'qlateral'):
         units = tv.units.decode() if isinstance(tv.units, bytes) else tv.units
         dates = _decode_cf_time(tv[:].copy(), units)
         return dates, np.array(ds.variables[var][:], dtype=np.float64)
+
+
+def read_variables(path, names):
+    """-> {name: (array, dims tuple, attrs dict)} for the named variables of one netCDF file (time variables stay raw:
+    decode with the `units` attribute).  Same backends as read_qlateral, minus xarray's decoding."""
+    out = {}
+    try:
+        import netCDF4 as nc
+        with nc.Dataset(str(path)) as ds:
+            ds.set_auto_mask(False)
+            for name in names:
+                v = ds[name]
+                out[name] = (np.asarray(v[:]), tuple(v.dimensions), {k: v.getncattr(k) for k in v.ncattrs()})
+        return out
+    except ImportError:
+        pass
+    from scipy.io import netcdf_file
+    with netcdf_file(str(path), 'r', mmap=False) as ds:
+        for name in names:
+            if name not in ds.variables:
+                raise KeyError(f'{name} not in {path}')
+            v = ds.variables[name]
+            attrs = {k: (a.decode() if isinstance(a, bytes) else a) for k, a in v._attributes.items()}
+            arr = np.array(v[:])
+            arr = arr.astype(arr.dtype.newbyteorder('='), copy=False)      # NetCDF-3 is big-endian on disk
+            if 'scale_factor' in attrs or 'add_offset' in attrs:      # CF packing, as xarray / netCDF4 decode it
+                arr = arr * np.float64(attrs.get('scale_factor', 1.0)) + np.float64(attrs.get('add_offset', 0.0))
+            out[name] = (arr, tuple(v.dimensions), attrs)
+    return out
 
 
 def write_discharge(path, dates, q_array, river_ids, var_river_id='river_id', var_discharge='Q', routed_file=''):

@@ -28,10 +28,18 @@ class TransformMuskingum(Muskingum, ABC):
                 dates, array = read_qlateral(lateral_file, self.cfg.var_t)
                 yield dates, array, lateral_file, discharge_file
         elif self.cfg.grid_runoff_files and self.cfg.grid_weights_file:
-            # runoff.py (grid -> catchment volumes) sits upstream of the hot path and is not part of this engine
-            raise NotImplementedError(
-                'grid_runoff_files: gridded-runoff to qlateral conversion (river_route.runoff.runoff_to_qlateral) is '
-                'outside the MI355X hot path; convert to qlateral files first or override _qlateral_generator')
+            # gridded runoff -> catchment inflow on the device (TransformMuskingum.py:38-51 -> runoff.runoff_to_qlateral)
+            from ..runoff import runoff_to_qlateral
+            for runoff_file, discharge_file in zip(self.cfg.grid_runoff_files, self.cfg.discharge_files):
+                self.logger.info('-' * 60)
+                self.logger.debug(f'Calculating qlateral: {runoff_file}')
+                ds = runoff_to_qlateral(runoff_file, grid_weights_file=self.cfg.grid_weights_file,
+                                        var_runoff=self.cfg.var_grid_runoff, var_x=self.cfg.var_x, var_y=self.cfg.var_y,
+                                        var_t=self.cfg.var_t, var_river_id=self.cfg.var_river_id,
+                                        cumulative=self.cfg.grid_accumulation_type == 'cumulative',
+                                        as_volumes=self._as_volumes, device=self.cfg.device)
+                yield (ds['time'].values.astype('datetime64[s]'),
+                       ds['qlateral'].values.astype(np.float64, copy=False), runoff_file, discharge_file)
 
     def _validate_router_configs(self) -> None:
         qlateral = self.cfg.qlateral_files
