@@ -352,6 +352,31 @@ struct WaveArgs {
 // lateral/halo prefetches stay in flight across ticks (__syncthreads() would drain vmcnt every tick).
 __device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Predicated global stores without a branch: a raw buffer store whose byte offset is pushed past the end of the
+// buffer is dropped by the bounds check.  Unlike `if (cond) *ptr = v` the instruction is always issued, so hipcc can
+// count it in vmcnt and the in-order wait for an older prefetch does not have to assume the worst (which drained the
+// younger prefetches too and tied every tick to a full store round trip).
+constexpr uint32_t kBufferFlags = 0x00020000;      // gfx9 raw buffer, 32-bit data format
+constexpr uint32_t kDropStore = 0xFFFFFFF0u;       // offset outside any buffer this file creates (< 4 GiB - 16)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, (int)kBufferFlags);
+}
+__device__ __forceinline__ void store_f64(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, double v)
+{
+    u32x2 bits;
+    __builtin_memcpy(&bits, &v, sizeof bits);
+    __builtin_amdgcn_raw_buffer_store_b64(bits, r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ void store_f64x2(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, double2 v)
+{
+    u32x4 bits;
+    __builtin_memcpy(&bits, &v, sizeof bits);
+    __builtin_amdgcn_raw_buffer_store_b128(bits, r, (int)byte_off, 0, 0);
+}
+
 // PPT positions per thread; HPT halo values per thread (halo <= HPT * 1024 positions); two ticks of HBM
 // prefetch in flight (stages A/B, the tick loop is unrolled by two so the stage registers are static).
 template <int TH, int PPT, int HPT, bool SINGLE_SUBSTEP, bool UNIT>
@@ -432,11 +457,11 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
     auto tick = [&](int32_t tau, const double (&lat)[PPT], const double (&h)[HPT]) {
         const double *rd = lds + (size_t)((tau + 1) & 1) * a.lh;   // values of tick tau-1
         double *wr = lds + (size_t)(tau & 1) * a.lh;
-        double *hrow = a.hist + (int64_t)hr_tick * a.n;
+        const __amdgpu_buffer_rsrc_t hist_row = make_rsrc(a.hist + (int64_t)hr_tick * a.n, (uint32_t)a.n * 8u);
         hr_tick = next_row(hr_tick);
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-            if (lg[k] < 0) continue;
+            // a slot past the end of the network has lag -1: no upstream range, never active, publishes 0.0 to nobody
             const int32_t p = position(k);
             double s_cur = 0.0, s_hw = 0.0;
             if (UNIT) {
@@ -475,9 +500,7 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
                                  __builtin_fma(c4[k], lat[k], c3[k] * q[k])));
                 q[k] = r;
                 if (lg[k] & kExportBit) a.exports[(int64_t)ts * a.n_export + slot[k]] = r;
-                if (SINGLE_SUBSTEP) {
-                    a.out[(int64_t)a.out_rows.mod((uint32_t)ts) * a.out_ld + p] = r > 0.0 ? r : 0.0;
-                } else {
+                if (!SINGLE_SUBSTEP) {
                     uint32_t sub;
                     const uint32_t t = a.nsub.div((uint32_t)ts, sub);
                     const double acc = (sub == 0 ? 0.0 : isum[k]) + r;
@@ -488,9 +511,17 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
                     isum[k] = acc;
                 }
             }
+            if (SINGLE_SUBSTEP && !UNIT) {
+                // the discharge row store is issued by every lane, every tick: lanes with nothing to write (pipeline
+                // fill and drain, ghosts, slots past the network) aim at the interval-sum array, unused with one
+                // sub-step.  An always-issued store is one hipcc can count in vmcnt (see store_f64).
+                const bool writes = active && !(lg[k] & kGhostBit);
+                double *dst = writes ? a.out + (int64_t)a.out_rows.mod((uint32_t)ts) * a.out_ld + p : a.si + min(p, a.n - 1);
+                *dst = q[k] > 0.0 ? q[k] : 0.0;
+            }
             s_prev[k] = s_cur;
             wr[nh + k * TH + tid] = q[k];
-            if (p >= halo_lo) hrow[p] = q[k];
+            store_f64(hist_row, p >= halo_lo ? (uint32_t)p * 8u : kDropStore, q[k]);     // positions >= n fall off the row
         }
         put_halo(wr, h);
     };
@@ -532,31 +563,6 @@ __global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
         if (!SINGLE_SUBSTEP) a.si[p] = isum[k];
         if (UNIT) a.sqch[p] = qch[k];
     }
-}
-
-// Predicated global stores without a branch: a raw buffer store whose byte offset is pushed past the end of the
-// buffer is dropped by the bounds check.  Unlike `if (cond) *ptr = v` the instruction is always issued, so hipcc can
-// count it in vmcnt and the in-order wait for an older prefetch does not have to assume the worst (which drained the
-// younger prefetches too and tied every tick to a full store round trip).
-constexpr uint32_t kBufferFlags = 0x00020000;      // gfx9 raw buffer, 32-bit data format
-constexpr uint32_t kDropStore = 0xFFFFFFF0u;       // offset outside any buffer this file creates (< 4 GiB - 16)
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes)
-{
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, (int)kBufferFlags);
-}
-__device__ __forceinline__ void store_f64(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, double v)
-{
-    u32x2 bits;
-    __builtin_memcpy(&bits, &v, sizeof bits);
-    __builtin_amdgcn_raw_buffer_store_b64(bits, r, (int)byte_off, 0, 0);
-}
-__device__ __forceinline__ void store_f64x2(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, double2 v)
-{
-    u32x4 bits;
-    __builtin_memcpy(&bits, &v, sizeof bits);
-    __builtin_amdgcn_raw_buffer_store_b128(bits, r, (int)byte_off, 0, 0);
 }
 
 __device__ __forceinline__ void load_f64x2(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, double &x, double &y)
