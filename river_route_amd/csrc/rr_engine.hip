@@ -594,12 +594,15 @@ constexpr int kStageStride = 10;   // doubles per position in the staging area: 
 // Lanes of one wave exchange data through its staging area without a workgroup barrier: a wave's LDS instructions
 // execute in order.  The compiler still has to be told that other lanes wrote (it would reuse earlier reads).
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-constexpr int kStageLanes = 32;    // positions transposed at a time (half a wave: keeps the area at 2.5 KiB per wave)
-// LDS in doubles: X[2][lh] | c1[BS] | c2[BS] | c3[BS] | stage[waves][kStageLanes * kStageStride].  The three
+// positions transposed at a time: half a wave (2.5 KiB of staging per wave).  (A 512-thread x 2-position shape with
+// quarter-wave staging fits two blocks per CU; measured at 500k reaches it is 20 % slower than one 1,024 x 2 block:
+// twice the halo traffic and barriers, and the load and tick phases of co-resident blocks do not overlap usefully.)
+constexpr int stage_lanes(int) { return 32; }
+// LDS in doubles: X[2][lh] | c1[BS] | c2[BS] | c3[BS] | stage[waves][stage_lanes * kStageStride].  The three
 // coefficients and the own discharge are read from LDS once per tick: the registers go to the records.
 constexpr size_t wave_rec_lds_bytes(int64_t lh, int threads, int ppt)
 {
-    return (size_t)(2 * lh + 3 * (int64_t)ppt * threads + (threads / 64) * kStageLanes * kStageStride) * sizeof(double);
+    return (size_t)(2 * lh + 3 * (int64_t)ppt * threads + (threads / 64) * stage_lanes(threads) * kStageStride) * sizeof(double);
 }
 
 template <int TH, int PPT, int HPT, bool UNIT>
@@ -608,6 +611,7 @@ __global__ __launch_bounds__(TH) void k_wave_rec(const WaveArgs a)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int BS = PPT * TH;
     constexpr int NS = 3;                  // history rows in flight (register stages)
+    constexpr int kStageLanes = stage_lanes(TH);
     const int tid = threadIdx.x;
     const int32_t b = a.b_first + (int32_t)blockIdx.x;
     const int64_t chunk = a.diag - b;
@@ -1437,8 +1441,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
     // the outlet-most reaches have passed them; the time-tiled schedule adds (blocks - 1) * K ticks of skew.
     const int64_t skew_ticks = dmax + (S.wave ? P->wave_nb * P->wave_K : 0);
     const int64_t lag_rows = (skew_ticks + nsub - 1) / nsub;
-    S.rec = S.wave && P->rec_enabled && nsub == 1 && P->wave_K == kRec && !S.direct && !host_io && n < (int64_t{1} << 25) &&
-            (P->wave_threads == 512 || P->wave_hpt == 2);    // the 1024-thread shape with a 4,096-wide halo would spill
+    S.rec = S.wave && P->rec_enabled && nsub == 1 && P->wave_K == kRec && !S.direct && !host_io && n < (int64_t{1} << 25);    // the 1024-thread shape with a 4,096-wide halo would spill
     if (S.rec) {
         // records are indexed by tick = row + lag: the live rows span (skew + depth) ticks
         // no wrap-around needed when every chunk the call can touch fits: batches * 4 + deepest lag + the look-ahead record
@@ -1448,6 +1451,12 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         if (P->dev_total_bytes > 0 && bytes > (int64_t)(P->dev_total_bytes / 2)) S.rec = false;
     }
     S.ring_rows = S.direct ? 0 : (S.rec ? S.rec_chunks * kRec : std::min<int64_t>(T, lag_rows + 2 * C + 2));
+    if (getenv("RR_VERBOSE"))
+        fprintf(stderr, "rr: n=%lld T=%lld nsub=%lld wave=%d rec=%d direct=%d threads=%d ppt=%d hpt=%d K=%lld blocks=%lld lh=%lld lds=%zu ring_rows=%lld\n",
+                (long long)n, (long long)T, (long long)nsub, (int)S.wave, (int)S.rec, (int)S.direct, P->wave_threads, P->wave_ppt,
+                P->wave_hpt, (long long)P->wave_K, (long long)P->wave_nb, (long long)P->wave_lh,
+                S.rec ? wave_rec_lds_bytes(P->wave_lh, P->wave_threads, P->wave_ppt) : (size_t)2 * P->wave_lh * sizeof(double),
+                (long long)S.ring_rows);
     if (S.ring_rows > 0xFFFFFFFFLL || T > 0x7FFFFFFFLL) { S.open = false; return fail(RR_E_INVALID, "route: too many time rows"); }
     int rc = RR_OK;
     if (!S.direct) rc = ensure_cap(&P->d_ring, &P->ring_cap, S.ring_rows * n);
@@ -2099,7 +2108,7 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         P->wave_jmax = jmax;
         const int small = threads == 1024 ? 2 : 4;     // halo registers per thread: 2,048 or 4,096 positions
         P->wave_hpt = halo_max <= (int64_t)small * threads ? small : 2 * small;
-        P->wave_lh = bs + (int64_t)P->wave_hpt * threads;
+        P->wave_lh = bs + std::max<int64_t>(64, (halo_max + 63) / 64 * 64);      // own positions + the widest halo
         if (halo_max > (int64_t)2 * small * threads) P->wave_enabled = false;   // a level wider than the LDS halo: stream with k_tick
         if (P->wave_K % 2) ++P->wave_K;
     }
@@ -2131,9 +2140,15 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
                                                 (int)(2 * P->wave_lh * sizeof(double)));
             if (ea != hipSuccess) P->wave_enabled = false;
         }
-        for (int v = 0; v < 2; ++v)
-            (void)hipFuncSetAttribute((const void *)wave_rec_kernel(P->wave_threads, P->wave_ppt, P->wave_hpt, v != 0),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)wave_rec_lds_bytes(P->wave_lh, P->wave_threads, P->wave_ppt));
+        // record mode needs its (larger) LDS image to fit the CU: 160 KB minus nothing else resident
+        const size_t rec_lds = wave_rec_lds_bytes(P->wave_lh, P->wave_threads, P->wave_ppt);
+        if (rec_lds > 160 * 1024) P->rec_enabled = false;
+        for (int v = 0; v < 2 && P->rec_enabled; ++v)
+            if (hipFuncSetAttribute((const void *)wave_rec_kernel(P->wave_threads, P->wave_ppt, P->wave_hpt, v != 0),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rec_lds) != hipSuccess) {
+                (void)hipGetLastError();
+                P->rec_enabled = false;
+            }
         const rr::HostPlan &H = P->h;
         const int64_t ni = (int64_t)H.inner_pos.size();
         rc = dev_alloc(&P->d_child_ptr, n + 1);
