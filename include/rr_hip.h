@@ -176,7 +176,9 @@ int rr_resample_cast_dev(int device, const double *discharge, int64_t num_rows, 
  * NaN -> 0 (unless RR_RUNOFF_KEEP_NAN: the host resamples irregular time steps before filling), and, when
  * area != NULL, times area[r] (volumes, the routers' as_volumes=True).  weights = proportion * unit conversion.
  * runoff element (t, p) is at runoff[t * stride_t + p * stride_p] (float when runoff_is_f32, else double): pass the
- * block point-major (stride_t = 1, stride_p = T) for contiguous gathers, or as read from the file (stride_p = 1).
+ * block point-major (stride_t = 1, stride_p >= T) for contiguous gathers -- with stride_p a multiple of 16 and the rows
+ * allocated in full (n_points * stride_p elements, 16-byte aligned) they are read as 16-byte vectors -- or as read
+ * from the file (stride_p = 1).
  * The non-uniform-time resampling of the reference (pandas, runoff.py:313-325) stays on the host.
  * rr_runoff_to_qlateral takes host arrays; the _dev form takes device arrays and only enqueues on `stream`. */
 #define RR_RUNOFF_CUMULATIVE 1

@@ -19,9 +19,10 @@ weights = rng.random(nnz)
 dev = torch.device('cuda:0')
 d_ip, d_ix, d_w = torch.from_numpy(indptr).to(dev), torch.from_numpy(indices).to(dev), torch.from_numpy(weights).to(dev)
 area = torch.rand(n, dtype=torch.float64, device=dev) * 1e7
-for layout in ('point-major', 'time-major'):
-    runoff = torch.rand((npts, T) if layout == 'point-major' else (T, npts), dtype=torch.float32, device=dev)
-    st, sp = (1, T) if layout == 'point-major' else (npts, 1)
+for layout in ('point-major padded', 'point-major', 'time-major'):
+    tp = -(-T // 16) * 16 if layout == 'point-major padded' else T
+    runoff = torch.rand((npts, tp) if layout != 'time-major' else (T, npts), dtype=torch.float32, device=dev)
+    st, sp = (1, tp) if layout != 'time-major' else (npts, 1)
     out = torch.empty((T, n), dtype=torch.float64, device=dev)
     s = torch.cuda.current_stream()
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]

@@ -1210,7 +1210,9 @@ __global__ __launch_bounds__(kBlock) void k_resample_cast(const double *__restri
 // with the runoff stored point-major (stride_t = 1) every gathered point is one contiguous run of the chunk's rows.
 constexpr int kRunoffRows = 16;
 
-template <typename RT>
+// VEC: the block is point-major with rows padded to a multiple of kRunoffRows elements (stride_t = 1,
+// stride_p % kRunoffRows == 0, 16-byte aligned base), so a chunk of one grid point is read as whole 16-byte vectors.
+template <typename RT, bool VEC>
 __global__ __launch_bounds__(kBlock) void k_runoff_to_qlateral(const int32_t *__restrict__ indptr, const int32_t *__restrict__ indices,
                                                                const double *__restrict__ weights, const RT *__restrict__ runoff,
                                                                int64_t stride_t, int64_t stride_p, const double *__restrict__ area,
@@ -1229,9 +1231,22 @@ __global__ __launch_bounds__(kBlock) void k_runoff_to_qlateral(const int32_t *__
     for (int32_t k = indptr[r]; k < indptr[r + 1]; ++k) {
         const double w = weights[k];
         const RT *src = runoff + (int64_t)indices[k] * stride_p + (t0 - 1) * stride_t;
+        if (VEC) {
+            constexpr int VL = 16 / (int)sizeof(RT);      // elements per 16-byte load
+            struct alignas(16) Vec { RT v[VL]; };
+            const Vec *vsrc = reinterpret_cast<const Vec *>(src + 1);
+            if (need_prev) acc[0] = __dadd_rn(acc[0], __dmul_rn(w, (double)src[0]));
 #pragma unroll
-        for (int j = 0; j <= kRunoffRows; ++j) {
-            if (j == 0 ? need_prev : j <= nt) acc[j] = __dadd_rn(acc[j], __dmul_rn(w, (double)src[(int64_t)j * stride_t]));
+            for (int q = 0; q < kRunoffRows / VL; ++q) {
+                const Vec x = vsrc[q];                    // rows past T lie in the row padding: read, never used
+#pragma unroll
+                for (int e = 0; e < VL; ++e) acc[1 + q * VL + e] = __dadd_rn(acc[1 + q * VL + e], __dmul_rn(w, (double)x.v[e]));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j <= kRunoffRows; ++j) {
+                if (j == 0 ? need_prev : j <= nt) acc[j] = __dadd_rn(acc[j], __dmul_rn(w, (double)src[(int64_t)j * stride_t]));
+            }
         }
     }
     const double a = area ? area[r] : 1.0;
@@ -2553,12 +2568,13 @@ int rr_runoff_to_qlateral_dev(int device, int64_t n_rivers, int64_t n_points, in
     const int64_t chunks = (T + kRunoffRows - 1) / kRunoffRows;
     if (chunks > 65535) return fail(RR_E_UNSUPPORTED, "rr_runoff_to_qlateral_dev: more than 1,048,560 time steps in one call");
     dim3 g((unsigned)((n_rivers + kBlock - 1) / kBlock), (unsigned)chunks);
-    if (runoff_is_f32)
-        hipLaunchKernelGGL(k_runoff_to_qlateral<float>, g, dim3(kBlock), 0, (hipStream_t)stream, indptr, indices, weights,
-                           (const float *)runoff, stride_t, stride_p, area, flags, qlateral, n_rivers, T);
-    else
-        hipLaunchKernelGGL(k_runoff_to_qlateral<double>, g, dim3(kBlock), 0, (hipStream_t)stream, indptr, indices, weights,
-                           (const double *)runoff, stride_t, stride_p, area, flags, qlateral, n_rivers, T);
+    const bool vec = stride_t == 1 && stride_p % kRunoffRows == 0 && ((uintptr_t)runoff & 15) == 0;
+#define RR_RUNOFF_LAUNCH(RT_, VEC_)                                                                                \
+    hipLaunchKernelGGL((k_runoff_to_qlateral<RT_, VEC_>), g, dim3(kBlock), 0, (hipStream_t)stream, indptr, indices, weights,  \
+                       (const RT_ *)runoff, stride_t, stride_p, area, flags, qlateral, n_rivers, T)
+    if (runoff_is_f32) { if (vec) RR_RUNOFF_LAUNCH(float, true); else RR_RUNOFF_LAUNCH(float, false); }
+    else { if (vec) RR_RUNOFF_LAUNCH(double, true); else RR_RUNOFF_LAUNCH(double, false); }
+#undef RR_RUNOFF_LAUNCH
     HIPCHK(hipGetLastError());
     return RR_OK;
 }
@@ -2575,7 +2591,9 @@ int rr_runoff_to_qlateral(int device, int64_t n_rivers, int64_t n_points, int64_
     // the runoff block spans max over (t, p) of t * stride_t + p * stride_p elements
     if (stride_t < 0 || stride_p < 0) return fail(RR_E_INVALID, "rr_runoff_to_qlateral: negative stride");
     const int64_t nnz = indptr[n_rivers];
-    const int64_t elems = (T - 1) * stride_t + (n_points > 0 ? (n_points - 1) * stride_p : 0) + 1;
+    // point-major blocks may pad their rows (stride_p > T): the whole padded image is copied
+    const int64_t elems = stride_t == 1 && stride_p >= T ? std::max<int64_t>(1, n_points) * stride_p
+                                                        : (T - 1) * stride_t + (n_points > 0 ? (n_points - 1) * stride_p : 0) + 1;
     const size_t esz = runoff_is_f32 ? sizeof(float) : sizeof(double);
     int32_t *d_indptr = nullptr, *d_indices = nullptr;
     double *d_w = nullptr, *d_area = nullptr, *d_out = nullptr;

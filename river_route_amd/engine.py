@@ -219,14 +219,16 @@ def runoff_to_qlateral(indptr, indices, weights, runoff_tp, area=None, flags: in
     n_rivers = indptr.shape[0] - 1
     if indices.shape[0] and (indices.min() < 0 or indices.max() >= n_points):
         raise ValueError('weight matrix refers to grid points outside the runoff block')
-    point_major = np.ascontiguousarray(runoff_tp.T)          # (n_points, T): stride_t = 1, stride_p = T
+    t_pad = -(-T // 16) * 16                                  # rows padded to whole 16-step chunks: vector gathers
+    point_major = np.zeros((n_points, t_pad), dtype=runoff_tp.dtype)
+    point_major[:, :T] = runoff_tp.T                          # (n_points, t_pad): stride_t = 1, stride_p = t_pad
     out = np.empty((T, n_rivers), dtype=np.float64)
     if area is not None:
         area = np.ascontiguousarray(area, dtype=np.float64)
         if area.shape != (n_rivers,):
             raise ValueError('area must have one value per river')
     check(_lib.lib().rr_runoff_to_qlateral(int(device), n_rivers, n_points, T, ptr(indptr), ptr(indices), ptr(weights),
-                                           ptr(point_major), int(point_major.dtype == np.float32), 1, T,
+                                           ptr(point_major), int(point_major.dtype == np.float32), 1, t_pad,
                                            ptr(area) if area is not None else None, int(flags), ptr(out)))
     return out
 
