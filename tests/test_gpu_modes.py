@@ -183,7 +183,8 @@ def _device_route(plan, q0, ql, T, nsub, out_rows=None):
 @pytest.mark.parametrize('env', [{'RR_WAVE': '1'}, {}, {'RR_WAVE': '1', 'RR_REC': '0'}, {'RR_WAVE': '0'},
                                  {'RR_WAVE': '1', 'RR_WAVE_THREADS': '512'}])
 @pytest.mark.parametrize('n,T,ql_rows', [(60000, 100, 100), (60000, 7, 7), (3000, 6000, 48), (60000, 5000, 96),
-                                        (300000, 70, 70)])     # > 256k reaches: the two-positions-per-thread shapes
+                                        (300000, 70, 70),      # > 256k reaches: the two-positions-per-thread shapes
+                                        (1000000, 80, 80)])    # BASELINE size: the bench's kernel shapes, full oracle comparison
 def test_device_resident_route_record_mode(monkeypatch, env, n, T, ql_rows):
     """Device arrays in params order (the bench path): record-mode ring + one-pass permutation (default), the
     row-mode tiled permutation (RR_REC=0) and the streaming kernel, incl. cyclic forcing and ring wrap-around."""
