@@ -4,6 +4,9 @@ ctypes front-end of the CPU oracle (oracle/rr_oracle.c).
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
 Nothing under river_route_amd/ may import this module.
 
+Parity: every function here is pinned to outputs of the reference itself (tests/golden/, tests/test_oracle.py) except
+`runoff_to_qlateral_core`, which is PARITY UNPINNED -- see its docstring.
+
 The function signatures mirror the reference call sites so a parity test reads like the reference:
 river_route/routers/_numba_kernels.py:9-14, 50-55, 89-99; uhkernels/UnitHydrograph.py:64-107;
 routers/Muskingum.py:172-193; tools.py:75-109.
