@@ -4,8 +4,8 @@ ctypes front-end of the CPU oracle (oracle/rr_oracle.c).
 TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
 Nothing under river_route_amd/ may import this module.
 
-Parity: every function here is pinned to outputs of the reference itself (tests/golden/, tests/test_oracle.py) except
-`runoff_to_qlateral_core`, which is PARITY UNPINNED -- see its docstring.
+Parity: every function here is pinned to outputs of the reference itself (tests/golden/*.npz; tests/test_oracle.py,
+tests/test_runoff.py).
 
 The function signatures mirror the reference call sites so a parity test reads like the reference:
 river_route/routers/_numba_kernels.py:9-14, 50-55, 89-99; uhkernels/UnitHydrograph.py:64-107;
@@ -172,9 +172,11 @@ def runoff_to_qlateral_core(weights, runoff_raw, catchment_area=None, cumulative
     (327-329), times catchment area for volumes (331-332).  `keep_nan` stops before the fill, where the reference's
     irregular-time-step branch resamples (313-325).
 
-    PARITY UNPINNED for this function: the reference's own tests of this path (tests/test_runoff.py:50-99) need the
-    downloaded ERA5 / VPU data set and xarray, neither of which is in the image, so there is no reference output to
-    pin it to; it is checked against an independent dense evaluation instead (tests/test_runoff.py)."""
+    Pinned to the reference: tests/golden/runoff.npz holds what river_route.runoff.runoff_to_qlateral itself returned
+    for five seeded cases (tests/golden/make_golden_runoff.py runs the reference function as written; xarray, absent
+    from the image, is replaced there by a file-access stand-in that does no arithmetic).  tests/test_runoff.py checks
+    this restatement -- through the host logic of river_route_amd.runoff -- against those outputs, and against an
+    independent dense evaluation."""
     q = np.array(np.asarray(weights @ np.asarray(runoff_raw).T).T, dtype=np.float64)      # (time, n_rivers)
     if cumulative:
         for i in range(q.shape[0] - 1, 0, -1):

@@ -1,10 +1,10 @@
 """Gridded runoff -> catchment inflow (river_route/runoff.py:218-352).
 
-CPU tests: the oracle restatement of the arithmetic against an independent dense evaluation, and the host logic of
-river_route_amd.runoff (weight-table bookkeeping, file handling, units, multi-file input, irregular time steps)
-with the device call replaced by that oracle.  The reference's own tests of this path (tests/test_runoff.py there)
-need a downloaded data set and xarray; this row is therefore "parity unpinned" (oracle/oracle.py).
-GPU tests (tests/test_gpu_runoff.py) compare the HIP kernel with the same oracle."""
+Pinned to the reference: tests/golden/runoff.npz holds the outputs of the reference's own runoff_to_qlateral for five
+seeded cases (tests/golden/make_golden_runoff.py); `test_against_reference_golden` reproduces them with the host
+logic of river_route_amd.runoff + the oracle's arithmetic (CPU) and + the HIP kernel (`-m gpu`).  The other CPU
+tests check the oracle against an independent dense evaluation and the host logic against a table-driven brute
+force.  tests/test_gpu_runoff.py compares the kernel alone with the oracle."""
 import os
 import sys
 
@@ -79,6 +79,27 @@ def write_nc3(path, dims, variables):
                 setattr(v, k, a)
 
 
+def write_grid_case(tmp_path, tab, grid, hours, units, files=1):
+    """Weight table + runoff grid(s) (dims time, lat, lon; NetCDF-3) from arrays -> (weights file, runoff files)."""
+    ny, nx = grid.shape[1:]
+    wfile = tmp_path / 'weights.nc'
+    write_nc3(wfile, {'index': len(tab)}, {
+        'river_id': (('index',), tab[:, 0].astype(np.int64), {}), 'x_index': (('index',), tab[:, 1].astype(np.int64), {}),
+        'y_index': (('index',), tab[:, 2].astype(np.int64), {}), 'proportion': (('index',), tab[:, 3], {}),
+        'area_sqm': (('index',), tab[:, 4], {})})
+    paths = []
+    per = len(hours) // files
+    for f in range(files):
+        sl = slice(f * per, (f + 1) * per if f < files - 1 else len(hours))
+        p = tmp_path / f'runoff_{f}.nc'
+        write_nc3(p, {'valid_time': len(hours[sl]), 'latitude': ny, 'longitude': nx}, {
+            'valid_time': (('valid_time',), hours[sl].astype(np.float64), {'units': 'hours since 2020-01-01 00:00:00'}),
+            'latitude': (('latitude',), np.linspace(50, 46, ny), {}), 'longitude': (('longitude',), np.linspace(5, 11, nx), {}),
+            'ro': (('valid_time', 'latitude', 'longitude'), grid[sl], {'units': units})})
+        paths.append(str(p))
+    return str(wfile), paths
+
+
 def make_grid_case(tmp_path, rng, n_rivers=30, nx=7, ny=5, T=10, units='mm', dtype=np.float32, cumulative=False,
                    files=1, hours=None):
     """Weight table with rivers in 'topological' (first-appearance) order, repeated cells and one duplicated entry;
@@ -94,27 +115,13 @@ def make_grid_case(tmp_path, rng, n_rivers=30, nx=7, ny=5, T=10, units='mm', dty
             rows.append((rid, c % nx, c // nx, p, float(rng.uniform(1e5, 1e7))))
     rows.append((rows[0][0], rows[0][1], rows[0][2], 0.125, 5e5))        # same river, same cell again
     tab = np.array(rows)
-    wfile = tmp_path / 'weights.nc'
-    write_nc3(wfile, {'index': len(rows)}, {
-        'river_id': (('index',), tab[:, 0].astype(np.int64), {}), 'x_index': (('index',), tab[:, 1].astype(np.int64), {}),
-        'y_index': (('index',), tab[:, 2].astype(np.int64), {}), 'proportion': (('index',), tab[:, 3], {}),
-        'area_sqm': (('index',), tab[:, 4], {})})
     hours = np.arange(T * files) if hours is None else np.asarray(hours)
     grid = (rng.random((len(hours), ny, nx)) * 3 - 0.3).astype(dtype)
     grid[2, 1, 2] = np.nan
     if cumulative:
         grid = np.cumsum(np.nan_to_num(grid), axis=0).astype(dtype)
-    paths = []
-    per = len(hours) // files
-    for f in range(files):
-        sl = slice(f * per, (f + 1) * per if f < files - 1 else len(hours))
-        p = tmp_path / f'runoff_{f}.nc'
-        write_nc3(p, {'valid_time': len(hours[sl]), 'latitude': ny, 'longitude': nx}, {
-            'valid_time': (('valid_time',), hours[sl].astype(np.float64), {'units': 'hours since 2020-01-01 00:00:00'}),
-            'latitude': (('latitude',), np.linspace(50, 46, ny), {}), 'longitude': (('longitude',), np.linspace(5, 11, nx), {}),
-            'ro': (('valid_time', 'latitude', 'longitude'), grid[sl], {'units': units})})
-        paths.append(str(p))
-    return str(wfile), paths, tab, grid, hours
+    wfile, paths = write_grid_case(tmp_path, tab, grid, hours, units, files)
+    return wfile, paths, tab, grid, hours
 
 
 def brute_force(tab, grid, conv, cumulative, clip, volumes):
@@ -191,6 +198,47 @@ def test_irregular_time_steps_are_resampled(tmp_path, oracle_device):
     raw = runoff_to_qlateral(paths[0], wfile, var_x='longitude', var_y='latitude', var_t='valid_time', as_volumes=True,
                              force_uniform_timesteps=False)
     assert raw['time'].values.shape[0] == 8
+
+
+# ---- pinned to the reference: tests/golden/runoff.npz holds what river_route.runoff.runoff_to_qlateral itself returned
+# for these cases (tests/golden/make_golden_runoff.py)
+GOLDEN_CASES = [   # tag, make_grid_case kwargs, runoff_to_qlateral kwargs
+    ('incr_mm_vol', dict(units='mm'), dict(as_volumes=True)),
+    ('cum_m_clip', dict(units='m', cumulative=True, dtype=np.float64), dict(cumulative=True, force_positive_runoff=True)),
+    ('three_files_kg', dict(units='kg m-2', files=3), dict(force_positive_runoff=True, as_volumes=True)),
+    ('irregular', dict(units='m', dtype=np.float64, hours=[0, 1, 2, 4, 5, 6, 9, 10]), dict(as_volumes=True)),
+    ('irregular_kept', dict(units='m', dtype=np.float64, hours=[0, 1, 2, 4, 5, 6, 9, 10]), dict(force_uniform_timesteps=False)),
+]
+
+
+@pytest.fixture(params=['oracle_device', pytest.param('hip', marks=pytest.mark.gpu)])
+def runoff_backend(request, monkeypatch):
+    """'oracle_device': host logic of river_route_amd.runoff + the oracle's arithmetic (pins both to the reference);
+    'hip': the same host logic + the HIP kernel."""
+    if request.param == 'oracle_device':
+        from river_route_amd import engine
+
+        def fake(indptr, indices, weights, runoff_tp, area=None, flags=0, device=0):
+            W = scipy.sparse.csr_matrix((weights, indices, indptr), shape=(len(indptr) - 1, runoff_tp.shape[1]))
+            return oracle.runoff_to_qlateral_core(W, runoff_tp, area, bool(flags & engine.RUNOFF_CUMULATIVE),
+                                                  bool(flags & engine.RUNOFF_FORCE_POSITIVE), bool(flags & engine.RUNOFF_KEEP_NAN))
+        monkeypatch.setattr(engine, 'runoff_to_qlateral', fake)
+    return request.param
+
+
+@pytest.mark.parametrize('case_id', range(len(GOLDEN_CASES)))
+def test_against_reference_golden(tmp_path, runoff_backend, case_id):
+    from river_route_amd.runoff import runoff_to_qlateral
+    tag, gk, rk = GOLDEN_CASES[case_id]
+    g = np.load(os.path.join(REPO, 'tests', 'golden', 'runoff.npz'))
+    wfile, paths = write_grid_case(tmp_path, g[f'{tag}/table'], g[f'{tag}/grid'], g[f'{tag}/hours'], gk['units'], gk.get('files', 1))
+    ds = runoff_to_qlateral(paths if len(paths) > 1 else paths[0], wfile, var_x='longitude', var_y='latitude',
+                            var_t='valid_time', **rk)
+    want = g[f'{tag}/qlateral']
+    np.testing.assert_array_equal(ds['river_id'].values, g[f'{tag}/river_id'])
+    np.testing.assert_array_equal(ds['time'].values.astype('datetime64[s]').astype(np.int64), g[f'{tag}/time'])
+    assert ds['qlateral'].attrs['units'] == str(g[f'{tag}/units'])
+    assert_close(ds['qlateral'].values, want, tag)
 
 
 # ---- the routers' grid_runoff_files branch (TransformMuskingum.py:38-51), both backends ----
