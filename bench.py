@@ -269,17 +269,18 @@ def main():
     # 88 B per reach-step at nsub=1), which a time-tiled kernel legitimately undercuts; `traffic` is what it
     # really moved (separate rocprofv3 --pmc passes, profiles/r01_pmc_traffic.json; default shape at 1M reaches).
     traffic = args.traffic_bytes_per_launch
+    traffic_per_reach_tick = None
     kernel_name = None
     if traffic is None and n == 1_000_000 and nsub == 1 and not plan.identity_order and \
             not any(k.startswith(('RR_WAVE', 'RR_REC')) for k in os.environ):
         try:
             with open(os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')) as f:
-                traffic = json.load(f)['kernels']['k_wave_rec']['hbm_bytes']
+                traffic_per_reach_tick = json.load(f)['kernels']['k_wave_rec']['hbm_bytes_per_reach_tick']
             kernel_name = 'k_wave_rec (time-tiled routing over tick-indexed records)'
         except (OSError, KeyError, ValueError):
-            traffic = None
+            traffic_per_reach_tick = None
     from river_route_amd.multi_gpu import roofline_from_profile
-    roofline = roofline_from_profile(prof, nsub, traffic, HBM_PEAK_GBS)
+    roofline = roofline_from_profile(prof, nsub, traffic, HBM_PEAK_GBS, traffic_per_reach_tick)
     if roofline and kernel_name:
         roofline['kernel'] = kernel_name
     line = {

@@ -1518,6 +1518,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         if (!P->d_hist || P->hist_cap < (int64_t)w.hist_rows * n) { S.open = false; return fail(RR_E_STATE, "time-tiled routing: history ring not initialised"); }
     }
     S.max_samples = P->sample_every >= kSampleGroup ? (size_t)std::min<int64_t>(4096, S.total_ticks / P->sample_every + 1) : 0;
+    if (S.wave && S.max_samples > 0) S.max_samples = (size_t)std::min<int64_t>(4096, S.n_diags / 8 + 1);     // every eighth launch
     while (P->ev.size() < 2 * S.max_samples) {
         hipEvent_t e;
         HIPCHK(hipEventCreate(&e));
@@ -1678,10 +1679,10 @@ int session_launch_diag(rr_plan *P, int64_t d)
     if (b_hi < b_lo) { ++P->prof_launches; return RR_OK; }
     WaveArgs &w = S.wa;
     w.diag = d; w.b_first = (int32_t)b_lo;
-    // a launch is sampled when every block takes part and every reach is active for all K ticks of its task
-    const int64_t dmax = P->h.depth - 1;
-    const bool full = b_lo == 0 && b_hi == nb - 1 && (d - (nb - 1)) * K >= dmax && (d + 1) * K <= S.total;
-    const bool sample = S.max_samples > 0 && full && (P->prof_launches % 8) == 0 && (size_t)P->prof_brackets < S.max_samples;
+    // every eighth launch is bracketed by HIP events, full or not (fill and drain launches run fewer blocks), so the
+    // sampled average is the average rocprofv3 reports for the kernel; the reach-ticks of a sample are those of the
+    // blocks it launched
+    const bool sample = S.max_samples > 0 && (P->prof_launches % 8) == 0 && (size_t)P->prof_brackets < S.max_samples;
     if (sample) HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets], S.stream));
     const dim3 g((unsigned)(b_hi - b_lo + 1));
     const size_t lds_bytes = S.rec ? wave_rec_lds_bytes(P->wave_lh, P->wave_threads, P->wave_ppt) : (size_t)2 * P->wave_lh * sizeof(double);
@@ -1691,7 +1692,7 @@ int session_launch_diag(rr_plan *P, int64_t d)
     hipLaunchKernelGGL(fn, g, t, lds_bytes, S.stream, w);
     if (sample) {
         HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));
-        P->ev_reaches.push_back(n * K);
+        P->ev_reaches.push_back((std::min<int64_t>(n, (b_hi + 1) * bs) - b_lo * bs) * K);
         P->prof_samples += K;
         ++P->prof_brackets;
     }

@@ -228,9 +228,12 @@ def run_in_process(engines, specs, T: int, nsub: int, chunk_rows: int) -> None:
             raise RuntimeError('run_in_process: parts are deadlocked (no message can be delivered)')
 
 
-def roofline_from_profile(prof: dict, nsub: int, traffic, peak_gbs: float = 8000.0):
+def roofline_from_profile(prof: dict, nsub: int, traffic, peak_gbs: float = 8000.0, traffic_per_reach_tick=None):
     """`roofline` object of bench.py from Plan.profile(): algorithmic bytes of SURVEY section 8(d) (72 B per reach
-    sub-step + 16 B per reach row) over the HIP-event time of the bracketed routing launches."""
+    sub-step + 16 B per reach row) over the HIP-event time of the bracketed routing launches.  Every eighth launch
+    is bracketed, fill and drain launches included, so `avg_launch_us` is the average rocprofv3 reports for the
+    kernel and the bytes are those of the average launch.  `traffic` = measured HBM bytes per launch, given directly
+    or as bytes per reach-tick (PMC passes over full launches) times the reach-ticks of the average launch."""
     if prof['sampled'] <= 0 or prof['sampled_ms'] <= 0:
         return None
     bytes_per_reach_tick = 72.0 + 16.0 / nsub
@@ -238,6 +241,8 @@ def roofline_from_profile(prof: dict, nsub: int, traffic, peak_gbs: float = 8000
     launches = prof['sampled'] / tpl
     avg_ms = prof['sampled_ms'] / launches
     reach_ticks = prof['sampled_reaches'] / launches
+    if traffic is None and traffic_per_reach_tick is not None:
+        traffic = round(traffic_per_reach_tick * reach_ticks)
     alg_bytes = bytes_per_reach_tick * reach_ticks
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
     return {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': peak_gbs, 'unit': 'GB/s',
