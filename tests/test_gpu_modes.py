@@ -180,6 +180,39 @@ def _device_route(plan, q0, ql, T, nsub, out_rows=None):
     return q, d
 
 
+def test_degenerate_network_shapes_record_mode(monkeypatch):
+    """The same extremes through the device-resident entry point with the time-tiled kernel forced (record mode): a
+    confluence of 3,000 tributaries (in-degree 3,000: the packed upstream range and a halo wider than a block), a
+    comb, a chain and unconnected reaches."""
+    monkeypatch.setenv('RR_WAVE', '1')
+    for k in ('RR_WAVE_K', 'RR_WAVE_PPT', 'RR_WAVE_THREADS', 'RR_REC'):
+        monkeypatch.delenv(k, raising=False)
+    m = 3000
+    fan = np.concatenate([np.full(m, m), m + 1 + np.arange(60)]).astype(np.int64)      # m tributaries -> reach m -> chain
+    fan[-1] = -1
+    mm = 1500
+    comb = np.concatenate([mm + np.arange(mm), mm + 1 + np.arange(mm)]).astype(np.int64)
+    comb[-1] = -1
+    chain = np.arange(1, 2501, dtype=np.int64)
+    chain[-1] = -1
+    lone = np.full(777, -1, dtype=np.int64)
+    for down, T in ((fan, 40), (comb, 33), (chain, 20), (lone, 17)):
+        n = down.shape[0]
+        indptr, indices = csc_from_down(down)
+        k_, x_ = 900.0 + 6300.0 * synth.u01(5, np.arange(n)), 0.05 + 0.4 * synth.u01(6, np.arange(n))
+        c1, c2, c3 = oracle.muskingum_coefficients(k_, x_, 900.0)
+        lhs, c4_dt = -c1[indices], (c1 + c2) / 900.0
+        ql = synth.synth_qlateral(n, 0, T)
+        q0 = 2.0 * synth.u01(7, np.arange(n))
+        q_ref, d_ref = q0.copy(), np.zeros((T, n))
+        oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql, d_ref, 1)
+        with Plan(indptr, indices) as plan:
+            plan.set_coeffs(lhs, c2, c3, c4_dt)
+            q, d = _device_route(plan, q0, ql, T, 1)
+        assert_close(q, q_ref, f'q_t n={n}')
+        assert_close(d, d_ref, f'discharge n={n}')
+
+
 @pytest.mark.parametrize('env', [{'RR_WAVE': '1'}, {}, {'RR_WAVE': '1', 'RR_REC': '0'}, {'RR_WAVE': '0'},
                                  {'RR_WAVE': '1', 'RR_WAVE_THREADS': '512'}])
 @pytest.mark.parametrize('n,T,ql_rows', [(60000, 100, 100), (60000, 7, 7), (3000, 6000, 48), (60000, 5000, 96),
