@@ -158,9 +158,11 @@ int rr_stream_advance(rr_plan *plan, int64_t lateral_rows_ready, int64_t ghost_s
 /* Closes the call (all T steps must have been routed) and writes the final state to q_t[n] (may be NULL). */
 int rr_stream_end(rr_plan *plan, double *q_t);
 
-/* Cuts a forest into at most n_parts connected parts minimising the largest part (so the part graph is a
- * forest too and boundary discharge flows one way).  part_of[n] receives the part of every reach, parts are
- * numbered upstream-first; part_sizes[n_parts] (may be NULL) their sizes.  Host-only, needs no GPU. */
+/* Cuts a forest into at most n_parts balanced parts whose part graph is acyclic (boundary discharge flows one way):
+ * main stems + the tributaries joining them farthest upstream in the last part, the other subtrees spread over the
+ * rest (part graph of depth two); chain-like networks fall back to a nested min-max cut.
+ * part_of[n] receives the part of every reach, parts are numbered upstream-first; part_sizes[n_parts] (may be NULL)
+ * their sizes.  Host-only, needs no GPU. */
 int rr_partition_forest(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indices, int32_t n_parts,
                         int32_t *part_of, int64_t *part_sizes);
 

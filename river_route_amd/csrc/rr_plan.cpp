@@ -1,6 +1,7 @@
 #include "rr_plan.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <limits>
 #include <utility>
 #include <vector>
@@ -112,11 +113,68 @@ int64_t pack_pieces(const Pieces &P, int64_t cap, std::vector<int32_t> &bin_of, 
 
 }  // namespace
 
+// "Trunk" partition: every maximal subtree of at most n / (4 parts) reaches is a piece, what remains (the reaches
+// with more than that upstream: the main stems) is the trunk.  Pieces go to the least-loaded part, largest first; the
+// trunk and the pieces that share its part form the last part.  Every cut edge then runs from a piece into the
+// trunk, so the part graph has depth two, and the cut reaches enter the last part near its outlets, where the lag
+// pipeline gives them the most slack: a downstream GPU starts almost together with its upstream ones (the nested
+// parts of the min-max cut below make chains four or five parts deep, each link costing its upstream part's whole
+// pipeline skew).  Returns false when the trunk is too large for that (chain-like networks).
+static bool partition_trunk(const std::vector<int32_t> &down, int32_t n_parts, int32_t *part_of, std::vector<int64_t> &sizes)
+{
+    const int64_t n = (int64_t)down.size();
+    if (n_parts < 2 || n < 64 * (int64_t)n_parts) return false;
+    std::vector<int64_t> sub(n, 1);
+    for (int64_t c = 0; c < n; ++c) if (down[c] >= 0) sub[down[c]] += sub[c];      // downstream reaches have larger indices
+    const int64_t s = std::max<int64_t>(1, n / (4 * (int64_t)n_parts));
+    std::vector<int32_t> root_of(n, -1);
+    std::vector<std::pair<int64_t, int32_t>> pieces;       // (size, root)
+    int64_t trunk = 0;
+    for (int64_t v = n - 1; v >= 0; --v) {
+        if (sub[v] > s) { ++trunk; continue; }
+        if (down[v] < 0 || sub[down[v]] > s) { root_of[v] = (int32_t)v; pieces.emplace_back(sub[v], (int32_t)v); }
+        else root_of[v] = root_of[down[v]];
+    }
+    const int64_t even = (n + n_parts - 1) / n_parts;
+    if (trunk > even / 2) return false;
+    // the pieces that join the trunk farthest from the outlets would be needed first by the trunk's part (smallest lag):
+    // they stay with the trunk, up to an even share; the rest is spread over the other parts, largest first
+    std::vector<int32_t> dist(n);
+    for (int64_t c = n - 1; c >= 0; --c) dist[c] = down[c] < 0 ? 0 : dist[down[c]] + 1;
+    std::sort(pieces.begin(), pieces.end(), [&](const auto &a, const auto &b) {
+        return dist[a.second] != dist[b.second] ? dist[a.second] > dist[b.second] : a.second < b.second; });
+    sizes.assign(n_parts, 0);
+    sizes[n_parts - 1] = trunk;
+    std::vector<int32_t> part_of_root(n, -1);
+    // tributaries too small to be worth a boundary series of their own stay with the trunk
+    const int64_t tiny = std::max<int64_t>(2, s / 1024);     // at 8M reaches / 8 parts: 550 boundary series instead of 11,800
+    for (const auto &pc : pieces)
+        if (pc.first < tiny) { sizes[n_parts - 1] += pc.first; part_of_root[pc.second] = n_parts - 1; }
+    std::vector<std::pair<int64_t, int32_t>> rest;
+    for (const auto &pc : pieces) {      // deepest junctions first
+        if (part_of_root[pc.second] >= 0) continue;
+        if (sizes[n_parts - 1] + pc.first <= even) { sizes[n_parts - 1] += pc.first; part_of_root[pc.second] = n_parts - 1; }
+        else rest.push_back(pc);
+    }
+    std::sort(rest.begin(), rest.end(), [](const auto &a, const auto &b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+    for (const auto &pc : rest) {
+        int32_t best = 0;
+        for (int32_t b = 1; b < n_parts - 1; ++b) if (sizes[b] < sizes[best]) best = b;
+        sizes[best] += pc.first;
+        part_of_root[pc.second] = best;
+    }
+    if (*std::max_element(sizes.begin(), sizes.end()) > even + even / 8) return false;
+    for (int64_t v = 0; v < n; ++v) part_of[v] = root_of[v] < 0 ? n_parts - 1 : part_of_root[root_of[v]];
+    return true;
+}
+
 void partition_forest(const std::vector<int32_t> &down, int32_t n_parts, int32_t *part_of, std::vector<int64_t> &sizes)
 {
     const int64_t n = (int64_t)down.size();
     sizes.clear();
     if (n == 0) return;
+    if (partition_trunk(down, n_parts, part_of, sizes)) return;
+    sizes.clear();
     std::vector<int32_t> up_ptr(n + 1, 0);
     for (int64_t c = 0; c < n; ++c) if (down[c] >= 0) ++up_ptr[down[c] + 1];
     for (int64_t i = 0; i < n; ++i) up_ptr[i + 1] += up_ptr[i];

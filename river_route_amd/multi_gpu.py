@@ -1,8 +1,9 @@
 """
 Graph-partitioned routing across the GPUs of one node (BASELINE config 5).
 
-The river network is cut into connected parts, one per GPU (`rr_partition_forest`: min-max greedy, parts
-numbered upstream-first, the part graph is a forest because discharge only flows downstream).  For every cut
+The river network is cut into balanced parts, one per GPU (`rr_partition_forest`: main stems and their farthest
+tributaries in the last part, the other subtrees spread over the rest; parts numbered upstream-first, the part
+graph is acyclic because discharge only flows downstream).  For every cut
 edge (u -> d) the part that owns `d` carries `u` as a GHOST reach whose discharge series is prescribed, and the
 part that owns `u` records `u`'s discharge after every routing sub-step in its export series
 (`rr_plan_set_boundary`).  The only data-path communication is that series, sent downstream in batches of
