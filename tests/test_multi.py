@@ -48,6 +48,24 @@ def test_partition_and_split_invariants(n, parts):
     assert np.all(seen == 1) and n_ghost == n_export == int((has & (part_of != part_of[np.maximum(net.down_index, 0)])).sum())
 
 
+def test_partition_shape_keeps_the_pipeline_shallow():
+    """The trunk partition: every cut edge enters the last part, parts are even; a chain, which
+    has no trunk to speak of, falls back to the nested min-max cut and still satisfies the invariants."""
+    net, indptr, indices, *_ = setup_case(200_000)
+    parts = 8
+    part_of, sizes = partition_forest(indptr, indices, parts)
+    has = net.down_index >= 0
+    cut = has & (part_of != part_of[np.maximum(net.down_index, 0)])
+    assert cut.sum() > 0 and np.all(part_of[net.down_index[cut]] == parts - 1)
+    assert sizes.max() <= 1.02 * 200_000 / parts and sizes.min() >= 0.9 * 200_000 / parts
+    n = 4000
+    chain_ptr = np.concatenate([np.arange(n), [n - 1]]).astype(np.int32)
+    chain_idx = np.arange(1, n, dtype=np.int32)
+    part_of, sizes = partition_forest(chain_ptr, chain_idx, 4)
+    assert sizes.sum() == n and sizes.max() <= 1.35 * n / 4
+    assert np.all(np.diff(part_of) >= 0)
+
+
 def single_domain(n, T):
     from oracle import oracle
     net, indptr, indices, c1, c2, c3, q0 = setup_case(n)
