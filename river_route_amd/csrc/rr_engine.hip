@@ -1463,7 +1463,9 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         const int64_t all_chunks = kRecBatch * ((T + 14) / (16 * kRecBatch) + 2) + (dmax >> 4) + 2;
         S.rec_chunks = std::min<int64_t>(all_chunks, (skew_ticks + dmax) / kRec + 32);
         const int64_t bytes = S.rec_chunks * kRec * n * (int64_t)sizeof(double);
-        if (P->dev_total_bytes > 0 && bytes > (int64_t)(P->dev_total_bytes / 2)) S.rec = false;
+        // up to five eighths of the card: a 1M-reach part of a partitioned 8M-reach network is deeper than a 1M-reach
+        // network of its own (the trunk part holds the main stems) and needs 152 GB of the 288
+        if (P->dev_total_bytes > 0 && bytes > (int64_t)(P->dev_total_bytes / 8 * 5)) S.rec = false;
     }
     S.ring_rows = S.direct ? 0 : (S.rec ? S.rec_chunks * kRec : std::min<int64_t>(T, lag_rows + 2 * C + 2));
     if (getenv("RR_VERBOSE"))
@@ -1475,6 +1477,12 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
     if (S.ring_rows > 0xFFFFFFFFLL || T > 0x7FFFFFFFLL) { S.open = false; return fail(RR_E_INVALID, "route: too many time rows"); }
     int rc = RR_OK;
     if (!S.direct) rc = ensure_cap(&P->d_ring, &P->ring_cap, S.ring_rows * n);
+    if (rc == RR_E_ALLOC && S.rec) {      // no room for the record ring after all: the (smaller) row ring
+        (void)hipGetLastError();
+        S.rec = false;
+        S.ring_rows = std::min<int64_t>(T, lag_rows + 2 * C + 2);
+        rc = ensure_cap(&P->d_ring, &P->ring_cap, S.ring_rows * n);
+    }
     if (!rc && !S.direct && !S.rec) rc = ensure_cap(&P->d_mrows, &P->mrows_cap, C * n);
     if (!rc && host_io) rc = ensure_cap(&P->d_stage, &P->stage_cap, C * n);
     if (rc) { S.open = false; return rc; }
@@ -2147,6 +2155,10 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
                 const int64_t budget_rows = (int64_t)(total_b / 3) / (n * (int64_t)sizeof(double));
                 int64_t k = (budget_rows - P->h.depth - 64) / std::max<int64_t>(1, P->wave_nb);
                 k = std::min<int64_t>(P->wave_K, k) & ~(int64_t)1;
+                // record mode needs K = 16 and a ring of (blocks * 16 + 2 depth) ticks; it may take five eighths of
+                // the card (session_begin), which a deep 1M-reach part of a partitioned network needs (152 GB)
+                const int64_t rec_bytes = (((int64_t)P->wave_nb * kRec + 2 * (int64_t)P->h.depth) / kRec + 32) * kRec * n * (int64_t)sizeof(double);
+                if (P->rec_enabled && P->wave_K == kRec && rec_bytes <= (int64_t)(total_b / 8 * 5)) k = kRec;
                 if (k < 4) P->wave_enabled = false; else P->wave_K = k;
             }
         }
