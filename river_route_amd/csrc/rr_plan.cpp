@@ -198,6 +198,177 @@ void partition_forest(const std::vector<int32_t> &down, int32_t n_parts, int32_t
     for (int64_t v = 0; v < n; ++v) part_of[v] = bin_of[P.root_of[v]];
 }
 
+
+void build_tile_plan(const std::vector<int32_t> &down, const std::vector<int32_t> &lag_of, int32_t block, TilePlan &T)
+{
+    T = TilePlan();
+    T.block = block;
+    const int64_t n = (int64_t)down.size();
+    T.tile_ptr.assign(1, 0);
+    T.level_start.assign(1, 0);
+    if (n == 0) { T.ok = true; return; }
+    std::vector<int32_t> up_ptr(n + 1, 0);
+    for (int64_t c = 0; c < n; ++c) if (down[c] >= 0) ++up_ptr[down[c] + 1];
+    for (int64_t i = 0; i < n; ++i) up_ptr[i + 1] += up_ptr[i];
+    std::vector<int32_t> up_idx(up_ptr[n]), fill(up_ptr.begin(), up_ptr.end() - 1);
+    for (int64_t c = 0; c < n; ++c) if (down[c] >= 0) up_idx[fill[down[c]]++] = (int32_t)c;
+    auto is_hw = [&](int32_t i) { return up_ptr[i + 1] == up_ptr[i]; };
+
+    std::vector<int64_t> sub(n, 1);
+    for (int64_t c = 0; c < n; ++c) if (down[c] >= 0) sub[down[c]] += sub[c];
+    auto big = [&](int64_t v) { return sub[v] > block; };
+    auto small_root = [&](int64_t v) { return !big(v) && (down[v] < 0 || big(down[v])); };
+
+    std::vector<int32_t> tile_of_reach(n, -1);
+    // ---- level 0: complete small subtrees, packed in order of their outlets' lag; a tile that the next subtree does not
+    // fit is topped up from the following kWindow subtrees (largest fit first) before it is closed
+    std::vector<int32_t> roots;
+    for (int64_t v = 0; v < n; ++v) if (small_root(v)) roots.push_back((int32_t)v);
+    std::stable_sort(roots.begin(), roots.end(), [&](int32_t a, int32_t b) { return lag_of[a] < lag_of[b]; });
+    int32_t n_tiles = 0;
+    {
+        constexpr size_t kWindow = 768;
+        std::vector<uint8_t> used(roots.size(), 0);
+        size_t head = 0;
+        while (head < roots.size()) {
+            if (used[head]) { ++head; continue; }
+            int64_t room = block;
+            for (size_t i = head; i < roots.size() && room > 0; ++i) {      // in order while they fit
+                if (used[i]) continue;
+                if (sub[roots[i]] > room) break;
+                used[i] = 1; tile_of_reach[roots[i]] = n_tiles; room -= sub[roots[i]];
+            }
+            while (room > 0) {                                              // top up: largest that still fits
+                int64_t best = -1, best_size = 0;
+                size_t seen = 0;
+                for (size_t i = head; i < roots.size() && seen < kWindow; ++i) {
+                    if (used[i]) continue;
+                    ++seen;
+                    if (sub[roots[i]] <= room && sub[roots[i]] > best_size) { best = (int64_t)i; best_size = sub[roots[i]]; }
+                }
+                if (best < 0) break;
+                used[best] = 1; tile_of_reach[roots[best]] = n_tiles; room -= best_size;
+            }
+            ++n_tiles;
+        }
+    }
+    const int32_t n_level0 = n_tiles;
+    std::vector<int32_t> tile_level((size_t)n_tiles, 0);
+
+    // ---- skeleton: weight = the reach + one ghost per small tributary; bottom-up cut into pieces of at most `block`
+    std::vector<int32_t> bigs;
+    for (int64_t v = 0; v < n; ++v) if (big(v)) bigs.push_back((int32_t)v);
+    std::vector<int64_t> res(n, 0);
+    std::vector<uint8_t> cut(n, 0);
+    std::vector<std::pair<int64_t, int32_t>> kids;
+    for (int32_t v : bigs) {
+        int64_t total = 1;
+        kids.clear();
+        for (int32_t e = up_ptr[v]; e < up_ptr[v + 1]; ++e) {
+            const int32_t c = up_idx[e];
+            if (big(c)) { kids.emplace_back(res[c], c); total += res[c]; } else ++total;
+        }
+        if (total > block) {
+            std::sort(kids.begin(), kids.end(), [](const auto &a, const auto &b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+            for (const auto &k : kids) {
+                if (total <= block) break;
+                cut[k.second] = 1;
+                total -= k.first - 1;      // the piece leaves, its ghost stays
+            }
+        }
+        if (total > block || up_ptr[v + 1] - up_ptr[v] > 65535) return;      // not tileable: T.ok stays false
+        res[v] = total;
+    }
+    std::vector<int32_t> piece_root(n, -1), piece_level(n, 0);
+    std::vector<int32_t> pieces;
+    for (auto it = bigs.rbegin(); it != bigs.rend(); ++it) {
+        const int32_t v = *it;
+        if (down[v] < 0 || cut[v]) { piece_root[v] = v; pieces.push_back(v); piece_level[v] = 1; }
+        else piece_root[v] = piece_root[down[v]];
+    }
+    for (int32_t v : bigs)      // upstream first: a cut reach is the outlet of its piece, whose level is final by now
+        if (cut[v]) { const int32_t r = piece_root[down[v]]; piece_level[r] = std::max(piece_level[r], piece_level[v] + 1); }
+    std::sort(pieces.begin(), pieces.end(), [&](int32_t a, int32_t b) {
+        if (piece_level[a] != piece_level[b]) return piece_level[a] < piece_level[b];
+        return lag_of[a] != lag_of[b] ? lag_of[a] < lag_of[b] : a < b; });
+    {
+        std::vector<int64_t> room;           // of the tiles of the current level
+        int32_t cur = -1, first_tile = n_tiles;
+        std::vector<int32_t> tile_of_piece(n, -1);
+        for (int32_t r : pieces) {
+            if (piece_level[r] != cur) { cur = piece_level[r]; first_tile = n_tiles; room.clear(); }
+            size_t b = 0;
+            for (; b < room.size(); ++b) if (room[b] >= res[r]) break;
+            if (b == room.size()) { room.push_back(block); tile_level.push_back(cur); ++n_tiles; }
+            room[b] -= res[r];
+            tile_of_piece[r] = first_tile + (int32_t)b;
+        }
+        for (int32_t v : bigs) tile_of_reach[v] = tile_of_piece[piece_root[v]];
+    }
+    for (int64_t v = n - 1; v >= 0; --v)      // small subtrees inherit the tile of their outlet
+        if (!big(v) && !small_root(v)) tile_of_reach[v] = tile_of_reach[down[v]];
+    (void)n_level0;
+
+    // ---- positions: breadth-first from each tile's outlets, upstream positions contiguous, headwater tributaries first
+    T.n_tiles = n_tiles;
+    T.tile_level = tile_level;
+    T.n_levels = tile_level.empty() ? 0 : tile_level.back() + 1;
+    T.level_start.assign((size_t)T.n_levels + 1, 0);
+    for (int32_t t = 0; t < n_tiles; ++t) ++T.level_start[tile_level[t] + 1];
+    for (int32_t l = 0; l < T.n_levels; ++l) T.level_start[l + 1] += T.level_start[l];
+    std::vector<int32_t> root_ptr((size_t)n_tiles + 1, 0);
+    auto tile_root = [&](int64_t v) { return down[v] < 0 || tile_of_reach[down[v]] != tile_of_reach[v]; };
+    for (int64_t v = 0; v < n; ++v) if (tile_root(v)) ++root_ptr[tile_of_reach[v] + 1];
+    for (int32_t t = 0; t < n_tiles; ++t) root_ptr[t + 1] += root_ptr[t];
+    std::vector<int32_t> root_list(root_ptr[n_tiles]), rfill(root_ptr.begin(), root_ptr.end() - 1);
+    for (int64_t v = n - 1; v >= 0; --v) if (tile_root(v)) root_list[rfill[tile_of_reach[v]]++] = (int32_t)v;    // outlet-most first
+
+    T.inv.assign(n, -1);
+    T.tile_ptr.assign((size_t)n_tiles + 1, 0);
+    T.tile_lag_lo.assign(n_tiles, 0); T.tile_lag_hi.assign(n_tiles, 0);
+    std::vector<int32_t> ghost_positions;
+    for (int32_t t = 0; t < n_tiles; ++t) {
+        const int64_t base = (int64_t)T.perm.size();
+        T.tile_ptr[t] = (int32_t)base;
+        for (int32_t k = root_ptr[t]; k < root_ptr[t + 1]; ++k) {
+            T.perm.push_back(root_list[k]); T.lag.push_back(lag_of[root_list[k]]);
+        }
+        for (int64_t head = base; head < (int64_t)T.perm.size(); ++head) {
+            const int32_t v = T.perm[head];
+            if (T.lag[head] & kTileGhost) { T.cfirst.push_back((int32_t)head); T.ccnt.push_back(0u); continue; }
+            T.inv[v] = (int32_t)head;
+            uint32_t cnt = 0, hw = 0;
+            T.cfirst.push_back((int32_t)T.perm.size());
+            for (int pass = 0; pass < 2; ++pass)
+                for (int32_t e = up_ptr[v]; e < up_ptr[v + 1]; ++e) {
+                    const int32_t c = up_idx[e];
+                    if (is_hw(c) != (pass == 0)) continue;
+                    const bool ghost = tile_of_reach[c] != t;
+                    T.perm.push_back(c);
+                    T.lag.push_back(lag_of[c] | (ghost ? kTileGhost : 0));
+                    if (ghost) ghost_positions.push_back((int32_t)T.perm.size() - 1);
+                    ++cnt; if (pass == 0) ++hw;
+                }
+            T.ccnt.push_back(cnt | (hw << 16));
+        }
+        int32_t lo = std::numeric_limits<int32_t>::max(), hi = 0;
+        for (int64_t p = base; p < (int64_t)T.perm.size(); ++p) { const int32_t l = T.lag[p] & (kTileExport - 1); lo = std::min(lo, l); hi = std::max(hi, l); }
+        T.tile_lag_lo[t] = lo; T.tile_lag_hi[t] = hi;
+        if ((int64_t)T.perm.size() - base > block) return;      // cannot happen by construction; refuse rather than overrun
+    }
+    T.np = (int64_t)T.perm.size();
+    T.tile_ptr[n_tiles] = (int32_t)T.np;
+    T.n_ghost = (int64_t)ghost_positions.size();
+    T.xpos.assign(T.np, -1);
+    T.tile_of.assign(T.np, 0);
+    for (int32_t t = 0; t < n_tiles; ++t) for (int32_t p = T.tile_ptr[t]; p < T.tile_ptr[t + 1]; ++p) T.tile_of[p] = t;
+    for (int32_t g : ghost_positions) {
+        const int32_t src = T.inv[T.perm[g]];
+        T.xpos[g] = src; T.xpos[src] = g; T.lag[src] |= kTileExport;
+    }
+    T.ok = true;
+}
+
 int build_host_plan(int64_t n, const int32_t *indptr, const int32_t *indices, HostPlan &P, std::string &err)
 {
     if (n < 0 || (n > 0 && (!indptr))) { err = "rr_plan_create: null csc_indptr or negative n"; return RR_E_INVALID; }
@@ -228,6 +399,7 @@ int build_host_plan(int64_t n, const int32_t *indptr, const int32_t *indices, Ho
         }
     }
     P.n_edges = indptr[n];
+    P.down = down;
 
     // ---- distance to outlet; downstream reaches have larger params indices, so walk backwards ----
     std::vector<int32_t> dist(n);

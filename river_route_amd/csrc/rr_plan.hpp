@@ -32,6 +32,7 @@ struct HostPlan {
     std::vector<int64_t> lag_start;  // [depth+1] first engine position with lag >= d
     std::vector<int32_t> edge_of;    // [n]   CSC entry index of the edge leaving params index i, -1 at outlets
     std::vector<int32_t> inner_pos;  // [n_inner] engine position of the k-th inner reach (ascending params order)
+    std::vector<int32_t> down;       // [n]   downstream params index, -1 at outlets
 };
 
 // Two-phase tiled permutation dst[q] = src[pi[q]].  A random 8-byte gather wastes 7/8
@@ -55,6 +56,47 @@ void build_tiled_permutation(const int32_t *pi, int64_t n, int32_t tile, TiledPe
 // piece between cuts is connected, and only pieces the same number of cuts away from their outlet share a part.
 // Parts are numbered upstream-first.  part_of[n], sizes[parts].
 void partition_forest(const std::vector<int32_t> &down, int32_t n_parts, int32_t *part_of, std::vector<int64_t> &sizes);
+
+
+// ---- subtree tiles: the layout of the time-tiled kernel ----
+//
+// The time-tiled kernel advances a TILE of at most `block` positions by K routing ticks per launch with everything
+// but the lateral/discharge records resident on chip.  A tile is a set of reaches closed under "upstream within the
+// tile": every upstream reach of a tile reach is either in the tile or is mirrored in it by a GHOST position whose
+// values the tile that owns the reach writes (one 8-byte store per tick into the ghost's record slot).  Tiles form a
+// DAG; a tile of level l runs chunk c in launch l + c, so the schedule's skew is (levels x K) ticks and no two tasks
+// of one launch depend on each other.
+//   * SMALL subtrees (at most `block` reaches, hanging off a reach with more than that upstream) are complete:
+//     they need no ghost, have level 0, and are bin-packed into tiles, neighbours in lag first (a tile is busy from
+//     its smallest to its largest lag, so tiles of similar lag waste the fewest ticks while the pipeline fills);
+//   * the remaining reaches (the SKELETON: ~1/sqrt(pi block) of a random network) are cut bottom-up into connected
+//     pieces of at most `block` positions, ghosts included; a piece's level is one more than the deepest piece or
+//     small subtree that feeds it, and pieces of one level share tiles.
+// Positions of a tile are in breadth-first order from the tile's outlets, so the upstream positions of a position
+// are contiguous: [cfirst[p], cfirst[p] + count), headwater tributaries first (UnitMuskingum needs them apart).
+constexpr int32_t kTileGhost = 1 << 28;    // lag[] flag: position mirrors a reach owned by another tile
+constexpr int32_t kTileExport = 1 << 27;   // lag[] flag: reach is mirrored by the ghost at position xpos[p]
+struct TilePlan {
+    bool ok = false;                 // false: a reach has more upstream reaches than a tile holds (use the streaming kernel)
+    int32_t block = 0;               // capacity of a tile in positions
+    int64_t np = 0;                  // positions = reaches + ghosts
+    int64_t n_ghost = 0;
+    int32_t n_tiles = 0, n_levels = 0;
+    std::vector<int32_t> tile_ptr;     // [n_tiles + 1] first position of each tile
+    std::vector<int32_t> tile_level;   // [n_tiles] non-decreasing
+    std::vector<int32_t> tile_lag_lo, tile_lag_hi;   // [n_tiles] smallest / largest lag of the tile's positions
+    std::vector<int32_t> level_start;  // [n_levels + 1] first tile of each level
+    std::vector<int32_t> perm;         // [np] params index of the reach at (or mirrored by) a position
+    std::vector<int32_t> inv;          // [n]  position of reach i
+    std::vector<int32_t> lag;          // [np] lag | kTileGhost | kTileExport
+    std::vector<int32_t> cfirst;       // [np] first upstream position
+    std::vector<uint32_t> ccnt;        // [np] upstream positions | headwater tributaries among them << 16
+    std::vector<int32_t> xpos;         // [np] kTileExport: position of the mirroring ghost; kTileGhost: position of the mirrored reach; else -1
+    std::vector<int32_t> tile_of;      // [np]
+};
+// down[i]: downstream reach or -1 (upstream reaches have smaller indices); lag_of[i]: levels between reach i and the
+// farthest headwater of the network.
+void build_tile_plan(const std::vector<int32_t> &down, const std::vector<int32_t> &lag_of, int32_t block, TilePlan &out);
 
 // Returns 0 or an RR_E_* code with a message in err.
 int build_host_plan(int64_t n, const int32_t *indptr, const int32_t *indices, HostPlan &plan, std::string &err);
