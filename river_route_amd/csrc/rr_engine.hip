@@ -43,7 +43,9 @@ constexpr int kSampleGroup = 16;   // routing-tick launches per HIP-event bracke
 // lag[] carries two flag bits for the boundary reaches of a partitioned network
 constexpr int32_t kGhostBit = 1 << 30;    // value prescribed from the ghost series (an upstream reach owned by another GPU)
 constexpr int32_t kExportBit = 1 << 29;   // value also copied to the export series (feeds another GPU)
-constexpr int32_t kLagMask = kExportBit - 1;
+constexpr int32_t kTileGhostBit = rr::kTileGhost;     // tile layout only: position mirrors a reach another tile owns
+constexpr int32_t kTileExportBit = rr::kTileExport;   // tile layout only: reach is mirrored by a ghost, values also go to the export ring
+constexpr int32_t kLagMask = kTileExportBit - 1;
 
 // ------------------------------------------------------------------------------------------------
 // kernels
@@ -309,55 +311,55 @@ __global__ __launch_bounds__(kBlock) void k_unit_state_out(double *q_ch, double 
     q_ch[k] = qch[p];
 }
 
-// ---- time-tiled routing: blocks of positions advance K ticks per launch ----
+// ---- time-tiled routing over subtree tiles ----
 //
-// k_tick streams ~88 B per reach-step because nothing survives from one tick to the next.  k_wave cuts the
-// engine order into blocks of BS = PPT * 1024 consecutive positions and lets one workgroup advance its block
-// by K ticks: coefficients and state sit in registers, the block's own discharges in LDS (double-buffered, one
-// barrier per tick), so HBM sees only the lateral read and the discharge write of every reach-step, plus
-//   * the block's state and coefficients once per K ticks, and
-//   * the "halo": upstream reaches of a block's first level live in the block(s) to its LEFT (upstream reaches
-//     always have smaller positions), so every block writes the values of its last level to a small history
-//     ring hist[tick % hist_rows][p] and its right neighbour reads them one tick later.
-// Task (block b, tick-chunk c) needs (b-1, c) (halo) and (b, c-1) (own state): all tasks on one anti-diagonal
-// b + c are independent, so there is ONE LAUNCH PER DIAGONAL and still no inter-workgroup synchronisation.
+// k_tick streams ~88 B per reach-step because nothing survives from one tick to the next.  k_tile lets one workgroup
+// advance one TILE (rr_plan.hpp: at most TH * PPT positions, closed under "upstream", ghosts mirroring the reaches other
+// tiles own) by K = 16 * KC routing ticks: coefficients and the tile's discharges of the previous tick sit in LDS
+// (double-buffered, one LDS-only barrier per tick), so HBM sees only the lateral read and the discharge write of every
+// reach-step plus the tile's state and coefficients once per task.  Task (tile, macro-chunk m) needs (tile, m - 1) and
+// the tiles its ghosts mirror at the same macro-chunk, all of which have a lower level: launch d runs the tasks
+// (tile, d - level(tile)) and nothing inside a launch depends on anything else inside it.
+//
+// Lateral inflow and discharge travel as RECORDS indexed by tick (kRec = 16 ticks, 128 bytes):
+//     rec[(tick / 16) % chunks][position][tick % 16]
+// holding c4dt * lateral on the way in and the clamped discharge on the way out, in place (k_rec_in / k_rec_out move
+// whole records to and from params order).  What a GHOST republishes comes from the export ring
+//     xrec[(tick / 16) % x_chunks][export slot][tick % 16]
+// into which the tile that owns the mirrored reach stores its (unclamped) discharge, 8 bytes per tick.
 
-struct WaveArgs {
-    const int32_t *child_ptr, *lag;
-    const double *c1row, *c2, *c3, *c4;   // c1row: the (uniform) weight of a reach's upstream terms
-    double *sq, *ss, *si;                 // carried state: discharge, sum of upstream discharges one tick back, interval sum
-    double *sqch;                         // UnitMuskingum: channel-only discharge of inner reaches
-    const uint16_t *hw_children;          // UnitMuskingum: headwater tributaries come first in a reach's upstream range
-    double *hist;                         // [hist_rows, n]
-    const int32_t *bidx;                  // ghost / export slots (flag bits live in lag[])
+struct TileArgs {
+    const int32_t *tile_ptr, *tile_level, *tile_lag_lo, *tile_lag_hi;
+    const int32_t *lag, *cfirst, *xpos, *xdelta;
+    const uint32_t *ccnt;
+    const double *c1row, *c2, *c3;        // c1row: the (uniform) weight of a reach's upstream terms
+    double *sq, *ss, *si, *sqch;          // carried state: discharge, sum of upstream discharges one tick back, interval sum, channel discharge
+    const int32_t *bidx;                  // slot of an external ghost / export in its boundary series (multi-GPU)
     const double *ghost;
     double *exports;
     int32_t n_ghost, n_export;
-    const double *in;
-    double *out;
-    int64_t in_ld, out_ld;
-    Div32 in_rows, out_rows;
-    double *rec;                          // record ring [rec_chunks][n][16] (record mode)
+    double *rec;                          // record ring [rec_chunks][np][16]
     Div32 rec_chunks;
+    double *xrec;                         // export ring [x_chunks][nx][16]
+    Div32 x_chunks;
+    int32_t nx;
 #ifdef RR_WAVE_TRACE
-    long long *trace; int64_t trace_diag;   // development build: per-block timestamps of one diagonal (profiles/microbench/wave_dbg.py)
+    long long *trace; int32_t trace_diag;   // development build: per-block timestamps of one launch (profiles/microbench/wave_dbg.py)
 #endif
-    int32_t n, hist_rows, K, b_first, lh;   // lh: LDS positions per tick buffer (halo capacity + block)
-    int64_t diag, total;
+    int32_t np, t_first, KC, diag, n_macro, total, has_lat;
     Div32 nsub;
     double inv_nsub;
 };
 
-// LDS-only workgroup barrier: waits for this wave's LDS traffic, not for its global loads/stores, so the
-// lateral/halo prefetches stay in flight across ticks (__syncthreads() would drain vmcnt every tick).
+// LDS-only workgroup barrier: waits for this wave's LDS traffic, not for its global loads/stores, so record
+// prefetches stay in flight across ticks (__syncthreads() would drain vmcnt every tick).
 __device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Predicated global stores without a branch: a raw buffer store whose byte offset is pushed past the end of the
-// buffer is dropped by the bounds check.  Unlike `if (cond) *ptr = v` the instruction is always issued, so hipcc can
-// count it in vmcnt and the in-order wait for an older prefetch does not have to assume the worst (which drained the
-// younger prefetches too and tied every tick to a full store round trip).
+// Predicated global accesses without a branch: a raw buffer access whose byte offset is pushed past the end of the
+// buffer is dropped by the bounds check (loads return zero).  Unlike `if (cond) *ptr = v` the instruction is always
+// issued, so hipcc can count it in vmcnt and an in-order wait for an older prefetch does not have to assume the worst.
 constexpr uint32_t kBufferFlags = 0x00020000;      // gfx9 raw buffer, 32-bit data format
-constexpr uint32_t kDropStore = 0xFFFFFFF0u;       // offset outside any buffer this file creates (< 4 GiB - 16)
+constexpr uint32_t kDropAccess = 0xFFFFFFF0u;      // offset outside any buffer this file creates (< 4 GiB - 16)
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes)
@@ -376,195 +378,6 @@ __device__ __forceinline__ void store_f64x2(__amdgpu_buffer_rsrc_t r, uint32_t b
     __builtin_memcpy(&bits, &v, sizeof bits);
     __builtin_amdgcn_raw_buffer_store_b128(bits, r, (int)byte_off, 0, 0);
 }
-
-// PPT positions per thread; HPT halo values per thread (halo <= HPT * 1024 positions); two ticks of HBM
-// prefetch in flight (stages A/B, the tick loop is unrolled by two so the stage registers are static).
-template <int TH, int PPT, int HPT, bool SINGLE_SUBSTEP, bool UNIT>
-__global__ __launch_bounds__(TH) void k_wave(const WaveArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) double lds[];   // [2][lh]: positions [h0, b1) of one tick
-    constexpr int BS = PPT * TH;
-    const int tid = threadIdx.x;
-    const int32_t b = a.b_first + (int32_t)blockIdx.x;
-    const int64_t chunk = a.diag - b;
-    const int32_t b0 = b * BS, b1 = min(a.n, b0 + BS);
-    const int32_t h0 = min(a.child_ptr[b0], b0);          // first halo position (upstream reaches left of the block)
-    const int32_t nh = b0 - h0;
-    const int32_t halo_lo = max(b0, a.child_ptr[b1]);     // own positions read by blocks to the right
-    auto position = [&](int k) { return b0 + k * TH + tid; };
-    // lg keeps the ghost / export flag bits of lag[]; slot is the column of a flagged reach in its boundary series
-    // UNIT (UnitMuskingum, _numba_kernels.py:113-171): q is what a reach publishes (q_full, or the lateral itself for a
-    // headwater), qch the channel-only discharge; uh splits the upstream range into headwater and inner tributaries.
-    int32_t lg[PPT], u0[PPT], u1[PPT], slot[PPT], uh[UNIT ? PPT : 1];
-    double c1[PPT], c2[PPT], c3[PPT], c4[PPT], q[PPT], s_prev[PPT], isum[SINGLE_SUBSTEP ? 1 : PPT], qch[UNIT ? PPT : 1];
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        const int32_t p = position(k);
-        slot[k] = 0;
-        if (UNIT) { uh[k] = 0; qch[k] = 0.0; }
-        if (p < b1) {
-            lg[k] = a.lag[p]; u0[k] = a.child_ptr[p] - h0; u1[k] = a.child_ptr[p + 1] - h0;
-            if (UNIT) { uh[k] = u0[k] + (int32_t)a.hw_children[p]; qch[k] = a.sqch[p]; }
-            if (lg[k] & (kGhostBit | kExportBit)) slot[k] = a.bidx[p];
-            c1[k] = a.c1row[p]; c2[k] = a.c2[p]; c3[k] = a.c3[p]; c4[k] = a.in ? a.c4[p] : 0.0;
-            q[k] = a.sq[p]; s_prev[k] = a.ss[p];
-            if (!SINGLE_SUBSTEP) isum[k] = a.si[p];
-        } else {
-            lg[k] = -1; u0[k] = u1[k] = 0; c1[k] = c2[k] = c3[k] = c4[k] = q[k] = s_prev[k] = 0.0;   // lg < 0: not a reach
-            if (!SINGLE_SUBSTEP) isum[k] = 0.0;
-        }
-    }
-    const int32_t tau0 = (int32_t)chunk * a.K, tau_end = tau0 + a.K, total = (int32_t)a.total;
-
-    // Prefetches are branch-free (addresses are clamped to something valid, the value is ignored where it does
-    // not apply) and nothing touches the loaded registers until the tick that consumes them, so hipcc leaves the
-    // loads in flight across the barriers instead of waiting right behind each one.
-    const double *lat_base = a.in ? a.in : a.sq;     // channel-only routing: any readable array, c4 is zero
-    const Div32 lat_rows = a.in ? a.in_rows : Div32(1u);
-    const int64_t lat_ld = a.in ? a.in_ld : 0;
-    auto fetch_lat = [&](int32_t tau, double (&lat)[PPT]) {     // lateral of the row each reach is at
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            int32_t ts = tau - (lg[k] < 0 ? 0 : (lg[k] & kLagMask));
-            ts = ts < 0 ? 0 : (ts >= total ? total - 1 : ts);
-            uint32_t sub;
-            const uint32_t t = SINGLE_SUBSTEP ? (uint32_t)ts : a.nsub.div((uint32_t)ts, sub);
-            const double *src = lat_base + (int64_t)lat_rows.mod(t) * lat_ld + min(position(k), b1 - 1);
-            if (lg[k] >= 0 && (lg[k] & kGhostBit)) src = a.ghost + (int64_t)ts * a.n_ghost + slot[k];   // prescribed boundary inflow
-            lat[k] = *src;
-        }
-    };
-    // the history ring is walked one row per tick: rows of the next halo fetch and of the next tick's own writes
-    const uint32_t hrows = (uint32_t)a.hist_rows;
-    auto next_row = [&](uint32_t r) { return r + 1 == hrows ? 0u : r + 1; };
-    uint32_t hr_fetch = Div32(hrows).mod((uint32_t)tau0 + hrows - 1), hr_tick = next_row(hr_fetch);
-    auto fetch_halo = [&](double (&h)[HPT]) {      // the left neighbours' values of the next tick in sequence
-        const double *hrow = a.hist + (int64_t)hr_fetch * a.n + h0;
-        hr_fetch = next_row(hr_fetch);
-#pragma unroll
-        for (int j = 0; j < HPT; ++j) {
-            const int32_t i = j * TH + tid;
-            h[j] = hrow[i < nh ? i : 0];
-        }
-    };
-    auto put_halo = [&](double *buf, const double (&h)[HPT]) {
-#pragma unroll
-        for (int j = 0; j < HPT; ++j) {
-            const int32_t i = j * TH + tid;
-            if (i < nh) buf[i] = h[j];
-        }
-    };
-    auto tick = [&](int32_t tau, const double (&lat)[PPT], const double (&h)[HPT]) {
-        const double *rd = lds + (size_t)((tau + 1) & 1) * a.lh;   // values of tick tau-1
-        double *wr = lds + (size_t)(tau & 1) * a.lh;
-        const __amdgpu_buffer_rsrc_t hist_row = make_rsrc(a.hist + (int64_t)hr_tick * a.n, (uint32_t)a.n * 8u);
-        hr_tick = next_row(hr_tick);
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            // a slot past the end of the network has lag -1: no upstream range, never active, publishes 0.0 to nobody
-            const int32_t p = position(k);
-            double s_cur = 0.0, s_hw = 0.0;
-            if (UNIT) {
-                for (int32_t u = u0[k]; u < uh[k]; ++u) s_hw += rd[u];       // headwater tributaries: "old" value is l_t too
-                for (int32_t u = uh[k]; u < u1[k]; ++u) s_cur += rd[u];
-            } else {
-                for (int32_t u = u0[k]; u < u1[k]; ++u) s_cur += rd[u];
-            }
-            const int32_t ts = tau - (lg[k] & kLagMask);
-            const bool active = ts >= 0 && ts < total;
-            if (UNIT && active) {
-                uint32_t sub = 0u;
-                const uint32_t t = SINGLE_SUBSTEP ? (uint32_t)ts : a.nsub.div((uint32_t)ts, sub);
-                double *orow = a.out + (int64_t)a.out_rows.mod(t) * a.out_ld;
-                if (u0[k] == u1[k]) {   // headwater: discharge is the lateral inflow, unclamped and un-averaged
-                    q[k] = lat[k];
-                    if (sub == 0) orow[p] = lat[k];
-                } else {
-                    const double r = __builtin_fma(c1[k], s_hw + s_cur, __builtin_fma(c2[k], s_hw + s_prev[k], c3[k] * qch[k]));
-                    qch[k] = r;
-                    const double qfull = r + lat[k];
-                    q[k] = qfull;
-                    if (SINGLE_SUBSTEP) {
-                        orow[p] = qfull > 0.0 ? qfull : 0.0;
-                    } else {
-                        const double acc = (sub == 0 ? 0.0 : isum[k]) + qfull;
-                        if (sub + 1 == a.nsub.d) { const double v = acc * a.inv_nsub; orow[p] = v > 0.0 ? v : 0.0; }
-                        isum[k] = acc;
-                    }
-                }
-            } else if (active && (lg[k] & kGhostBit)) {
-                q[k] = lat[k];      // a ghost only republishes what its owner computed
-            } else if (active) {
-                // explicit fma: the unrolled copies of this tick must round identically (split run == joint run)
-                const double r = __builtin_fma(c1[k], s_cur, __builtin_fma(c2[k], s_prev[k],
-                                 __builtin_fma(c4[k], lat[k], c3[k] * q[k])));
-                q[k] = r;
-                if (lg[k] & kExportBit) a.exports[(int64_t)ts * a.n_export + slot[k]] = r;
-                if (!SINGLE_SUBSTEP) {
-                    uint32_t sub;
-                    const uint32_t t = a.nsub.div((uint32_t)ts, sub);
-                    const double acc = (sub == 0 ? 0.0 : isum[k]) + r;
-                    if (sub + 1 == a.nsub.d) {
-                        const double v = acc * a.inv_nsub;
-                        a.out[(int64_t)a.out_rows.mod(t) * a.out_ld + p] = v > 0.0 ? v : 0.0;
-                    }
-                    isum[k] = acc;
-                }
-            }
-            if (SINGLE_SUBSTEP && !UNIT) {
-                // the discharge row store is issued by every lane, every tick: lanes with nothing to write (pipeline
-                // fill and drain, ghosts, slots past the network) aim at the interval-sum array, unused with one
-                // sub-step.  An always-issued store is one hipcc can count in vmcnt (see store_f64).
-                const bool writes = active && !(lg[k] & kGhostBit);
-                double *dst = writes ? a.out + (int64_t)a.out_rows.mod((uint32_t)ts) * a.out_ld + p : a.si + min(p, a.n - 1);
-                *dst = q[k] > 0.0 ? q[k] : 0.0;
-            }
-            s_prev[k] = s_cur;
-            wr[nh + k * TH + tid] = q[k];
-            store_f64(hist_row, p >= halo_lo ? (uint32_t)p * 8u : kDropStore, q[k]);     // positions >= n fall off the row
-        }
-        put_halo(wr, h);
-    };
-
-    // Three register stages, each fetched two ticks before it is consumed and BEFORE the tick in between issues
-    // its stores: vmcnt retires in order, so a wait for stage s only has to cover ops older than the two younger
-    // fetches and never the stores of the tick just finished.
-    double lat0[PPT], lat1[PPT], lat2[PPT], h0v[HPT], h1v[HPT], h2v[HPT];
-    {   // tick tau0 reads the buffer of tick tau0 - 1: own discharges + the halo row of that tick
-        double *buf = lds + (size_t)((tau0 + 1) & 1) * a.lh;
-        fetch_halo(h0v);                                      // tick tau0 - 1
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) buf[nh + k * TH + tid] = q[k];
-        put_halo(buf, h0v);
-    }
-    fetch_lat(tau0, lat0); fetch_halo(h0v);
-    fetch_lat(tau0 + 1, lat1); fetch_halo(h1v);               // rows past the chunk are clamped, never used
-    barrier_lds();
-    for (int32_t tau = tau0; tau < tau_end; tau += 3) {
-        fetch_lat(tau + 2, lat2); fetch_halo(h2v);
-        tick(tau, lat0, h0v);
-        barrier_lds();
-        if (tau + 1 < tau_end) {
-            fetch_lat(tau + 3, lat0); fetch_halo(h0v);
-            tick(tau + 1, lat1, h1v);
-        }
-        barrier_lds();
-        if (tau + 2 < tau_end) {
-            fetch_lat(tau + 4, lat1); fetch_halo(h1v);
-            tick(tau + 2, lat2, h2v);
-        }
-        barrier_lds();
-    }
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        if (lg[k] < 0) continue;
-        const int32_t p = position(k);
-        a.sq[p] = q[k]; a.ss[p] = s_prev[k];
-        if (!SINGLE_SUBSTEP) a.si[p] = isum[k];
-        if (UNIT) a.sqch[p] = qch[k];
-    }
-}
-
 __device__ __forceinline__ void load_f64x2(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, double &x, double &y)
 {
     const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);   // one 16-byte request per lane
@@ -578,295 +391,326 @@ __device__ __forceinline__ void load_f64x2(__amdgpu_buffer_rsrc_t r, uint32_t by
 // back as an opaque value: the two-instruction unpacking is redone each tick and the registers stay free.
 __device__ __forceinline__ int32_t fresh(int32_t v) { asm volatile("" : "+v"(v)); return v; }
 
-// ---- record mode ----
-// With one sub-step per row, a task (block, chunk of kRec = 16 ticks) consumes for every position exactly the 16
-// consecutive rows t = tick - lag.  The work ring is therefore kept as RECORDS indexed by tick:
-//     rec[(tick / 16) % chunks][position][tick % 16]        (128 bytes per position and chunk)
-// A task reads its block's records as one contiguous 128 B * BS stream into registers, routes 16 ticks with the
-// lateral values (already scaled by c4dt) taken from and the discharges written back to those registers, and
-// stores the records in place.  The permutation to and from params order becomes ONE pass each way that moves
-// whole 128-byte records (k_rec_in / k_rec_out) instead of two tiled passes over rows.
 constexpr int kRec = 16;
-// Record stores go through a per-wave LDS transpose: a lane owns a position (its record lives in registers), but a
-// store instruction in which every lane writes 16 bytes of a different record costs L2 one request per lane.  After
-// the transpose four neighbouring lanes write the 64 contiguous bytes of one half record: a quarter of the requests.
+// Records move between HBM and their owning lanes through a per-wave LDS transpose: a lane owns a position (its record
+// lives in registers), but a memory instruction in which every lane touches 16 bytes of a different record costs L2 one
+// request per lane.  Through the transpose four neighbouring lanes load or store the 64 contiguous bytes of one half
+// record: a quarter of the requests.
 constexpr int kStageStride = 10;   // doubles per position in the staging area: 64 bytes + 16 of padding (bank spread, skip flag)
+constexpr int kStageLanes = 32;    // positions transposed at a time: half a wave (2.5 KiB of staging per wave)
 // Lanes of one wave exchange data through its staging area without a workgroup barrier: a wave's LDS instructions
 // execute in order.  The compiler still has to be told that other lanes wrote (it would reuse earlier reads).
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-// positions transposed at a time: half a wave (2.5 KiB of staging per wave).  (A 512-thread x 2-position shape with
-// quarter-wave staging fits two blocks per CU; measured at 500k reaches it is 20 % slower than one 1,024 x 2 block:
-// twice the halo traffic and barriers, and the load and tick phases of co-resident blocks do not overlap usefully.)
-constexpr int stage_lanes(int) { return 32; }
-// LDS in doubles: X[2][lh] | c1[BS] | c2[BS] | c3[BS] | stage[waves][stage_lanes * kStageStride].  The three
+// LDS in doubles: X[2][BS] | c1[BS] | c2[BS] | c3[BS] | stage[waves][kStageLanes * kStageStride].  The three
 // coefficients and the own discharge are read from LDS once per tick: the registers go to the records.
-constexpr size_t wave_rec_lds_bytes(int64_t lh, int threads, int ppt)
+constexpr size_t tile_lds_bytes(int threads, int ppt)
 {
-    return (size_t)(2 * lh + 3 * (int64_t)ppt * threads + (threads / 64) * stage_lanes(threads) * kStageStride) * sizeof(double);
+    return (size_t)(5 * (int64_t)ppt * threads + (threads / 64) * kStageLanes * kStageStride) * sizeof(double);
 }
 
-template <int TH, int PPT, int HPT, bool UNIT>
-__global__ __launch_bounds__(TH) void k_wave_rec(const WaveArgs a)
+// One task: KC record chunks of one tile.  The 16 record slots of a position are registers, used in place (lateral in,
+// discharge out) and in two halves of 8 ticks: as soon as a half has been stored its registers receive the same half
+// of the NEXT chunk, which is in flight during the following 8 ticks, so inside a task HBM and the tick arithmetic
+// overlap and only the first chunk's load is exposed.
+template <int TH, int PPT, bool UNIT, bool SUB>
+__global__ __launch_bounds__(TH) void k_tile(const TileArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int BS = PPT * TH;
-    constexpr int NS = 3;                  // history rows in flight (register stages)
-    constexpr int kStageLanes = stage_lanes(TH);
-    const int tid = threadIdx.x;
-    const int32_t b = a.b_first + (int32_t)blockIdx.x;
-    const int64_t chunk = a.diag - b;
-    const int32_t b0 = b * BS, b1 = min(a.n, b0 + BS);
-    const int32_t h0 = min(a.child_ptr[b0], b0);
-    const int32_t nh = b0 - h0;
-    const int32_t halo_lo = max(b0, a.child_ptr[b1]);
-    auto position = [&](int k) { return b0 + k * TH + tid; };
-    const int32_t tau0 = (int32_t)chunk * kRec, total = (int32_t)a.total;
-    const int lane = tid & 63;
-    double *cc1 = lds + 2 * (size_t)a.lh, *cc2 = cc1 + BS, *cc3 = cc2 + BS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int32_t tile = a.t_first + (int32_t)blockIdx.x;
+    const int32_t m = a.diag - a.tile_level[tile];
+    if (m < 0 || m >= a.n_macro) return;
+    const int32_t total = a.total, tau_begin = m * a.KC * kRec;
+    // a tile none of whose positions is active during the task has nothing to do (pipeline fill and drain); a ghost has
+    // the lag of the reach it mirrors, so it is idle exactly when its owner did not write its record
+    if (tau_begin >= a.tile_lag_hi[tile] + total || tau_begin + a.KC * kRec <= a.tile_lag_lo[tile]) return;
+    const int32_t b0 = a.tile_ptr[tile], b1 = a.tile_ptr[tile + 1];
+    double *cc1 = lds + 2 * BS, *cc2 = cc1 + BS, *cc3 = cc2 + BS;
     double *stage = cc3 + BS + (size_t)(tid >> 6) * (kStageLanes * kStageStride);   // this wave's transpose area
 #ifdef RR_WAVE_TRACE
     const bool trace = a.trace && a.diag == a.trace_diag && tid == 0;
-    long long *tq = a.trace + (int64_t)b * 8;
+    long long *tq = a.trace + (int64_t)tile * 8;
 #define RR_TRACE(i) do { if (trace) tq[i] = wall_clock64(); } while (0)
 #else
 #define RR_TRACE(i) do { } while (0)
 #endif
     RR_TRACE(0);
+    auto ring = [&](int32_t chunk) { return make_rsrc(a.rec + (int64_t)a.rec_chunks.mod((uint32_t)chunk) * a.np * kRec, (uint32_t)a.np * 128u); };   // np < 2^25
+    auto xring = [&](int32_t chunk) { return make_rsrc(a.xrec + (int64_t)a.x_chunks.mod((uint32_t)chunk) * a.nx * kRec, (uint32_t)a.nx * 128u); };
+    __amdgpu_buffer_rsrc_t rec_cur = ring(m * a.KC);
+    const bool has_ghosts = a.tile_level[tile] > 0;      // level-0 tiles are complete subtrees
 
-    double *rbase = a.rec + (int64_t)a.rec_chunks.mod((uint32_t)chunk) * a.n * kRec;
-    const __amdgpu_buffer_rsrc_t rec_chunk = make_rsrc(rbase, (uint32_t)a.n * 128u);   // n < 2^25 in record mode (session_begin)
-    double *first_buf = lds + (size_t)((tau0 + 1) & 1) * a.lh;     // tick tau0 reads the buffer of tick tau0 - 1
+    // R[k]: the record of the k-th position of this lane.  While a half is in flight its registers hold OTHER lanes' data
+    // (the pieces this lane fetched), receive() hands them to their owners.
+    double R[PPT][kRec];
+    auto issue_loads = [&](__amdgpu_buffer_rsrc_t src, int half, bool real) {
+        const int32_t t = fresh(tid), ln = t & 63;      // addresses are rebuilt at every use, not kept in registers across the task
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {      // i = (half wave, group of 16 positions)
+                const int32_t pos = min(b0 + k * TH + (t - ln) + (i >> 1) * kStageLanes + 16 * (i & 1) + (ln >> 2), b1 - 1);
+                load_f64x2(src, real ? (uint32_t)pos * 128u + (uint32_t)(half * 64 + (ln & 3) * 16) : kDropAccess,
+                           R[k][8 * half + 2 * i], R[k][8 * half + 2 * i + 1]);
+            }
+    };
+    auto receive = [&](int half) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+            double2 mine[4];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    reinterpret_cast<double2 *>(stage + (16 * g + (lane >> 2)) * kStageStride)[lane & 3] =
+                        make_double2(R[k][8 * half + 2 * (2 * h + g)], R[k][8 * half + 2 * (2 * h + g) + 1]);
+                wave_lds_fence();
+                if (lane / kStageLanes == h) {
+                    const double2 *src = reinterpret_cast<const double2 *>(stage + (lane % kStageLanes) * kStageStride);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mine[j] = src[j];
+                }
+                wave_lds_fence();
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { R[k][8 * half + 2 * j] = mine[j].x; R[k][8 * half + 2 * j + 1] = mine[j].y; }
+        }
+    };
+    issue_loads(rec_cur, 0, true);
+    issue_loads(rec_cur, 1, true);
 
-    // A slot past the end of the network keeps lag -1: no upstream range, never active, publishes 0.0 to nobody.
-    // up[k]: LDS slot of the first upstream value (low 16 bits) and the number of upstream reaches (high 16 bits)
-    int32_t lg[PPT], up[PPT], uh[UNIT ? PPT : 1];
-    double s_prev[PPT], qch[UNIT ? PPT : 1];
+    // A slot past the end of the tile keeps lag -1: no upstream range, never active, publishes 0.0 to nobody.
+    // up[k]: LDS slot of the first upstream value (low 16 bits) and the number of upstream positions (high 16 bits)
+    int32_t lg[PPT], up[PPT], xp[PPT], uh[UNIT ? PPT : 1], sub[SUB ? PPT : 1];
+    double s_prev[PPT], qch[UNIT ? PPT : 1], isum[SUB ? PPT : 1];
+    double *first_buf = lds + (size_t)((tau_begin + 1) & 1) * BS;     // tick tau_begin reads the buffer of tick tau_begin - 1
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
-        const int32_t p = position(k);
+        const int32_t p = b0 + k * TH + tid;
         if (UNIT) { uh[k] = 0; qch[k] = 0.0; }
+        if (SUB) { sub[k] = 0; isum[k] = 0.0; }
         if (p < b1) {
-            const int32_t first_up = a.child_ptr[p];
-            lg[k] = a.lag[p]; up[k] = (first_up - h0) | ((a.child_ptr[p + 1] - first_up) << 16);
-            if (UNIT) { uh[k] = (first_up - h0) + (int32_t)a.hw_children[p]; qch[k] = a.sqch[p]; }
+            const uint32_t cc = a.ccnt[p];
+            const int32_t first_up = a.cfirst[p] - b0;
+            lg[k] = a.lag[p]; up[k] = first_up | (int32_t)((cc & 0xFFFFu) << 16);
+            xp[k] = (lg[k] & (kTileExportBit | kTileGhostBit)) ? a.xpos[p] : 0;
+            if (UNIT) { uh[k] = first_up + (int32_t)(cc >> 16); qch[k] = a.sqch[p]; }
+            if (SUB) {      // phase of the position's sub-step counter at the first tick of the task
+                const int32_t ts0 = tau_begin - (lg[k] & kLagMask);
+                const uint32_t r = a.nsub.mod((uint32_t)(ts0 < 0 ? -ts0 : ts0));
+                sub[k] = ts0 >= 0 ? (int32_t)r : (r ? (int32_t)(a.nsub.d - r) : 0);
+                isum[k] = a.si[p];
+            }
             s_prev[k] = a.ss[p];
-            first_buf[nh + k * TH + tid] = a.sq[p];
+            first_buf[k * TH + tid] = a.sq[p];
             cc1[k * TH + tid] = a.c1row[p]; cc2[k * TH + tid] = a.c2[p]; cc3[k * TH + tid] = a.c3[p];
         } else {
-            lg[k] = -1; up[k] = 0; s_prev[k] = 0.0;
-            first_buf[nh + k * TH + tid] = 0.0;
+            lg[k] = -1; up[k] = 0; xp[k] = 0; s_prev[k] = 0.0;
+            first_buf[k * TH + tid] = 0.0;
             cc1[k * TH + tid] = cc2[k * TH + tid] = cc3[k * TH + tid] = 0.0;
         }
     }
-    // Records: like the stores, the loads are issued four lanes per 64-byte sector (a quarter of the L2 requests of
-    // one record per lane), all of them back to back, and then handed to the owning lanes through the staging area.
-    double rec[PPT][kRec];
-    {
-        constexpr int HW = 64 / kStageLanes, MS = kStageLanes / 16, ROUNDS = PPT * 2 * HW;   // round = (k, half, h)
-        double raw_x[ROUNDS * MS], raw_y[ROUNDS * MS];      // (an array of double2 is not promoted to registers)
-#pragma unroll
-        for (int i = 0; i < ROUNDS * MS; ++i) {
-            const int k = i / (2 * HW * MS), half = i / (HW * MS) % 2, h = i / MS % HW, m = i % MS;
-            const int32_t pos = min(b0 + k * TH + (tid - lane) + h * kStageLanes + 16 * m + (lane >> 2), b1 - 1);
-            load_f64x2(rec_chunk, (uint32_t)pos * 128u + (uint32_t)(half * 64 + (lane & 3) * 16), raw_x[i], raw_y[i]);
-        }
-#pragma unroll
-        for (int r = 0; r < ROUNDS; ++r) {
-            const int k = r / (2 * HW), half = r / HW % 2, h = r % HW;
-#pragma unroll
-            for (int m = 0; m < MS; ++m)
-                reinterpret_cast<double2 *>(stage + (16 * m + (lane >> 2)) * kStageStride)[lane & 3] = make_double2(raw_x[r * MS + m], raw_y[r * MS + m]);
-            wave_lds_fence();
-            if (lane / kStageLanes == h) {
-                const double2 *mine = reinterpret_cast<const double2 *>(stage + (lane % kStageLanes) * kStageStride);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const double2 v = mine[j]; rec[k][8 * half + 2 * j] = v.x; rec[k][8 * half + 2 * j + 1] = v.y; }
-            }
-            wave_lds_fence();
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        if (lg[k] < 0) {
-#pragma unroll
-            for (int j = 0; j < kRec; ++j) rec[k][j] = 0.0;
-        } else if (lg[k] & kGhostBit) {   // boundary inflow: this chunk of the ghost series instead of the ring
-            const int32_t g = a.bidx[position(k)];
-#pragma unroll
-            for (int j = 0; j < kRec; ++j) {
-                int32_t ts = tau0 + j - (lg[k] & kLagMask);
-                ts = ts < 0 ? 0 : (ts >= total ? total - 1 : ts);
-                rec[k][j] = a.ghost[(int64_t)ts * a.n_ghost + g];
-            }
-        }
-    }
-    const bool has_lat = a.in != nullptr;   // channel-only routing: the records only carry discharge
+    const bool has_lat = a.has_lat != 0;   // channel-only routing: the records only carry discharge
 
-    // the history ring is walked one row per tick: rows of the next halo fetch and of the next tick's own writes
-    const uint32_t hrows = (uint32_t)a.hist_rows;
-    auto next_row = [&](uint32_t r) { return r + 1 == hrows ? 0u : r + 1; };
-    uint32_t hr_fetch = Div32(hrows).mod((uint32_t)tau0 + hrows - 1), hr_tick = next_row(hr_fetch);
-    auto fetch_halo = [&](double (&h)[HPT]) {      // one history row per call, starting at tick tau0 - 1
-        const double *hrow = a.hist + (int64_t)hr_fetch * a.n + h0;
-        hr_fetch = next_row(hr_fetch);
-        const int32_t t = fresh(tid);
-#pragma unroll
-        for (int j = 0; j < HPT; ++j) {
-            const int32_t i = j * TH + t;
-            h[j] = hrow[i < nh ? i : 0];
-        }
-    };
-    auto put_halo = [&](double *buf, const double (&h)[HPT]) {
-        const int32_t t = fresh(tid);
-#pragma unroll
-        for (int j = 0; j < HPT; ++j) {
-            const int32_t i = j * TH + t;
-            if (i < nh) buf[i] = h[j];
-        }
-    };
     // Eight slots of every record are final: write that 64-byte sector.  Half a wave at a time parks its sectors in
     // the wave's staging area, then all 64 lanes store them, four lanes per sector.
-    auto store_half_records = [&](int k, int half) {
+    auto store_half = [&](__amdgpu_buffer_rsrc_t dst, int half) {
 #pragma unroll
-        for (int h = 0; h < 64 / kStageLanes; ++h) {
-            if (lane / kStageLanes == h) {
-                double2 *mine = reinterpret_cast<double2 *>(stage + (lane % kStageLanes) * kStageStride);
+        for (int k = 0; k < PPT; ++k)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mine[j] = make_double2(rec[k][8 * half + 2 * j], rec[k][8 * half + 2 * j + 1]);
-                reinterpret_cast<int32_t *>(mine + 4)[0] = (lg[k] < 0 || (lg[k] & kGhostBit)) ? 1 : 0;   // not this block's to write
+            for (int h = 0; h < 2; ++h) {
+                if (lane / kStageLanes == h) {
+                    double2 *mine = reinterpret_cast<double2 *>(stage + (lane % kStageLanes) * kStageStride);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mine[j] = make_double2(R[k][8 * half + 2 * j], R[k][8 * half + 2 * j + 1]);
+                    reinterpret_cast<int32_t *>(mine + 4)[0] = (lg[k] < 0 || (lg[k] & (kGhostBit | kTileGhostBit))) ? 1 : 0;   // not this tile's to write
+                }
+                wave_lds_fence();
+                const int32_t t = fresh(tid), ln = t & 63;
+                const uint32_t first = (uint32_t)(b0 + k * TH + (t - ln) + h * kStageLanes) * 128u + (uint32_t)half * 64u;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {       // lanes 4i .. 4i+3: the four 16-byte pieces of position 16 g + i
+                    const int pm = 16 * g + (ln >> 2), piece = ln & 3;
+                    const double2 *theirs = reinterpret_cast<const double2 *>(stage + pm * kStageStride);
+                    const double2 v = theirs[piece];
+                    const bool skip = reinterpret_cast<const int32_t *>(theirs + 4)[0] != 0;
+                    store_f64x2(dst, skip ? kDropAccess : first + (uint32_t)pm * 128u + (uint32_t)piece * 16u, v);
+                }
+                wave_lds_fence();
             }
-            wave_lds_fence();
-            const uint32_t first = (uint32_t)(b0 + k * TH + (tid - lane) + h * kStageLanes) * 128u + (uint32_t)half * 64u;
+    };
+    // external boundary inflow (multi-GPU): this half chunk of the ghost series instead of the ring
+    auto external_ghosts = [&](int32_t tau0, int half) {
 #pragma unroll
-            for (int m = 0; m < kStageLanes / 16; ++m) {       // lanes 4i .. 4i+3: the four 16-byte pieces of position 16 m + i
-                const int pm = 16 * m + (lane >> 2), piece = lane & 3;
-                const double2 *theirs = reinterpret_cast<const double2 *>(stage + pm * kStageStride);
-                const double2 v = theirs[piece];
-                const bool skip = reinterpret_cast<const int32_t *>(theirs + 4)[0] != 0;
-                store_f64x2(rec_chunk, skip ? kDropStore : first + (uint32_t)pm * 128u + (uint32_t)piece * 16u, v);
+        for (int k = 0; k < PPT; ++k)
+            if (lg[k] >= 0 && (lg[k] & kGhostBit)) {
+                const int32_t g = a.bidx[b0 + k * TH + tid];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    int32_t ts = tau0 + 8 * half + j - (lg[k] & kLagMask);
+                    ts = ts < 0 ? 0 : (ts >= total ? total - 1 : ts);
+                    R[k][8 * half + j] = a.ghost[(int64_t)ts * a.n_ghost + g];
+                }
             }
-            wave_lds_fence();
+    };
+    // what the ghosts republish during this half chunk: the owner computed it xdelta ticks earlier
+    auto tile_ghosts = [&](int32_t tau0, int half) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+            if (lg[k] >= 0 && (lg[k] & kTileGhostBit)) {
+                const int32_t first = tau0 + 8 * half - a.xdelta[b0 + k * TH + tid];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int32_t tick = first + j < 0 ? 0 : first + j;
+                    R[k][8 * half + j] = a.xrec[((int64_t)a.x_chunks.mod((uint32_t)tick >> 4) * a.nx + xp[k]) * kRec + (tick & 15)];
+                }
+            }
+    };
+    auto ticks = [&](int32_t tau0, int half, __amdgpu_buffer_rsrc_t x_cur) {
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) {
+            const int s = 8 * half + s8;
+            const int32_t tau = tau0 + s;
+            const double *rd = lds + (size_t)((tau + 1) & 1) * BS;
+            double *wr = lds + (size_t)(tau & 1) * BS;
+            const int32_t t = fresh(tid);       // slot and offset arithmetic is redone per tick, not held in registers
+#pragma unroll
+            for (int k = 0; k < PPT; ++k) {
+                const int32_t lgk = fresh(lg[k]), upk = fresh(up[k]);
+                const int32_t u0 = upk & 0xFFFF, u1 = u0 + (int32_t)((uint32_t)upk >> 16);
+                double qk = rd[k * TH + t];       // own discharge one tick back
+                const double c1 = cc1[k * TH + t], c2 = cc2[k * TH + t], c3 = cc3[k * TH + t];
+                double s_cur = 0.0, s_hw = 0.0;
+                if (UNIT) {   // headwater tributaries come first in the upstream range
+                    for (int32_t u = u0; u < uh[k]; ++u) s_hw += rd[u];
+                    for (int32_t u = uh[k]; u < u1; ++u) s_cur += rd[u];
+                } else {
+                    for (int32_t u = u0; u < u1; ++u) s_cur += rd[u];
+                }
+                const int32_t ts = tau - (lgk & kLagMask);
+                if (ts >= 0 && ts < total) {
+                    const double lat = has_lat ? R[k][s] : 0.0;
+                    double outv = 0.0;
+                    bool routed = false;
+                    if (lgk & (kGhostBit | kTileGhostBit)) {
+                        qk = R[k][s];        // a ghost republishes what its owner computed
+                    } else if (UNIT) {
+                        if (u0 == u1) {
+                            qk = lat;        // headwater: discharge = lateral, the record slot already holds it (unclamped, un-averaged)
+                        } else {
+                            const double r = __builtin_fma(c1, s_hw + s_cur, __builtin_fma(c2, s_hw + s_prev[k], c3 * qch[k]));
+                            qch[k] = r;
+                            qk = r + lat;
+                            outv = qk; routed = true;
+                        }
+                    } else {
+                        // explicit fma: every copy of this tick must round identically (split run == joint run)
+                        qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev[k], __builtin_fma(c3, qk, lat)));
+                        outv = qk; routed = true;
+                        if (lgk & kExportBit) a.exports[(int64_t)ts * a.n_export + a.bidx[b0 + k * TH + t]] = qk;
+                    }
+                    if (routed) {
+                        if (SUB) {      // mean over the sub-steps of a row, written to the slot of the row's last sub-step
+                            const double acc = (sub[k] == 0 ? 0.0 : isum[k]) + outv;
+                            isum[k] = acc;
+                            if (sub[k] + 1 == (int32_t)a.nsub.d) { const double v = acc * a.inv_nsub; R[k][s] = v > 0.0 ? v : 0.0; }
+                        } else {
+                            R[k][s] = outv > 0.0 ? outv : 0.0;
+                        }
+                    }
+                }
+                if (SUB) sub[k] = sub[k] + 1 == (int32_t)a.nsub.d ? 0 : sub[k] + 1;
+                s_prev[k] = s_cur;
+                wr[k * TH + t] = qk;
+                // a reach mirrored by a ghost of another tile: 8 bytes into its export slot, always issued (see store_f64)
+                store_f64(x_cur, (lgk >= 0 && (lgk & kTileExportBit)) ? (uint32_t)fresh(xp[k]) * 128u + (uint32_t)s * 8u : kDropAccess, qk);
+            }
+            barrier_lds();
         }
     };
 
-    double hs[NS][HPT];
-    fetch_halo(hs[NS - 1]);
-    put_halo(first_buf, hs[NS - 1]);
-#pragma unroll
-    for (int i = 0; i < NS - 1; ++i) fetch_halo(hs[i]);
-    barrier_lds();
+    barrier_lds();      // first_buf and the coefficients are in place
     RR_TRACE(1);
-#pragma unroll
-    for (int s = 0; s < kRec; ++s) {
-        const int32_t tau = tau0 + s;
-        if (s == 1) RR_TRACE(2);
-        if (s == 8) RR_TRACE(3);
-        fetch_halo(hs[(s + NS - 1) % NS]);
-        const double *rd = lds + (size_t)((tau + 1) & 1) * a.lh;
-        double *wr = lds + (size_t)(tau & 1) * a.lh;
-        const __amdgpu_buffer_rsrc_t hist_row = make_rsrc(a.hist + (int64_t)hr_tick * a.n, (uint32_t)a.n * 8u);
-        hr_tick = next_row(hr_tick);
-        const int32_t t = fresh(tid);       // slot and offset arithmetic is redone per tick, not held in registers
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            const int32_t p = b0 + k * TH + t, lgk = fresh(lg[k]), upk = fresh(up[k]);
-            const int32_t u0 = upk & 0xFFFF, u1 = u0 + (upk >> 16);
-            double qk = rd[nh + k * TH + t];       // own discharge one tick back
-            const double c1 = cc1[k * TH + t], c2 = cc2[k * TH + t], c3 = cc3[k * TH + t];
-            double s_cur = 0.0, s_hw = 0.0;
-            if (UNIT) {   // headwater tributaries come first in the upstream range
-                for (int32_t u = u0; u < uh[k]; ++u) s_hw += rd[u];
-                for (int32_t u = uh[k]; u < u1; ++u) s_cur += rd[u];
-            } else {
-                for (int32_t u = u0; u < u1; ++u) s_cur += rd[u];
-            }
-            const int32_t ts = tau - (lgk & kLagMask);
-            if (ts >= 0 && ts < total) {
-                const double lat = has_lat ? rec[k][s] : 0.0;
-                if (UNIT) {
-                    if (u0 == u1) {
-                        qk = lat;        // headwater: discharge = lateral, the record slot already holds it
-                    } else {
-                        const double r = __builtin_fma(c1, s_hw + s_cur, __builtin_fma(c2, s_hw + s_prev[k], c3 * qch[k]));
-                        qch[k] = r;
-                        qk = r + lat;
-                        rec[k][s] = qk > 0.0 ? qk : 0.0;
-                    }
-                } else if (lgk & kGhostBit) {
-                    qk = rec[k][s];
-                } else {
-                    // explicit fma: every copy of this tick must round identically (split run == joint run)
-                    qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev[k], __builtin_fma(c3, qk, lat)));
-                    if (lgk & kExportBit) a.exports[(int64_t)ts * a.n_export + a.bidx[p]] = qk;
-                    rec[k][s] = qk > 0.0 ? qk : 0.0;
-                }
-            }
-            s_prev[k] = s_cur;
-            wr[nh + k * TH + t] = qk;
-            store_f64(hist_row, p >= halo_lo ? (uint32_t)p * 8u : kDropStore, qk);   // positions >= n fall off the row
-        }
-        put_halo(wr, hs[s % NS]);
-        if ((s & 7) == 7) {
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) store_half_records(k, s >> 3);
-        }
-        barrier_lds();
+    for (int32_t cc = 0; cc < a.KC; ++cc) {
+        const int32_t chunk = m * a.KC + cc, tau0 = chunk * kRec;
+        const bool more = cc + 1 < a.KC;
+        const __amdgpu_buffer_rsrc_t rec_next = ring(chunk + 1), x_cur = xring(chunk);
+        receive(0);
+        if (has_ghosts) tile_ghosts(tau0, 0);
+        external_ghosts(tau0, 0);
+        ticks(tau0, 0, x_cur);
+        store_half(rec_cur, 0);
+        issue_loads(rec_next, 0, more);
+        receive(1);
+        if (has_ghosts) tile_ghosts(tau0, 1);
+        external_ghosts(tau0, 1);
+        ticks(tau0, 1, x_cur);
+        store_half(rec_cur, 1);
+        issue_loads(rec_next, 1, more);
+        rec_cur = rec_next;
     }
-    const double *last = lds + (size_t)((tau0 + kRec - 1) & 1) * a.lh;
+    RR_TRACE(2);
+    const double *last = lds + (size_t)((tau_begin + a.KC * kRec - 1) & 1) * BS;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         if (lg[k] < 0) continue;
-        const int32_t p = position(k);
-        a.sq[p] = last[nh + k * TH + tid]; a.ss[p] = s_prev[k];
+        const int32_t p = b0 + k * TH + tid;
+        a.sq[p] = last[k * TH + tid]; a.ss[p] = s_prev[k];
         if (UNIT) a.sqch[p] = qch[k];
+        if (SUB) a.si[p] = isum[k];
     }
-    RR_TRACE(4);
+    RR_TRACE(3);
 #undef RR_TRACE
 }
 
-// sq = q0 in engine order, ss = sum of the upstream reaches' q0, every history row = q0
-__global__ __launch_bounds__(kBlock) void k_wave_state_in(double *sq, double *ss, double *hist, int32_t hist_rows,
-                                                          const double *q_t, const int32_t *perm,
-                                                          const int32_t *child_ptr, int32_t n)
+// sq = q0 at every position (a ghost starts from the state of the reach it mirrors), ss = sum of the upstream q0
+__global__ __launch_bounds__(kBlock) void k_tile_state_in(double *sq, double *ss, double *si, const double *q_t, const int32_t *perm,
+                                                          const int32_t *cfirst, const uint32_t *ccnt, int32_t np)
 {
     const int32_t p = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
-    if (p >= n) return;
-    const double v = q_t[perm[p]];
+    if (p >= np) return;
     double s = 0.0;
-    for (int32_t u = child_ptr[p]; u < child_ptr[p + 1]; ++u) s += q_t[perm[u]];
-    sq[p] = v; ss[p] = s;
-    for (int32_t r = 0; r < hist_rows; ++r) hist[(int64_t)r * n + p] = v;
+    const int32_t u0 = cfirst[p], u1 = u0 + (int32_t)(ccnt[p] & 0xFFFFu);
+    for (int32_t u = u0; u < u1; ++u) s += q_t[perm[u]];
+    sq[p] = q_t[perm[p]]; ss[p] = s; si[p] = 0.0;
 }
 
 // UnitMuskingum state for the time-tiled kernel: published discharge = q_full on inner reaches (0 on headwaters until
-// their first tick), ss = sum over the INNER tributaries only, qch = channel discharge; history rows = published values.
-__global__ __launch_bounds__(kBlock) void k_wave_unit_state_in(double *sq, double *ss, double *qch, double *hist,
-                                                               int32_t hist_rows, const double *x0,
-                                                               const int32_t *child_ptr, int32_t n)
+// their first tick), ss = sum over the INNER tributaries only (the headwater ones come first), qch = channel discharge.
+// full[i] / chan[i]: q_full / q_ch scattered to params order, zeros on headwaters (k_unit_scatter).
+__global__ __launch_bounds__(kBlock) void k_tile_unit_state_in(double *sq, double *ss, double *si, double *sqch, const double *full,
+                                                               const double *chan, const int32_t *perm, const int32_t *cfirst,
+                                                               const uint32_t *ccnt, int32_t np)
 {
     const int32_t p = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
-    if (p >= n) return;
-    const double v = x0[p];     // x0: q_full scattered to engine positions, zeros on headwaters (k_unit_state_in)
+    if (p >= np) return;
     double s = 0.0;
-    for (int32_t u = child_ptr[p]; u < child_ptr[p + 1]; ++u)
-        if (child_ptr[u + 1] > child_ptr[u]) s += x0[u];
-    sq[p] = v; ss[p] = s;
-    for (int32_t r = 0; r < hist_rows; ++r) hist[(int64_t)r * n + p] = v;
-    (void)qch;
+    const uint32_t cc = ccnt[p];
+    const int32_t u0 = cfirst[p] + (int32_t)(cc >> 16), u1 = cfirst[p] + (int32_t)(cc & 0xFFFFu);
+    for (int32_t u = u0; u < u1; ++u) s += full[perm[u]];
+    sq[p] = full[perm[p]]; ss[p] = s; si[p] = 0.0; sqch[p] = chan[perm[p]];
 }
 
-__global__ __launch_bounds__(kBlock) void k_wave_unit_state_out(double *q_ch, double *q_full, const double *sq,
-                                                                const double *qch, const int32_t *inner_pos,
-                                                                int32_t n_inner)
+__global__ __launch_bounds__(kBlock) void k_unit_scatter(double *full, double *chan, const double *q_full, const double *q_ch,
+                                                         const int32_t *inner_idx, int32_t n_inner)
 {
     const int32_t k = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
     if (k >= n_inner) return;
-    const int32_t p = inner_pos[k];
-    q_full[k] = sq[p];
-    q_ch[k] = qch[p];
+    full[inner_idx[k]] = q_full[k]; chan[inner_idx[k]] = q_ch[k];
 }
 
-__global__ __launch_bounds__(kBlock) void k_wave_state_out(double *q_t, const double *sq, const int32_t *inv, int32_t n)
+__global__ __launch_bounds__(kBlock) void k_tile_unit_state_out(double *q_ch, double *q_full, const double *sq, const double *sqch,
+                                                                const int32_t *inner_idx, const int32_t *inv, int32_t n_inner)
+{
+    const int32_t k = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (k >= n_inner) return;
+    const int32_t p = inv[inner_idx[k]];
+    q_full[k] = sq[p];
+    q_ch[k] = sqch[p];
+}
+
+__global__ __launch_bounds__(kBlock) void k_tile_state_out(double *q_t, const double *sq, const int32_t *inv, int32_t n)
 {
     const int32_t i = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
     if (i < n) q_t[i] = sq[inv[i]];
@@ -1070,12 +914,14 @@ __global__ __launch_bounds__(kBlock) void k_uh_tail(const double *__restrict__ k
     new_state[(int64_t)s * n + i] = acc;
 }
 
-// ---- record-mode permutation (one pass each way), see k_wave_rec ----
-// Column i of the params-order rows is engine position p = inv[i] with lag L = 16 * sh + o.  Row t of that column
-// is slot (t + L) % 16 of record (t + L) / 16, so the 64 rows [64 j - o, 64 j + 64 - o) are exactly the four
-// records 4 j + sh .. 4 j + sh + 3.  k_rec_in reads the 79 rows [64 j - 15, 64 j + 64) of a 64-column tile
-// coalesced into LDS and writes four whole 128-byte records per column (8 lanes x 16 B per record); k_rec_out
-// reads five records per column the same way and writes the 64 rows [64 j, 64 j + 64) of the tile coalesced.
+// ---- record permutation (one pass each way), see k_tile ----
+// Column i of the params-order rows is position p = inv[i] with lag L = 16 * sh + o.  Tick-row r of that column (tick-row =
+// routing sub-step: runoff row r / nsub, sub-step r % nsub) is slot (r + L) % 16 of record (r + L) / 16, so the 128 tick-rows
+// [128 j - o, 128 j + 128 - o) are exactly the eight records 8 j + sh .. 8 j + sh + 7.  k_rec_in reads the runoff rows
+// behind the 143 tick-rows [128 j - 15, 128 j + 128) of a 32-column tile coalesced into LDS (all loads in flight before the
+// first LDS write) and writes eight whole 128-byte records per column (8 lanes x 16 B per record), every sub-step slot of a
+// row holding the row's lateral value; k_rec_out reads nine records per column the same way and writes the tile's rows of
+// the batch coalesced: the slot of a row's LAST sub-step holds the row's mean discharge.
 #ifndef RR_REC_BATCH
 #define RR_REC_BATCH 8
 #define RR_REC_COLS 32
@@ -1084,32 +930,39 @@ __global__ __launch_bounds__(kBlock) void k_uh_tail(const double *__restrict__ k
 #define RR_REC_THREADS 256
 #endif
 constexpr int kRecCols = RR_REC_COLS, kRecBatch = RR_REC_BATCH, kRecThreads = RR_REC_THREADS;
-constexpr int kRecRows = 16 * kRecBatch;    // rows of one batch
+constexpr int kRecRows = 16 * kRecBatch;    // tick-rows of one batch
 
 struct RecPermArgs {
     double *rec;
     Div32 rec_chunks;
-    int64_t n, T, batch;
-    const int2 *colmeta;      // per params column: {engine position, lag}
+    int64_t n, np, T, total, batch;   // T runoff rows, total = T * nsub tick-rows
+    Div32 nsub;
+    const int2 *colmeta;      // per params column: {position, lag}
     const double *scale;      // c4dt in PARAMS order (RapidMuskingum: the ring holds c4dt * lateral) or NULL
     RowView rows;             // params-order rows (source of k_rec_in, destination of k_rec_out)
+    float *rows32;            // k_rec_out: float32 destination with `factor` rows averaged (router post-processing), or NULL
+    Div32 factor;
 };
 
+template <bool SUB>
 __global__ __launch_bounds__(kRecThreads) void k_rec_in(const RecPermArgs a)
 {
     constexpr int R = 16 * kRecBatch + 15;
     __shared__ double tile[R][kRecCols + 1];
     const int tid = threadIdx.x;
     const int64_t col0 = (int64_t)blockIdx.x * kRecCols;
-    const int64_t row_first = kRecRows * a.batch - 15;
+    const int64_t tick_first = kRecRows * a.batch - 15;                 // may be negative in the first batch
+    uint32_t sub_unused;
+    const int64_t row_first = SUB ? (int64_t)a.nsub.div((uint32_t)(tick_first < 0 ? 0 : tick_first), sub_unused) : tick_first;
     {   // all row loads in flight first (branch-free: out-of-range rows/columns are clamped and zeroed afterwards)
         constexpr int RPT = (R + kRecThreads / kRecCols - 1) / (kRecThreads / kRecCols);
         const int c = tid % kRecCols, r0 = tid / kRecCols;
         const int64_t i = min(col0 + c, a.n - 1);
+        const int need = SUB ? (int)((uint32_t)(R - 1) / a.nsub.d) + 2 : R;     // runoff rows behind the batch's tick-rows
         double v[RPT];
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-            const int64_t t = row_first + r0 + q * (kRecThreads / kRecCols);
+            const int64_t t = row_first + min(r0 + q * (kRecThreads / kRecCols), need - 1);
             v[q] = a.rows.row(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t))[i];
         }
 #pragma unroll
@@ -1142,13 +995,25 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_in(const RecPermArgs a)
         const int32_t lag = meta[it].y;
         const int o = lag & 15;
         const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)(lag >> 4) + k;
-        const int r = 15 - o + 16 * k + 2 * part;
-        const double v0 = tile[r][c] * f[it], v1 = tile[r + 1][c] * f[it];
-        double2 *dst = reinterpret_cast<double2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.n + p) * kRec) + part;
+        const int r = 15 - o + 16 * k + 2 * part;       // tick-row tick_first + r
+        double v0, v1;
+        if (SUB) {
+            const int64_t t0 = tick_first + r, t1 = t0 + 1;
+            uint32_t s;
+            const int r0 = t0 < 0 ? 0 : (int)((int64_t)a.nsub.div((uint32_t)t0, s) - row_first);
+            const int r1 = t1 < 0 ? 0 : (int)((int64_t)a.nsub.div((uint32_t)t1, s) - row_first);
+            v0 = tile[min(r0, R - 1)][c] * f[it]; v1 = tile[min(r1, R - 1)][c] * f[it];
+        } else {
+            v0 = tile[r][c] * f[it]; v1 = tile[r + 1][c] * f[it];
+        }
+        double2 *dst = reinterpret_cast<double2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.np + p) * kRec) + part;
         *dst = make_double2(v0, v1);
     }
 }
 
+// OUT32: the router's post-processing fused in (TransformMuskingum.py:128-142): mean over `factor` consecutive rows
+// (sequential sum, one division, as numpy reduces a strided axis) and the float32 cast; 128 % (factor * nsub) == 0.
+template <bool SUB, bool OUT32>
 __global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
 {
     constexpr int S = 16 * (kRecBatch + 1);
@@ -1169,7 +1034,7 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
         const int k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
         const int32_t p = meta[it].x < 0 ? 0 : meta[it].x;
         const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)(meta[it].y >> 4) + k;
-        v[it] = *(reinterpret_cast<const double2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.n + p) * kRec) + part);
+        v[it] = *(reinterpret_cast<const double2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.np + p) * kRec) + part);
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -1183,9 +1048,30 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
     const int64_t i = col0 + c;
     if (i >= a.n) return;
     const int o = a.colmeta[i].y & 15;
-    for (int r = tid / kRecCols; r < 16 * kRecBatch; r += kRecThreads / kRecCols) {
-        const int64_t t = kRecRows * a.batch + r;
-        if (t < a.T) a.rows.row(t)[i] = recs[c][o + r];
+    const int64_t tick0 = kRecRows * a.batch;
+    if (OUT32) {
+        // output row q averages runoff rows [q * factor, (q + 1) * factor), each the slot of its last sub-step
+        const int step = (int)(a.factor.d * (SUB ? a.nsub.d : 1u));          // tick-rows per output row, divides 128
+        const int64_t q0 = tick0 / step;
+        for (int q = tid / kRecCols; q < kRecRows / step; q += kRecThreads / kRecCols) {
+            if ((q0 + q + 1) * step > a.total) break;
+            const int nsub = SUB ? (int)a.nsub.d : 1;
+            double acc = recs[c][o + q * step + nsub - 1];
+            for (int j = 1; j < (int)a.factor.d; ++j) acc += recs[c][o + q * step + j * nsub + nsub - 1];
+            a.rows32[(q0 + q) * a.n + i] = (float)(a.factor.d > 1 ? acc / (double)a.factor.d : acc);
+        }
+        return;
+    }
+    for (int r = tid / kRecCols; r < kRecRows; r += kRecThreads / kRecCols) {
+        const int64_t tick = tick0 + r;
+        if (tick >= a.total) break;
+        if (SUB) {
+            uint32_t s;
+            const uint32_t t = a.nsub.div((uint32_t)tick, s);
+            if (s + 1 == a.nsub.d) a.rows.row(t)[i] = recs[c][o + r];
+        } else {
+            a.rows.row(tick)[i] = recs[c][o + r];
+        }
     }
 }
 
@@ -1278,6 +1164,8 @@ struct Rows {
     double *dev_out = nullptr;
     double *host_out = nullptr;
     int64_t rows_out = 0;
+    float *dev_out32 = nullptr;       // instead of dev_out: float32 rows, each the mean of out_factor routed rows
+    int64_t out_factor = 1;
 };
 
 // One routing call in flight: rows enter (permutation in), ticks run, finished rows leave (permutation out).
@@ -1295,11 +1183,13 @@ struct Session {
     const double *ghost_series = nullptr;
     double *export_series = nullptr;
     TickArgs a{};
-    bool wave = false;            // time-tiled k_wave instead of per-tick k_tick
-    bool rec = false;             // record-mode ring + one-pass permutation (k_wave_rec, k_rec_in, k_rec_out)
-    int64_t rec_chunks = 0, in_batches = 0, n_in_batches = 0, out_batches = 0, n_out_batches = 0;
-    int64_t diag = 0, n_diags = 0, n_chunks = 0;
-    WaveArgs wa{};
+    bool wave = false;            // time-tiled k_tile over records instead of per-tick k_tick over rows
+    int64_t KC = 1;               // record chunks per task: K = 16 * KC ticks
+    int64_t rec_chunks = 0, x_chunks = 0, in_batches = 0, n_in_batches = 0, out_batches = 0, n_out_batches = 0;
+    int64_t ticks_stored = 0;     // tick-rows that have left the record ring
+    int64_t diag = 0, n_diags = 0, n_macro = 0;
+    int64_t ghost_slack = 0, export_skew = 0;   // external boundary reaches in the time-tiled schedule (level skew included)
+    TileArgs ta{};
     bool bracket_open = false;
     int64_t bracket_reaches = 0;
     size_t max_samples = 0;
@@ -1311,6 +1201,7 @@ struct rr_plan {
     bool coeffs_set = false, has_c4 = false;
     int64_t chunk_rows = 16, sample_every = 0;
 
+    // streaming kernel (k_tick): lag-ordered layout of rr::HostPlan
     int32_t *d_child_ptr = nullptr, *d_lag = nullptr, *d_perm = nullptr, *d_inv = nullptr, *d_inner_pos = nullptr;
     int32_t *d_bidx = nullptr;   // ghost / export slot of flagged positions
     uint16_t *d_hwc = nullptr;
@@ -1327,22 +1218,28 @@ struct rr_plan {
     int32_t *d_m_index[2] = {nullptr, nullptr};
     int64_t perm_rows_per_block = 2;
 
-    // time-tiled routing (k_wave)
+    // time-tiled routing (k_tile): subtree tiles of rr::TilePlan
+    rr::TilePlan tp;
     bool wave_enabled = true, wave_forced = false, wave_now = false, weights_uniform = false;
-    int wave_threads = 512, wave_ppt = 4, wave_hpt = 4;
-    int64_t wave_K = 16, wave_nb = 0, wave_jmax = 0, wave_lh = 0;
-    double *d_c1row = nullptr, *d_sq = nullptr, *d_ss = nullptr, *d_si = nullptr, *d_hist = nullptr;
-    int64_t hist_cap = 0;
-    int2 *d_colmeta = nullptr;   // per params column {engine position, lag}
-    double *d_c4_params = nullptr;   // c4dt in params order (scale of the record-mode permutation)
-    bool rec_enabled = true;     // record mode where it applies (one sub-step, K = 16, permuted order, device rows)
+    int wave_threads = 1024, wave_ppt = 2;
+    int64_t wave_K = 0;          // ticks per task (multiple of 16); 0 = chosen per call
+    int64_t next_KC = 1, next_chunks = 0;   // decide_wave: task length and record ring of the call about to start
+    int32_t *d_tile_ptr = nullptr, *d_tile_level = nullptr, *d_tile_lag_lo = nullptr, *d_tile_lag_hi = nullptr;
+    int32_t *d_tlag = nullptr, *d_cfirst = nullptr, *d_xpos = nullptr, *d_xdelta = nullptr, *d_tperm = nullptr, *d_tinv = nullptr;
+    int32_t *d_tbidx = nullptr, *d_inner_idx = nullptr;
+    uint32_t *d_ccnt = nullptr;
+    double *d_c1row = nullptr, *d_tc2 = nullptr, *d_tc3 = nullptr, *d_sq = nullptr, *d_ss = nullptr, *d_si = nullptr, *d_sqch = nullptr;
+    double *d_full = nullptr, *d_chan = nullptr;   // UnitMuskingum state scattered to params order
+    double *d_xrec = nullptr;    // export ring
+    int64_t xrec_cap = 0;
+    int2 *d_colmeta = nullptr;   // per params column {position, lag}
+    double *d_c4_params = nullptr;   // c4dt in params order (scale of the record permutation)
     size_t dev_total_bytes = 0;
 
     // boundary reaches of a partitioned network
     int64_t n_ghost = 0, n_export = 0;
     int64_t ghost_min_lag = 0, export_max_lag = 0;
-    int64_t wave_ghost_slack = 0, wave_export_skew = 0;   // the same bounds in the time-tiled schedule (block skew included)
-    std::vector<int32_t> ghost_pos;   // engine positions of the ghosts, in the caller's ghost order
+    std::vector<int32_t> ghost_reach, export_reach;   // params indices, in the caller's order
 
     Session ses;
 
@@ -1398,25 +1295,47 @@ int ensure_cap(T **buf, int64_t *cap, int64_t count)
 
 // ---- session -------------------------------------------------------------------------------------
 
-// Which routing kernel a call of `total` sub-steps uses.  The time-tiled schedule pays (blocks * K) extra ticks of
-// fill/drain per call but runs a full tick ~2.8x faster than the streaming kernel, and its partly filled launches are
-// cheap; measured at 1M reaches (blocks * K = 7,824): 744 steps 35 vs 29 ms, 2,976 steps 73 vs 96 ms, break-even
-// near 1,200 steps.  RR_WAVE=1 forces it, RR_WAVE=0 forbids it.
-bool decide_wave(rr_plan *P, Mode mode, int64_t total)
+// Record chunks per task.  A longer task amortises the load of the tile's state and of its first half chunk, which
+// nothing overlaps; every tile level adds one task of skew to the pipeline and to the record ring.
+int64_t pick_KC(const rr_plan *P, int64_t total_ticks)
 {
-    bool ok = P->wave_enabled && P->weights_uniform && P->h.n > 0 &&
+    if (P->wave_K > 0) return std::max<int64_t>(1, P->wave_K / kRec);
+    return total_ticks >= 4096 ? 4 : (total_ticks >= 512 ? 2 : 1);
+}
+
+// Which routing kernel a call uses.  The time-tiled schedule needs device rows, one upstream weight per reach, a
+// network that tiles (rr::TilePlan) and room for its record ring; its fill and drain cost (levels x K) ticks more than
+// the streaming kernel's, a few launches, so only calls of a handful of sub-steps stream.  RR_WAVE=1 forces it where it
+// applies, RR_WAVE=0 forbids it.
+//
+// Records are indexed by tick = tick-row + lag.  Rows enter for all columns at once and leave for all columns at once,
+// so a record lives from (its first tick - depth) until every tile has passed (its last tick + depth): the ring spans
+// 2 depth + levels * K ticks plus the batching of the two permutation passes.  It may take five eighths of the card; a
+// deep network that does not fit gets shorter tasks, then the streaming kernel.
+bool decide_wave(rr_plan *P, Mode mode, int64_t total, bool host_rows)
+{
+    bool ok = P->wave_enabled && P->tp.ok && P->weights_uniform && P->h.n > 0 && !host_rows && P->tp.np < (int64_t{1} << 25) &&
               (mode != Mode::Unit || (P->n_ghost == 0 && P->n_export == 0));
-    if (ok && !P->wave_forced) {
-        ok = 6 * total >= P->wave_nb * P->wave_K;
+    if (ok && !P->wave_forced) ok = total >= 32;
+    if (ok) {
+        const int64_t dmax = P->h.depth - 1, np = P->tp.np, levels = P->tp.n_levels;
+        const int64_t all_chunks = kRecBatch * ((total + 14) / kRecRows + 2) + (dmax >> 4) + 2;
+        ok = false;
+        for (int64_t KC = pick_KC(P, total + dmax); KC >= 1; KC /= 2) {
+            const int64_t chunks = std::min<int64_t>(all_chunks, (2 * dmax + levels * KC * kRec) / kRec + 4 * kRecBatch);
+            const int64_t bytes = chunks * kRec * np * (int64_t)sizeof(double);
+            if (P->dev_total_bytes > 0 && bytes > (int64_t)(P->dev_total_bytes / 8 * 5)) continue;
+            if (ensure_cap(&P->d_ring, &P->ring_cap, chunks * kRec * np) != RR_OK) { (void)hipGetLastError(); continue; }
+            P->next_KC = KC; P->next_chunks = chunks;
+            ok = true;
+            break;
+        }
     }
     P->wave_now = ok;
     return ok;
 }
 
 bool use_wave(const rr_plan *P, Mode) { return P->wave_now; }
-
-int64_t wave_hist_rows(const rr_plan *P) { return (P->wave_jmax + 2) * P->wave_K; }
-
 
 int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io, hipStream_t stream,
                   const double *ghost_series, double *export_series)
@@ -1435,7 +1354,8 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         return fail(RR_E_UNSUPPORTED, "more than 2^31 routing ticks or rows in one call: split it into several calls");
     S.has_in = mode != Mode::Muskingum;
     const bool host_io = io.host_out != nullptr || io.host_in != nullptr;
-    S.direct = H.identity && !host_io;   // engine order == params order: stream the caller's arrays
+    S.wave = use_wave(P, mode);
+    S.direct = H.identity && !host_io && !S.wave;   // engine order == params order: the streaming kernel reads the caller's arrays
     const int64_t C = std::max<int64_t>(1, P->chunk_rows);
 
     P->prof_launches = P->prof_samples = P->prof_brackets = 0;
@@ -1446,87 +1366,83 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
     if (n == 0 || S.total == 0) return RR_OK;
     if (P->n_ghost > 0 && !ghost_series) { S.open = false; return fail(RR_E_INVALID, "plan has ghost reaches but no ghost series was given"); }
     if (P->n_export > 0 && !export_series) { S.open = false; return fail(RR_E_INVALID, "plan has export reaches but no export series was given"); }
+    if (io.dev_out32 && !S.wave) { S.open = false; return fail(RR_E_UNSUPPORTED, "float32 output needs the time-tiled kernel"); }
 
-    S.wave = use_wave(P, mode);
-    if (S.wave) {
-        S.n_chunks = (S.total_ticks + P->wave_K - 1) / P->wave_K;
-        S.n_diags = S.n_chunks + P->wave_nb - 1;
-    }
-    // work ring in engine order: lateral rows come in, discharge rows overwrite them in place.  Rows stay until
-    // the outlet-most reaches have passed them; the time-tiled schedule adds (blocks - 1) * K ticks of skew.
-    const int64_t skew_ticks = dmax + (S.wave ? P->wave_nb * P->wave_K : 0);
-    const int64_t lag_rows = (skew_ticks + nsub - 1) / nsub;
-    S.rec = S.wave && P->rec_enabled && nsub == 1 && P->wave_K == kRec && !S.direct && !host_io && n < (int64_t{1} << 25);    // the 1024-thread shape with a 4,096-wide halo would spill
-    if (S.rec) {
-        // records are indexed by tick = row + lag: the live rows span (skew + depth) ticks
-        // no wrap-around needed when every chunk the call can touch fits: batches * 4 + deepest lag + the look-ahead record
-        const int64_t all_chunks = kRecBatch * ((T + 14) / (16 * kRecBatch) + 2) + (dmax >> 4) + 2;
-        S.rec_chunks = std::min<int64_t>(all_chunks, (skew_ticks + dmax) / kRec + 32);
-        const int64_t bytes = S.rec_chunks * kRec * n * (int64_t)sizeof(double);
-        // up to five eighths of the card: a 1M-reach part of a partitioned 8M-reach network is deeper than a 1M-reach
-        // network of its own (the trunk part holds the main stems) and needs 152 GB of the 288
-        if (P->dev_total_bytes > 0 && bytes > (int64_t)(P->dev_total_bytes / 8 * 5)) S.rec = false;
-    }
-    S.ring_rows = S.direct ? 0 : (S.rec ? S.rec_chunks * kRec : std::min<int64_t>(T, lag_rows + 2 * C + 2));
-    if (getenv("RR_VERBOSE"))
-        fprintf(stderr, "rr: n=%lld T=%lld nsub=%lld wave=%d rec=%d direct=%d threads=%d ppt=%d hpt=%d K=%lld blocks=%lld lh=%lld lds=%zu ring_rows=%lld\n",
-                (long long)n, (long long)T, (long long)nsub, (int)S.wave, (int)S.rec, (int)S.direct, P->wave_threads, P->wave_ppt,
-                P->wave_hpt, (long long)P->wave_K, (long long)P->wave_nb, (long long)P->wave_lh,
-                S.rec ? wave_rec_lds_bytes(P->wave_lh, P->wave_threads, P->wave_ppt) : (size_t)2 * P->wave_lh * sizeof(double),
-                (long long)S.ring_rows);
-    if (S.ring_rows > 0xFFFFFFFFLL || T > 0x7FFFFFFFLL) { S.open = false; return fail(RR_E_INVALID, "route: too many time rows"); }
     int rc = RR_OK;
-    if (!S.direct) rc = ensure_cap(&P->d_ring, &P->ring_cap, S.ring_rows * n);
-    if (rc == RR_E_ALLOC && S.rec) {      // no room for the record ring after all: the (smaller) row ring
-        (void)hipGetLastError();
-        S.rec = false;
-        S.ring_rows = std::min<int64_t>(T, lag_rows + 2 * C + 2);
-        rc = ensure_cap(&P->d_ring, &P->ring_cap, S.ring_rows * n);
-    }
-    if (!rc && !S.direct && !S.rec) rc = ensure_cap(&P->d_mrows, &P->mrows_cap, C * n);
-    if (!rc && host_io) rc = ensure_cap(&P->d_stage, &P->stage_cap, C * n);
-    if (rc) { S.open = false; return rc; }
-    if (S.rec) {
-        S.n_in_batches = S.has_in ? (T + 14) / (16 * kRecBatch) + 1 : 0;
-        S.n_out_batches = (T + 16 * kRecBatch - 1) / (16 * kRecBatch);
-    }
-
-    TickArgs &a = S.a;
-    a.child_ptr = P->d_child_ptr; a.lag = P->d_lag; a.w = P->d_w; a.c2 = P->d_c2; a.c3 = P->d_c3; a.c4 = P->d_c4;
-    a.isum = P->d_isum; a.bidx = P->d_bidx;
-    a.ghost = ghost_series; a.exports = export_series; a.n_ghost = (int32_t)P->n_ghost; a.n_export = (int32_t)P->n_export;
-    a.total_substeps = S.total; a.nsub = Div32((uint32_t)nsub); a.inv_nsub = 1.0 / (double)nsub;
-    if (S.direct) {
-        a.in = io.dev_in; a.in_ld = n; a.in_rows = Div32((uint32_t)std::max<int64_t>(1, io.rows_in));
-        a.out = io.dev_out; a.out_ld = n; a.out_rows = Div32((uint32_t)io.rows_out);
-    } else {
-        a.in = S.has_in ? P->d_ring : nullptr; a.in_ld = n; a.in_rows = Div32((uint32_t)S.ring_rows);
-        a.out = P->d_ring; a.out_ld = n; a.out_rows = Div32((uint32_t)S.ring_rows);
-    }
-
+    if (S.wave) { S.KC = P->next_KC; S.rec_chunks = P->next_chunks; }     // ring sized and allocated by decide_wave
     if (S.wave) {
-        WaveArgs &w = S.wa;
-        w.child_ptr = P->d_child_ptr; w.lag = P->d_lag; w.c1row = P->d_c1row; w.c2 = P->d_c2; w.c3 = P->d_c3; w.c4 = P->d_c4;
-        w.sq = P->d_sq; w.ss = P->d_ss; w.si = P->d_si; w.sqch = P->d_qch; w.hw_children = P->d_hwc; w.hist = P->d_hist; w.hist_rows = (int32_t)wave_hist_rows(P);
-        w.bidx = P->d_bidx; w.ghost = ghost_series; w.exports = export_series;
+        const rr::TilePlan &TP = P->tp;
+        const int64_t K = S.KC * kRec;
+        S.n_macro = (S.total_ticks + K - 1) / K;
+        S.n_diags = S.n_macro + TP.n_levels - 1;
+        S.n_in_batches = S.has_in ? (S.total + 14) / kRecRows + 1 : 0;
+        S.n_out_batches = (S.total + kRecRows - 1) / kRecRows;
+        S.x_chunks = (int64_t)TP.n_levels * S.KC + 4;
+        if (S.x_chunks * std::max<int64_t>(1, TP.n_ghost) * 128 >= (int64_t{1} << 32)) { S.open = false; return fail(RR_E_UNSUPPORTED, "export ring of the tile schedule exceeds 4 GiB"); }
+        rc = ensure_cap(&P->d_xrec, &P->xrec_cap, S.x_chunks * std::max<int64_t>(1, TP.n_ghost) * kRec);
+        if (rc) { S.open = false; return rc; }
+        // external boundary reaches: a ghost in a tile of level l at lag L is read for sub-steps below (diag - l + 1) K - L,
+        // an export reach there has produced the sub-steps below (diag - l) K - L
+        S.ghost_slack = S.total_ticks + (int64_t)TP.n_levels * K; S.export_skew = 0;
+        for (int32_t i : P->ghost_reach) { const int32_t p = TP.inv[i]; S.ghost_slack = std::min<int64_t>(S.ghost_slack, (int64_t)TP.tile_level[TP.tile_of[p]] * K + (TP.lag[p] & kLagMask)); }
+        for (int32_t i : P->export_reach) { const int32_t p = TP.inv[i]; S.export_skew = std::max<int64_t>(S.export_skew, (int64_t)TP.tile_level[TP.tile_of[p]] * K + (TP.lag[p] & kLagMask)); }
+        if (P->ghost_reach.empty()) S.ghost_slack = 0;
+        if (io.dev_out32) {
+            const int64_t step = io.out_factor * nsub;
+            if (io.out_factor < 1 || kRecRows % step != 0 || T % io.out_factor != 0) { S.open = false; return fail(RR_E_UNSUPPORTED, "float32 output: factor * sub-steps must divide 128 and factor the number of rows"); }
+        }
+        TileArgs &w = S.ta;
+        w.tile_ptr = P->d_tile_ptr; w.tile_level = P->d_tile_level; w.tile_lag_lo = P->d_tile_lag_lo; w.tile_lag_hi = P->d_tile_lag_hi;
+        w.lag = P->d_tlag; w.cfirst = P->d_cfirst; w.xpos = P->d_xpos; w.xdelta = P->d_xdelta; w.ccnt = P->d_ccnt;
+        w.c1row = P->d_c1row; w.c2 = P->d_tc2; w.c3 = P->d_tc3;
+        w.sq = P->d_sq; w.ss = P->d_ss; w.si = P->d_si; w.sqch = P->d_sqch;
+        w.bidx = P->d_tbidx; w.ghost = ghost_series; w.exports = export_series;
         w.n_ghost = (int32_t)P->n_ghost; w.n_export = (int32_t)P->n_export;
-        w.in = a.in; w.out = a.out; w.in_ld = a.in_ld; w.out_ld = a.out_ld; w.in_rows = a.in_rows; w.out_rows = a.out_rows;
-        w.lh = (int32_t)P->wave_lh;
+        w.rec = P->d_ring; w.rec_chunks = Div32((uint32_t)S.rec_chunks);
+        w.xrec = P->d_xrec; w.x_chunks = Div32((uint32_t)S.x_chunks); w.nx = (int32_t)std::max<int64_t>(1, TP.n_ghost);
 #ifdef RR_WAVE_TRACE
         w.trace = nullptr; w.trace_diag = -1;
         if (getenv("RR_WAVE_TRACE_DIAG")) {
             static long long *tbuf = nullptr;
             if (!tbuf) (void)hipMalloc(&tbuf, 8 * 8 * 4096);
             (void)hipMemset(tbuf, 0, 8 * 8 * 4096);
-            w.trace = tbuf; w.trace_diag = atoll(getenv("RR_WAVE_TRACE_DIAG"));
+            w.trace = tbuf; w.trace_diag = atoi(getenv("RR_WAVE_TRACE_DIAG"));
         }
 #endif
-        w.rec = S.rec ? P->d_ring : nullptr; w.rec_chunks = Div32((uint32_t)S.rec_chunks);
-        w.n = (int32_t)n; w.K = (int32_t)P->wave_K; w.total = S.total; w.nsub = Div32((uint32_t)nsub); w.inv_nsub = 1.0 / (double)nsub;
-        if (!P->d_hist || P->hist_cap < (int64_t)w.hist_rows * n) { S.open = false; return fail(RR_E_STATE, "time-tiled routing: history ring not initialised"); }
+        w.np = (int32_t)TP.np; w.KC = (int32_t)S.KC; w.n_macro = (int32_t)S.n_macro; w.total = (int32_t)S.total;
+        w.has_lat = S.has_in ? 1 : 0; w.nsub = Div32((uint32_t)nsub); w.inv_nsub = 1.0 / (double)nsub;
+    }
+    if (getenv("RR_VERBOSE"))
+        fprintf(stderr, "rr: n=%lld T=%lld nsub=%lld tiled=%d K=%lld tiles=%d levels=%d block=%d ghosts=%lld ring_chunks=%lld (%.1f GB) lds=%zu\n",
+                (long long)n, (long long)T, (long long)nsub, (int)S.wave, (long long)(S.KC * kRec), P->tp.n_tiles, P->tp.n_levels, P->tp.block,
+                (long long)P->tp.n_ghost, (long long)S.rec_chunks, S.wave ? (double)S.rec_chunks * kRec * P->tp.np * 8 / 1e9 : 0.0,
+                tile_lds_bytes(P->wave_threads, P->wave_ppt));
+    if (!S.wave) {
+        // work ring in engine order: lateral rows come in, discharge rows overwrite them in place; rows stay until the
+        // outlet-most reaches have passed them
+        const int64_t lag_rows = (dmax + nsub - 1) / nsub;
+        S.ring_rows = S.direct ? 0 : std::min<int64_t>(T, lag_rows + 2 * C + 2);
+        if (S.ring_rows > 0xFFFFFFFFLL || T > 0x7FFFFFFFLL) { S.open = false; return fail(RR_E_INVALID, "route: too many time rows"); }
+        rc = RR_OK;
+        if (!S.direct) rc = ensure_cap(&P->d_ring, &P->ring_cap, S.ring_rows * n);
+        if (!rc && !S.direct) rc = ensure_cap(&P->d_mrows, &P->mrows_cap, C * n);
+        if (!rc && host_io) rc = ensure_cap(&P->d_stage, &P->stage_cap, C * n);
+        if (rc) { S.open = false; return rc; }
+        TickArgs &a = S.a;
+        a.child_ptr = P->d_child_ptr; a.lag = P->d_lag; a.w = P->d_w; a.c2 = P->d_c2; a.c3 = P->d_c3; a.c4 = P->d_c4;
+        a.isum = P->d_isum; a.bidx = P->d_bidx;
+        a.ghost = ghost_series; a.exports = export_series; a.n_ghost = (int32_t)P->n_ghost; a.n_export = (int32_t)P->n_export;
+        a.total_substeps = S.total; a.nsub = Div32((uint32_t)nsub); a.inv_nsub = 1.0 / (double)nsub;
+        if (S.direct) {
+            a.in = io.dev_in; a.in_ld = n; a.in_rows = Div32((uint32_t)std::max<int64_t>(1, io.rows_in));
+            a.out = io.dev_out; a.out_ld = n; a.out_rows = Div32((uint32_t)io.rows_out);
+        } else {
+            a.in = S.has_in ? P->d_ring : nullptr; a.in_ld = n; a.in_rows = Div32((uint32_t)S.ring_rows);
+            a.out = P->d_ring; a.out_ld = n; a.out_rows = Div32((uint32_t)S.ring_rows);
+        }
     }
     S.max_samples = P->sample_every >= kSampleGroup ? (size_t)std::min<int64_t>(4096, S.total_ticks / P->sample_every + 1) : 0;
-    if (S.wave && S.max_samples > 0) S.max_samples = (size_t)std::min<int64_t>(4096, S.n_diags / 8 + 1);     // every eighth launch
+    if (S.wave && S.max_samples > 0) S.max_samples = (size_t)std::min<int64_t>(4096, S.n_diags / 4 + 1);     // every fourth launch
     while (P->ev.size() < 2 * S.max_samples) {
         hipEvent_t e;
         HIPCHK(hipEventCreate(&e));
@@ -1641,66 +1557,49 @@ int session_launch_tick(rr_plan *P, int64_t tau)
     return RR_OK;
 }
 
-typedef void (*wave_kernel_t)(const WaveArgs);
+typedef void (*tile_kernel_t)(const TileArgs);
 
-// Block = threads * ppt positions, halo capacity = threads * hpt.  Two shapes are built:
-//   1024 threads x {1,2} positions (16 waves, latency hidden by occupancy) and
-//    512 threads x {2,4} positions (8 waves, up to 256 VGPRs: latency hidden by the prefetch stages).
-wave_kernel_t wave_kernel(int threads, int ppt, int hpt, bool one, bool unit)
+// Tile = 1,024 threads x {1, 2} positions: 16 waves whose record slots fill the register file.
+tile_kernel_t tile_kernel(int ppt, bool unit, bool sub)
 {
-#define RR_WAVE_PICK(T_, P_, H_)                                                                                    \
-    (unit ? (one ? (wave_kernel_t)k_wave<T_, P_, H_, true, true> : (wave_kernel_t)k_wave<T_, P_, H_, false, true>)   \
-          : (one ? (wave_kernel_t)k_wave<T_, P_, H_, true, false> : (wave_kernel_t)k_wave<T_, P_, H_, false, false>))
-    if (threads == 1024) {
-        if (hpt <= 2) return ppt == 1 ? RR_WAVE_PICK(1024, 1, 2) : RR_WAVE_PICK(1024, 2, 2);
-        return ppt == 1 ? RR_WAVE_PICK(1024, 1, 4) : RR_WAVE_PICK(1024, 2, 4);
-    }
-    if (hpt <= 4) return ppt == 2 ? RR_WAVE_PICK(512, 2, 4) : RR_WAVE_PICK(512, 4, 4);
-    return ppt == 2 ? RR_WAVE_PICK(512, 2, 8) : RR_WAVE_PICK(512, 4, 8);
-#undef RR_WAVE_PICK
+#define RR_TILE_PICK(P_) (unit ? (sub ? (tile_kernel_t)k_tile<1024, P_, true, true> : (tile_kernel_t)k_tile<1024, P_, true, false>)   \
+                               : (sub ? (tile_kernel_t)k_tile<1024, P_, false, true> : (tile_kernel_t)k_tile<1024, P_, false, false>))
+    return ppt == 1 ? RR_TILE_PICK(1) : RR_TILE_PICK(2);
+#undef RR_TILE_PICK
 }
 
-wave_kernel_t wave_rec_kernel(int threads, int ppt, int hpt, bool unit)
-{
-#define RR_REC_PICK(T_, P_, H_) (unit ? (wave_kernel_t)k_wave_rec<T_, P_, H_, true> : (wave_kernel_t)k_wave_rec<T_, P_, H_, false>)
-    if (threads == 1024) {
-        if (hpt <= 2) return ppt == 1 ? RR_REC_PICK(1024, 1, 2) : RR_REC_PICK(1024, 2, 2);
-        return ppt == 1 ? RR_REC_PICK(1024, 1, 4) : RR_REC_PICK(1024, 2, 4);
-    }
-    if (hpt <= 4) return ppt == 2 ? RR_REC_PICK(512, 2, 4) : RR_REC_PICK(512, 4, 4);
-    return ppt == 2 ? RR_REC_PICK(512, 2, 8) : RR_REC_PICK(512, 4, 8);
-#undef RR_REC_PICK
-}
-
-// One anti-diagonal of the time-tiled schedule: tasks (block b, chunk diag - b) for every block whose chunk exists.
+// Launch d of the time-tiled schedule: the tasks (tile, macro-chunk d - level) of every tile whose macro-chunk exists.
+// Tiles are stored by level, so they are one contiguous range; a tile with no active position returns at once.
 int session_launch_diag(rr_plan *P, int64_t d)
 {
     Session &S = P->ses;
-    const int64_t nb = P->wave_nb, K = P->wave_K, n = P->h.n;
-    int64_t b_lo = std::max<int64_t>(0, d - (S.n_chunks - 1)), b_hi = std::min<int64_t>(nb - 1, d);
-    // fill / drain: a block none of whose reaches is active during its chunk has nothing to do (lag is sorted, so the
-    // idle blocks are a suffix while the pipeline fills and a prefix while it drains; history rows they leave
-    // untouched are only ever read by reaches that are inactive themselves)
-    const int64_t bs = (int64_t)P->wave_ppt * P->wave_threads;
-    while (b_hi >= b_lo && (d - b_hi + 1) * K <= P->h.lag[b_hi * bs]) --b_hi;
-    while (b_lo <= b_hi && (d - b_lo) * K >= (int64_t)P->h.lag[std::min(n, (b_lo + 1) * bs) - 1] + S.total) ++b_lo;
-    if (b_hi < b_lo) { ++P->prof_launches; return RR_OK; }
-    WaveArgs &w = S.wa;
-    w.diag = d; w.b_first = (int32_t)b_lo;
-    // every eighth launch is bracketed by HIP events, full or not (fill and drain launches run fewer blocks), so the
+    const rr::TilePlan &TP = P->tp;
+    const int64_t l_lo = std::max<int64_t>(0, d - (S.n_macro - 1)), l_hi = std::min<int64_t>(TP.n_levels - 1, d);
+    if (l_hi < l_lo) { ++P->prof_launches; return RR_OK; }
+    int64_t t_lo = TP.level_start[l_lo], t_hi = TP.level_start[l_hi + 1];
+    // tiles are sorted by their smallest lag inside a level; while the pipeline fills, the tiles of level 0 that
+    // have not started yet are a suffix of it
+    const int64_t K = S.KC * kRec;
+    if (l_lo == 0) {
+        const int64_t end0 = TP.level_start[1];
+        int64_t hi = std::min<int64_t>(t_hi, end0);
+        while (hi > t_lo && (d + 1) * K <= TP.tile_lag_lo[hi - 1]) --hi;
+        if (t_hi <= end0) t_hi = hi;     // only level 0 in this launch: trim; otherwise the idle ones just return
+    }
+    if (t_hi <= t_lo) { ++P->prof_launches; return RR_OK; }
+    TileArgs &w = S.ta;
+    w.diag = (int32_t)d; w.t_first = (int32_t)t_lo;
+    // every fourth launch is bracketed by HIP events, full or not (fill and drain launches run fewer tiles), so the
     // sampled average is the average rocprofv3 reports for the kernel; the reach-ticks of a sample are those of the
-    // blocks it launched
-    const bool sample = S.max_samples > 0 && (P->prof_launches % 8) == 0 && (size_t)P->prof_brackets < S.max_samples;
+    // tiles it launched
+    const bool sample = S.max_samples > 0 && (P->prof_launches % 4) == 0 && (size_t)P->prof_brackets < S.max_samples;
     if (sample) HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets], S.stream));
-    const dim3 g((unsigned)(b_hi - b_lo + 1));
-    const size_t lds_bytes = S.rec ? wave_rec_lds_bytes(P->wave_lh, P->wave_threads, P->wave_ppt) : (size_t)2 * P->wave_lh * sizeof(double);
-    const dim3 t((unsigned)P->wave_threads);
-    wave_kernel_t fn = S.rec ? wave_rec_kernel(P->wave_threads, P->wave_ppt, P->wave_hpt, S.mode == Mode::Unit)
-                             : wave_kernel(P->wave_threads, P->wave_ppt, P->wave_hpt, S.nsub == 1, S.mode == Mode::Unit);
-    hipLaunchKernelGGL(fn, g, t, lds_bytes, S.stream, w);
+    const dim3 g((unsigned)(t_hi - t_lo));
+    const size_t lds_bytes = tile_lds_bytes(P->wave_threads, P->wave_ppt);
+    hipLaunchKernelGGL(tile_kernel(P->wave_ppt, S.mode == Mode::Unit, S.nsub > 1), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
     if (sample) {
         HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));
-        P->ev_reaches.push_back((std::min<int64_t>(n, (b_hi + 1) * bs) - b_lo * bs) * K);
+        P->ev_reaches.push_back((int64_t)(TP.tile_ptr[t_hi] - TP.tile_ptr[t_lo]) * K);
         P->prof_samples += K;
         ++P->prof_brackets;
     }
@@ -1713,93 +1612,86 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
     Session &S = P->ses;
     const int64_t n = P->h.n;
     RecPermArgs ra{};
-    ra.rec = P->d_ring; ra.rec_chunks = Div32((uint32_t)S.rec_chunks); ra.n = n; ra.T = S.T; ra.batch = batch;
+    ra.rec = P->d_ring; ra.rec_chunks = Div32((uint32_t)S.rec_chunks); ra.n = n; ra.np = P->tp.np; ra.T = S.T; ra.total = S.total; ra.batch = batch;
+    ra.nsub = Div32((uint32_t)S.nsub);
     ra.colmeta = P->d_colmeta;
     ra.scale = (in && S.mode == Mode::Rapid) ? P->d_c4_params : nullptr;
     ra.rows = in ? RowView{const_cast<double *>(S.io.dev_in), n, 0, (uint32_t)S.io.rows_in}
-                 : RowView{S.io.dev_out, n, 0, (uint32_t)S.io.rows_out};
+                 : RowView{S.io.dev_out, n, 0, (uint32_t)std::max<int64_t>(1, S.io.rows_out)};
+    ra.rows32 = in ? nullptr : S.io.dev_out32;
+    ra.factor = Div32((uint32_t)std::max<int64_t>(1, S.io.out_factor));
     const dim3 g((unsigned)((n + kRecCols - 1) / kRecCols));
-    if (in) hipLaunchKernelGGL(k_rec_in, g, dim3(kRecThreads), 0, S.stream, ra);
-    else hipLaunchKernelGGL(k_rec_out, g, dim3(kRecThreads), 0, S.stream, ra);
+    const bool sub = S.nsub > 1;
+    if (in) {
+        if (sub) hipLaunchKernelGGL(k_rec_in<true>, g, dim3(kRecThreads), 0, S.stream, ra);
+        else hipLaunchKernelGGL(k_rec_in<false>, g, dim3(kRecThreads), 0, S.stream, ra);
+    } else if (ra.rows32) {
+        if (sub) hipLaunchKernelGGL((k_rec_out<true, true>), g, dim3(kRecThreads), 0, S.stream, ra);
+        else hipLaunchKernelGGL((k_rec_out<false, true>), g, dim3(kRecThreads), 0, S.stream, ra);
+    } else {
+        if (sub) hipLaunchKernelGGL((k_rec_out<true, false>), g, dim3(kRecThreads), 0, S.stream, ra);
+        else hipLaunchKernelGGL((k_rec_out<false, false>), g, dim3(kRecThreads), 0, S.stream, ra);
+    }
 }
 
-int session_advance_wave(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, int64_t *export_ready)
+// Time-tiled schedule: batches of 128 tick-rows become records as soon as their rows are there and their ring slots
+// are free, launches run while their input is present, finished batches leave.
+int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, int64_t *export_ready)
 {
     Session &S = P->ses;
-    const int64_t dmax = P->h.depth - 1, C = std::max<int64_t>(1, P->chunk_rows);
-    const int64_t nb = P->wave_nb, K = P->wave_K;
-    const int64_t rows_per_batch = 16 * kRecBatch;
-    rows_ready = std::min(rows_ready, S.T);
+    const int64_t dmax = P->h.depth - 1, levels = P->tp.n_levels, K = S.KC * kRec;
+    const int64_t ticks_ready = std::min(rows_ready, S.T) * S.nsub;
     for (;;) {
         bool progressed = false;
-        int64_t have_rows;
-        if (S.rec) {
-            // one batch of 64 rows -> records; a record slot is recycled only after every row it can hold has left
-            if (S.in_batches < S.n_in_batches) {
-                const int64_t j = S.in_batches;
-                const int64_t hi = kRecBatch * j + (dmax >> 4) + kRecBatch - 1;
-                const bool rows_here = rows_ready >= std::min(rows_per_batch * (j + 1), S.T);
-                const bool slot_free = hi < S.rec_chunks || S.rows_stored >= std::min(S.T, kRec * (hi - S.rec_chunks + 1));
-                if (rows_here && slot_free) {
-                    launch_rec_permute(P, true, j);
-                    ++S.in_batches;
-                    progressed = true;
-                }
-            }
-            const int64_t loaded = S.in_batches >= S.n_in_batches ? S.T : std::max<int64_t>(0, rows_per_batch * S.in_batches - 15);
-            S.rows_loaded = loaded;
-            have_rows = S.has_in ? loaded : rows_ready;
-        } else {
-            if (S.has_in && S.rows_loaded < rows_ready) {
-                const int64_t r1 = std::min(rows_ready, S.rows_loaded + C);
-                int rc = session_load_rows(P, S.rows_loaded, r1);
-                if (rc) return rc;
-                S.rows_loaded = r1;
+        // one batch of 128 tick-rows -> records; a record slot is recycled only after every tick-row it can hold has left
+        if (S.in_batches < S.n_in_batches) {
+            const int64_t j = S.in_batches;
+            const int64_t hi = kRecBatch * j + (dmax >> 4) + kRecBatch - 1;
+            const bool rows_here = ticks_ready >= std::min(kRecRows * (j + 1), S.total);
+            const bool slot_free = hi < S.rec_chunks || S.ticks_stored >= std::min(S.total, kRec * (hi - S.rec_chunks + 1));
+            if (rows_here && slot_free) {
+                launch_rec_permute(P, true, j);
+                ++S.in_batches;
                 progressed = true;
             }
-            have_rows = S.has_in ? S.rows_loaded : rows_ready;
         }
-        // diagonal d runs chunk d of block 0 (lag 0): ticks below (d+1)*K need rows below ceil((d+1)*K / nsub)
+        const int64_t loaded = S.in_batches >= S.n_in_batches ? S.total : std::max<int64_t>(0, kRecRows * S.in_batches - 15);
+        const int64_t have = S.has_in ? loaded : S.total;
+        S.rows_loaded = have / S.nsub;
+        // launch d runs macro-chunk d of the tiles of level 0: ticks below (d + 1) K need the tick-rows below that
         int64_t launched = 0;
-        const int64_t batch = std::max<int64_t>(1, (S.rec ? rows_per_batch : C) * S.nsub / K);
+        const int64_t batch = std::max<int64_t>(1, kRecRows / K);
         while (S.diag < S.n_diags && launched < batch) {
             const int64_t need_ticks = std::min((S.diag + 1) * K, S.total);
-            if (have_rows < S.T && have_rows * S.nsub < need_ticks) break;
-            // a ghost in block b at lag L is read for sub-steps below (diag - b + 1) * K - L
-            if (P->n_ghost > 0 && ghost_ready < S.total &&
-                ghost_ready < std::min((S.diag + 1) * K - P->wave_ghost_slack, S.total)) break;
+            if (have < need_ticks) break;
+            if (P->n_ghost > 0 && ghost_ready < std::min((S.diag + 1) * K - S.ghost_slack, S.total)) break;
+            // the tasks of this launch overwrite records in place: nothing they write may still be waiting to leave from
+            // one ring revolution earlier (their chunks are at most (d + 1) KC - 1)
+            const int64_t top = std::min(S.diag + 1, S.n_macro) * S.KC - 1;
+            if (top >= S.rec_chunks && S.ticks_stored < std::min(S.total, kRec * (top - S.rec_chunks + 1))) break;
             int rc = session_launch_diag(P, S.diag);
             if (rc) return rc;
             ++S.diag; ++launched;
             progressed = true;
         }
-        // the last block has finished chunk diag - nb; every other block is further along
-        const int64_t c_done = S.diag - nb;   // chunks [0, c_done] complete everywhere
+        // the tiles of the last level have finished macro-chunk diag - levels; every other tile is further along
+        const int64_t m_done = S.diag - levels;
         int64_t done = 0;
-        if (S.diag >= S.n_diags) done = S.T;
-        else if (c_done >= 0) {
-            const int64_t ticks = (c_done + 1) * K;
-            done = ticks - dmax <= 0 ? 0 : (ticks - dmax) / S.nsub;
-        }
-        done = std::min(done, S.T);
-        if (S.rec) {
-            while (S.out_batches < S.n_out_batches && done >= std::min(rows_per_batch * (S.out_batches + 1), S.T)) {
-                launch_rec_permute(P, false, S.out_batches);
-                ++S.out_batches;
-                S.rows_stored = std::min(S.T, rows_per_batch * S.out_batches);
-                progressed = true;
-            }
-        } else if (done > S.rows_stored) {
-            int rc = session_store_rows(P, S.rows_stored, done);
-            if (rc) return rc;
-            S.rows_stored = done;
+        if (S.diag >= S.n_diags) done = S.total;
+        else if (m_done >= 0) done = std::max<int64_t>(0, (m_done + 1) * K - dmax);
+        done = std::min(done, S.total);
+        while (S.out_batches < S.n_out_batches && done >= std::min(kRecRows * (S.out_batches + 1), S.total)) {
+            launch_rec_permute(P, false, S.out_batches);
+            ++S.out_batches;
+            S.ticks_stored = std::min(S.total, kRecRows * S.out_batches);
             progressed = true;
         }
         if (!progressed) break;
     }
+    S.rows_stored = S.ticks_stored / S.nsub;
     if (S.diag >= S.n_diags) S.tau = S.total_ticks;
-    if (export_ready) {   // an export reach in block b at lag L has produced sub-steps below (diag - b) * K - L
-        const int64_t e = S.diag >= S.n_diags ? S.total : S.diag * K - P->wave_export_skew;
+    if (export_ready) {
+        const int64_t e = S.diag >= S.n_diags ? S.total : S.diag * K - S.export_skew;
         *export_ready = std::max<int64_t>(0, std::min(e, S.total));
     }
     return RR_OK;
@@ -1814,7 +1706,7 @@ int session_advance(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, int64_t
     const int64_t n = P->h.n, dmax = P->h.depth - 1, C = std::max<int64_t>(1, P->chunk_rows);
     if (export_ready) *export_ready = 0;
     if (n == 0 || S.total == 0) { if (export_ready) *export_ready = S.total; return RR_OK; }
-    if (S.wave) return session_advance_wave(P, rows_ready, std::min(ghost_ready, S.total), export_ready);
+    if (S.wave) return session_advance_tile(P, rows_ready, std::min(ghost_ready, S.total), export_ready);
     rows_ready = std::min(rows_ready, S.T);
     ghost_ready = std::min(ghost_ready, S.total);
     // a ghost at lag L is read at tick tau for sub-step tau - L: ticks below ghost_ready + min lag are safe
@@ -1869,13 +1761,13 @@ int session_end(rr_plan *P)
     HIPCHK(hipEventRecord(P->ev_last, S.stream));
     HIPCHK(hipGetLastError());
 #ifdef RR_WAVE_TRACE
-    if (S.wave && S.wa.trace) {
+    if (S.wave && S.ta.trace) {
         std::vector<long long> hbuf(8 * 4096);
         (void)hipStreamSynchronize(S.stream);
-        (void)hipMemcpy(hbuf.data(), S.wa.trace, hbuf.size() * 8, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hbuf.data(), S.ta.trace, hbuf.size() * 8, hipMemcpyDeviceToHost);
         if (FILE *f = fopen(getenv("RR_WAVE_TRACE_FILE") ? getenv("RR_WAVE_TRACE_FILE") : "/tmp/wave_trace.txt", "w")) {
             for (int b = 0; b < 4096; ++b)
-                if (hbuf[8 * b]) fprintf(f, "%d %lld %lld %lld %lld %lld\n", b, hbuf[8 * b], hbuf[8 * b + 1], hbuf[8 * b + 2], hbuf[8 * b + 3], hbuf[8 * b + 4]);
+                if (hbuf[8 * b]) fprintf(f, "%d %lld %lld %lld %lld\n", b, hbuf[8 * b], hbuf[8 * b + 1], hbuf[8 * b + 2], hbuf[8 * b + 3]);
             fclose(f);
         }
     }
@@ -1910,11 +1802,9 @@ int launch_state_in(rr_plan *P, Mode mode, const double *d_q, hipStream_t stream
 {
     const int64_t n = P->h.n;
     if (use_wave(P, mode)) {
-        const int64_t hr = wave_hist_rows(P);
-        int rc = ensure_cap(&P->d_hist, &P->hist_cap, hr * n);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_wave_state_in, grid1(n), dim3(kBlock), 0, stream, P->d_sq, P->d_ss, P->d_hist, (int32_t)hr,
-                           d_q, P->d_perm, P->d_child_ptr, (int32_t)n);
+        const int64_t np = P->tp.np;
+        hipLaunchKernelGGL(k_tile_state_in, grid1(np), dim3(kBlock), 0, stream, P->d_sq, P->d_ss, P->d_si, d_q, P->d_tperm,
+                           P->d_cfirst, P->d_ccnt, (int32_t)np);
         return RR_OK;
     }
     hipLaunchKernelGGL(k_state_in, grid1(n), dim3(kBlock), 0, stream, P->d_x, P->d_x + n, P->d_x + 2 * n, d_q,
@@ -1926,7 +1816,7 @@ void launch_state_out(rr_plan *P, Mode mode, double *d_q, int64_t total, hipStre
 {
     const int64_t n = P->h.n;
     if (use_wave(P, mode)) {
-        hipLaunchKernelGGL(k_wave_state_out, grid1(n), dim3(kBlock), 0, stream, d_q, (const double *)P->d_sq, P->d_inv,
+        hipLaunchKernelGGL(k_tile_state_out, grid1(n), dim3(kBlock), 0, stream, d_q, (const double *)P->d_sq, P->d_tinv,
                            (int32_t)n);
         return;
     }
@@ -1934,20 +1824,64 @@ void launch_state_out(rr_plan *P, Mode mode, double *d_q, int64_t total, hipStre
                        P->d_lag, P->d_inv, (int32_t)n, total);
 }
 
-int rapid_like(rr_plan *P, Mode mode, double *q_t, const Rows &io, int64_t T, int64_t nsub, hipStream_t stream,
+// Host-pointer calls whose rows fit on the card are routed as device calls on whole staged arrays (the time-tiled
+// kernel works on device rows); larger ones go through the streaming kernel chunk by chunk.
+struct StagedRows {
+    double *d_in = nullptr, *d_out = nullptr;
+    Rows io;
+    bool active = false;
+    void release() { if (d_in) (void)hipFree(d_in); if (d_out) (void)hipFree(d_out); d_in = d_out = nullptr; }
+};
+
+int stage_host_rows(rr_plan *P, const Rows &io, int64_t T, StagedRows &st, hipStream_t stream)
+{
+    st.io = io;
+    if (!io.host_in && !io.host_out) return RR_OK;
+    const int64_t n = P->h.n;
+    const size_t row_bytes = (size_t)n * sizeof(double), need = (size_t)T * row_bytes * (io.host_in ? 2 : 1);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > free_b / 2) return RR_OK;      // chunked path
+    if (io.host_in && hipMalloc((void **)&st.d_in, (size_t)T * row_bytes) != hipSuccess) { (void)hipGetLastError(); return RR_OK; }
+    if (hipMalloc((void **)&st.d_out, (size_t)T * row_bytes) != hipSuccess) { (void)hipGetLastError(); st.release(); return RR_OK; }
+    if (io.host_in) HIPCHK(hipMemcpyAsync(st.d_in, io.host_in, (size_t)T * row_bytes, hipMemcpyHostToDevice, stream));
+    st.io = Rows();
+    st.io.dev_in = st.d_in; st.io.rows_in = T; st.io.dev_out = st.d_out; st.io.rows_out = T;
+    st.active = true;
+    return RR_OK;
+}
+
+int unstage_host_rows(rr_plan *P, const Rows &io, int64_t T, StagedRows &st, hipStream_t stream, int rc)
+{
+    if (!st.active) return rc;
+    if (rc == RR_OK) {
+        hipError_t e = hipMemcpyAsync(io.host_out, st.d_out, (size_t)T * P->h.n * sizeof(double), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) rc = fail(RR_E_HIP, hipGetErrorString(e));
+    } else {
+        (void)hipStreamSynchronize(stream);
+    }
+    st.release();
+    return rc;
+}
+
+int rapid_like(rr_plan *P, Mode mode, double *q_t, const Rows &io_in, int64_t T, int64_t nsub, hipStream_t stream,
                bool q_on_host)
 {
     const int64_t n = P->h.n;
     if (n == 0 || T == 0) return RR_OK;
-    decide_wave(P, mode, T * nsub);
+    StagedRows st;
+    int rc0 = stage_host_rows(P, io_in, T, st, stream);
+    if (rc0) return rc0;
+    const Rows &io = st.io;
+    decide_wave(P, mode, T * nsub, io.host_in != nullptr || io.host_out != nullptr);
     double *d_q = q_t;
     double *tmp = nullptr;
     if (q_on_host) {
         int rc = dev_alloc(&tmp, n);
-        if (rc) return rc;
+        if (rc) { st.release(); return rc; }
         d_q = tmp;
         hipError_t e = hipMemcpyAsync(d_q, q_t, n * sizeof(double), hipMemcpyHostToDevice, stream);
-        if (e != hipSuccess) { (void)hipFree(tmp); return fail(RR_E_HIP, hipGetErrorString(e)); }
+        if (e != hipSuccess) { (void)hipFree(tmp); st.release(); return fail(RR_E_HIP, hipGetErrorString(e)); }
     }
     int rc = launch_state_in(P, mode, d_q, stream);
     if (rc == RR_OK) rc = route_core(P, mode, T, nsub, io, stream);
@@ -1959,48 +1893,58 @@ int rapid_like(rr_plan *P, Mode mode, double *q_t, const Rows &io, int64_t T, in
             if (e != hipSuccess) rc = fail(RR_E_HIP, hipGetErrorString(e));
         }
     }
+    rc = unstage_host_rows(P, io_in, T, st, stream, rc);
     if (tmp) { (void)hipStreamSynchronize(stream); (void)hipFree(tmp); }
     return rc;
 }
 
-int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io, int64_t T, int64_t nsub,
+int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io_in, int64_t T, int64_t nsub,
               hipStream_t stream, bool q_on_host)
 {
     const int64_t n = P->h.n, ni = (int64_t)P->h.inner_pos.size();
     if (n == 0 || T == 0) return RR_OK;
-    decide_wave(P, Mode::Unit, T * nsub);
+    StagedRows st;
+    int rc0 = stage_host_rows(P, io_in, T, st, stream);
+    if (rc0) return rc0;
+    const Rows &io = st.io;
+    decide_wave(P, Mode::Unit, T * nsub, io.host_in != nullptr || io.host_out != nullptr);
     double *d_qch = q_ch, *d_qfull = q_full, *tmp = nullptr;
     if (q_on_host) {
         int rc = dev_alloc(&tmp, 2 * std::max<int64_t>(ni, 1));
-        if (rc) return rc;
+        if (rc) { st.release(); return rc; }
         d_qch = tmp; d_qfull = tmp + std::max<int64_t>(ni, 1);
         hipError_t e = hipMemcpyAsync(d_qch, q_ch, ni * sizeof(double), hipMemcpyHostToDevice, stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_qfull, q_full, ni * sizeof(double), hipMemcpyHostToDevice, stream);
-        if (e != hipSuccess) { (void)hipFree(tmp); return fail(RR_E_HIP, hipGetErrorString(e)); }
+        if (e != hipSuccess) { (void)hipFree(tmp); st.release(); return fail(RR_E_HIP, hipGetErrorString(e)); }
     }
-    hipError_t e0 = hipMemsetAsync(P->d_x, 0, 3 * n * sizeof(double), stream);
-    if (e0 != hipSuccess) { if (tmp) (void)hipFree(tmp); return fail(RR_E_HIP, hipGetErrorString(e0)); }
-    if (ni > 0)
-        hipLaunchKernelGGL(k_unit_state_in, grid1(ni), dim3(kBlock), 0, stream, P->d_x, P->d_x + n, P->d_x + 2 * n,
-                           P->d_qch, (const double *)d_qch, (const double *)d_qfull, P->d_inner_pos, (int32_t)ni);
     const bool wave = use_wave(P, Mode::Unit);
     int rc = RR_OK;
-    if (wave) {   // d_x[0] now holds q_full in engine order, d_qch the channel discharge
-        const int64_t hr = wave_hist_rows(P);
-        rc = ensure_cap(&P->d_hist, &P->hist_cap, hr * n);
-        if (rc == RR_OK)
-            hipLaunchKernelGGL(k_wave_unit_state_in, grid1(n), dim3(kBlock), 0, stream, P->d_sq, P->d_ss, P->d_qch,
-                               P->d_hist, (int32_t)hr, (const double *)P->d_x, P->d_child_ptr, (int32_t)n);
+    hipError_t e0 = hipSuccess;
+    if (wave) {   // q_full / q_ch scattered to params order (zeros on headwaters), then gathered position by position
+        e0 = hipMemsetAsync(P->d_full, 0, n * sizeof(double), stream);
+        if (e0 == hipSuccess) e0 = hipMemsetAsync(P->d_chan, 0, n * sizeof(double), stream);
+        if (e0 == hipSuccess && ni > 0)
+            hipLaunchKernelGGL(k_unit_scatter, grid1(ni), dim3(kBlock), 0, stream, P->d_full, P->d_chan, (const double *)d_qfull,
+                               (const double *)d_qch, P->d_inner_idx, (int32_t)ni);
+        if (e0 == hipSuccess)
+            hipLaunchKernelGGL(k_tile_unit_state_in, grid1(P->tp.np), dim3(kBlock), 0, stream, P->d_sq, P->d_ss, P->d_si, P->d_sqch,
+                               (const double *)P->d_full, (const double *)P->d_chan, P->d_tperm, P->d_cfirst, P->d_ccnt, (int32_t)P->tp.np);
+    } else {
+        e0 = hipMemsetAsync(P->d_x, 0, 3 * n * sizeof(double), stream);
+        if (e0 == hipSuccess && ni > 0)
+            hipLaunchKernelGGL(k_unit_state_in, grid1(ni), dim3(kBlock), 0, stream, P->d_x, P->d_x + n, P->d_x + 2 * n,
+                               P->d_qch, (const double *)d_qch, (const double *)d_qfull, P->d_inner_pos, (int32_t)ni);
     }
+    if (e0 != hipSuccess) { if (tmp) (void)hipFree(tmp); st.release(); return fail(RR_E_HIP, hipGetErrorString(e0)); }
     if (rc == RR_OK) rc = route_core(P, Mode::Unit, T, nsub, io, stream);
     if (rc == RR_OK && ni > 0) {
         if (wave)
-            hipLaunchKernelGGL(k_wave_unit_state_out, grid1(ni), dim3(kBlock), 0, stream, d_qch, d_qfull,
-                               (const double *)P->d_sq, (const double *)P->d_qch, P->d_inner_pos, (int32_t)ni);
+            hipLaunchKernelGGL(k_tile_unit_state_out, grid1(ni), dim3(kBlock), 0, stream, d_qch, d_qfull,
+                               (const double *)P->d_sq, (const double *)P->d_sqch, P->d_inner_idx, P->d_tinv, (int32_t)ni);
         else
-        hipLaunchKernelGGL(k_unit_state_out, grid1(ni), dim3(kBlock), 0, stream, d_qch, d_qfull,
-                           (const double *)P->d_x, n, (const double *)P->d_qch, P->d_lag, P->d_inner_pos,
-                           (int32_t)ni, T * nsub);
+            hipLaunchKernelGGL(k_unit_state_out, grid1(ni), dim3(kBlock), 0, stream, d_qch, d_qfull,
+                               (const double *)P->d_x, n, (const double *)P->d_qch, P->d_lag, P->d_inner_pos,
+                               (int32_t)ni, T * nsub);
         if (q_on_host) {
             hipError_t e = hipMemcpyAsync(q_ch, d_qch, ni * sizeof(double), hipMemcpyDeviceToHost, stream);
             if (e == hipSuccess) e = hipMemcpyAsync(q_full, d_qfull, ni * sizeof(double), hipMemcpyDeviceToHost, stream);
@@ -2008,6 +1952,7 @@ int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io, int64_t 
             if (e != hipSuccess) rc = fail(RR_E_HIP, hipGetErrorString(e));
         }
     }
+    rc = unstage_host_rows(P, io_in, T, st, stream, rc);
     if (tmp) { (void)hipStreamSynchronize(stream); (void)hipFree(tmp); }
     return rc;
 }
@@ -2085,7 +2030,9 @@ void rr_plan_destroy(rr_plan *P)
     if (!P) return;
     if (P->device >= 0 && hipSetDevice(P->device) == hipSuccess) {
         void *ptrs[] = {P->d_child_ptr, P->d_lag, P->d_perm, P->d_inv, P->d_inner_pos, P->d_bidx, P->d_hwc, P->d_w, P->d_c2,
-                        P->d_c1row, P->d_sq, P->d_ss, P->d_si, P->d_hist, P->d_colmeta, P->d_c4_params,
+                        P->d_c1row, P->d_tc2, P->d_tc3, P->d_sq, P->d_ss, P->d_si, P->d_sqch, P->d_full, P->d_chan, P->d_xrec,
+                        P->d_tile_ptr, P->d_tile_level, P->d_tile_lag_lo, P->d_tile_lag_hi, P->d_tlag, P->d_cfirst, P->d_xpos,
+                        P->d_xdelta, P->d_tperm, P->d_tinv, P->d_tbidx, P->d_inner_idx, P->d_ccnt, P->d_colmeta, P->d_c4_params,
                         P->d_c3, P->d_c4, P->d_x, P->d_isum, P->d_qch, P->d_ring, P->d_stage, P->d_mrows,
                         P->d_slot_a[0], P->d_slot_a[1], P->d_slot_b[0], P->d_slot_b[1], P->d_m_index[0], P->d_m_index[1]};
         for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -2105,36 +2052,20 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
     if (const char *e = getenv("RR_CHUNK_ROWS")) P->chunk_rows = std::max(1, atoi(e));        // tuning knobs
     if (const char *e = getenv("RR_PERM_ROWS_PER_BLOCK")) P->perm_rows_per_block = std::max(1, atoi(e));
     if (const char *e = getenv("RR_WAVE")) { P->wave_enabled = atoi(e) != 0; P->wave_forced = atoi(e) == 1; }
-    if (const char *e = getenv("RR_REC")) P->rec_enabled = atoi(e) != 0;
-    if (const char *e = getenv("RR_WAVE_K")) P->wave_K = std::max(1, atoi(e));
+    if (const char *e = getenv("RR_WAVE_K")) P->wave_K = std::max(kRec, atoi(e) / kRec * kRec);
     std::string err;
     int rc = rr::build_host_plan(n, csc_indptr, csc_indices, P->h, err);
     if (rc) { delete P; return fail(rc, err); }
-    {   // time-tiled schedule: 2,048-position blocks (1,024 for small networks), see wave_kernel()
-        int threads = 1024;
-        if (const char *e = getenv("RR_WAVE_THREADS")) threads = atoi(e) == 512 ? 512 : 1024;
-        int ppt = threads == 1024 ? 2 : 4;
-        if (n <= 256 * 1024) ppt /= 2;
-        if (const char *e = getenv("RR_WAVE_PPT")) {
-            const int v = atoi(e);
-            if ((threads == 1024 && (v == 1 || v == 2)) || (threads == 512 && (v == 2 || v == 4))) ppt = v;
-        }
-        P->wave_threads = threads;
+    {   // time-tiled schedule: tiles of 2,048 positions (1,024 for small networks: more tiles than CUs matter more there)
+        int ppt = n <= 256 * 1024 ? 1 : 2;
+        if (const char *e = getenv("RR_WAVE_PPT")) { const int v = atoi(e); if (v == 1 || v == 2) ppt = v; }
+        P->wave_threads = 1024;
         P->wave_ppt = ppt;
-        const int64_t bs = (int64_t)ppt * threads;
-        P->wave_nb = (n + bs - 1) / bs;
-        int64_t jmax = 0, halo_max = 0;
-        for (int64_t b = 0; b < P->wave_nb; ++b) {
-            const int64_t first_up = std::min<int64_t>(P->h.child_ptr[b * bs], b * bs);
-            jmax = std::max(jmax, b - first_up / bs);
-            halo_max = std::max(halo_max, b * bs - first_up);
-        }
-        P->wave_jmax = jmax;
-        const int small = threads == 1024 ? 2 : 4;     // halo registers per thread: 2,048 or 4,096 positions
-        P->wave_hpt = halo_max <= (int64_t)small * threads ? small : 2 * small;
-        P->wave_lh = bs + std::max<int64_t>(64, (halo_max + 63) / 64 * 64);      // own positions + the widest halo
-        if (halo_max > (int64_t)2 * small * threads) P->wave_enabled = false;   // a level wider than the LDS halo: stream with k_tick
-        if (P->wave_K % 2) ++P->wave_K;
+        int32_t block = ppt * P->wave_threads;
+        if (const char *e = getenv("RR_TILE_BLOCK")) block = std::max(8, std::min(block, atoi(e)));     // tests: many small tiles
+        std::vector<int32_t> lag_of((size_t)n);
+        for (int64_t i = 0; i < n; ++i) lag_of[i] = P->h.lag[P->h.inv[i]];
+        rr::build_tile_plan(P->h.down, lag_of, block, P->tp);
     }
     if (device != RR_DEVICE_NONE) {
         int count = rr_device_count();
@@ -2146,36 +2077,15 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) { delete P; return fail(RR_E_HIP, hipGetErrorString(e)); }
         P->device = device;
-        if (!getenv("RR_WAVE_K") && n > 0) {
-            // The time-tiled schedule keeps (depth + blocks * K) rows of the work ring alive.  Keep that under a
-            // third of the card's memory: shrink K, and below K = 4 stream with k_tick (ring = depth rows only).
+        {
             size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0) {
-                P->dev_total_bytes = total_b;
-                const int64_t budget_rows = (int64_t)(total_b / 3) / (n * (int64_t)sizeof(double));
-                int64_t k = (budget_rows - P->h.depth - 64) / std::max<int64_t>(1, P->wave_nb);
-                k = std::min<int64_t>(P->wave_K, k) & ~(int64_t)1;
-                // record mode needs K = 16 and a ring of (blocks * 16 + 2 depth) ticks; it may take five eighths of
-                // the card (session_begin), which a deep 1M-reach part of a partitioned network needs (152 GB)
-                const int64_t rec_bytes = (((int64_t)P->wave_nb * kRec + 2 * (int64_t)P->h.depth) / kRec + 32) * kRec * n * (int64_t)sizeof(double);
-                if (P->rec_enabled && P->wave_K == kRec && rec_bytes <= (int64_t)(total_b / 8 * 5)) k = kRec;
-                if (k < 4) P->wave_enabled = false; else P->wave_K = k;
-            }
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) P->dev_total_bytes = total_b;
         }
-        for (int v = 0; v < 4; ++v) {   // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
-            hipError_t ea = hipFuncSetAttribute((const void *)wave_kernel(P->wave_threads, P->wave_ppt, P->wave_hpt, (v & 1) != 0, (v & 2) != 0),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                (int)(2 * P->wave_lh * sizeof(double)));
-            if (ea != hipSuccess) P->wave_enabled = false;
-        }
-        // record mode needs its (larger) LDS image to fit the CU: 160 KB minus nothing else resident
-        const size_t rec_lds = wave_rec_lds_bytes(P->wave_lh, P->wave_threads, P->wave_ppt);
-        if (rec_lds > 160 * 1024) P->rec_enabled = false;
-        for (int v = 0; v < 2 && P->rec_enabled; ++v)
-            if (hipFuncSetAttribute((const void *)wave_rec_kernel(P->wave_threads, P->wave_ppt, P->wave_hpt, v != 0),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)rec_lds) != hipSuccess) {
+        for (int v = 0; v < 4; ++v)    // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
+            if (hipFuncSetAttribute((const void *)tile_kernel(P->wave_ppt, (v & 1) != 0, (v & 2) != 0), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)tile_lds_bytes(P->wave_threads, P->wave_ppt)) != hipSuccess) {
                 (void)hipGetLastError();
-                P->rec_enabled = false;
+                P->wave_enabled = false;
             }
         const rr::HostPlan &H = P->h;
         const int64_t ni = (int64_t)H.inner_pos.size();
@@ -2187,16 +2097,51 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         if (!rc) rc = dev_alloc(&P->d_hwc, n);
         if (!rc) rc = dev_alloc(&P->d_bidx, n);
         if (!rc) rc = dev_alloc(&P->d_c4_params, n);
-        if (!rc) rc = dev_alloc(&P->d_colmeta, n);
-        if (!rc) {
+        if (!rc && P->tp.ok) {      // tile layout of the time-tiled kernel
+            const rr::TilePlan &TP = P->tp;
+            const int64_t np = TP.np;
             std::vector<int2> cm(n);
-            for (int64_t i = 0; i < n; ++i) cm[i] = make_int2(H.inv[i], H.lag[H.inv[i]]);
-            rc = dev_upload(P->d_colmeta, cm);
+            for (int64_t i = 0; i < n; ++i) cm[i] = make_int2(TP.inv[i], TP.lag[TP.inv[i]] & kLagMask);
+            std::vector<int32_t> inner_idx;
+            inner_idx.reserve(ni);
+            for (int64_t i = 0; i < n; ++i) if (H.child_ptr[H.inv[i] + 1] > H.child_ptr[H.inv[i]]) inner_idx.push_back((int32_t)i);
+            rc = dev_alloc(&P->d_colmeta, n);
+            if (!rc) rc = dev_upload(P->d_colmeta, cm);
+            if (!rc) rc = dev_alloc(&P->d_inner_idx, ni);
+            if (!rc) rc = dev_upload(P->d_inner_idx, inner_idx);
+            if (!rc) rc = dev_alloc(&P->d_tile_ptr, (int64_t)TP.tile_ptr.size());
+            if (!rc) rc = dev_upload(P->d_tile_ptr, TP.tile_ptr);
+            if (!rc) rc = dev_alloc(&P->d_tile_level, TP.n_tiles);
+            if (!rc) rc = dev_upload(P->d_tile_level, TP.tile_level);
+            if (!rc) rc = dev_alloc(&P->d_tile_lag_lo, TP.n_tiles);
+            if (!rc) rc = dev_upload(P->d_tile_lag_lo, TP.tile_lag_lo);
+            if (!rc) rc = dev_alloc(&P->d_tile_lag_hi, TP.n_tiles);
+            if (!rc) rc = dev_upload(P->d_tile_lag_hi, TP.tile_lag_hi);
+            if (!rc) rc = dev_alloc(&P->d_tlag, np);
+            if (!rc) rc = dev_upload(P->d_tlag, TP.lag);
+            if (!rc) rc = dev_alloc(&P->d_cfirst, np);
+            if (!rc) rc = dev_upload(P->d_cfirst, TP.cfirst);
+            if (!rc) rc = dev_alloc(&P->d_ccnt, np);
+            if (!rc) rc = dev_upload(P->d_ccnt, TP.ccnt);
+            if (!rc) rc = dev_alloc(&P->d_xpos, np);
+            if (!rc) rc = dev_upload(P->d_xpos, TP.xpos);
+            if (!rc) rc = dev_alloc(&P->d_xdelta, np);
+            if (!rc) rc = dev_upload(P->d_xdelta, TP.xdelta);
+            if (!rc) rc = dev_alloc(&P->d_tperm, np);
+            if (!rc) rc = dev_upload(P->d_tperm, TP.perm);
+            if (!rc) rc = dev_alloc(&P->d_tinv, n);
+            if (!rc) rc = dev_upload(P->d_tinv, TP.inv);
+            if (!rc) rc = dev_alloc(&P->d_tbidx, np);
+            if (!rc) rc = dev_alloc(&P->d_c1row, np);
+            if (!rc) rc = dev_alloc(&P->d_tc2, np);
+            if (!rc) rc = dev_alloc(&P->d_tc3, np);
+            if (!rc) rc = dev_alloc(&P->d_sq, np);
+            if (!rc) rc = dev_alloc(&P->d_ss, np);
+            if (!rc) rc = dev_alloc(&P->d_si, np);
+            if (!rc) rc = dev_alloc(&P->d_sqch, np);
+            if (!rc) rc = dev_alloc(&P->d_full, n);
+            if (!rc) rc = dev_alloc(&P->d_chan, n);
         }
-        if (!rc) rc = dev_alloc(&P->d_c1row, n);
-        if (!rc) rc = dev_alloc(&P->d_sq, n);
-        if (!rc) rc = dev_alloc(&P->d_ss, n);
-        if (!rc) rc = dev_alloc(&P->d_si, n);
         if (!rc) rc = dev_alloc(&P->d_w, n);
         if (!rc) rc = dev_alloc(&P->d_c2, n);
         if (!rc) rc = dev_alloc(&P->d_c3, n);
@@ -2283,7 +2228,18 @@ int rr_plan_set_coeffs(rr_plan *P, const double *lhs_off_data, const double *c2,
     }
     P->weights_uniform = uniform;
     rc = dev_upload(P->d_w, w);
-    if (!rc) rc = dev_upload(P->d_c1row, c1row);
+    if (!rc && P->tp.ok) {      // the same in tile order; a ghost computes nothing
+        const rr::TilePlan &TP = P->tp;
+        std::vector<double> t1(TP.np, 0.0), t2(TP.np, 0.0), t3(TP.np, 0.0);
+        for (int64_t p = 0; p < TP.np; ++p) {
+            if (TP.lag[p] & kTileGhostBit) continue;
+            const int32_t i = TP.perm[p];
+            t1[p] = c1row[H.inv[i]]; t2[p] = c2[i]; t3[p] = c3[i];
+        }
+        rc = dev_upload(P->d_c1row, t1);
+        if (!rc) rc = dev_upload(P->d_tc2, t2);
+        if (!rc) rc = dev_upload(P->d_tc3, t3);
+    }
     if (!rc) rc = dev_upload(P->d_c2, a2);
     if (!rc) rc = dev_upload(P->d_c3, a3);
     if (!rc) rc = dev_upload(P->d_c4, a4);
@@ -2336,7 +2292,6 @@ int rr_plan_set_boundary(rr_plan *P, int64_t n_ghost, const int64_t *ghost_reach
         return fail(RR_E_INVALID, "rr_plan_set_boundary: bad argument");
     if (P->ses.open) return fail(RR_E_STATE, "rr_plan_set_boundary: a routing call is open");
     std::vector<int32_t> lag(H.lag), bidx(n, 0);
-    P->ghost_pos.assign(n_ghost, 0);
     int64_t gmin = H.depth, emax = 0;
     for (int64_t g = 0; g < n_ghost; ++g) {
         const int64_t i = ghost_reaches[g];
@@ -2346,7 +2301,6 @@ int rr_plan_set_boundary(rr_plan *P, int64_t n_ghost, const int64_t *ghost_reach
             return fail(RR_E_INVALID, "rr_plan_set_boundary: a ghost reach must be a headwater of this part, listed once");
         lag[p] |= kGhostBit;
         bidx[p] = (int32_t)g;
-        P->ghost_pos[g] = p;
         gmin = std::min<int64_t>(gmin, H.lag[p]);
     }
     for (int64_t e = 0; e < n_export; ++e) {
@@ -2365,13 +2319,17 @@ int rr_plan_set_boundary(rr_plan *P, int64_t n_ghost, const int64_t *ghost_reach
     P->n_ghost = n_ghost; P->n_export = n_export;
     P->ghost_min_lag = n_ghost ? gmin : 0;
     P->export_max_lag = n_export ? emax : 0;
-    {
-        const int64_t bs = (int64_t)P->wave_ppt * P->wave_threads, K = P->wave_K;
-        int64_t slack = (int64_t)H.depth + P->wave_nb * K, skew = 0;
-        for (int64_t g = 0; g < n_ghost; ++g) { const int64_t p = H.inv[ghost_reaches[g]]; slack = std::min(slack, (p / bs) * K + H.lag[p]); }
-        for (int64_t e = 0; e < n_export; ++e) { const int64_t p = H.inv[export_reaches[e]]; skew = std::max(skew, (p / bs) * K + H.lag[p]); }
-        P->wave_ghost_slack = n_ghost ? slack : 0;
-        P->wave_export_skew = n_export ? skew : 0;
+    P->ghost_reach.assign(n_ghost, 0); P->export_reach.assign(n_export, 0);
+    for (int64_t g = 0; g < n_ghost; ++g) P->ghost_reach[g] = (int32_t)ghost_reaches[g];
+    for (int64_t e = 0; e < n_export; ++e) P->export_reach[e] = (int32_t)export_reaches[e];
+    if (P->tp.ok) {      // the same flags and slots in the tile layout
+        const rr::TilePlan &TP = P->tp;
+        std::vector<int32_t> tlag(TP.lag), tbidx(TP.np, 0);
+        for (int64_t g = 0; g < n_ghost; ++g) { const int32_t p = TP.inv[ghost_reaches[g]]; tlag[p] |= kGhostBit; tbidx[p] = (int32_t)g; }
+        for (int64_t e = 0; e < n_export; ++e) { const int32_t p = TP.inv[export_reaches[e]]; tlag[p] |= kExportBit; tbidx[p] = (int32_t)e; }
+        rc = dev_upload(P->d_tlag, tlag);
+        if (!rc) rc = dev_upload(P->d_tbidx, tbidx);
+        if (rc) return rc;
     }
     return RR_OK;
 }
@@ -2387,7 +2345,7 @@ int rr_stream_begin(rr_plan *P, int has_lateral, const double *q_t, const double
     Rows io; io.dev_in = has_lateral ? lateral : nullptr; io.rows_in = lat_rows; io.dev_out = discharge; io.rows_out = out_rows;
     const Mode mode = has_lateral ? Mode::Rapid : Mode::Muskingum;
     if (P->ses.open) return fail(RR_E_STATE, "a routing call is already open on this plan (rr_stream_end it first)");
-    decide_wave(P, mode, T * nsub);
+    decide_wave(P, mode, T * nsub, false);
     if (P->h.n > 0 && T > 0) {
         rc = launch_state_in(P, mode, q_t, (hipStream_t)stream);
         if (rc) return rc;

@@ -1,6 +1,6 @@
-"""The engine has three routing kernels behind one C ABI: the per-tick streaming kernel (k_tick), the time-tiled
-kernel (k_wave, default) and its 512-thread shape.  All must agree with the oracle; the choice is an
-RR_WAVE* environment knob read at plan creation."""
+"""The engine has two routing kernels behind one C ABI: the per-tick streaming kernel (k_tick) and the time-tiled
+kernel over subtree tiles (k_tile, default) in several shapes (positions per thread, ticks per task, tile capacity).
+All must agree with the oracle; the choice is an RR_WAVE* / RR_TILE_BLOCK environment knob read at plan creation."""
 import os
 
 import numpy as np
@@ -20,12 +20,17 @@ def csc_from_down(down_index):
     return indptr, down_index[has].astype(np.int32)
 
 
-@pytest.mark.parametrize('env', [{'RR_WAVE': '0'}, {'RR_WAVE': '1', 'RR_WAVE_K': '4'}, {'RR_WAVE': '1', 'RR_WAVE_K': '16', 'RR_WAVE_PPT': '1'},
-                                 {'RR_WAVE': '1', 'RR_WAVE_THREADS': '512', 'RR_WAVE_K': '6'},
-                                 {'RR_WAVE': '1', 'RR_WAVE_THREADS': '512', 'RR_WAVE_PPT': '2', 'RR_WAVE_K': '32'}])
+KNOBS = ('RR_WAVE', 'RR_WAVE_K', 'RR_WAVE_PPT', 'RR_TILE_BLOCK')
+# tile capacity 64 / 333 on these networks: hundreds of tiles, 10-30 tile levels, thousands of ghosts
+SHAPES = [{'RR_WAVE': '0'}, {'RR_WAVE': '1', 'RR_WAVE_K': '16'}, {'RR_WAVE': '1', 'RR_WAVE_K': '32', 'RR_WAVE_PPT': '2'},
+          {'RR_WAVE': '1', 'RR_TILE_BLOCK': '64', 'RR_WAVE_K': '16'},
+          {'RR_WAVE': '1', 'RR_TILE_BLOCK': '333', 'RR_WAVE_K': '64', 'RR_WAVE_PPT': '2'}]
+
+
+@pytest.mark.parametrize('env', SHAPES)
 @pytest.mark.parametrize('n,T,nsub,has_lateral', [(60000, 70, 1, True), (60000, 23, 3, True), (60000, 31, 2, False)])
 def test_every_kernel_shape_matches_the_oracle(monkeypatch, env, n, T, nsub, has_lateral):
-    for k in ('RR_WAVE', 'RR_WAVE_K', 'RR_WAVE_PPT', 'RR_WAVE_THREADS'):
+    for k in KNOBS:
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -80,14 +85,14 @@ def test_per_edge_weights_fall_back_to_the_streaming_kernel():
     assert_close(d, d_ref, 'discharge')
 
 
-@pytest.mark.parametrize('env', [{'RR_WAVE': '0'}, {'RR_WAVE': '1'}, {}, {'RR_WAVE': '1', 'RR_WAVE_K': '4'}, {'RR_WAVE': '1', 'RR_WAVE_THREADS': '512', 'RR_WAVE_K': '10'}])
+@pytest.mark.parametrize('env', SHAPES + [{}])
 @pytest.mark.parametrize('n,T,nsub,n_ks', [(40000, 50, 1, 48), (40000, 17, 3, 5)])
 def test_unit_route_every_kernel_shape(monkeypatch, env, n, T, nsub, n_ks):
     """UnitMuskingum through the streaming kernel (k_tick_unit) and the time-tiled kernel (k_wave, UNIT) vs the oracle,
     two consecutive files with state hand-off as UnitMuskingum._router does it."""
     from conftest import unit_split
     from river_route_amd.engine import uh_convolve
-    for k in ('RR_WAVE', 'RR_WAVE_K', 'RR_WAVE_PPT', 'RR_WAVE_THREADS'):
+    for k in KNOBS:
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -147,7 +152,7 @@ def _route_vs_oracle(down, T=25, nsub=1, seed=3):
 @pytest.mark.parametrize('wave', ['0', '1'])
 def test_degenerate_network_shapes(monkeypatch, wave):
     """Extremes of the lag pipeline: a single chain (depth = n, every level one reach wide), a star (one level of
-    5,000 tributaries into one outlet: in-degree 5,000, wider than the time-tiled kernel's LDS halo, so it streams),
+    5,000 tributaries into one outlet: in-degree 5,000, more than a tile holds, so it streams),
     unconnected reaches only, and a comb (a main stem with one tributary per reach)."""
     monkeypatch.setenv('RR_WAVE', wave)
     n = 3000
@@ -181,11 +186,11 @@ def _device_route(plan, q0, ql, T, nsub, out_rows=None):
 
 
 def test_degenerate_network_shapes_record_mode(monkeypatch):
-    """The same extremes through the device-resident entry point with the time-tiled kernel forced (record mode): a
-    confluence of 3,000 tributaries (in-degree 3,000: the packed upstream range and a halo wider than a block), a
-    comb, a chain and unconnected reaches."""
+    """The same extremes through the device-resident entry point with the time-tiled kernel forced: a confluence of
+    3,000 tributaries (more upstream reaches than a tile holds: not tileable, streams), a comb (every stem reach has a
+    ghost-free tributary), a chain (every tile of the skeleton one level above the last) and unconnected reaches."""
     monkeypatch.setenv('RR_WAVE', '1')
-    for k in ('RR_WAVE_K', 'RR_WAVE_PPT', 'RR_WAVE_THREADS', 'RR_REC'):
+    for k in KNOBS[1:]:
         monkeypatch.delenv(k, raising=False)
     m = 3000
     fan = np.concatenate([np.full(m, m), m + 1 + np.arange(60)]).astype(np.int64)      # m tributaries -> reach m -> chain
@@ -213,15 +218,14 @@ def test_degenerate_network_shapes_record_mode(monkeypatch):
         assert_close(d, d_ref, f'discharge n={n}')
 
 
-@pytest.mark.parametrize('env', [{'RR_WAVE': '1'}, {}, {'RR_WAVE': '1', 'RR_REC': '0'}, {'RR_WAVE': '0'},
-                                 {'RR_WAVE': '1', 'RR_WAVE_THREADS': '512'}])
+@pytest.mark.parametrize('env', [{'RR_WAVE': '1'}, {}, {'RR_WAVE': '0'}, {'RR_WAVE': '1', 'RR_WAVE_K': '16', 'RR_TILE_BLOCK': '777'}])
 @pytest.mark.parametrize('n,T,ql_rows', [(60000, 100, 100), (60000, 7, 7), (3000, 6000, 48), (60000, 5000, 96),
                                         (300000, 70, 70),      # > 256k reaches: the two-positions-per-thread shapes
                                         (1000000, 80, 80)])    # BASELINE size: the bench's kernel shapes, full oracle comparison
 def test_device_resident_route_record_mode(monkeypatch, env, n, T, ql_rows):
-    """Device arrays in params order (the bench path): record-mode ring + one-pass permutation (default), the
-    row-mode tiled permutation (RR_REC=0) and the streaming kernel, incl. cyclic forcing and ring wrap-around."""
-    for k in ('RR_WAVE', 'RR_WAVE_K', 'RR_WAVE_PPT', 'RR_WAVE_THREADS', 'RR_REC'):
+    """Device arrays in params order (the bench path): record ring + one-pass permutation around the time-tiled kernel
+    (default) and the streaming kernel, incl. cyclic forcing and ring wrap-around."""
+    for k in KNOBS:
         monkeypatch.delenv(k, raising=False)
     for k, v in env.items():
         monkeypatch.setenv(k, v)

@@ -117,7 +117,7 @@ def test_hip_parts_on_one_gpu_match_single_plan(monkeypatch, wave, n, T, nsub, p
     # record mode (k_wave_rec, K = 16; one sub-step per row only)
     monkeypatch.setenv('RR_WAVE', '0' if wave == '0' else '1')
     if wave == '1':
-        monkeypatch.setenv('RR_WAVE_K', '8')
+        monkeypatch.setenv('RR_WAVE_K', '16')
     else:
         monkeypatch.delenv('RR_WAVE_K', raising=False)
     net, indptr, indices, c1, c2, c3, q0 = setup_case(n)
