@@ -1,17 +1,32 @@
-"""Breakdown of one k_wave_rec launch from the per-block timestamps a debug build writes (development aid)."""
-import numpy as np, sys
+"""Per-tile phase breakdown of one k_tile launch from the timestamps a -DRR_WAVE_TRACE build writes (development aid).
+
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DRR_WAVE_TRACE river_route_amd/csrc/rr_plan.cpp \
+        river_route_amd/csrc/rr_engine.hip -o /tmp/librr_trace.so
+    RR_LIB_PATH=/tmp/librr_trace.so RR_WAVE_TRACE_DIAG=300 RR_WAVE_TRACE_FILE=/tmp/t.txt python bench.py --steps 1 --warmup 0 --no-cpu-baseline
+    python profiles/microbench/wave_dbg.py /tmp/t.txt
+"""
+import sys
+import numpy as np
 a = np.loadtxt(sys.argv[1])
-t0 = a[:,1].min()
-a[:,1:6] -= t0
-a[:,1:6] /= 100.0   # us (100 MHz)
-print("blocks", len(a), "launch span us", a[:,5].max())
-start, pre, s1, s8, end = a[:,1], a[:,2], a[:,3], a[:,4], a[:,5]
-def row(name, v):
-    print(f"{name:22s} mean {v.mean():8.2f} p10 {np.percentile(v,10):8.2f} p50 {np.percentile(v,50):8.2f} p90 {np.percentile(v,90):8.2f} max {v.max():8.2f}")
-for name, v in [("start", start), ("setup(start->loop)", pre-start), ("tick0 (rec wait)", s1-pre), ("ticks1-7", s8-s1), ("ticks8-15+state", end-s8), ("total", end-start), ("end", end)]:
-    row(name, v)
-sec = start >= 5
-print("first-round blocks (start<5us):", (~sec).sum(), " second:", sec.sum())
-if sec.any():
-    for name, v in [("R2 start", start[sec]), ("R2 total", (end-start)[sec]), ("R1 total", (end-start)[~sec]), ("R1 setup", (pre-start)[~sec]), ("R2 setup", (pre-start)[sec]), ("R1 tick0", (s1-pre)[~sec]), ("R2 tick0", (s1-pre)[sec]), ("R1 t1-7", (s8-s1)[~sec]), ("R2 t1-7", (s8-s1)[sec]), ("R1 t8-15", (end-s8)[~sec]), ("R2 t8-15", (end-s8)[sec])]:
-        row(name, v)
+t = a[:, 1:15]
+t0 = t[:, 0].min()
+t = (t - t0) / 100.0   # us (100 MHz)
+names = ['start', 'prologue', 'c0 receive A', 'c0 ticks A', 'c0 store A + issue', 'c0 receive B', 'c0 ticks B', 'c0 store B + issue',
+         'c1 receive A', 'c1 ticks A', 'c1 receive B', 'c1 ticks B', 'loop end', 'end']
+print('tiles', len(a), 'launch span us', t[:, 13].max())
+first = t[:, 0] < 5
+print('first round', first.sum(), 'second', (~first).sum())
+for grp, m in (('R1', first), ('R2', ~first)):
+    if not m.any():
+        continue
+    print(grp)
+    prev = t[m, 0]
+    print(f"  {'start':22s} mean {prev.mean():8.2f} max {prev.max():8.2f}")
+    for k in range(1, 14):
+        cur = t[m, k]
+        ok = cur > 0
+        if not ok.any():
+            continue
+        d = (cur - prev)[ok]
+        print(f"  {names[k]:22s} mean {d.mean():8.2f} p10 {np.percentile(d, 10):8.2f} p90 {np.percentile(d, 90):8.2f} max {d.max():8.2f}   (at {cur[ok].mean():8.2f})")
+        prev = np.where(ok, cur, prev)

@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'librr_hip.so')
+LIB_PATH = os.environ.get('RR_LIB_PATH') or os.path.join(_HERE, 'librr_hip.so')      # RR_LIB_PATH: a development build
 CSRC = os.path.join(_HERE, 'csrc')
 SOURCES = ('rr_plan.cpp', 'rr_engine.hip')
 

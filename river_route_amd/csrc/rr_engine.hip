@@ -324,25 +324,21 @@ __global__ __launch_bounds__(kBlock) void k_unit_state_out(double *q_ch, double 
 // Lateral inflow and discharge travel as RECORDS indexed by tick (kRec = 16 ticks, 128 bytes):
 //     rec[(tick / 16) % chunks][position][tick % 16]
 // holding c4dt * lateral on the way in and the clamped discharge on the way out, in place (k_rec_in / k_rec_out move
-// whole records to and from params order).  What a GHOST republishes comes from the export ring
-//     xrec[(tick / 16) % x_chunks][export slot][tick % 16]
-// into which the tile that owns the mirrored reach stores its (unclamped) discharge, 8 bytes per tick.
+// whole records to and from params order).  A GHOST's record slot is written by the tile that owns the mirrored reach
+// (its unclamped discharge, 8 bytes per tick; a ghost has the lag of its reach, so the ticks line up), and the ghost
+// receives its record like any other position and republishes it: no load, wait or branch of its own.
 
 struct TileArgs {
     const int32_t *tile_ptr, *tile_level, *tile_lag_lo, *tile_lag_hi;
-    const int32_t *lag, *cfirst, *xpos, *xdelta;
+    const int32_t *lag, *cfirst, *xpos;
     const uint32_t *ccnt;
     const double *c1row, *c2, *c3;        // c1row: the (uniform) weight of a reach's upstream terms
     double *sq, *ss, *si, *sqch;          // carried state: discharge, sum of upstream discharges one tick back, interval sum, channel discharge
-    const int32_t *bidx;                  // slot of an external ghost / export in its boundary series (multi-GPU)
-    const double *ghost;
+    const int32_t *bidx;                  // slot of an export reach in the boundary series another GPU reads (multi-GPU)
     double *exports;
-    int32_t n_ghost, n_export;
+    int32_t n_export;
     double *rec;                          // record ring [rec_chunks][np][16]
     Div32 rec_chunks;
-    double *xrec;                         // export ring [x_chunks][nx][16]
-    Div32 x_chunks;
-    int32_t nx;
 #ifdef RR_WAVE_TRACE
     long long *trace; int32_t trace_diag;   // development build: per-block timestamps of one launch (profiles/microbench/wave_dbg.py)
 #endif
@@ -430,16 +426,14 @@ __global__ __launch_bounds__(TH) void k_tile(const TileArgs a)
     double *stage = cc3 + BS + (size_t)(tid >> 6) * (kStageLanes * kStageStride);   // this wave's transpose area
 #ifdef RR_WAVE_TRACE
     const bool trace = a.trace && a.diag == a.trace_diag && tid == 0;
-    long long *tq = a.trace + (int64_t)tile * 8;
+    long long *tq = a.trace + (int64_t)tile * 16;
 #define RR_TRACE(i) do { if (trace) tq[i] = wall_clock64(); } while (0)
 #else
 #define RR_TRACE(i) do { } while (0)
 #endif
     RR_TRACE(0);
     auto ring = [&](int32_t chunk) { return make_rsrc(a.rec + (int64_t)a.rec_chunks.mod((uint32_t)chunk) * a.np * kRec, (uint32_t)a.np * 128u); };   // np < 2^25
-    auto xring = [&](int32_t chunk) { return make_rsrc(a.xrec + (int64_t)a.x_chunks.mod((uint32_t)chunk) * a.nx * kRec, (uint32_t)a.nx * 128u); };
     __amdgpu_buffer_rsrc_t rec_cur = ring(m * a.KC);
-    const bool has_ghosts = a.tile_level[tile] > 0;      // level-0 tiles are complete subtrees
 
     // R[k]: the record of the k-th position of this lane.  While a half is in flight its registers hold OTHER lanes' data
     // (the pieces this lane fetched), receive() hands them to their owners.
@@ -477,14 +471,14 @@ __global__ __launch_bounds__(TH) void k_tile(const TileArgs a)
             for (int j = 0; j < 4; ++j) { R[k][8 * half + 2 * j] = mine[j].x; R[k][8 * half + 2 * j + 1] = mine[j].y; }
         }
     };
-    issue_loads(rec_cur, 0, true);
-    issue_loads(rec_cur, 1, true);
-
     // A slot past the end of the tile keeps lag -1: no upstream range, never active, publishes 0.0 to nobody.
     // up[k]: LDS slot of the first upstream value (low 16 bits) and the number of upstream positions (high 16 bits)
     int32_t lg[PPT], up[PPT], xp[PPT], uh[UNIT ? PPT : 1], sub[SUB ? PPT : 1];
     double s_prev[PPT], qch[UNIT ? PPT : 1], isum[SUB ? PPT : 1];
     double *first_buf = lds + (size_t)((tau_begin + 1) & 1) * BS;     // tick tau_begin reads the buffer of tick tau_begin - 1
+    // State and coefficients are requested BEFORE the records: memory operations retire in order, so the wait for
+    // them below leaves the (much larger) record loads in flight.
+    double st_q[PPT], st_c1[PPT], st_c2[PPT], st_c3[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
         const int32_t p = b0 + k * TH + tid;
@@ -494,21 +488,29 @@ __global__ __launch_bounds__(TH) void k_tile(const TileArgs a)
             const uint32_t cc = a.ccnt[p];
             const int32_t first_up = a.cfirst[p] - b0;
             lg[k] = a.lag[p]; up[k] = first_up | (int32_t)((cc & 0xFFFFu) << 16);
-            xp[k] = (lg[k] & (kTileExportBit | kTileGhostBit)) ? a.xpos[p] : 0;
+            xp[k] = a.xpos[p];
             if (UNIT) { uh[k] = first_up + (int32_t)(cc >> 16); qch[k] = a.sqch[p]; }
-            if (SUB) {      // phase of the position's sub-step counter at the first tick of the task
-                const int32_t ts0 = tau_begin - (lg[k] & kLagMask);
-                const uint32_t r = a.nsub.mod((uint32_t)(ts0 < 0 ? -ts0 : ts0));
-                sub[k] = ts0 >= 0 ? (int32_t)r : (r ? (int32_t)(a.nsub.d - r) : 0);
-                isum[k] = a.si[p];
-            }
+            if (SUB) isum[k] = a.si[p];
             s_prev[k] = a.ss[p];
-            first_buf[k * TH + tid] = a.sq[p];
-            cc1[k * TH + tid] = a.c1row[p]; cc2[k * TH + tid] = a.c2[p]; cc3[k * TH + tid] = a.c3[p];
+            st_q[k] = a.sq[p]; st_c1[k] = a.c1row[p]; st_c2[k] = a.c2[p]; st_c3[k] = a.c3[p];
         } else {
             lg[k] = -1; up[k] = 0; xp[k] = 0; s_prev[k] = 0.0;
-            first_buf[k * TH + tid] = 0.0;
-            cc1[k * TH + tid] = cc2[k * TH + tid] = cc3[k * TH + tid] = 0.0;
+            st_q[k] = st_c1[k] = st_c2[k] = st_c3[k] = 0.0;
+        }
+    }
+    issue_loads(rec_cur, 0, true);
+    issue_loads(rec_cur, 1, true);
+    // everything but the 8 * PPT record loads has arrived (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 |
+    // vmcnt[5:4] << 14); a real s_waitcnt, so hipcc knows that no state register is pending inside the tick loop
+    __builtin_amdgcn_s_waitcnt(0x0F70 | ((8 * PPT) & 15) | (((8 * PPT) >> 4) << 14));
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+        first_buf[k * TH + tid] = st_q[k];
+        cc1[k * TH + tid] = st_c1[k]; cc2[k * TH + tid] = st_c2[k]; cc3[k * TH + tid] = st_c3[k];
+        if (SUB && lg[k] >= 0) {      // phase of the position's sub-step counter at the first tick of the task
+            const int32_t ts0 = tau_begin - (lg[k] & kLagMask);
+            const uint32_t r = a.nsub.mod((uint32_t)(ts0 < 0 ? -ts0 : ts0));
+            sub[k] = ts0 >= 0 ? (int32_t)r : (r ? (int32_t)(a.nsub.d - r) : 0);
         }
     }
     const bool has_lat = a.has_lat != 0;   // channel-only routing: the records only carry discharge
@@ -540,34 +542,7 @@ __global__ __launch_bounds__(TH) void k_tile(const TileArgs a)
                 wave_lds_fence();
             }
     };
-    // external boundary inflow (multi-GPU): this half chunk of the ghost series instead of the ring
-    auto external_ghosts = [&](int32_t tau0, int half) {
-#pragma unroll
-        for (int k = 0; k < PPT; ++k)
-            if (lg[k] >= 0 && (lg[k] & kGhostBit)) {
-                const int32_t g = a.bidx[b0 + k * TH + tid];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    int32_t ts = tau0 + 8 * half + j - (lg[k] & kLagMask);
-                    ts = ts < 0 ? 0 : (ts >= total ? total - 1 : ts);
-                    R[k][8 * half + j] = a.ghost[(int64_t)ts * a.n_ghost + g];
-                }
-            }
-    };
-    // what the ghosts republish during this half chunk: the owner computed it xdelta ticks earlier
-    auto tile_ghosts = [&](int32_t tau0, int half) {
-#pragma unroll
-        for (int k = 0; k < PPT; ++k)
-            if (lg[k] >= 0 && (lg[k] & kTileGhostBit)) {
-                const int32_t first = tau0 + 8 * half - a.xdelta[b0 + k * TH + tid];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int32_t tick = first + j < 0 ? 0 : first + j;
-                    R[k][8 * half + j] = a.xrec[((int64_t)a.x_chunks.mod((uint32_t)tick >> 4) * a.nx + xp[k]) * kRec + (tick & 15)];
-                }
-            }
-    };
-    auto ticks = [&](int32_t tau0, int half, __amdgpu_buffer_rsrc_t x_cur) {
+    auto ticks = [&](int32_t tau0, int half) {
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8) {
             const int s = 8 * half + s8;
@@ -623,8 +598,10 @@ __global__ __launch_bounds__(TH) void k_tile(const TileArgs a)
                 if (SUB) sub[k] = sub[k] + 1 == (int32_t)a.nsub.d ? 0 : sub[k] + 1;
                 s_prev[k] = s_cur;
                 wr[k * TH + t] = qk;
-                // a reach mirrored by a ghost of another tile: 8 bytes into its export slot, always issued (see store_f64)
-                store_f64(x_cur, (lgk >= 0 && (lgk & kTileExportBit)) ? (uint32_t)fresh(xp[k]) * 128u + (uint32_t)s * 8u : kDropAccess, qk);
+                // a reach mirrored by a ghost of another tile: 8 bytes into the ghost's record, always issued (see store_f64)
+#ifndef RR_EXPERIMENT_NO_EXPORT
+                store_f64(rec_cur, (lgk >= 0 && (lgk & kTileExportBit)) ? (uint32_t)fresh(xp[k]) * 128u + (uint32_t)s * 8u : kDropAccess, qk);
+#endif
             }
             barrier_lds();
         }
@@ -635,22 +612,28 @@ __global__ __launch_bounds__(TH) void k_tile(const TileArgs a)
     for (int32_t cc = 0; cc < a.KC; ++cc) {
         const int32_t chunk = m * a.KC + cc, tau0 = chunk * kRec;
         const bool more = cc + 1 < a.KC;
-        const __amdgpu_buffer_rsrc_t rec_next = ring(chunk + 1), x_cur = xring(chunk);
+        const __amdgpu_buffer_rsrc_t rec_next = ring(chunk + 1);
         receive(0);
-        if (has_ghosts) tile_ghosts(tau0, 0);
-        external_ghosts(tau0, 0);
-        ticks(tau0, 0, x_cur);
+        if (cc == 0) RR_TRACE(2);
+        if (cc == 1) RR_TRACE(8);
+        ticks(tau0, 0);
+        if (cc == 0) RR_TRACE(3);
+        if (cc == 1) RR_TRACE(9);
         store_half(rec_cur, 0);
         issue_loads(rec_next, 0, more);
+        if (cc == 0) RR_TRACE(4);
         receive(1);
-        if (has_ghosts) tile_ghosts(tau0, 1);
-        external_ghosts(tau0, 1);
-        ticks(tau0, 1, x_cur);
+        if (cc == 0) RR_TRACE(5);
+        if (cc == 1) RR_TRACE(10);
+        ticks(tau0, 1);
+        if (cc == 0) RR_TRACE(6);
+        if (cc == 1) RR_TRACE(11);
         store_half(rec_cur, 1);
         issue_loads(rec_next, 1, more);
+        if (cc == 0) RR_TRACE(7);
         rec_cur = rec_next;
     }
-    RR_TRACE(2);
+    RR_TRACE(12);
     const double *last = lds + (size_t)((tau_begin + a.KC * kRec - 1) & 1) * BS;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
@@ -660,7 +643,7 @@ __global__ __launch_bounds__(TH) void k_tile(const TileArgs a)
         if (UNIT) a.sqch[p] = qch[k];
         if (SUB) a.si[p] = isum[k];
     }
-    RR_TRACE(3);
+    RR_TRACE(13);
 #undef RR_TRACE
 }
 
@@ -1185,10 +1168,10 @@ struct Session {
     TickArgs a{};
     bool wave = false;            // time-tiled k_tile over records instead of per-tick k_tick over rows
     int64_t KC = 1;               // record chunks per task: K = 16 * KC ticks
-    int64_t rec_chunks = 0, x_chunks = 0, in_batches = 0, n_in_batches = 0, out_batches = 0, n_out_batches = 0;
+    int64_t rec_chunks = 0, in_batches = 0, n_in_batches = 0, out_batches = 0, n_out_batches = 0;
     int64_t ticks_stored = 0;     // tick-rows that have left the record ring
     int64_t diag = 0, n_diags = 0, n_macro = 0;
-    int64_t ghost_slack = 0, export_skew = 0;   // external boundary reaches in the time-tiled schedule (level skew included)
+    int64_t export_skew = 0;      // export reaches of a partitioned network in the time-tiled schedule (level skew included)
     TileArgs ta{};
     bool bracket_open = false;
     int64_t bracket_reaches = 0;
@@ -1225,14 +1208,13 @@ struct rr_plan {
     int64_t wave_K = 0;          // ticks per task (multiple of 16); 0 = chosen per call
     int64_t next_KC = 1, next_chunks = 0;   // decide_wave: task length and record ring of the call about to start
     int32_t *d_tile_ptr = nullptr, *d_tile_level = nullptr, *d_tile_lag_lo = nullptr, *d_tile_lag_hi = nullptr;
-    int32_t *d_tlag = nullptr, *d_cfirst = nullptr, *d_xpos = nullptr, *d_xdelta = nullptr, *d_tperm = nullptr, *d_tinv = nullptr;
+    int32_t *d_tlag = nullptr, *d_cfirst = nullptr, *d_xpos = nullptr, *d_tperm = nullptr, *d_tinv = nullptr;
     int32_t *d_tbidx = nullptr, *d_inner_idx = nullptr;
     uint32_t *d_ccnt = nullptr;
     double *d_c1row = nullptr, *d_tc2 = nullptr, *d_tc3 = nullptr, *d_sq = nullptr, *d_ss = nullptr, *d_si = nullptr, *d_sqch = nullptr;
     double *d_full = nullptr, *d_chan = nullptr;   // UnitMuskingum state scattered to params order
-    double *d_xrec = nullptr;    // export ring
-    int64_t xrec_cap = 0;
     int2 *d_colmeta = nullptr;   // per params column {position, lag}
+    int2 *d_ghostmeta = nullptr; // the same per boundary ghost (column of the ghost series)
     double *d_c4_params = nullptr;   // c4dt in params order (scale of the record permutation)
     size_t dev_total_bytes = 0;
 
@@ -1375,37 +1357,28 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         const int64_t K = S.KC * kRec;
         S.n_macro = (S.total_ticks + K - 1) / K;
         S.n_diags = S.n_macro + TP.n_levels - 1;
-        S.n_in_batches = S.has_in ? (S.total + 14) / kRecRows + 1 : 0;
+        S.n_in_batches = (S.has_in || P->n_ghost > 0) ? (S.total + 14) / kRecRows + 1 : 0;
         S.n_out_batches = (S.total + kRecRows - 1) / kRecRows;
-        S.x_chunks = (int64_t)TP.n_levels * S.KC + 4;
-        if (S.x_chunks * std::max<int64_t>(1, TP.n_ghost) * 128 >= (int64_t{1} << 32)) { S.open = false; return fail(RR_E_UNSUPPORTED, "export ring of the tile schedule exceeds 4 GiB"); }
-        rc = ensure_cap(&P->d_xrec, &P->xrec_cap, S.x_chunks * std::max<int64_t>(1, TP.n_ghost) * kRec);
-        if (rc) { S.open = false; return rc; }
-        // external boundary reaches: a ghost in a tile of level l at lag L is read for sub-steps below (diag - l + 1) K - L,
-        // an export reach there has produced the sub-steps below (diag - l) K - L
-        S.ghost_slack = S.total_ticks + (int64_t)TP.n_levels * K; S.export_skew = 0;
-        for (int32_t i : P->ghost_reach) { const int32_t p = TP.inv[i]; S.ghost_slack = std::min<int64_t>(S.ghost_slack, (int64_t)TP.tile_level[TP.tile_of[p]] * K + (TP.lag[p] & kLagMask)); }
+        // external boundary reaches: an export reach in a tile of level l at lag L has produced the sub-steps below (diag - l) K - L
+        S.export_skew = 0;
         for (int32_t i : P->export_reach) { const int32_t p = TP.inv[i]; S.export_skew = std::max<int64_t>(S.export_skew, (int64_t)TP.tile_level[TP.tile_of[p]] * K + (TP.lag[p] & kLagMask)); }
-        if (P->ghost_reach.empty()) S.ghost_slack = 0;
         if (io.dev_out32) {
             const int64_t step = io.out_factor * nsub;
             if (io.out_factor < 1 || kRecRows % step != 0 || T % io.out_factor != 0) { S.open = false; return fail(RR_E_UNSUPPORTED, "float32 output: factor * sub-steps must divide 128 and factor the number of rows"); }
         }
         TileArgs &w = S.ta;
         w.tile_ptr = P->d_tile_ptr; w.tile_level = P->d_tile_level; w.tile_lag_lo = P->d_tile_lag_lo; w.tile_lag_hi = P->d_tile_lag_hi;
-        w.lag = P->d_tlag; w.cfirst = P->d_cfirst; w.xpos = P->d_xpos; w.xdelta = P->d_xdelta; w.ccnt = P->d_ccnt;
+        w.lag = P->d_tlag; w.cfirst = P->d_cfirst; w.xpos = P->d_xpos; w.ccnt = P->d_ccnt;
         w.c1row = P->d_c1row; w.c2 = P->d_tc2; w.c3 = P->d_tc3;
         w.sq = P->d_sq; w.ss = P->d_ss; w.si = P->d_si; w.sqch = P->d_sqch;
-        w.bidx = P->d_tbidx; w.ghost = ghost_series; w.exports = export_series;
-        w.n_ghost = (int32_t)P->n_ghost; w.n_export = (int32_t)P->n_export;
+        w.bidx = P->d_tbidx; w.exports = export_series; w.n_export = (int32_t)P->n_export;
         w.rec = P->d_ring; w.rec_chunks = Div32((uint32_t)S.rec_chunks);
-        w.xrec = P->d_xrec; w.x_chunks = Div32((uint32_t)S.x_chunks); w.nx = (int32_t)std::max<int64_t>(1, TP.n_ghost);
 #ifdef RR_WAVE_TRACE
         w.trace = nullptr; w.trace_diag = -1;
         if (getenv("RR_WAVE_TRACE_DIAG")) {
             static long long *tbuf = nullptr;
-            if (!tbuf) (void)hipMalloc(&tbuf, 8 * 8 * 4096);
-            (void)hipMemset(tbuf, 0, 8 * 8 * 4096);
+            if (!tbuf) (void)hipMalloc(&tbuf, 8 * 16 * 4096);
+            (void)hipMemset(tbuf, 0, 8 * 16 * 4096);
             w.trace = tbuf; w.trace_diag = atoi(getenv("RR_WAVE_TRACE_DIAG"));
         }
 #endif
@@ -1607,6 +1580,19 @@ int session_launch_diag(rr_plan *P, int64_t d)
     return RR_OK;
 }
 
+// Boundary inflow of a partitioned network: the ghost series (total sub-steps x ghosts, row = sub-step) is a matrix of
+// tick-rows like the lateral rows, and its columns become the records of the ghost positions by the same pass.
+void launch_ghost_permute(rr_plan *P, int64_t batch)
+{
+    Session &S = P->ses;
+    RecPermArgs ra{};
+    ra.rec = P->d_ring; ra.rec_chunks = Div32((uint32_t)S.rec_chunks); ra.n = P->n_ghost; ra.np = P->tp.np; ra.T = S.total; ra.total = S.total;
+    ra.batch = batch; ra.nsub = Div32(1u); ra.colmeta = P->d_ghostmeta; ra.scale = nullptr;
+    ra.rows = RowView{const_cast<double *>(S.ghost_series), P->n_ghost, 0, (uint32_t)S.total};
+    ra.factor = Div32(1u);
+    hipLaunchKernelGGL(k_rec_in<false>, dim3((unsigned)((P->n_ghost + kRecCols - 1) / kRecCols)), dim3(kRecThreads), 0, S.stream, ra);
+}
+
 void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
 {
     Session &S = P->ses;
@@ -1647,16 +1633,18 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
         if (S.in_batches < S.n_in_batches) {
             const int64_t j = S.in_batches;
             const int64_t hi = kRecBatch * j + (dmax >> 4) + kRecBatch - 1;
-            const bool rows_here = ticks_ready >= std::min(kRecRows * (j + 1), S.total);
+            const bool rows_here = (!S.has_in || ticks_ready >= std::min(kRecRows * (j + 1), S.total)) &&
+                                   (P->n_ghost == 0 || ghost_ready >= std::min(kRecRows * (j + 1), S.total));
             const bool slot_free = hi < S.rec_chunks || S.ticks_stored >= std::min(S.total, kRec * (hi - S.rec_chunks + 1));
             if (rows_here && slot_free) {
-                launch_rec_permute(P, true, j);
+                if (S.has_in) launch_rec_permute(P, true, j);
+                if (P->n_ghost > 0) launch_ghost_permute(P, j);
                 ++S.in_batches;
                 progressed = true;
             }
         }
         const int64_t loaded = S.in_batches >= S.n_in_batches ? S.total : std::max<int64_t>(0, kRecRows * S.in_batches - 15);
-        const int64_t have = S.has_in ? loaded : S.total;
+        const int64_t have = (S.has_in || P->n_ghost > 0) ? loaded : S.total;
         S.rows_loaded = have / S.nsub;
         // launch d runs macro-chunk d of the tiles of level 0: ticks below (d + 1) K need the tick-rows below that
         int64_t launched = 0;
@@ -1664,7 +1652,6 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
         while (S.diag < S.n_diags && launched < batch) {
             const int64_t need_ticks = std::min((S.diag + 1) * K, S.total);
             if (have < need_ticks) break;
-            if (P->n_ghost > 0 && ghost_ready < std::min((S.diag + 1) * K - S.ghost_slack, S.total)) break;
             // the tasks of this launch overwrite records in place: nothing they write may still be waiting to leave from
             // one ring revolution earlier (their chunks are at most (d + 1) KC - 1)
             const int64_t top = std::min(S.diag + 1, S.n_macro) * S.KC - 1;
@@ -1762,12 +1749,12 @@ int session_end(rr_plan *P)
     HIPCHK(hipGetLastError());
 #ifdef RR_WAVE_TRACE
     if (S.wave && S.ta.trace) {
-        std::vector<long long> hbuf(8 * 4096);
+        std::vector<long long> hbuf(16 * 4096);
         (void)hipStreamSynchronize(S.stream);
         (void)hipMemcpy(hbuf.data(), S.ta.trace, hbuf.size() * 8, hipMemcpyDeviceToHost);
         if (FILE *f = fopen(getenv("RR_WAVE_TRACE_FILE") ? getenv("RR_WAVE_TRACE_FILE") : "/tmp/wave_trace.txt", "w")) {
             for (int b = 0; b < 4096; ++b)
-                if (hbuf[8 * b]) fprintf(f, "%d %lld %lld %lld %lld\n", b, hbuf[8 * b], hbuf[8 * b + 1], hbuf[8 * b + 2], hbuf[8 * b + 3]);
+                if (hbuf[16 * b]) { fprintf(f, "%d", b); for (int k = 0; k < 14; ++k) fprintf(f, " %lld", hbuf[16 * b + k]); fprintf(f, "\n"); }
             fclose(f);
         }
     }
@@ -2030,9 +2017,9 @@ void rr_plan_destroy(rr_plan *P)
     if (!P) return;
     if (P->device >= 0 && hipSetDevice(P->device) == hipSuccess) {
         void *ptrs[] = {P->d_child_ptr, P->d_lag, P->d_perm, P->d_inv, P->d_inner_pos, P->d_bidx, P->d_hwc, P->d_w, P->d_c2,
-                        P->d_c1row, P->d_tc2, P->d_tc3, P->d_sq, P->d_ss, P->d_si, P->d_sqch, P->d_full, P->d_chan, P->d_xrec,
+                        P->d_c1row, P->d_tc2, P->d_tc3, P->d_sq, P->d_ss, P->d_si, P->d_sqch, P->d_full, P->d_chan,
                         P->d_tile_ptr, P->d_tile_level, P->d_tile_lag_lo, P->d_tile_lag_hi, P->d_tlag, P->d_cfirst, P->d_xpos,
-                        P->d_xdelta, P->d_tperm, P->d_tinv, P->d_tbidx, P->d_inner_idx, P->d_ccnt, P->d_colmeta, P->d_c4_params,
+                        P->d_tperm, P->d_tinv, P->d_tbidx, P->d_inner_idx, P->d_ccnt, P->d_colmeta, P->d_ghostmeta, P->d_c4_params,
                         P->d_c3, P->d_c4, P->d_x, P->d_isum, P->d_qch, P->d_ring, P->d_stage, P->d_mrows,
                         P->d_slot_a[0], P->d_slot_a[1], P->d_slot_b[0], P->d_slot_b[1], P->d_m_index[0], P->d_m_index[1]};
         for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -2125,8 +2112,6 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
             if (!rc) rc = dev_upload(P->d_ccnt, TP.ccnt);
             if (!rc) rc = dev_alloc(&P->d_xpos, np);
             if (!rc) rc = dev_upload(P->d_xpos, TP.xpos);
-            if (!rc) rc = dev_alloc(&P->d_xdelta, np);
-            if (!rc) rc = dev_upload(P->d_xdelta, TP.xdelta);
             if (!rc) rc = dev_alloc(&P->d_tperm, np);
             if (!rc) rc = dev_upload(P->d_tperm, TP.perm);
             if (!rc) rc = dev_alloc(&P->d_tinv, n);
@@ -2329,6 +2314,11 @@ int rr_plan_set_boundary(rr_plan *P, int64_t n_ghost, const int64_t *ghost_reach
         for (int64_t e = 0; e < n_export; ++e) { const int32_t p = TP.inv[export_reaches[e]]; tlag[p] |= kExportBit; tbidx[p] = (int32_t)e; }
         rc = dev_upload(P->d_tlag, tlag);
         if (!rc) rc = dev_upload(P->d_tbidx, tbidx);
+        if (P->d_ghostmeta) { (void)hipFree(P->d_ghostmeta); P->d_ghostmeta = nullptr; }
+        std::vector<int2> gm((size_t)n_ghost);
+        for (int64_t g = 0; g < n_ghost; ++g) { const int32_t p = TP.inv[ghost_reaches[g]]; gm[g] = make_int2(p, TP.lag[p] & kLagMask); }
+        if (!rc) rc = dev_alloc(&P->d_ghostmeta, n_ghost);
+        if (!rc) rc = dev_upload(P->d_ghostmeta, gm);
         if (rc) return rc;
     }
     return RR_OK;

@@ -362,12 +362,9 @@ void build_tile_plan(const std::vector<int32_t> &down, const std::vector<int32_t
     T.xpos.assign(T.np, -1);
     T.tile_of.assign(T.np, 0);
     for (int32_t t = 0; t < n_tiles; ++t) for (int32_t p = T.tile_ptr[t]; p < T.tile_ptr[t + 1]; ++p) T.tile_of[p] = t;
-    T.xdelta.assign(T.np, 0);
-    T.ghost_pos = ghost_positions;
-    for (int32_t e = 0; e < (int32_t)ghost_positions.size(); ++e) {
-        const int32_t g = ghost_positions[e], src = T.inv[T.perm[g]];
-        T.xpos[g] = e; T.xpos[src] = e; T.lag[src] |= kTileExport;
-        T.xdelta[g] = (T.lag[g] & (kTileExport - 1)) - (T.lag[src] & (kTileExport - 1));
+    for (int32_t g : ghost_positions) {
+        const int32_t src = T.inv[T.perm[g]];
+        T.xpos[g] = src; T.xpos[src] = g; T.lag[src] |= kTileExport;
     }
     T.ok = true;
 }

@@ -62,8 +62,8 @@ void partition_forest(const std::vector<int32_t> &down, int32_t n_parts, int32_t
 //
 // The time-tiled kernel advances a TILE of at most `block` positions by K routing ticks per launch with everything
 // but the lateral/discharge records resident on chip.  A tile is a set of reaches closed under "upstream within the
-// tile": every upstream reach of a tile reach is either in the tile or is mirrored in it by a GHOST position that
-// republishes what the tile owning the reach has written, tick by tick, into a small EXPORT ring.  Tiles form a
+// tile": every upstream reach of a tile reach is either in the tile or is mirrored in it by a GHOST position whose
+// record the tile that owns the reach writes (one 8-byte store per tick into the ghost's record slot).  Tiles form a
 // DAG; a tile of level l runs chunk c in launch l + c, so the schedule's skew is (levels x K) ticks and no two tasks
 // of one launch depend on each other.
 //   * SMALL subtrees (at most `block` reaches, hanging off a reach with more than that upstream) are complete:
@@ -75,7 +75,7 @@ void partition_forest(const std::vector<int32_t> &down, int32_t n_parts, int32_t
 // Positions of a tile are in breadth-first order from the tile's outlets, so the upstream positions of a position
 // are contiguous: [cfirst[p], cfirst[p] + count), headwater tributaries first (UnitMuskingum needs them apart).
 constexpr int32_t kTileGhost = 1 << 28;    // lag[] flag: position mirrors a reach owned by another tile
-constexpr int32_t kTileExport = 1 << 27;   // lag[] flag: reach is mirrored by a ghost; its values go to export slot xpos[p]
+constexpr int32_t kTileExport = 1 << 27;   // lag[] flag: reach is mirrored by the ghost at position xpos[p]
 struct TilePlan {
     bool ok = false;                 // false: a reach has more upstream reaches than a tile holds (use the streaming kernel)
     int32_t block = 0;               // capacity of a tile in positions
@@ -91,9 +91,7 @@ struct TilePlan {
     std::vector<int32_t> lag;          // [np] lag | kTileGhost | kTileExport
     std::vector<int32_t> cfirst;       // [np] first upstream position
     std::vector<uint32_t> ccnt;        // [np] upstream positions | headwater tributaries among them << 16
-    std::vector<int32_t> xpos;         // [np] export slot (= ordinal of the ghost) of a kTileExport reach and of the kTileGhost that mirrors it; else -1
-    std::vector<int32_t> xdelta;       // [np] kTileGhost: ticks between the owner computing a sub-step and the ghost republishing it
-    std::vector<int32_t> ghost_pos;    // [n_ghost] position of the ghost with export slot e
+    std::vector<int32_t> xpos;         // [np] kTileExport: position of the mirroring ghost; kTileGhost: position of the mirrored reach; else -1
     std::vector<int32_t> tile_of;      // [np]
 };
 // down[i]: downstream reach or -1 (upstream reaches have smaller indices); lag_of[i]: levels between reach i and the
