@@ -78,14 +78,26 @@ int rr_plan_info(const rr_plan *plan, int64_t info[8]);
  * child_ptr[n+1] engine-position range [child_ptr[p], child_ptr[p+1]) of the reaches flowing into p. */
 int rr_plan_layout(const rr_plan *plan, int32_t *perm, int32_t *lag, int32_t *child_ptr);
 
+/* Layout of the time-tiled kernel (subtree tiles), for inspection/tests.
+ * info[0]=1 if the network tiles (else the streaming kernel routes it), [1]=tile capacity in positions, [2]=positions
+ * (reaches + ghosts), [3]=ghosts, [4]=tiles, [5]=tile levels, [6]=threads per workgroup.
+ * rr_plan_tile_layout (any pointer may be NULL): tile_ptr[tiles+1] first position of each tile; tile_level[tiles];
+ * perm[np] params index of the reach at (or mirrored by) each position; lag[np] pipeline lag, bit 28 set on a ghost, bit 27 on
+ * a reach that a ghost of another tile mirrors; cfirst[np] first upstream position; ccnt[np] upstream positions (low 16 bits)
+ * and how many of them are headwaters (high 16 bits, they come first); xpos[np] position of the mirroring ghost / mirrored
+ * reach, -1 elsewhere. */
+int rr_plan_tile_info(const rr_plan *plan, int64_t info[8]);
+int rr_plan_tile_layout(const rr_plan *plan, int32_t *tile_ptr, int32_t *tile_level, int32_t *perm, int32_t *lag,
+                        int32_t *cfirst, uint32_t *ccnt, int32_t *xpos);
+
 /* Coefficients in params order.  lhs_off_data[e] is the off-diagonal of (I - diag(c1) A) for CSC entry e,
  * i.e. -c1[row(e)] (Muskingum.py:192); c2, c3 per reach; c4_dt per reach or NULL (channel-only / unit). */
 int rr_plan_set_coeffs(rr_plan *plan, const double *lhs_off_data, const double *c2, const double *c3,
                        const double *c4_dt);
 
-/* Tuning / measurement.  rows_per_chunk: time rows moved per row-mode permutation launch (default 16).
- * sample_every >= 16: every sample_every-th routing-tick launch opens a HIP-event bracket around 16
- * consecutive routing-tick launches on the call's stream (0 switches sampling off). */
+/* Tuning / measurement.  rows_per_chunk: time rows moved per permutation launch of the streaming kernel (default 16).
+ * sample_every >= 16: HIP-event brackets on the call's stream around sampled routing launches (every fourth launch of the
+ * time-tiled kernel; every sample_every-th tick of the streaming kernel opens a bracket of 16 launches); 0 switches it off. */
 int rr_plan_set_options(rr_plan *plan, int64_t rows_per_chunk, int64_t sample_every);
 
 /* prof[0]=routing launches of the last route call, [1]=routing ticks inside brackets, [2]=sum of the bracket

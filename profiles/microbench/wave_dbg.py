@@ -11,8 +11,8 @@ a = np.loadtxt(sys.argv[1])
 t = a[:, 1:15]
 t0 = t[:, 0].min()
 t = (t - t0) / 100.0   # us (100 MHz)
-names = ['start', 'prologue', 'c0 receive A', 'c0 ticks A', 'c0 store A + issue', 'c0 receive B', 'c0 ticks B', 'c0 store B + issue',
-         'c1 receive A', 'c1 ticks A', 'c1 receive B', 'c1 ticks B', 'loop end', 'end']
+names = ['start', 'prologue (state)', 'first record', 'c0 issue + ticks 0-7', 'c0 store A', '-', 'c0 ticks 8-15', 'c0 store B',
+         'c0 receive next', 'c1 issue + ticks 0-7', '-', 'c1 store A + ticks 8-15', 'rest of the loop', 'state out']
 print('tiles', len(a), 'launch span us', t[:, 13].max())
 first = t[:, 0] < 5
 print('first round', first.sum(), 'second', (~first).sum())

@@ -75,6 +75,8 @@ _SIGNATURES = {
     'rr_plan_destroy': (None, [_vp]),
     'rr_plan_info': (C.c_int, [_vp, _vp]),
     'rr_plan_layout': (C.c_int, [_vp, _vp, _vp, _vp]),
+    'rr_plan_tile_info': (C.c_int, [_vp, _vp]),
+    'rr_plan_tile_layout': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     'rr_plan_set_coeffs': (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     'rr_plan_set_options': (C.c_int, [_vp, _i64, _i64]),
     'rr_plan_profile': (C.c_int, [_vp, _vp]),

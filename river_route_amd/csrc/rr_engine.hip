@@ -75,6 +75,7 @@ struct TickArgs {
     const int32_t *child_ptr;  // [n+1]
     const int32_t *lag;        // [n]
     const double *w;           // [n] c1 of the downstream reach, stored at the UPSTREAM position
+    const double *c1row;       // [n] the same as ONE weight per reach, or NULL when the weights into a reach differ
     const double *c2, *c3, *c4;
     const double *xa;          // values written one tick ago
     const double *xb;          // values written two ticks ago
@@ -114,11 +115,21 @@ __global__ __launch_bounds__(kBlock) void k_tick(const TickArgs a)
     else t = a.nsub.div((uint32_t)ts, s);
 
     const int32_t u0 = a.child_ptr[p], u1 = a.child_ptr[p + 1];
-    double r = a.c3[p] * a.xa[p];
-    if (HAS_LATERAL) r += a.c4[p] * a.in[(int64_t)a.in_rows.mod(t) * a.in_ld + p];
-    const double c2 = a.c2[p];
-    for (int32_t u = u0; u < u1; ++u) r += c2 * a.xb[u];
-    for (int32_t u = u0; u < u1; ++u) r += a.w[u] * a.xa[u];
+    double r;
+    if (a.c1row) {
+        // one upstream weight per reach (what the reference's callers produce): the arithmetic of k_tile, operation for
+        // operation, so a call routed here and one routed there agree bit for bit (split run == joint run)
+        double s_new = 0.0, s_old = 0.0;
+        for (int32_t u = u0; u < u1; ++u) { s_new += a.xa[u]; s_old += a.xb[u]; }
+        const double lat = HAS_LATERAL ? a.c4[p] * a.in[(int64_t)a.in_rows.mod(t) * a.in_ld + p] : 0.0;
+        r = __builtin_fma(a.c1row[p], s_new, __builtin_fma(a.c2[p], s_old, __builtin_fma(a.c3[p], a.xa[p], lat)));
+    } else {
+        r = a.c3[p] * a.xa[p];
+        if (HAS_LATERAL) r += a.c4[p] * a.in[(int64_t)a.in_rows.mod(t) * a.in_ld + p];
+        const double c2 = a.c2[p];
+        for (int32_t u = u0; u < u1; ++u) r += c2 * a.xb[u];
+        for (int32_t u = u0; u < u1; ++u) r += a.w[u] * a.xa[u];
+    }
     if (lag_bits & kExportBit) a.exports[(int64_t)ts * a.n_export + a.bidx[p]] = r;
     a.xc[p] = r;
 
@@ -164,11 +175,19 @@ __global__ __launch_bounds__(kBlock) void k_tick_unit(const UnitTickArgs ua)
         return;
     }
     const int32_t uh = u0 + (int32_t)ua.hw_children[p];
-    double r = a.c3[p] * ua.qch[p];
-    const double c2 = a.c2[p];
-    for (int32_t u = u0; u < uh; ++u) r += c2 * a.xa[u];   // headwater tributaries: "old" value is l_t too
-    for (int32_t u = uh; u < u1; ++u) r += c2 * a.xb[u];
-    for (int32_t u = u0; u < u1; ++u) r += a.w[u] * a.xa[u];
+    double r;
+    if (a.c1row) {      // the arithmetic of k_tile, operation for operation (see k_tick)
+        double s_hw = 0.0, s_new = 0.0, s_old = 0.0;
+        for (int32_t u = u0; u < uh; ++u) s_hw += a.xa[u];   // headwater tributaries: "old" value is l_t too
+        for (int32_t u = uh; u < u1; ++u) { s_new += a.xa[u]; s_old += a.xb[u]; }
+        r = __builtin_fma(a.c1row[p], s_hw + s_new, __builtin_fma(a.c2[p], s_hw + s_old, a.c3[p] * ua.qch[p]));
+    } else {
+        r = a.c3[p] * ua.qch[p];
+        const double c2 = a.c2[p];
+        for (int32_t u = u0; u < uh; ++u) r += c2 * a.xa[u];
+        for (int32_t u = uh; u < u1; ++u) r += c2 * a.xb[u];
+        for (int32_t u = u0; u < u1; ++u) r += a.w[u] * a.xa[u];
+    }
     ua.qch[p] = r;
     const double qfull = r + lat;
     a.xc[p] = qfull;
@@ -342,7 +361,7 @@ struct TileArgs {
 #ifdef RR_WAVE_TRACE
     long long *trace; int32_t trace_diag;   // development build: per-block timestamps of one launch (profiles/microbench/wave_dbg.py)
 #endif
-    int32_t np, t_first, KC, diag, n_macro, total, has_lat;
+    int32_t np, t_last, KC, diag, n_macro, total, has_lat;
     Div32 nsub;
     double inv_nsub;
 };
@@ -397,24 +416,23 @@ constexpr int kStageLanes = 32;    // positions transposed at a time: half a wav
 // Lanes of one wave exchange data through its staging area without a workgroup barrier: a wave's LDS instructions
 // execute in order.  The compiler still has to be told that other lanes wrote (it would reuse earlier reads).
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-// LDS in doubles: X[2][BS] | c1[BS] | c2[BS] | c3[BS] | stage[waves][kStageLanes * kStageStride].  The three
-// coefficients and the own discharge are read from LDS once per tick: the registers go to the records.
-constexpr size_t tile_lds_bytes(int threads, int ppt)
+// LDS in doubles: X[2][TH] | stage[waves][kStageLanes * kStageStride]: the tile's discharges of the last two ticks and the
+// per-wave transpose areas.
+constexpr size_t tile_lds_bytes(int threads)
 {
-    return (size_t)(5 * (int64_t)ppt * threads + (threads / 64) * kStageLanes * kStageStride) * sizeof(double);
+    return (size_t)(2 * (int64_t)threads + (threads / 64) * kStageLanes * kStageStride) * sizeof(double);
 }
 
-// One task: KC record chunks of one tile.  The 16 record slots of a position are registers, used in place (lateral in,
-// discharge out) and in two halves of 8 ticks: as soon as a half has been stored its registers receive the same half
-// of the NEXT chunk, which is in flight during the following 8 ticks, so inside a task HBM and the tick arithmetic
-// overlap and only the first chunk's load is exposed.
-template <int TH, int PPT, bool UNIT, bool SUB>
-__global__ __launch_bounds__(TH) void k_tile(const TileArgs a)
+// One task: KC record chunks of one tile, one position per thread.  R[16] is the record the ticks work on, in place
+// (lateral in, discharge out); N[16] receives the NEXT chunk's record while the 16 ticks of this one run, so inside a task
+// HBM traffic and tick arithmetic overlap and only the first chunk's load is exposed.  Whole 128-byte records are
+// requested at once (a half record would cost the fabric a full line: measured, FETCH_SIZE 1.8x).
+template <int TH, bool UNIT, bool SUB>
+__global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 waves per CU: 1,024 / TH workgroups of 128 VGPRs
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int BS = PPT * TH;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int32_t tile = a.t_first + (int32_t)blockIdx.x;
+    const int32_t tile = a.t_last - (int32_t)blockIdx.x;      // highest level first: the few tiles with ghosts start in the first round
     const int32_t m = a.diag - a.tile_level[tile];
     if (m < 0 || m >= a.n_macro) return;
     const int32_t total = a.total, tau_begin = m * a.KC * kRec;
@@ -422,8 +440,7 @@ __global__ __launch_bounds__(TH) void k_tile(const TileArgs a)
     // the lag of the reach it mirrors, so it is idle exactly when its owner did not write its record
     if (tau_begin >= a.tile_lag_hi[tile] + total || tau_begin + a.KC * kRec <= a.tile_lag_lo[tile]) return;
     const int32_t b0 = a.tile_ptr[tile], b1 = a.tile_ptr[tile + 1];
-    double *cc1 = lds + 2 * BS, *cc2 = cc1 + BS, *cc3 = cc2 + BS;
-    double *stage = cc3 + BS + (size_t)(tid >> 6) * (kStageLanes * kStageStride);   // this wave's transpose area
+    double *stage = lds + 2 * TH + (size_t)(tid >> 6) * (kStageLanes * kStageStride);   // this wave's transpose area
 #ifdef RR_WAVE_TRACE
     const bool trace = a.trace && a.diag == a.trace_diag && tid == 0;
     long long *tq = a.trace + (int64_t)tile * 16;
@@ -435,213 +452,183 @@ __global__ __launch_bounds__(TH) void k_tile(const TileArgs a)
     auto ring = [&](int32_t chunk) { return make_rsrc(a.rec + (int64_t)a.rec_chunks.mod((uint32_t)chunk) * a.np * kRec, (uint32_t)a.np * 128u); };   // np < 2^25
     __amdgpu_buffer_rsrc_t rec_cur = ring(m * a.KC);
 
-    // R[k]: the record of the k-th position of this lane.  While a half is in flight its registers hold OTHER lanes' data
-    // (the pieces this lane fetched), receive() hands them to their owners.
-    double R[PPT][kRec];
-    auto issue_loads = [&](__amdgpu_buffer_rsrc_t src, int half, bool real) {
+    // Four lanes fetch (store) the four 16-byte pieces of one 64-byte sector: in flight a lane's N[] holds OTHER
+    // positions' pieces; receive() hands them to their owners through the wave's staging area.
+    double R[kRec], N[kRec];
+    // load j of a record: (i = j / 2: half wave and group of 16 positions, half = j % 2: which 64-byte sector), so the two
+    // sectors of a 128-byte line are requested by consecutive loads
+    auto issue_load = [&](__amdgpu_buffer_rsrc_t src, int j, bool real) {
         const int32_t t = fresh(tid), ln = t & 63;      // addresses are rebuilt at every use, not kept in registers across the task
-#pragma unroll
-        for (int k = 0; k < PPT; ++k)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {      // i = (half wave, group of 16 positions)
-                const int32_t pos = min(b0 + k * TH + (t - ln) + (i >> 1) * kStageLanes + 16 * (i & 1) + (ln >> 2), b1 - 1);
-                load_f64x2(src, real ? (uint32_t)pos * 128u + (uint32_t)(half * 64 + (ln & 3) * 16) : kDropAccess,
-                           R[k][8 * half + 2 * i], R[k][8 * half + 2 * i + 1]);
-            }
+        const int i = j >> 1, half = j & 1;
+        const int32_t pos = min(b0 + (t - ln) + (i >> 1) * kStageLanes + 16 * (i & 1) + (ln >> 2), b1 - 1);
+        load_f64x2(src, real ? (uint32_t)pos * 128u + (uint32_t)(half * 64 + (ln & 3) * 16) : kDropAccess,
+                   N[8 * half + 2 * i], N[8 * half + 2 * i + 1]);
     };
-    auto receive = [&](int half) {
+    auto receive = [&]() {
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-            double2 mine[4];
+        for (int half = 0; half < 2; ++half)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
 #pragma unroll
                 for (int g = 0; g < 2; ++g)
                     reinterpret_cast<double2 *>(stage + (16 * g + (lane >> 2)) * kStageStride)[lane & 3] =
-                        make_double2(R[k][8 * half + 2 * (2 * h + g)], R[k][8 * half + 2 * (2 * h + g) + 1]);
+                        make_double2(N[8 * half + 2 * (2 * h + g)], N[8 * half + 2 * (2 * h + g) + 1]);
                 wave_lds_fence();
                 if (lane / kStageLanes == h) {
                     const double2 *src = reinterpret_cast<const double2 *>(stage + (lane % kStageLanes) * kStageStride);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) mine[j] = src[j];
+                    for (int j = 0; j < 4; ++j) { const double2 v = src[j]; R[8 * half + 2 * j] = v.x; R[8 * half + 2 * j + 1] = v.y; }
                 }
                 wave_lds_fence();
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { R[k][8 * half + 2 * j] = mine[j].x; R[k][8 * half + 2 * j + 1] = mine[j].y; }
-        }
     };
+
     // A slot past the end of the tile keeps lag -1: no upstream range, never active, publishes 0.0 to nobody.
-    // up[k]: LDS slot of the first upstream value (low 16 bits) and the number of upstream positions (high 16 bits)
-    int32_t lg[PPT], up[PPT], xp[PPT], uh[UNIT ? PPT : 1], sub[SUB ? PPT : 1];
-    double s_prev[PPT], qch[UNIT ? PPT : 1], isum[SUB ? PPT : 1];
-    double *first_buf = lds + (size_t)((tau_begin + 1) & 1) * BS;     // tick tau_begin reads the buffer of tick tau_begin - 1
+    // up: LDS slot of the first upstream value (low 16 bits) and the number of upstream positions (high 16 bits)
+    int32_t lg = -1, up = 0, xp = 0, uh = 0, sub = 0;
+    double c1 = 0.0, c2 = 0.0, c3 = 0.0, s_prev = 0.0, qch = 0.0, isum = 0.0, st_q = 0.0;
+    double *first_buf = lds + (size_t)((tau_begin + 1) & 1) * TH;     // tick tau_begin reads the buffer of tick tau_begin - 1
     // State and coefficients are requested BEFORE the records: memory operations retire in order, so the wait for
     // them below leaves the (much larger) record loads in flight.
-    double st_q[PPT], st_c1[PPT], st_c2[PPT], st_c3[PPT];
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        const int32_t p = b0 + k * TH + tid;
-        if (UNIT) { uh[k] = 0; qch[k] = 0.0; }
-        if (SUB) { sub[k] = 0; isum[k] = 0.0; }
+    {
+        const int32_t p = b0 + tid;
         if (p < b1) {
             const uint32_t cc = a.ccnt[p];
             const int32_t first_up = a.cfirst[p] - b0;
-            lg[k] = a.lag[p]; up[k] = first_up | (int32_t)((cc & 0xFFFFu) << 16);
-            xp[k] = a.xpos[p];
-            if (UNIT) { uh[k] = first_up + (int32_t)(cc >> 16); qch[k] = a.sqch[p]; }
-            if (SUB) isum[k] = a.si[p];
-            s_prev[k] = a.ss[p];
-            st_q[k] = a.sq[p]; st_c1[k] = a.c1row[p]; st_c2[k] = a.c2[p]; st_c3[k] = a.c3[p];
-        } else {
-            lg[k] = -1; up[k] = 0; xp[k] = 0; s_prev[k] = 0.0;
-            st_q[k] = st_c1[k] = st_c2[k] = st_c3[k] = 0.0;
+            lg = a.lag[p]; up = first_up | (int32_t)((cc & 0xFFFFu) << 16);
+            xp = a.xpos[p];
+            if (UNIT) { uh = first_up + (int32_t)(cc >> 16); qch = a.sqch[p]; }
+            if (SUB) isum = a.si[p];
+            s_prev = a.ss[p];
+            st_q = a.sq[p]; c1 = a.c1row[p]; c2 = a.c2[p]; c3 = a.c3[p];
         }
     }
-    issue_loads(rec_cur, 0, true);
-    issue_loads(rec_cur, 1, true);
-    // everything but the 8 * PPT record loads has arrived (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 |
-    // vmcnt[5:4] << 14); a real s_waitcnt, so hipcc knows that no state register is pending inside the tick loop
-    __builtin_amdgcn_s_waitcnt(0x0F70 | ((8 * PPT) & 15) | (((8 * PPT) >> 4) << 14));
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        first_buf[k * TH + tid] = st_q[k];
-        cc1[k * TH + tid] = st_c1[k]; cc2[k * TH + tid] = st_c2[k]; cc3[k * TH + tid] = st_c3[k];
-        if (SUB && lg[k] >= 0) {      // phase of the position's sub-step counter at the first tick of the task
-            const int32_t ts0 = tau_begin - (lg[k] & kLagMask);
-            const uint32_t r = a.nsub.mod((uint32_t)(ts0 < 0 ? -ts0 : ts0));
-            sub[k] = ts0 >= 0 ? (int32_t)r : (r ? (int32_t)(a.nsub.d - r) : 0);
-        }
+    for (int j = 0; j < 8; ++j) issue_load(rec_cur, j, true);
+    // everything but the 8 record loads has arrived (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 |
+    // vmcnt[5:4] << 14); a real s_waitcnt, so hipcc knows that no state register is pending inside the tick loop
+    __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
+    first_buf[tid] = st_q;
+    if (SUB && lg >= 0) {      // phase of the position's sub-step counter at the first tick of the task
+        const int32_t ts0 = tau_begin - (lg & kLagMask);
+        const uint32_t r = a.nsub.mod((uint32_t)(ts0 < 0 ? -ts0 : ts0));
+        sub = ts0 >= 0 ? (int32_t)r : (r ? (int32_t)(a.nsub.d - r) : 0);
     }
     const bool has_lat = a.has_lat != 0;   // channel-only routing: the records only carry discharge
 
-    // Eight slots of every record are final: write that 64-byte sector.  Half a wave at a time parks its sectors in
+    // Eight slots of the record are final: write that 64-byte sector.  Half a wave at a time parks its sectors in
     // the wave's staging area, then all 64 lanes store them, four lanes per sector.
     auto store_half = [&](__amdgpu_buffer_rsrc_t dst, int half) {
 #pragma unroll
-        for (int k = 0; k < PPT; ++k)
+        for (int h = 0; h < 2; ++h) {
+            if (lane / kStageLanes == h) {
+                double2 *mine = reinterpret_cast<double2 *>(stage + (lane % kStageLanes) * kStageStride);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (lane / kStageLanes == h) {
-                    double2 *mine = reinterpret_cast<double2 *>(stage + (lane % kStageLanes) * kStageStride);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) mine[j] = make_double2(R[k][8 * half + 2 * j], R[k][8 * half + 2 * j + 1]);
-                    reinterpret_cast<int32_t *>(mine + 4)[0] = (lg[k] < 0 || (lg[k] & (kGhostBit | kTileGhostBit))) ? 1 : 0;   // not this tile's to write
-                }
-                wave_lds_fence();
-                const int32_t t = fresh(tid), ln = t & 63;
-                const uint32_t first = (uint32_t)(b0 + k * TH + (t - ln) + h * kStageLanes) * 128u + (uint32_t)half * 64u;
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {       // lanes 4i .. 4i+3: the four 16-byte pieces of position 16 g + i
-                    const int pm = 16 * g + (ln >> 2), piece = ln & 3;
-                    const double2 *theirs = reinterpret_cast<const double2 *>(stage + pm * kStageStride);
-                    const double2 v = theirs[piece];
-                    const bool skip = reinterpret_cast<const int32_t *>(theirs + 4)[0] != 0;
-                    store_f64x2(dst, skip ? kDropAccess : first + (uint32_t)pm * 128u + (uint32_t)piece * 16u, v);
-                }
-                wave_lds_fence();
+                for (int j = 0; j < 4; ++j) mine[j] = make_double2(R[8 * half + 2 * j], R[8 * half + 2 * j + 1]);
+                reinterpret_cast<int32_t *>(mine + 4)[0] = (lg < 0 || (lg & (kGhostBit | kTileGhostBit))) ? 1 : 0;   // not this tile's to write
             }
+            wave_lds_fence();
+            const int32_t t = fresh(tid), ln = t & 63;
+            const uint32_t first = (uint32_t)(b0 + (t - ln) + h * kStageLanes) * 128u + (uint32_t)half * 64u;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {       // lanes 4i .. 4i+3: the four 16-byte pieces of position 16 g + i
+                const int pm = 16 * g + (ln >> 2), piece = ln & 3;
+                const double2 *theirs = reinterpret_cast<const double2 *>(stage + pm * kStageStride);
+                const double2 v = theirs[piece];
+                const bool skip = reinterpret_cast<const int32_t *>(theirs + 4)[0] != 0;
+                store_f64x2(dst, skip ? kDropAccess : first + (uint32_t)pm * 128u + (uint32_t)piece * 16u, v);
+            }
+            wave_lds_fence();
+        }
     };
-    auto ticks = [&](int32_t tau0, int half) {
+    auto ticks = [&](int32_t tau0, int half, __amdgpu_buffer_rsrc_t rec_next, bool more) {
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8) {
             const int s = 8 * half + s8;
+            // the next chunk's record is requested one load per tick: a CU accepts only so many requests at a time, and a
+            // wave that waits to issue its loads cannot tick
+            if (half == 0) issue_load(rec_next, s8, more);
             const int32_t tau = tau0 + s;
-            const double *rd = lds + (size_t)((tau + 1) & 1) * BS;
-            double *wr = lds + (size_t)(tau & 1) * BS;
-            const int32_t t = fresh(tid);       // slot and offset arithmetic is redone per tick, not held in registers
-#pragma unroll
-            for (int k = 0; k < PPT; ++k) {
-                const int32_t lgk = fresh(lg[k]), upk = fresh(up[k]);
-                const int32_t u0 = upk & 0xFFFF, u1 = u0 + (int32_t)((uint32_t)upk >> 16);
-                double qk = rd[k * TH + t];       // own discharge one tick back
-                const double c1 = cc1[k * TH + t], c2 = cc2[k * TH + t], c3 = cc3[k * TH + t];
-                double s_cur = 0.0, s_hw = 0.0;
-                if (UNIT) {   // headwater tributaries come first in the upstream range
-                    for (int32_t u = u0; u < uh[k]; ++u) s_hw += rd[u];
-                    for (int32_t u = uh[k]; u < u1; ++u) s_cur += rd[u];
-                } else {
-                    for (int32_t u = u0; u < u1; ++u) s_cur += rd[u];
-                }
-                const int32_t ts = tau - (lgk & kLagMask);
-                if (ts >= 0 && ts < total) {
-                    const double lat = has_lat ? R[k][s] : 0.0;
-                    double outv = 0.0;
-                    bool routed = false;
-                    if (lgk & (kGhostBit | kTileGhostBit)) {
-                        qk = R[k][s];        // a ghost republishes what its owner computed
-                    } else if (UNIT) {
-                        if (u0 == u1) {
-                            qk = lat;        // headwater: discharge = lateral, the record slot already holds it (unclamped, un-averaged)
-                        } else {
-                            const double r = __builtin_fma(c1, s_hw + s_cur, __builtin_fma(c2, s_hw + s_prev[k], c3 * qch[k]));
-                            qch[k] = r;
-                            qk = r + lat;
-                            outv = qk; routed = true;
-                        }
-                    } else {
-                        // explicit fma: every copy of this tick must round identically (split run == joint run)
-                        qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev[k], __builtin_fma(c3, qk, lat)));
-                        outv = qk; routed = true;
-                        if (lgk & kExportBit) a.exports[(int64_t)ts * a.n_export + a.bidx[b0 + k * TH + t]] = qk;
-                    }
-                    if (routed) {
-                        if (SUB) {      // mean over the sub-steps of a row, written to the slot of the row's last sub-step
-                            const double acc = (sub[k] == 0 ? 0.0 : isum[k]) + outv;
-                            isum[k] = acc;
-                            if (sub[k] + 1 == (int32_t)a.nsub.d) { const double v = acc * a.inv_nsub; R[k][s] = v > 0.0 ? v : 0.0; }
-                        } else {
-                            R[k][s] = outv > 0.0 ? outv : 0.0;
-                        }
-                    }
-                }
-                if (SUB) sub[k] = sub[k] + 1 == (int32_t)a.nsub.d ? 0 : sub[k] + 1;
-                s_prev[k] = s_cur;
-                wr[k * TH + t] = qk;
-                // a reach mirrored by a ghost of another tile: 8 bytes into the ghost's record, always issued (see store_f64)
-#ifndef RR_EXPERIMENT_NO_EXPORT
-                store_f64(rec_cur, (lgk >= 0 && (lgk & kTileExportBit)) ? (uint32_t)fresh(xp[k]) * 128u + (uint32_t)s * 8u : kDropAccess, qk);
-#endif
+            const double *rd = lds + (size_t)((tau + 1) & 1) * TH;
+            double *wr = lds + (size_t)(tau & 1) * TH;
+            const int32_t t = fresh(tid), lgk = fresh(lg), upk = fresh(up);
+            const int32_t u0 = upk & 0xFFFF, u1 = u0 + (int32_t)((uint32_t)upk >> 16);
+            double qk = rd[t];       // own discharge one tick back
+            double s_cur = 0.0, s_hw = 0.0;
+            if (UNIT) {   // headwater tributaries come first in the upstream range
+                for (int32_t u = u0; u < uh; ++u) s_hw += rd[u];
+                for (int32_t u = uh; u < u1; ++u) s_cur += rd[u];
+            } else {
+                for (int32_t u = u0; u < u1; ++u) s_cur += rd[u];
             }
+            const int32_t ts = tau - (lgk & kLagMask);
+            if (ts >= 0 && ts < total) {
+                const double lat = has_lat ? R[s] : 0.0;
+                double outv = 0.0;
+                bool routed = false;
+                if (lgk & (kGhostBit | kTileGhostBit)) {
+                    qk = R[s];        // a ghost republishes what its owner computed
+                } else if (UNIT) {
+                    if (u0 == u1) {
+                        qk = lat;        // headwater: discharge = lateral, the record slot already holds it (unclamped, un-averaged)
+                    } else {
+                        const double r = __builtin_fma(c1, s_hw + s_cur, __builtin_fma(c2, s_hw + s_prev, c3 * qch));
+                        qch = r;
+                        qk = r + lat;
+                        outv = qk; routed = true;
+                    }
+                } else {
+                    // explicit fma: every copy of this tick must round identically (split run == joint run)
+                    qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev, __builtin_fma(c3, qk, lat)));
+                    outv = qk; routed = true;
+                    if (lgk & kExportBit) a.exports[(int64_t)ts * a.n_export + a.bidx[b0 + t]] = qk;
+                }
+                if (routed) {
+                    if (SUB) {      // mean over the sub-steps of a row, written to the slot of the row's last sub-step
+                        const double acc = (sub == 0 ? 0.0 : isum) + outv;
+                        isum = acc;
+                        if (sub + 1 == (int32_t)a.nsub.d) { const double v = acc * a.inv_nsub; R[s] = v > 0.0 ? v : 0.0; }
+                    } else {
+                        R[s] = outv > 0.0 ? outv : 0.0;
+                    }
+                }
+            }
+            if (SUB) sub = sub + 1 == (int32_t)a.nsub.d ? 0 : sub + 1;
+            s_prev = s_cur;
+            wr[t] = qk;
+            // a reach mirrored by a ghost of another tile: 8 bytes into the ghost's record, always issued (see store_f64)
+            store_f64(rec_cur, (lgk >= 0 && (lgk & kTileExportBit)) ? (uint32_t)fresh(xp) * 128u + (uint32_t)s * 8u : kDropAccess, qk);
             barrier_lds();
         }
     };
 
-    barrier_lds();      // first_buf and the coefficients are in place
+    barrier_lds();      // first_buf is in place
     RR_TRACE(1);
+    receive();          // the first chunk's record: the only load nothing overlaps
+    RR_TRACE(2);
     for (int32_t cc = 0; cc < a.KC; ++cc) {
         const int32_t chunk = m * a.KC + cc, tau0 = chunk * kRec;
-        const bool more = cc + 1 < a.KC;
         const __amdgpu_buffer_rsrc_t rec_next = ring(chunk + 1);
-        receive(0);
-        if (cc == 0) RR_TRACE(2);
-        if (cc == 1) RR_TRACE(8);
-        ticks(tau0, 0);
+        ticks(tau0, 0, rec_next, cc + 1 < a.KC);
         if (cc == 0) RR_TRACE(3);
         if (cc == 1) RR_TRACE(9);
         store_half(rec_cur, 0);
-        issue_loads(rec_next, 0, more);
         if (cc == 0) RR_TRACE(4);
-        receive(1);
-        if (cc == 0) RR_TRACE(5);
-        if (cc == 1) RR_TRACE(10);
-        ticks(tau0, 1);
+        ticks(tau0, 1, rec_next, false);
         if (cc == 0) RR_TRACE(6);
         if (cc == 1) RR_TRACE(11);
         store_half(rec_cur, 1);
-        issue_loads(rec_next, 1, more);
         if (cc == 0) RR_TRACE(7);
+        receive();      // the next chunk's record has had 16 ticks to arrive (zeros after the last chunk)
+        if (cc == 0) RR_TRACE(8);
         rec_cur = rec_next;
     }
     RR_TRACE(12);
-    const double *last = lds + (size_t)((tau_begin + a.KC * kRec - 1) & 1) * BS;
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) {
-        if (lg[k] < 0) continue;
-        const int32_t p = b0 + k * TH + tid;
-        a.sq[p] = last[k * TH + tid]; a.ss[p] = s_prev[k];
-        if (UNIT) a.sqch[p] = qch[k];
-        if (SUB) a.si[p] = isum[k];
+    if (lg >= 0) {
+        const int32_t p = b0 + tid;
+        a.sq[p] = lds[(size_t)((tau_begin + a.KC * kRec - 1) & 1) * TH + tid]; a.ss[p] = s_prev;
+        if (UNIT) a.sqch[p] = qch;
+        if (SUB) a.si[p] = isum;
     }
     RR_TRACE(13);
 #undef RR_TRACE
@@ -1188,7 +1175,7 @@ struct rr_plan {
     int32_t *d_child_ptr = nullptr, *d_lag = nullptr, *d_perm = nullptr, *d_inv = nullptr, *d_inner_pos = nullptr;
     int32_t *d_bidx = nullptr;   // ghost / export slot of flagged positions
     uint16_t *d_hwc = nullptr;
-    double *d_w = nullptr, *d_c2 = nullptr, *d_c3 = nullptr, *d_c4 = nullptr;
+    double *d_w = nullptr, *d_c1row_h = nullptr, *d_c2 = nullptr, *d_c3 = nullptr, *d_c4 = nullptr;
     double *d_x = nullptr, *d_isum = nullptr, *d_qch = nullptr;
     double *d_ring = nullptr;
     int64_t ring_cap = 0;  // doubles
@@ -1389,7 +1376,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         fprintf(stderr, "rr: n=%lld T=%lld nsub=%lld tiled=%d K=%lld tiles=%d levels=%d block=%d ghosts=%lld ring_chunks=%lld (%.1f GB) lds=%zu\n",
                 (long long)n, (long long)T, (long long)nsub, (int)S.wave, (long long)(S.KC * kRec), P->tp.n_tiles, P->tp.n_levels, P->tp.block,
                 (long long)P->tp.n_ghost, (long long)S.rec_chunks, S.wave ? (double)S.rec_chunks * kRec * P->tp.np * 8 / 1e9 : 0.0,
-                tile_lds_bytes(P->wave_threads, P->wave_ppt));
+                tile_lds_bytes(P->wave_threads));
     if (!S.wave) {
         // work ring in engine order: lateral rows come in, discharge rows overwrite them in place; rows stay until the
         // outlet-most reaches have passed them
@@ -1403,6 +1390,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         if (rc) { S.open = false; return rc; }
         TickArgs &a = S.a;
         a.child_ptr = P->d_child_ptr; a.lag = P->d_lag; a.w = P->d_w; a.c2 = P->d_c2; a.c3 = P->d_c3; a.c4 = P->d_c4;
+        a.c1row = P->weights_uniform ? P->d_c1row_h : nullptr;
         a.isum = P->d_isum; a.bidx = P->d_bidx;
         a.ghost = ghost_series; a.exports = export_series; a.n_ghost = (int32_t)P->n_ghost; a.n_export = (int32_t)P->n_export;
         a.total_substeps = S.total; a.nsub = Div32((uint32_t)nsub); a.inv_nsub = 1.0 / (double)nsub;
@@ -1532,12 +1520,12 @@ int session_launch_tick(rr_plan *P, int64_t tau)
 
 typedef void (*tile_kernel_t)(const TileArgs);
 
-// Tile = 1,024 threads x {1, 2} positions: 16 waves whose record slots fill the register file.
-tile_kernel_t tile_kernel(int ppt, bool unit, bool sub)
+// Tile = one position per thread; 16 waves per CU whose two record buffers fill the register file, as 1, 2 or 4 workgroups.
+tile_kernel_t tile_kernel(int threads, bool unit, bool sub)
 {
-#define RR_TILE_PICK(P_) (unit ? (sub ? (tile_kernel_t)k_tile<1024, P_, true, true> : (tile_kernel_t)k_tile<1024, P_, true, false>)   \
-                               : (sub ? (tile_kernel_t)k_tile<1024, P_, false, true> : (tile_kernel_t)k_tile<1024, P_, false, false>))
-    return ppt == 1 ? RR_TILE_PICK(1) : RR_TILE_PICK(2);
+#define RR_TILE_PICK(T_) (unit ? (sub ? (tile_kernel_t)k_tile<T_, true, true> : (tile_kernel_t)k_tile<T_, true, false>)   \
+                               : (sub ? (tile_kernel_t)k_tile<T_, false, true> : (tile_kernel_t)k_tile<T_, false, false>))
+    return threads == 256 ? RR_TILE_PICK(256) : (threads == 512 ? RR_TILE_PICK(512) : RR_TILE_PICK(1024));
 #undef RR_TILE_PICK
 }
 
@@ -1561,15 +1549,15 @@ int session_launch_diag(rr_plan *P, int64_t d)
     }
     if (t_hi <= t_lo) { ++P->prof_launches; return RR_OK; }
     TileArgs &w = S.ta;
-    w.diag = (int32_t)d; w.t_first = (int32_t)t_lo;
+    w.diag = (int32_t)d; w.t_last = (int32_t)t_hi - 1;
     // every fourth launch is bracketed by HIP events, full or not (fill and drain launches run fewer tiles), so the
     // sampled average is the average rocprofv3 reports for the kernel; the reach-ticks of a sample are those of the
     // tiles it launched
     const bool sample = S.max_samples > 0 && (P->prof_launches % 4) == 0 && (size_t)P->prof_brackets < S.max_samples;
     if (sample) HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets], S.stream));
     const dim3 g((unsigned)(t_hi - t_lo));
-    const size_t lds_bytes = tile_lds_bytes(P->wave_threads, P->wave_ppt);
-    hipLaunchKernelGGL(tile_kernel(P->wave_ppt, S.mode == Mode::Unit, S.nsub > 1), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
+    const size_t lds_bytes = tile_lds_bytes(P->wave_threads);
+    hipLaunchKernelGGL(tile_kernel(P->wave_threads, S.mode == Mode::Unit, S.nsub > 1), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
     if (sample) {
         HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));
         P->ev_reaches.push_back((int64_t)(TP.tile_ptr[t_hi] - TP.tile_ptr[t_lo]) * K);
@@ -2016,7 +2004,7 @@ void rr_plan_destroy(rr_plan *P)
 {
     if (!P) return;
     if (P->device >= 0 && hipSetDevice(P->device) == hipSuccess) {
-        void *ptrs[] = {P->d_child_ptr, P->d_lag, P->d_perm, P->d_inv, P->d_inner_pos, P->d_bidx, P->d_hwc, P->d_w, P->d_c2,
+        void *ptrs[] = {P->d_child_ptr, P->d_lag, P->d_perm, P->d_inv, P->d_inner_pos, P->d_bidx, P->d_hwc, P->d_w, P->d_c1row_h, P->d_c2,
                         P->d_c1row, P->d_tc2, P->d_tc3, P->d_sq, P->d_ss, P->d_si, P->d_sqch, P->d_full, P->d_chan,
                         P->d_tile_ptr, P->d_tile_level, P->d_tile_lag_lo, P->d_tile_lag_hi, P->d_tlag, P->d_cfirst, P->d_xpos,
                         P->d_tperm, P->d_tinv, P->d_tbidx, P->d_inner_idx, P->d_ccnt, P->d_colmeta, P->d_ghostmeta, P->d_c4_params,
@@ -2043,12 +2031,13 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
     std::string err;
     int rc = rr::build_host_plan(n, csc_indptr, csc_indices, P->h, err);
     if (rc) { delete P; return fail(rc, err); }
-    {   // time-tiled schedule: tiles of 2,048 positions (1,024 for small networks: more tiles than CUs matter more there)
-        int ppt = n <= 256 * 1024 ? 1 : 2;
-        if (const char *e = getenv("RR_WAVE_PPT")) { const int v = atoi(e); if (v == 1 || v == 2) ppt = v; }
-        P->wave_threads = 1024;
-        P->wave_ppt = ppt;
-        int32_t block = ppt * P->wave_threads;
+    {   // time-tiled schedule: tiles of 512 positions, one per thread, two workgroups per CU (while the waves of one
+        // wait to issue their record loads the other one ticks: measured 368 ms per year at 1M reaches against 391 with
+        // one 1,024-thread workgroup and 382 with four 256-thread ones)
+        P->wave_threads = 512;
+        if (const char *e = getenv("RR_WAVE_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) P->wave_threads = v; }
+        P->wave_ppt = 1;
+        int32_t block = P->wave_threads;
         if (const char *e = getenv("RR_TILE_BLOCK")) block = std::max(8, std::min(block, atoi(e)));     // tests: many small tiles
         std::vector<int32_t> lag_of((size_t)n);
         for (int64_t i = 0; i < n; ++i) lag_of[i] = P->h.lag[P->h.inv[i]];
@@ -2069,8 +2058,8 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) P->dev_total_bytes = total_b;
         }
         for (int v = 0; v < 4; ++v)    // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
-            if (hipFuncSetAttribute((const void *)tile_kernel(P->wave_ppt, (v & 1) != 0, (v & 2) != 0), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)tile_lds_bytes(P->wave_threads, P->wave_ppt)) != hipSuccess) {
+            if (hipFuncSetAttribute((const void *)tile_kernel(P->wave_threads, (v & 1) != 0, (v & 2) != 0), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)tile_lds_bytes(P->wave_threads)) != hipSuccess) {
                 (void)hipGetLastError();
                 P->wave_enabled = false;
             }
@@ -2128,6 +2117,7 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
             if (!rc) rc = dev_alloc(&P->d_chan, n);
         }
         if (!rc) rc = dev_alloc(&P->d_w, n);
+        if (!rc) rc = dev_alloc(&P->d_c1row_h, n);
         if (!rc) rc = dev_alloc(&P->d_c2, n);
         if (!rc) rc = dev_alloc(&P->d_c3, n);
         if (!rc) rc = dev_alloc(&P->d_c4, n);
@@ -2177,6 +2167,27 @@ int rr_plan_layout(const rr_plan *P, int32_t *perm, int32_t *lag, int32_t *child
     return RR_OK;
 }
 
+int rr_plan_tile_info(const rr_plan *P, int64_t info[8])
+{
+    if (!P || !info) return fail(RR_E_INVALID, "rr_plan_tile_info: null argument");
+    const rr::TilePlan &T = P->tp;
+    info[0] = T.ok ? 1 : 0; info[1] = T.block; info[2] = T.np; info[3] = T.n_ghost; info[4] = T.n_tiles; info[5] = T.n_levels;
+    info[6] = P->wave_threads; info[7] = 0;
+    return RR_OK;
+}
+
+int rr_plan_tile_layout(const rr_plan *P, int32_t *tile_ptr, int32_t *tile_level, int32_t *perm, int32_t *lag, int32_t *cfirst,
+                        uint32_t *ccnt, int32_t *xpos)
+{
+    if (!P) return fail(RR_E_INVALID, "rr_plan_tile_layout: null plan");
+    const rr::TilePlan &T = P->tp;
+    if (!T.ok) return fail(RR_E_UNSUPPORTED, "rr_plan_tile_layout: this network does not tile (a reach has more upstream reaches than a tile holds)");
+    auto copy = [](auto *dst, const auto &src) { if (dst && !src.empty()) std::memcpy(dst, src.data(), src.size() * sizeof(src[0])); };
+    copy(tile_ptr, T.tile_ptr); copy(tile_level, T.tile_level); copy(perm, T.perm); copy(lag, T.lag); copy(cfirst, T.cfirst);
+    copy(ccnt, T.ccnt); copy(xpos, T.xpos);
+    return RR_OK;
+}
+
 int rr_plan_set_options(rr_plan *P, int64_t rows_per_chunk, int64_t sample_every)
 {
     if (!P) return fail(RR_E_INVALID, "rr_plan_set_options: null plan");
@@ -2213,6 +2224,7 @@ int rr_plan_set_coeffs(rr_plan *P, const double *lhs_off_data, const double *c2,
     }
     P->weights_uniform = uniform;
     rc = dev_upload(P->d_w, w);
+    if (!rc) rc = dev_upload(P->d_c1row_h, c1row);
     if (!rc && P->tp.ok) {      // the same in tile order; a ghost computes nothing
         const rr::TilePlan &TP = P->tp;
         std::vector<double> t1(TP.np, 0.0), t2(TP.np, 0.0), t3(TP.np, 0.0);

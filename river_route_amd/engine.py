@@ -80,6 +80,24 @@ class Plan:
         check(_lib.lib().rr_plan_layout(self._h, ptr(perm), ptr(lag), ptr(child_ptr)))
         return perm, lag, child_ptr
 
+    def tile_info(self) -> dict:
+        """Shape of the time-tiled kernel's layout, see rr_plan_tile_info."""
+        info = np.zeros(8, dtype=np.int64)
+        check(_lib.lib().rr_plan_tile_info(self._h, ptr(info)))
+        return dict(ok=bool(info[0]), block=int(info[1]), positions=int(info[2]), ghosts=int(info[3]), tiles=int(info[4]),
+                    levels=int(info[5]), threads=int(info[6]))
+
+    def tile_layout(self) -> dict:
+        """Arrays of the subtree-tile layout, see rr_plan_tile_layout."""
+        t = self.tile_info()
+        nt, npos = t['tiles'], t['positions']
+        out = dict(tile_ptr=np.empty(nt + 1, np.int32), tile_level=np.empty(nt, np.int32), perm=np.empty(npos, np.int32),
+                   lag=np.empty(npos, np.int32), cfirst=np.empty(npos, np.int32), ccnt=np.empty(npos, np.uint32),
+                   xpos=np.empty(npos, np.int32))
+        check(_lib.lib().rr_plan_tile_layout(self._h, *(ptr(out[k]) for k in ('tile_ptr', 'tile_level', 'perm', 'lag', 'cfirst',
+                                                                               'ccnt', 'xpos'))))
+        return out
+
     def set_options(self, rows_per_chunk: int = 0, sample_every: int = -1) -> None:
         check(_lib.lib().rr_plan_set_options(self._h, int(rows_per_chunk), int(sample_every)))
 

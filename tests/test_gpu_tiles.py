@@ -1,0 +1,289 @@
+"""The time-tiled kernel (k_tile) on exactly the paths bench.py times and the routers use: device arrays, forced
+(RR_WAVE=1), BASELINE sizes, every mode (Rapid / Muskingum / Unit), sub-steps, consecutive files -- each against the
+oracle -- and the partitioned path against the oracle at the part size of BASELINE config 5."""
+import numpy as np
+import pytest
+
+from conftest import assert_close, unit_split
+from oracle import oracle
+from river_route_amd import synth
+from river_route_amd.engine import DeviceBuffer, Plan, partition_forest, uh_convolve
+
+pytestmark = pytest.mark.gpu
+KNOBS = ('RR_WAVE', 'RR_WAVE_K', 'RR_WAVE_THREADS', 'RR_TILE_BLOCK')
+
+
+def csc_from_down(down_index):
+    has = down_index >= 0
+    indptr = np.concatenate([[0], np.cumsum(has)]).astype(np.int32)
+    return indptr, down_index[has].astype(np.int32)
+
+
+def set_env(monkeypatch, env):
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+
+
+@pytest.mark.parametrize('n,T,env', [(300_000, 80, {'RR_WAVE': '1'}), (1_000_000, 80, {'RR_WAVE': '1'}),
+                                      (300_000, 70, {'RR_WAVE': '1', 'RR_WAVE_THREADS': '1024', 'RR_WAVE_K': '32'}),
+                                      (60_000, 50, {'RR_WAVE': '1', 'RR_TILE_BLOCK': '64', 'RR_WAVE_THREADS': '256', 'RR_WAVE_K': '16'})])
+def test_unit_route_dev_time_tiled_vs_oracle(monkeypatch, n, T, env):
+    """BASELINE config 4's timed kernel (k_tile, UNIT) over many tiles and tile levels, device arrays, two consecutive
+    files with the state hand-off of UnitMuskingum._router (river_route/routers/UnitMuskingum.py:72-98)."""
+    set_env(monkeypatch, env)
+    net = synth.synth_network(n, seed=31)
+    indptr, indices = csc_from_down(net.down_index)
+    hw_idx, inner_idx, A_in, A_hw = unit_split(indptr, indices, n)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0)
+    c1i, c2i, c3i = c1[inner_idx], c2[inner_idx], c3[inner_idx]
+    args = (A_in.indptr, A_in.indices, -c1i[A_in.indices], A_in.indptr, A_in.indices, A_in.data,
+            A_hw.indptr, A_hw.indices, A_hw.data, c1i, c2i, c3i, hw_idx, inner_idx)
+    n_ks = 12
+    kern = synth.synth_uh_kernel(n, n_ks)
+    uh = oracle.UnitHydrograph(kern)
+    state_ref = 3.0 * synth.u01(7, np.arange(n))
+    state = state_ref.copy()
+    ni = inner_idx.size
+    with Plan(indptr, indices) as plan:
+        assert plan.tile_info()['ok'] and plan.tile_info()['levels'] > 2
+        plan.set_coeffs(-c1[indices], c2, c3, None)
+        d_conv, d_out = DeviceBuffer(T * n * 8), DeviceBuffer(T * n * 8)
+        d_qc, d_qf = DeviceBuffer(ni * 8), DeviceBuffer(ni * 8)
+        for f in range(2):
+            conv_ref = uh.convolve(synth.synth_runoff_depth(n, f * T, (f + 1) * T))
+            qc_ref, qf_ref, d_ref = state_ref[inner_idx].copy(), state_ref[inner_idx].copy(), np.zeros((T, n))
+            oracle.unit_route(*args, qc_ref, qf_ref, conv_ref, d_ref, 1)
+            state_ref[hw_idx], state_ref[inner_idx] = conv_ref[-1][hw_idx], qf_ref
+            d_conv.upload(conv_ref)
+            d_qc.upload(state[inner_idx].copy()); d_qf.upload(state[inner_idx].copy())
+            plan.unit_route_dev(d_qc, d_qf, d_conv, T, d_out, T, T, 1)
+            qc, qf, d = d_qc.download(np.float64, (ni,)), d_qf.download(np.float64, (ni,)), d_out.download(np.float64, (T, n))
+            state[hw_idx], state[inner_idx] = conv_ref[-1][hw_idx], qf
+            assert_close(qc, qc_ref, f'file {f} q_ch')
+            assert_close(qf, qf_ref, f'file {f} q_full')
+            assert_close(d, d_ref, f'file {f} discharge')
+            np.testing.assert_array_equal(d[:, hw_idx], conv_ref[:, hw_idx])     # headwaters: unclamped, un-averaged
+        for b in (d_conv, d_out, d_qc, d_qf):
+            b.free()
+
+
+@pytest.mark.parametrize('n,T,nsub,mode', [(1_000_000, 40, 4, 'rapid'), (1_000_000, 36, 3, 'rapid'), (300_000, 30, 4, 'muskingum'),
+                                           (300_000, 40, 3, 'unit')])
+def test_substeps_time_tiled_vs_oracle(monkeypatch, n, T, nsub, mode):
+    """num_substeps > 1 (river_route/routers/_numba_kernels.py:66-84): records in sub-step space, the row mean in the slot
+    of the row's last sub-step, two consecutive calls."""
+    set_env(monkeypatch, {'RR_WAVE': '1'})
+    net = synth.synth_network(n, seed=5)
+    indptr, indices = csc_from_down(net.down_index)
+    dt = 900.0
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, dt)
+    lhs = -c1[indices]
+    q0 = 5.0 * synth.u01(99, np.arange(n))
+    with Plan(indptr, indices) as plan:
+        d_out = DeviceBuffer(T * n * 8)
+        if mode == 'rapid':
+            c4_dt = (c1 + c2) / (dt * nsub)
+            plan.set_coeffs(lhs, c2, c3, c4_dt)
+            d_q, d_ql = DeviceBuffer(n * 8).upload(q0), DeviceBuffer(T * n * 8)
+            q_ref = q0.copy()
+            for f in range(2):
+                ql = synth.synth_qlateral(n, f * T, (f + 1) * T, dt=dt * nsub)
+                d_ref = np.zeros((T, n))
+                oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql, d_ref, nsub)
+                d_ql.upload(ql)
+                plan.rapid_route_dev(d_q, d_ql, T, d_out, T, T, nsub)
+                assert_close(d_out.download(np.float64, (T, n)), d_ref, f'call {f} discharge')
+                assert_close(d_q.download(np.float64, (n,)), q_ref, f'call {f} q_t')
+            d_q.free(); d_ql.free()
+        elif mode == 'muskingum':
+            plan.set_coeffs(lhs, c2, c3, None)
+            q_ref, d_ref = q0.copy(), np.zeros((T, n))
+            oracle.muskingum_route(indptr, indices, lhs, c2, c3, q_ref, d_ref, T, nsub)
+            d_q = DeviceBuffer(n * 8).upload(q0)
+            plan.muskingum_route_dev(d_q, d_out, T, T, nsub)
+            assert_close(d_out.download(np.float64, (T, n)), d_ref, 'discharge')
+            assert_close(d_q.download(np.float64, (n,)), q_ref, 'q_t')
+            d_q.free()
+        else:
+            hw_idx, inner_idx, A_in, A_hw = unit_split(indptr, indices, n)
+            cs1, cs2, cs3 = oracle.muskingum_coefficients(net.k, net.x, dt / nsub)
+            c1i, c2i, c3i = cs1[inner_idx], cs2[inner_idx], cs3[inner_idx]
+            plan.set_coeffs(-cs1[indices], cs2, cs3, None)
+            conv = synth.synth_qlateral(n, 0, T) / 900.0
+            qc_ref, qf_ref, d_ref = q0[inner_idx].copy(), q0[inner_idx].copy(), np.zeros((T, n))
+            oracle.unit_route(A_in.indptr, A_in.indices, -c1i[A_in.indices], A_in.indptr, A_in.indices, A_in.data,
+                              A_hw.indptr, A_hw.indices, A_hw.data, c1i, c2i, c3i, hw_idx, inner_idx, qc_ref, qf_ref, conv, d_ref, nsub)
+            ni = inner_idx.size
+            d_qc, d_qf = DeviceBuffer(ni * 8).upload(q0[inner_idx].copy()), DeviceBuffer(ni * 8).upload(q0[inner_idx].copy())
+            d_conv = DeviceBuffer(T * n * 8).upload(conv)
+            plan.unit_route_dev(d_qc, d_qf, d_conv, T, d_out, T, T, nsub)
+            assert_close(d_out.download(np.float64, (T, n)), d_ref, 'discharge')
+            assert_close(d_qf.download(np.float64, (ni,)), qf_ref, 'q_full')
+            assert_close(d_qc.download(np.float64, (ni,)), qc_ref, 'q_ch')
+            for b in (d_qc, d_qf, d_conv):
+                b.free()
+        d_out.free()
+
+
+def test_short_file_at_1m_uses_the_time_tiled_kernel(monkeypatch, capfd):
+    """A one-month hourly file (744 rows) at 1M reaches: the schedule's skew is (tile levels x K) ticks, so calls of this
+    length are time-tiled (they streamed in round 1), and the record ring stays a small part of the card."""
+    set_env(monkeypatch, {})
+    monkeypatch.setenv('RR_VERBOSE', '1')
+    n, T = 1_000_000, 744
+    net = synth.synth_network(n)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0)
+    lhs, c4_dt = -c1[indices], (c1 + c2) / 900.0
+    rows = 48
+    ql = synth.synth_qlateral(n, 0, rows)
+    Tc = 60           # the oracle checks the first rows of the call; the cyclic sink keeps the last
+    q_ref, d_ref = np.zeros(n), np.zeros((Tc, n))
+    oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, np.ascontiguousarray(np.tile(ql, (2, 1))[:Tc]), d_ref, 1)
+    with Plan(indptr, indices) as plan:
+        plan.set_coeffs(lhs, c2, c3, c4_dt)
+        d_q, d_ql, d_out = DeviceBuffer(n * 8).upload(np.zeros(n)), DeviceBuffer(ql.nbytes).upload(ql), DeviceBuffer(T * n * 8)
+        plan.rapid_route_dev(d_q, d_ql, rows, d_out, T, T, 1)
+        d = d_out.download(np.float64, (Tc, n))
+        for b in (d_q, d_ql, d_out):
+            b.free()
+    assert_close(d, d_ref, 'first rows of the file')
+    err = capfd.readouterr().err
+    line = [ln for ln in err.splitlines() if ln.startswith('rr: n=1000000 T=744')][-1]
+    assert 'tiled=1' in line
+    ring_gb = float(line.split('(')[1].split(' GB')[0])
+    assert ring_gb <= 48.0, line
+
+
+def _route_parts_vs_oracle(n, parts, T, chunk, sample_cols=None, seed=4):
+    from river_route_amd.multi_gpu import HipPartEngine, run_in_process, split_network
+    net = synth.synth_network(n, seed=seed) if isinstance(n, int) else n
+    n = net.n
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0)
+    c4_dt = (c1 + c2) / 900.0
+    q0 = 4.0 * synth.u01(8, np.arange(n))
+    ql = synth.synth_qlateral(n, 0, T)
+    q_ref, d_ref = q0.copy(), np.zeros((T, n))
+    oracle.rapid_route(indptr, indices, -c1[indices], c2, c3, c4_dt, q_ref, ql, d_ref, 1)
+    part_of, sizes = partition_forest(indptr, indices, parts)
+    specs = [split_network(net.down_index, part_of, p, parts) for p in range(parts)]
+    engines = [HipPartEngine(s, c1, c2, c3, c4_dt, q0, ql[:, s.real_global], T, 1, 0, out_rows=T) for s in specs]
+    run_in_process(engines, specs, T, 1, chunk)
+    q, d = np.zeros(n), np.zeros((T, n))
+    for s, e in zip(specs, engines):
+        q[s.real_global] = e.final_state()
+        d[:, s.real_global] = e.discharge.cpu().numpy()[:, s.n_ghost:]
+    assert_close(q, q_ref, 'state')
+    assert_close(d, d_ref, 'discharge')
+    return specs
+
+
+@pytest.mark.parametrize('wave', ['0', '1'])
+def test_partitioned_path_vs_oracle_eight_parts(monkeypatch, wave):
+    """BASELINE config 5's path (8 parts, boundary series handed downstream in batches) against the ORACLE on the
+    undivided network: the trunk partition of a random network, and the nested min-max cut a chain-like network
+    falls back to."""
+    set_env(monkeypatch, {'RR_WAVE': wave})
+    specs = _route_parts_vs_oracle(200_000, 8, 150, 32)
+    assert sum(s.n_ghost for s in specs) > 50
+    # chain-like: a comb whose stem is far longer than a share
+    m = 30_000
+    comb = np.concatenate([m + np.arange(m), m + 1 + np.arange(m)]).astype(np.int64)
+    comb[-1] = -1
+    net = synth.synth_network(2 * m, seed=9)
+    net.down_index[:] = comb
+    net.river_ids[:] = np.arange(2 * m)
+    net.downstream_ids[:] = comb
+    specs = _route_parts_vs_oracle(net, 8, 70, 16)
+    assert max(len(s.upstream_parts) for s in specs) >= 1
+
+
+def test_trunk_part_of_config5_size_vs_oracle(monkeypatch):
+    """One GPU's share of BASELINE config 5 (10M reaches / 8): the trunk part of a 5M-reach network cut in four is
+    1.25M reaches deep in the main stems, with hundreds of boundary inflows.  Its ghost series come from the oracle on
+    the whole network; its result is compared with the oracle's on sampled rows and all of its reaches."""
+    from river_route_amd.multi_gpu import split_network
+    set_env(monkeypatch, {'RR_WAVE': '1'})
+    monkeypatch.setenv('RR_VERBOSE', '1')
+    n, parts, T = 5_000_000, 4, 96
+    net = synth.synth_network(n)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0)
+    c4_dt = (c1 + c2) / 900.0
+    part_of, sizes = partition_forest(indptr, indices, parts)
+    spec = split_network(net.down_index, part_of, parts - 1, parts)
+    assert spec.real_global.size >= 1_200_000 and spec.n_ghost > 100
+    members = np.concatenate([spec.ghost_global, spec.real_global])
+    # oracle on the whole network, one 16-row block at a time (a (T, 5M) array would be 3.8 GB)
+    q = np.zeros(n)
+    ghost_series = np.zeros((T, spec.n_ghost))
+    d_ref = np.zeros((T, spec.real_global.size))
+    ql_part = np.zeros((T, members.size))
+    for t0 in range(0, T, 16):
+        ql = synth.synth_qlateral(n, t0, t0 + 16)
+        d = np.zeros((16, n))
+        # export series need the unclamped state: route row by row
+        for r in range(16):
+            oracle.rapid_route(indptr, indices, -c1[indices], c2, c3, c4_dt, q, ql[r:r + 1], d[r:r + 1], 1)
+            ghost_series[t0 + r] = q[spec.ghost_global]
+        d_ref[t0:t0 + 16] = d[:, spec.real_global]
+        ql_part[t0:t0 + 16, spec.n_ghost:] = ql[:, spec.real_global]
+    q_ref = q[spec.real_global]
+    c1m = c1[members]
+    has = spec.down_local >= 0
+    with Plan(spec.indptr, spec.indices) as plan:
+        info = plan.tile_info()
+        assert info['ok']
+        def loc(v):
+            a = v[members].copy(); a[:spec.n_ghost] = 0.0; return a
+        plan.set_coeffs(-c1m[spec.down_local[has]], loc(c2), loc(c3), loc(c4_dt))
+        export_local = spec.n_ghost + np.searchsorted(spec.real_global, spec.export_global)
+        plan.set_boundary(np.arange(spec.n_ghost), export_local)
+        nl = members.size
+        d_q = DeviceBuffer(nl * 8).upload(np.zeros(nl))
+        d_ql, d_out = DeviceBuffer(ql_part.nbytes).upload(ql_part), DeviceBuffer(T * nl * 8)
+        d_g = DeviceBuffer(ghost_series.nbytes).upload(ghost_series)
+        d_e = DeviceBuffer(max(1, T * max(1, spec.export_global.size)) * 8)
+        plan.stream_begin(d_q, d_ql, T, d_out, T, T, 1, d_g, d_e)
+        plan.stream_advance(T, T)
+        plan.stream_end(d_q)
+        d = d_out.download(np.float64, (T, nl))[:, spec.n_ghost:]
+        qf = d_q.download(np.float64, (nl,))[spec.n_ghost:]
+        for b in (d_q, d_ql, d_out, d_g, d_e):
+            b.free()
+    assert_close(qf, q_ref, 'state of the trunk part')
+    assert_close(d, d_ref, 'discharge of the trunk part')
+
+
+def test_uhkernels_convolve_equals_incremental_on_the_gpu():
+    """The reference's own known-answer test (tests/test_uhkernels.py:52-78) on river_route_amd.uhkernels.UnitHydrograph:
+    convolve() on the whole series == convolve_incrementally() step by step, rtol 1e-12; and the impulse response
+    reproduces the kernel (tests/test_uhkernels.py:81-99)."""
+    from river_route_amd.uhkernels import UnitHydrograph
+    rng = np.random.default_rng(123)
+    n_ks, n, T = 3, 4, 10
+    kernel = rng.random((n_ks, n))
+    kernel /= kernel.sum(axis=0)
+    runoff = rng.random((T, n))
+    whole = UnitHydrograph.from_array(kernel).convolve(runoff)
+    uh = UnitHydrograph.from_array(kernel)
+    stepwise = np.stack([uh.convolve_incrementally(runoff[t]) for t in range(T)])
+    np.testing.assert_allclose(whole, stepwise, rtol=1e-12, atol=0)
+    impulse = np.zeros((n_ks + 2, n))
+    impulse[0] = 1.0
+    resp = UnitHydrograph.from_array(kernel).convolve(impulse)
+    np.testing.assert_allclose(resp[:n_ks], kernel, rtol=1e-12)
+    np.testing.assert_allclose(resp[n_ks:], 0.0, atol=1e-15)
+    # the same at a size where the long-series kernel runs, state carried across two calls
+    n_ks, n, T = 48, 5000, 200
+    kernel = synth.synth_uh_kernel(n, n_ks)
+    depth = synth.synth_runoff_depth(n, 0, T)
+    a = UnitHydrograph.from_array(kernel)
+    first, second = a.convolve(depth[:120]), a.convolve(depth[120:])
+    b = UnitHydrograph.from_array(kernel)
+    whole = b.convolve(depth)
+    np.testing.assert_allclose(np.vstack([first, second]), whole, rtol=1e-12, atol=1e-12 * np.abs(whole).max())
+    np.testing.assert_allclose(a.state, b.state, rtol=1e-12, atol=1e-12 * np.abs(whole).max())
