@@ -11,10 +11,16 @@ discharge goes to a 96-row cyclic sink; every routed row is still read from and 
 params-order <-> engine-order permutation passes are inside the timed region.  Inputs are resident in HBM
 when the timed region starts (the PCIe-inclusive host-pointer rate is noted in DESIGN.md, never here).
 
-The JSON line carries `roofline` for the dominant kernel (the routing tick, k_tick) from HIP events recorded
-by the engine around sampled launches on its own stream, and `cpu_baseline`: the oracle (oracle/rr_oracle.c,
--O3 -march=native -ffast-math, 1 thread -- the reference path is single-threaded by construction) timed on a
-bounded sample of the same workload on this box's host cores.
+The JSON line carries `roofline` for the dominant kernel (the time-tiled routing kernel, k_tile) from HIP events
+recorded by the engine around sampled launches on its own stream -- algorithmic bytes of the time-tiled step over the
+launch time, a fraction of the 8 TB/s peak by construction, with the measured device-copy rate beside it (DESIGN.md
+section 5) -- and `cpu_baseline`: the oracle (oracle/rr_oracle.c, -O3 -march=native -ffast-math, 1 thread -- the
+reference path is single-threaded by construction) timed on a bounded sample of the same workload on this box's host
+cores.  Before anything is timed the result of the SAME kernels (time-tiled kernel + record permutation passes, forced)
+is compared with the oracle's on every row of the forcing; a mismatch refuses to report.
+
+N > 1 (one rank per GPU, torch.distributed.run): BASELINE config 5 -- ONE network of 1.25M reaches per GPU (10M at
+N = 8) graph-partitioned over the GPUs, boundary discharge exchanged over RCCL (river_route_amd/multi_gpu.py).
 """
 import argparse
 import json
@@ -28,8 +34,6 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-BYTES_PER_REACH_SUBSTEP = 72    # structure 8 + coefficients 32 + state 32
-BYTES_PER_REACH_ROW = 16        # lateral read 8 + discharge write 8
 
 
 def parse_args():
@@ -37,7 +41,7 @@ def parse_args():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--reaches', type=int, default=1_000_000, help='reaches per GPU')
+    ap.add_argument('--reaches', type=int, default=None, help='reaches per GPU (default 1,000,000 at N = 1; 1,250,000 at N > 1: BASELINE config 5 is 10M reaches on 8 GPUs)')
     ap.add_argument('--runoff-steps', type=int, default=35_040, help='runoff steps per bench step (1 yr @ 15 min)')
     ap.add_argument('--substeps', type=int, default=1)
     ap.add_argument('--forcing-rows', type=int, default=96)
@@ -52,9 +56,13 @@ def parse_args():
                     help="'unit' = BASELINE config 4 (UnitMuskingum + 48-step UH kernel); secondary line, not the headline")
     ap.add_argument('--uh-steps', type=int, default=48)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--traffic-bytes-per-launch', type=float, default=None,
-                    help='HBM bytes per routing-tick launch from a separate rocprofv3 --pmc run (profiles/)')
-    return ap.parse_args()
+    ap.add_argument('--cpu-replicas', type=int, default=-1,
+                    help="also time N independent oracle replicas on N cores (the only parallelism the reference endorses, "
+                         "docs/references/parallelism.md:67-114); 0 = off, -1 = one per core up to 16")
+    a = ap.parse_args()
+    if a.reaches is None:
+        a.reaches = 1_000_000 if a.gpus == 1 and int(os.environ.get('WORLD_SIZE', '1')) == 1 else 1_250_000
+    return a
 
 
 def csc_from_down(down_index):
@@ -70,7 +78,7 @@ def muskingum_coefficients(k, x, dt):
     return (r - 2.0 * x) / den, (r + 2.0 * x) / den, (2.0 * (1.0 - x) - r) / den
 
 
-def cpu_baseline(net, indptr, indices, c1, c2, c3, dt, nsub, steps, seconds):
+def cpu_baseline(net, indptr, indices, c1, c2, c3, dt, nsub, steps, seconds, replicas=0):
     """Oracle on the host: same network, first `steps` runoff steps of the same forcing."""
     from oracle import oracle
     from river_route_amd import synth
@@ -84,20 +92,50 @@ def cpu_baseline(net, indptr, indices, c1, c2, c3, dt, nsub, steps, seconds):
     q, d = np.zeros(n), np.zeros((steps, n))
     oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q, ql[:2], d[:2], nsub, fast=True, out_dir=out_dir)
     q[:] = 0.0
-    check_row = None
+    first_pass = None
     reps, dt_s = 0, 0.0
     while dt_s < seconds and reps < 64:      # the same `steps` rows again and again, state carried over
         t0 = time.perf_counter()
         oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q, ql, d, nsub, fast=True, out_dir=out_dir)
         dt_s += time.perf_counter() - t0
         reps += 1
-        if check_row is None:
-            check_row = d[min(steps, 8) - 1].copy()
-    return {'value': n * steps * nsub * reps / dt_s, 'unit': 'reach-steps/s', 'cores': 1, 'kind': 'port',
-            'sample': f'{n} reaches x {steps * reps} runoff steps ({reps} passes over {steps} forcing rows) x {nsub} '
-                      f'sub-step(s), {dt_s:.2f} s, oracle/rr_oracle.c gcc -O3 -march=native -ffast-math, 1 thread '
-                      f'of {os.cpu_count()} host cores',
-            'check_row': check_row}
+        if first_pass is None:
+            first_pass = d.copy()       # zero initial state, rows [0, steps): what the GPU self-check must reproduce
+    out = {'value': n * steps * nsub * reps / dt_s, 'unit': 'reach-steps/s', 'cores': 1, 'kind': 'port',
+           'sample': f'{n} reaches x {steps * reps} runoff steps ({reps} passes over {steps} forcing rows) x {nsub} '
+                     f'sub-step(s), {dt_s:.2f} s, oracle/rr_oracle.c gcc -O3 -march=native -ffast-math, 1 thread '
+                     f'of {os.cpu_count()} host cores',
+           'first_pass': first_pass}
+    if replicas:
+        out['replicas'] = cpu_replicas(replicas, indptr, indices, lhs, c2, c3, c4_dt, ql, nsub, out_dir, seconds)
+    return out
+
+
+def _replica_worker(args):
+    """One independent oracle replica pinned to nothing in particular: the OS spreads the processes over the cores."""
+    indptr, indices, lhs, c2, c3, c4_dt, ql, nsub, out_dir, seconds = args
+    from oracle import oracle
+    n, steps = c2.shape[0], ql.shape[0]
+    q, d = np.zeros(n), np.zeros((steps, n))
+    reps, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q, ql, d, nsub, fast=True, out_dir=out_dir)
+        reps += 1
+    return n * steps * nsub * reps, time.perf_counter() - t0
+
+
+def cpu_replicas(replicas, indptr, indices, lhs, c2, c3, c4_dt, ql, nsub, out_dir, seconds):
+    """N independent replicas on N cores (docs/references/parallelism.md:67-114: one process per ensemble member or
+    watershed is the only parallelism the reference endorses).  Shorter forcing so N copies fit host memory."""
+    import multiprocessing as mp
+    cores = os.cpu_count() or 1
+    N = min(cores, 16) if replicas < 0 else min(replicas, cores)
+    rows = ql[:min(ql.shape[0], 16)]
+    with mp.get_context('fork').Pool(N) as pool:
+        res = pool.map(_replica_worker, [(indptr, indices, lhs, c2, c3, c4_dt, rows, nsub, out_dir, min(seconds, 8.0))] * N)
+    total = sum(r[0] for r in res) / max(r[1] for r in res)
+    return {'value': total, 'unit': 'reach-steps/s', 'cores': N,
+            'sample': f'{N} independent single-thread replicas of the same network, {rows.shape[0]} forcing rows each'}
 
 
 def bench_unit(args, device_index):
@@ -163,8 +201,12 @@ def bench_unit(args, device_index):
         plan.unit_route_dev(q_ch, q_full, conv_c, Tc, chk, Tc, Tc, nsub, stream)
         torch.cuda.synchronize()
         got = chk.cpu().numpy()
+        chk_kernel = plan.profile()['ticks_per_launch']
         if not np.allclose(got, dd, rtol=1e-10, atol=1e-10 * np.abs(dd).max()):
             raise SystemExit('bench.py: GPU UnitMuskingum result differs from the oracle; refusing to report a number')
+        base['parity_gate'] = (f'{Tc} rows x {n} reaches, convolution + routing by the timed kernels '
+                               f'({"k_tile, " + str(chk_kernel) + " ticks per task" if chk_kernel > 1 else "k_tick"}) == oracle, '
+                               f'rtol 1e-10, max |diff| {float(np.abs(got - dd).max()):.3e}')
 
     for _ in range(args.warmup):
         one_pass()
@@ -174,13 +216,19 @@ def bench_unit(args, device_index):
         one_pass()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    from river_route_amd.engine import copy_bandwidth
+    from river_route_amd.multi_gpu import roofline_from_profile
+    prof = plan.profile()
+    if base is not None and prof['ticks_per_launch'] > 1 and chk_kernel <= 1:
+        raise SystemExit('bench.py: the parity gate did not run the timed kernel; refusing to report a number')
+    roofline = roofline_from_profile(prof, nsub, HBM_PEAK_GBS, copy_gbs=copy_bandwidth(device_index), unit=True)
     line = {'metric': 'reach-steps/sec', 'value': float(n) * T * nsub * args.steps / elapsed, 'unit': 'reach-steps/s',
             'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'UnitMuskingum, {n}-reach synthetic network + {n_ks}-step UH kernel, {T} runoff steps, '
                                    f'{nsub} sub-step(s), fp64, 1xMI355X (BASELINE config 4; convolution + routing)',
                        'reaches': n, 'runoff_steps': T, 'uh_steps': n_ks, 'headwaters': plan.n_headwaters},
-            'roofline': None, 'cpu_baseline': base}
+            'roofline': roofline, 'cpu_baseline': base}
     print(json.dumps(line))
 
 
@@ -194,10 +242,22 @@ def main():
             raise SystemExit('bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
         args.gpus = world
 
+    from river_route_amd import synth
+    n, T, nsub, dt = args.reaches, args.runoff_steps, args.substeps, 900.0
+    rows = min(args.forcing_rows, T)
+    net = indptr = indices = c1 = c2 = c3 = base = None
+    if world == 1 and args.workload == 'rapid':
+        net = synth.synth_network(n, order=args.order)
+        indptr, indices = csc_from_down(net.down_index)
+        c1, c2, c3 = muskingum_coefficients(net.k, net.x, dt)
+        if not args.no_cpu_baseline:      # on the host cores, BEFORE this process touches the GPU (the replicas fork)
+            base = cpu_baseline(net, indptr, indices, c1, c2, c3, dt, nsub, min(args.cpu_baseline_steps, rows),
+                                args.cpu_baseline_seconds, args.cpu_replicas)
+
     import torch
     import torch.distributed as dist
-    from river_route_amd import _lib, synth
-    from river_route_amd.engine import Plan
+    from river_route_amd import _lib
+    from river_route_amd.engine import Plan, copy_bandwidth
 
     if not torch.cuda.is_available() or _lib.device_count() < 1:
         raise SystemExit('bench.py needs a GPU: the HIP engine has no CPU fallback')
@@ -219,15 +279,10 @@ def main():
     if args.workload == 'unit':
         bench_unit(args, device_index)
         return
-    n, T, nsub, dt = args.reaches, args.runoff_steps, args.substeps, 900.0
-    net = synth.synth_network(n, order=args.order)
-    indptr, indices = csc_from_down(net.down_index)
-    c1, c2, c3 = muskingum_coefficients(net.k, net.x, dt)
     plan = Plan(indptr, indices, device=local_rank)
     plan.set_coeffs(-c1[indices], c2, c3, (c1 + c2) / (dt * nsub))
     plan.set_options(rows_per_chunk=args.chunk_rows, sample_every=args.sample_every)
 
-    rows = min(args.forcing_rows, T)
     ql = torch.from_numpy(synth.synth_qlateral(n, 0, rows, dt=dt * nsub)).to(dev)
     out = torch.zeros((rows, n), dtype=torch.float64, device=dev)
     q_t = torch.zeros(n, dtype=torch.float64, device=dev)
@@ -237,20 +292,24 @@ def main():
         q_t.zero_()
         plan.rapid_route_dev(q_t, ql, rows, out, rows, T, nsub, stream)
 
-    # parity spot check before timing: first rows of a short pass against the oracle
-    base = None
-    if not args.no_cpu_baseline:
-        base = cpu_baseline(net, indptr, indices, c1, c2, c3, dt, nsub, min(args.cpu_baseline_steps, rows),
-                            args.cpu_baseline_seconds)
-        chk_T = min(rows, 8)
+    # Parity gate before timing, through the kernels the timed passes run (the time-tiled kernel and the record
+    # permutation passes take every call of 32 sub-steps or more): all rows of the forcing routed from a zero state
+    # into a plain array, compared element by element with the oracle's first pass over the same rows.
+    if base is not None:
+        want = base.pop('first_pass')
+        chk_T = want.shape[0]
         chk_out = torch.zeros((chk_T, n), dtype=torch.float64, device=dev)
         q_t.zero_()
         plan.rapid_route_dev(q_t, ql, rows, chk_out, chk_T, chk_T, nsub, stream)
         torch.cuda.synchronize()
-        got = chk_out[chk_T - 1].cpu().numpy()
-        want = base.pop('check_row')
+        chk_kernel = plan.profile()['ticks_per_launch']
+        got = chk_out.cpu().numpy()
         if not np.allclose(got, want, rtol=1e-10, atol=1e-10 * np.abs(want).max()):
             raise SystemExit('bench.py: GPU result differs from the oracle; refusing to report a number')
+        base['parity_gate'] = (f'{chk_T} rows x {n} reaches routed by the timed kernel family '
+                               f'({"k_tile, " + str(chk_kernel) + " ticks per task" if chk_kernel > 1 else "k_tick"}) == oracle, '
+                               f'rtol 1e-10, max |diff| {float(np.abs(got - want).max()):.3e}')
+        del chk_out
 
     for _ in range(args.warmup):
         one_pass()
@@ -262,27 +321,13 @@ def main():
     elapsed = time.perf_counter() - t0
 
     prof = plan.profile()      # HIP events of the last timed pass, on the engine's stream
+    if base is not None and prof['ticks_per_launch'] > 1 and chk_kernel <= 1:
+        raise SystemExit('bench.py: the parity gate did not run the timed kernel; refusing to report a number')
     reach_steps = float(n) * T * nsub * args.steps
-    bytes_per_reach_tick = BYTES_PER_REACH_SUBSTEP + BYTES_PER_REACH_ROW / nsub
-    # roofline of the dominant kernel: the routing kernel (k_wave: one launch = `ticks_per_launch` routing ticks over
-    # all reaches).  `achieved` prices the launch at the ALGORITHMIC bytes of SURVEY section 8(d) (streaming model,
-    # 88 B per reach-step at nsub=1), which a time-tiled kernel legitimately undercuts; `traffic` is what it
-    # really moved (separate rocprofv3 --pmc passes, profiles/r01_pmc_traffic.json; default shape at 1M reaches).
-    traffic = args.traffic_bytes_per_launch
-    traffic_per_reach_tick = None
-    kernel_name = None
-    if traffic is None and n == 1_000_000 and nsub == 1 and not plan.identity_order and \
-            not any(k.startswith(('RR_WAVE', 'RR_REC')) for k in os.environ):
-        try:
-            with open(os.path.join(REPO, 'profiles', 'r01_pmc_traffic.json')) as f:
-                traffic_per_reach_tick = json.load(f)['kernels']['k_wave_rec']['hbm_bytes_per_reach_tick']
-            kernel_name = 'k_wave_rec (time-tiled routing over tick-indexed records)'
-        except (OSError, KeyError, ValueError):
-            traffic_per_reach_tick = None
     from river_route_amd.multi_gpu import roofline_from_profile
-    roofline = roofline_from_profile(prof, nsub, traffic, HBM_PEAK_GBS, traffic_per_reach_tick)
-    if roofline and kernel_name:
-        roofline['kernel'] = kernel_name
+    copy_gbs = copy_bandwidth(local_rank)
+    roofline = roofline_from_profile(prof, nsub, HBM_PEAK_GBS, *pmc_traffic(plan, n, nsub), copy_gbs=copy_gbs)
+    tiles = plan.tile_info()
     line = {
         'metric': 'reach-steps/sec', 'value': reach_steps / elapsed, 'unit': 'reach-steps/s',
         'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
@@ -293,11 +338,37 @@ def main():
                                f'(1 yr @ 15 min), {nsub} sub-step(s), fp64, 1xMI355X',
                    'reaches': n, 'runoff_steps': T, 'substeps': nsub, 'network_depth': plan.depth,
                    'forcing': f'{rows}-row device-resident cyclic array', 'params_order': args.order,
-                   'permutation_passes_in_timed_region': not plan.identity_order},
+                   'permutation_passes_in_timed_region': True,
+                   'tiles': tiles['tiles'], 'tile_levels': tiles['levels'], 'ghost_positions': tiles['ghosts']},
         'roofline': roofline,
         'cpu_baseline': base,
     }
     print(json.dumps(line))
+
+
+def engine_sha16():
+    import hashlib
+    h = hashlib.sha256()
+    for name in ('rr_engine.hip', 'rr_plan.cpp', 'rr_plan.hpp'):
+        with open(os.path.join(REPO, 'river_route_amd', 'csrc', name), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(plan, n, nsub, kernel='k_tile', key='hbm_bytes_per_position_tick'):
+    """(bytes per position-tick, source) of the routing kernel from the committed counter passes -- only for the
+    configuration they were taken on and only while the kernel sources are the ones they were taken with."""
+    path = os.path.join(REPO, 'profiles', 'r02_pmc_traffic.json')
+    if n != 1_000_000 or nsub != 1 or any(k.startswith(('RR_WAVE', 'RR_TILE')) for k in os.environ):
+        return None, None
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+        if rec.get('engine_sha16') != engine_sha16():
+            return None, f'profiles/r02_pmc_traffic.json is from other kernel sources ({rec.get("engine_sha16")}): not used'
+        return rec['kernels'][kernel][key], f'profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, engine {rec["engine_sha16"]})'
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 if __name__ == '__main__':

@@ -144,6 +144,17 @@ int rr_unit_route_dev(rr_plan *plan, double *q_ch, double *q_full, const double 
 int rr_uh_convolve_dev(int device, const double *kernel, double *state, const double *lateral, double *out,
                        int64_t T, int64_t n_ks, int64_t n, void *stream);
 
+/* The same with the routers' post-processing (river_route/routers/TransformMuskingum.py:128-142) fused into the pass that
+ * returns the rows to params order: discharge32[o, i] = (float) mean_{j < factor} discharge[o * factor + j, i], (T / factor, n)
+ * rows, 4 bytes written per value instead of 8 + 8 + 4.  RR_E_UNSUPPORTED when the call is not time-tiled or factor x
+ * sub-steps does not divide 128: use the float64 form and rr_resample_cast_dev then. */
+int rr_rapid_route_f32_dev(rr_plan *plan, double *q_t, const double *qlateral, int64_t ql_rows, float *discharge32,
+                           int64_t num_runoff_steps, int64_t num_substeps, int64_t factor, void *stream);
+int rr_muskingum_route_f32_dev(rr_plan *plan, double *q_t, float *discharge32, int64_t num_output_steps,
+                               int64_t num_routing_per_output, void *stream);
+int rr_unit_route_f32_dev(rr_plan *plan, double *q_ch, double *q_full, const double *convolved_lateral, int64_t conv_rows,
+                          float *discharge32, int64_t num_runoff_steps, int64_t num_substeps, int64_t factor, void *stream);
+
 /* ---- partitioned networks (multi-GPU): boundary reaches and streaming calls ----
  *
  * A network cut into parts (rr_partition_forest) is routed one part per GPU.  In the part that holds the
@@ -212,6 +223,9 @@ int rr_dev_free(int device, void *ptr);
 int rr_dev_upload(int device, void *dst_dev, const void *src_host, int64_t bytes);
 int rr_dev_download(int device, void *dst_host, const void *src_dev, int64_t bytes);
 int rr_dev_synchronize(int device);
+/* Measured device copy rate (GB/s, bytes read + bytes written) of a 16-byte-per-lane copy kernel over `bytes` bytes,
+ * `reps` launches: the achievable HBM rate bench.py reports beside the nominal 8 TB/s. */
+int rr_copy_bandwidth(int device, int64_t bytes, int reps, double *gbps);
 
 #ifdef __cplusplus
 }

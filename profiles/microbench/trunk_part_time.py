@@ -1,4 +1,4 @@
-"""One part of the 8-GPU bench run on one GPU: the LAST part (main stems, deepest) and the FIRST part of the 8M-reach
+"""One part of the 8-GPU bench run on one GPU: the LAST part (main stems, deepest) and the FIRST part of the 10M-reach (BASELINE config 5)
 network cut into 8, each routed alone for one year with all boundary inflow already present (zeros).  Shows what each
 of the 8 GPUs has to do per pass, which routing kernel its part gets (RR_VERBOSE line) and how long it takes."""
 import sys, time
@@ -9,7 +9,7 @@ from river_route_amd import synth
 from river_route_amd.engine import partition_forest
 from river_route_amd.multi_gpu import split_network, HipPartEngine
 
-world, per = 8, int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+world, per = 8, int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000
 n, T, nsub, dt = per * world, 35040, 1, 900.0
 net = synth.synth_network(n, order='random')
 has = net.down_index >= 0

@@ -88,6 +88,9 @@ _SIGNATURES = {
     'rr_muskingum_route_dev': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     'rr_unit_route_dev': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
     'rr_uh_convolve_dev': (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    'rr_rapid_route_f32_dev': (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
+    'rr_muskingum_route_f32_dev': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),
+    'rr_unit_route_f32_dev': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
     'rr_plan_set_boundary': (C.c_int, [_vp, _i64, _vp, _i64, _vp]),
     'rr_stream_begin': (C.c_int, [_vp, C.c_int, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     'rr_stream_advance': (C.c_int, [_vp, _i64, _i64, C.POINTER(_i64)]),
@@ -102,6 +105,7 @@ _SIGNATURES = {
     'rr_dev_upload': (C.c_int, [C.c_int, _vp, _vp, _i64]),
     'rr_dev_download': (C.c_int, [C.c_int, _vp, _vp, _i64]),
     'rr_dev_synchronize': (C.c_int, [C.c_int]),
+    'rr_copy_bandwidth': (C.c_int, [C.c_int, _i64, C.c_int, C.POINTER(C.c_double)]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -732,6 +732,7 @@ __global__ __launch_bounds__(kBlock) void k_uh_convolve(const double *__restrict
 #define RR_UH48 64, 48, 8, 2
 #endif
 constexpr int kUhThreads = RR_UH_THREADS;
+constexpr int kUhTailThreads = 64;
 
 // NK window slots (power of two), R outputs per pass (every window value read from LDS feeds R accumulators),
 // D passes of lateral rows in flight.  The window costs NK * 8 B of LDS per thread, which caps the kernel at about
@@ -863,25 +864,44 @@ __global__ __launch_bounds__(kUhThreads) void k_uh_convolve_ring(const double *_
     }
 }
 
-// Carry-over tail: new_state[s, i] = buf[T + s, i] for s < n_ks - 1, 0 for s = n_ks - 1 (lines 103-105), where
-// buf[m] = sum_{s'} kernel[s'] lateral[m - s'] (+ state[m] when m < n_ks).
-__global__ __launch_bounds__(kBlock) void k_uh_tail(const double *__restrict__ kernel,
-                                                    const double *__restrict__ state,
-                                                    const double *__restrict__ lateral,
-                                                    double *__restrict__ new_state, int64_t T, int32_t n_ks, int64_t n)
+// Carry-over tail, IN PLACE: state[s, i] <- buf[T + s, i] for s < n_ks - 1, 0 for s = n_ks - 1 (UnitHydrograph.py:103-105),
+// where buf[m] = sum_{k} kernel[k] lateral[m - k] (+ the old state[m] when m < n_ks).  One thread owns a basin and walks s
+// upwards: row s is written after row T + s > s has been read, so no second buffer (and no allocation, copy or
+// synchronisation inside an enqueue-only call) is needed.  NK > 0: taps and the last n_ks - 1 lateral rows sit in
+// registers (static indices, n_ks <= NK); NK == 0: any n_ks, straight from memory.
+template <int NK>
+__global__ __launch_bounds__(kUhTailThreads) void k_uh_tail(const double *__restrict__ kernel, double *__restrict__ state,
+                                                            const double *__restrict__ lateral, int64_t T, int32_t n_ks, int64_t n)
 {
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kUhTailThreads + threadIdx.x;
     if (i >= n) return;
-    const int32_t s = (int32_t)blockIdx.y;
-    if (s == n_ks - 1) { new_state[(int64_t)s * n + i] = 0.0; return; }
-    const int64_t m = T + s;
-    double acc = m < n_ks ? state[m * n + i] : 0.0;
-    for (int32_t k = s + 1; k < n_ks; ++k) {
-        const int64_t tt = m - k;
-        if (tt < 0) break;
-        acc += kernel[(int64_t)k * n + i] * lateral[tt * n + i];
+    if (NK > 0) {
+        double kv[NK > 0 ? NK : 1], lat[NK > 0 ? NK : 1];      // lat[j] = lateral[T - 1 - j]
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            kv[k] = k < n_ks ? kernel[(int64_t)k * n + i] : 0.0;
+            lat[k] = (k < n_ks - 1 && k < T) ? lateral[(T - 1 - k) * n + i] : 0.0;
+        }
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+            const int64_t m = T + s;
+            double acc = (s < n_ks && m < n_ks) ? state[m * n + i] : 0.0;
+#pragma unroll
+            for (int k = s + 1; k < NK; ++k) acc += kv[k] * lat[k - s - 1];      // taps beyond n_ks and rows before 0 are zeros
+            if (s < n_ks) state[(int64_t)s * n + i] = s == n_ks - 1 ? 0.0 : acc;
+        }
+    } else {
+        for (int32_t s = 0; s < n_ks; ++s) {
+            const int64_t m = T + s;
+            double acc = m < n_ks ? state[m * n + i] : 0.0;
+            for (int32_t k = s + 1; k < n_ks; ++k) {
+                const int64_t tt = m - k;
+                if (tt < 0) break;
+                acc += kernel[(int64_t)k * n + i] * lateral[tt * n + i];
+            }
+            state[(int64_t)s * n + i] = s == n_ks - 1 ? 0.0 : acc;
+        }
     }
-    new_state[(int64_t)s * n + i] = acc;
 }
 
 // ---- record permutation (one pass each way), see k_tile ----
@@ -1114,6 +1134,18 @@ __global__ __launch_bounds__(kBlock) void k_runoff_to_qlateral(const int32_t *__
         if (v != v && !keep_nan) v = 0.0;
         out[(t0 + j - 1) * n_rivers + r] = area ? v * a : v;
     }
+}
+
+// Device copy rate probe (bench.py reports it beside the nominal HBM peak): 16 bytes per lane, grid-stride.
+__global__ __launch_bounds__(kBlock) void k_copy16(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t count)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    for (; i + 3 * stride < count; i += 4 * stride) {      // four loads in flight per lane
+        const double2 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < count; i += stride) dst[i] = src[i];
 }
 
 inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
@@ -1939,9 +1971,6 @@ int uh_convolve_core(const double *d_kernel, double *d_state, const double *d_la
     if (n == 0) return RR_OK;
     if (n_ks > 0x7FFFFFFF || T > 0x7FFFFFFFLL * 8) return fail(RR_E_INVALID, "rr_uh_convolve: sizes out of range");
     constexpr int TB = 8;
-    double *d_tail = nullptr;
-    int rc = dev_alloc(&d_tail, n_ks * n);
-    if (rc) return rc;
     if (n_ks <= 57 && T >= 64) {
         // long series: register-resident taps + LDS window; split time only as far as needed to fill the chip
         const int64_t blocks_x = (n + kUhThreads - 1) / kUhThreads;
@@ -1970,13 +1999,11 @@ int uh_convolve_core(const double *d_kernel, double *d_state, const double *d_la
         hipLaunchKernelGGL(k_uh_convolve<TB>, g, dim3(kBlock), 0, stream, d_kernel, (const double *)d_state, d_lateral,
                            d_out, T, (int32_t)n_ks, n);
     }
-    dim3 gt((unsigned)((n + kBlock - 1) / kBlock), (unsigned)n_ks);
-    hipLaunchKernelGGL(k_uh_tail, gt, dim3(kBlock), 0, stream, d_kernel, (const double *)d_state, d_lateral, d_tail,
-                       T, (int32_t)n_ks, n);
-    hipError_t e = hipMemcpyAsync(d_state, d_tail, (size_t)n_ks * n * sizeof(double), hipMemcpyDeviceToDevice, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);   // d_tail is freed below
-    (void)hipFree(d_tail);
-    if (e != hipSuccess) return fail(RR_E_HIP, hipGetErrorString(e));
+    // carry-over state, in place, after the rows above have read the old one (same stream)
+    const dim3 gt((unsigned)((n + kUhTailThreads - 1) / kUhTailThreads));
+    if (n_ks <= 16) hipLaunchKernelGGL(k_uh_tail<16>, gt, dim3(kUhTailThreads), 0, stream, d_kernel, d_state, d_lateral, T, (int32_t)n_ks, n);
+    else if (n_ks <= 48) hipLaunchKernelGGL(k_uh_tail<48>, gt, dim3(kUhTailThreads), 0, stream, d_kernel, d_state, d_lateral, T, (int32_t)n_ks, n);
+    else hipLaunchKernelGGL(k_uh_tail<0>, gt, dim3(kUhTailThreads), 0, stream, d_kernel, d_state, d_lateral, T, (int32_t)n_ks, n);
     HIPCHK(hipGetLastError());
     return RR_OK;
 }
@@ -2256,7 +2283,7 @@ int rr_plan_profile(rr_plan *P, double prof[10])
     for (int k = 0; k < 10; ++k) prof[k] = 0.0;
     prof[0] = (double)P->prof_launches;
     prof[8] = (double)P->prof_brackets;
-    prof[9] = P->ses.wave ? (double)P->wave_K : 1.0;
+    prof[9] = P->ses.wave ? (double)(P->ses.KC * kRec) : 1.0;
     prof[7] = (double)P->prof_reach_steps;
     if (P->device < 0 || !P->ev_first || P->prof_launches == 0) return RR_OK;
     HIPCHK(hipSetDevice(P->device));
@@ -2423,6 +2450,56 @@ int rr_unit_route_dev(rr_plan *P, double *q_ch, double *q_full, const double *co
                                 (!P->h.inner_pos.empty() && (!q_ch || !q_full))))
         return fail(RR_E_INVALID, "rr_unit_route_dev: null array or empty row count");
     Rows io; io.dev_in = conv; io.rows_in = conv_rows; io.dev_out = discharge; io.rows_out = out_rows;
+    return unit_like(P, q_ch, q_full, io, T, nsub, (hipStream_t)stream, false);
+}
+
+// float32 output fused into the record pass (k_rec_out): applies when the call is time-tiled and factor x sub-steps divides
+// the 128 tick-rows of a batch; otherwise RR_E_UNSUPPORTED and the caller uses the float64 form + rr_resample_cast_dev.
+static int f32_output_applies(rr_plan *P, Mode mode, int64_t T, int64_t nsub, int64_t factor)
+{
+    if (factor < 1 || T % factor != 0) return fail(RR_E_INVALID, "float32 output: the number of rows must be a multiple of factor >= 1");
+    if (kRecRows % (factor * nsub) != 0) return fail(RR_E_UNSUPPORTED, "float32 output: factor x sub-steps must divide 128");
+    if (!decide_wave(P, mode, T * nsub, false)) return fail(RR_E_UNSUPPORTED, "float32 output needs the time-tiled kernel, which this call does not get");
+    return RR_OK;
+}
+
+int rr_rapid_route_f32_dev(rr_plan *P, double *q_t, const double *qlateral, int64_t ql_rows, float *discharge32, int64_t T,
+                           int64_t nsub, int64_t factor, void *stream)
+{
+    int rc = check_route_args(P, true, T, nsub);
+    if (rc) return rc;
+    if (P->h.n > 0 && T > 0 && (!q_t || !qlateral || !discharge32 || ql_rows < 1))
+        return fail(RR_E_INVALID, "rr_rapid_route_f32_dev: null array or empty row count");
+    if (P->h.n == 0 || T == 0) return RR_OK;
+    rc = f32_output_applies(P, Mode::Rapid, T, nsub, factor);
+    if (rc) return rc;
+    Rows io; io.dev_in = qlateral; io.rows_in = ql_rows; io.dev_out32 = discharge32; io.out_factor = factor; io.rows_out = T / factor;
+    return rapid_like(P, Mode::Rapid, q_t, io, T, nsub, (hipStream_t)stream, false);
+}
+
+int rr_muskingum_route_f32_dev(rr_plan *P, double *q_t, float *discharge32, int64_t n_out, int64_t n_per_out, void *stream)
+{
+    int rc = check_route_args(P, false, n_out, n_per_out);
+    if (rc) return rc;
+    if (P->h.n > 0 && n_out > 0 && (!q_t || !discharge32)) return fail(RR_E_INVALID, "rr_muskingum_route_f32_dev: null array");
+    if (P->h.n == 0 || n_out == 0) return RR_OK;
+    rc = f32_output_applies(P, Mode::Muskingum, n_out, n_per_out, 1);
+    if (rc) return rc;
+    Rows io; io.dev_out32 = discharge32; io.out_factor = 1; io.rows_out = n_out;
+    return rapid_like(P, Mode::Muskingum, q_t, io, n_out, n_per_out, (hipStream_t)stream, false);
+}
+
+int rr_unit_route_f32_dev(rr_plan *P, double *q_ch, double *q_full, const double *conv, int64_t conv_rows, float *discharge32,
+                          int64_t T, int64_t nsub, int64_t factor, void *stream)
+{
+    int rc = check_route_args(P, false, T, nsub);
+    if (rc) return rc;
+    if (P->h.n > 0 && T > 0 && (!conv || !discharge32 || conv_rows < 1 || (!P->h.inner_pos.empty() && (!q_ch || !q_full))))
+        return fail(RR_E_INVALID, "rr_unit_route_f32_dev: null array or empty row count");
+    if (P->h.n == 0 || T == 0) return RR_OK;
+    rc = f32_output_applies(P, Mode::Unit, T, nsub, factor);
+    if (rc) return rc;
+    Rows io; io.dev_in = conv; io.rows_in = conv_rows; io.dev_out32 = discharge32; io.out_factor = factor; io.rows_out = T / factor;
     return unit_like(P, q_ch, q_full, io, T, nsub, (hipStream_t)stream, false);
 }
 
@@ -2631,6 +2708,41 @@ int rr_dev_download(int device, void *dst_host, const void *src_dev, int64_t byt
     if (device < 0 || device >= rr_device_count()) return fail(RR_E_NO_DEVICE, "rr_dev_download: no such HIP device");
     HIPCHK(hipSetDevice(device));
     if (bytes > 0) HIPCHK(hipMemcpy(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost));
+    return RR_OK;
+}
+
+int rr_copy_bandwidth(int device, int64_t bytes, int reps, double *gbps)
+{
+    if (!gbps || bytes < 1024 || reps < 1) return fail(RR_E_INVALID, "rr_copy_bandwidth: bad argument");
+    if (device < 0 || device >= rr_device_count()) return fail(RR_E_NO_DEVICE, "rr_copy_bandwidth: no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    const int64_t count = bytes / 16;
+    double2 *a = nullptr, *b = nullptr;
+    int rc = dev_alloc(&a, count);
+    if (!rc) rc = dev_alloc(&b, count);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms = 0.f;
+    if (!rc) {
+        hipError_t e = hipMemset(a, 0, (size_t)count * 16);
+        if (e == hipSuccess) e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        const dim3 g((unsigned)std::min<int64_t>((count + kBlock - 1) / kBlock, 256 * 16));
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_copy16, g, dim3(kBlock), 0, nullptr, (const double2 *)a, b, count);      // warm-up
+            e = hipEventRecord(e0, nullptr);
+            for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_copy16, g, dim3(kBlock), 0, nullptr, (const double2 *)a, b, count);
+            if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        }
+        if (e != hipSuccess) rc = fail(RR_E_HIP, hipGetErrorString(e));
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    if (rc) return rc;
+    *gbps = 2.0 * (double)count * 16.0 * reps / ((double)ms * 1e-3) / 1e9;      // bytes read + bytes written
     return RR_OK;
 }
 

@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import RRError, check, ptr
 
 __all__ = ['Plan', 'RRError', 'uh_convolve', 'uh_convolve_dev', 'runoff_to_qlateral', 'DeviceBuffer', 'partition_forest', 'synchronize',
-           'resample_cast_dev']
+           'resample_cast_dev', 'copy_bandwidth']
 
 
 def _f64(a, name):
@@ -164,6 +164,19 @@ class Plan:
                                            ptr(discharge), int(out_rows), int(T), int(num_substeps), stream))
 
 
+    # -- device-pointer routing with the routers' post-processing fused in: float32 rows, `factor` routed rows averaged --
+    def rapid_route_f32_dev(self, q_t, qlateral, ql_rows, discharge32, T, num_substeps, factor=1, stream=None) -> None:
+        check(_lib.lib().rr_rapid_route_f32_dev(self._h, ptr(q_t), ptr(qlateral), int(ql_rows), ptr(discharge32), int(T),
+                                                int(num_substeps), int(factor), stream))
+
+    def muskingum_route_f32_dev(self, q_t, discharge32, num_output_steps, num_routing_per_output, stream=None) -> None:
+        check(_lib.lib().rr_muskingum_route_f32_dev(self._h, ptr(q_t), ptr(discharge32), int(num_output_steps),
+                                                    int(num_routing_per_output), stream))
+
+    def unit_route_f32_dev(self, q_ch, q_full, convolved, conv_rows, discharge32, T, num_substeps, factor=1, stream=None) -> None:
+        check(_lib.lib().rr_unit_route_f32_dev(self._h, ptr(q_ch), ptr(q_full), ptr(convolved), int(conv_rows),
+                                               ptr(discharge32), int(T), int(num_substeps), int(factor), stream))
+
     # -- partitioned networks: boundary reaches + streaming calls (include/rr_hip.h) --
     def set_boundary(self, ghost_reaches, export_reaches) -> None:
         g = np.ascontiguousarray(ghost_reaches, dtype=np.int64)
@@ -285,6 +298,13 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def copy_bandwidth(device: int = 0, nbytes: int = 1 << 31, reps: int = 10) -> float:
+    """Measured device copy rate in GB/s (read + write), see rr_copy_bandwidth."""
+    out = C.c_double(0.0)
+    check(_lib.lib().rr_copy_bandwidth(int(device), int(nbytes), int(reps), C.byref(out)))
+    return float(out.value)
 
 
 def synchronize(device: int = 0) -> None:

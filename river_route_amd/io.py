@@ -49,22 +49,52 @@ def read_qlateral(path, var_t: str = 'time', var: str = 'qlateral'):
         return dates, np.array(ds.variables[var][:], dtype=np.float64)
 
 
+def _cf_decode(raw: np.ndarray, attrs: dict) -> np.ndarray:
+    """CF conventions as xarray's mask_and_scale applies them (the reference reads runoff through xarray.open_mfdataset,
+    river_route/runoff.py:255-270): cells equal to _FillValue / missing_value (or outside valid_min / valid_max /
+    valid_range) become NaN -- compared on the RAW stored values -- then scale_factor / add_offset unpack the rest."""
+    mask = None
+    for key in ('_FillValue', 'missing_value'):
+        if key in attrs:
+            for fill in np.atleast_1d(attrs[key]):
+                hit = np.isnan(raw) if isinstance(fill, (float, np.floating)) and np.isnan(fill) else raw == fill
+                mask = hit if mask is None else (mask | hit)
+    lo, hi = attrs.get('valid_min'), attrs.get('valid_max')
+    if 'valid_range' in attrs:
+        lo, hi = np.atleast_1d(attrs['valid_range'])[:2]
+    if lo is not None:
+        mask = (raw < lo) if mask is None else (mask | (raw < lo))
+    if hi is not None:
+        mask = (raw > hi) if mask is None else (mask | (raw > hi))
+    packed = 'scale_factor' in attrs or 'add_offset' in attrs
+    if mask is None and not packed:
+        return raw
+    out = raw.astype(np.float64) if (packed or not np.issubdtype(raw.dtype, np.floating)) else raw.astype(raw.dtype, copy=True)
+    if packed:
+        out = out * np.float64(attrs.get('scale_factor', 1.0)) + np.float64(attrs.get('add_offset', 0.0))
+    if mask is not None and mask.any():
+        out[mask] = np.nan
+    return out
+
+
 def read_variables(path, names):
-    """-> {name: (array, dims tuple, attrs dict)} for the named variables of one netCDF file (time variables stay raw:
-    decode with the `units` attribute).  Same backends as read_qlateral, minus xarray's decoding."""
+    """-> {name: (array, dims tuple, attrs dict)} for the named variables of one netCDF file, fill values masked to NaN and
+    packed values unpacked (time variables stay raw numbers: decode them with the `units` attribute).  Same backends as
+    read_qlateral, minus xarray's time decoding."""
     out = {}
     try:
         import netCDF4 as nc
         with nc.Dataset(str(path)) as ds:
-            ds.set_auto_mask(False)
+            ds.set_auto_maskandscale(False)       # raw values: one decoder for both backends
             for name in names:
                 v = ds[name]
-                out[name] = (np.asarray(v[:]), tuple(v.dimensions), {k: v.getncattr(k) for k in v.ncattrs()})
+                attrs = {k: v.getncattr(k) for k in v.ncattrs()}
+                out[name] = (_cf_decode(np.asarray(v[:]), attrs), tuple(v.dimensions), attrs)
         return out
     except ImportError:
         pass
     from scipy.io import netcdf_file
-    with netcdf_file(str(path), 'r', mmap=False) as ds:
+    with netcdf_file(str(path), 'r', mmap=False, maskandscale=False) as ds:
         for name in names:
             if name not in ds.variables:
                 raise KeyError(f'{name} not in {path}')
@@ -72,9 +102,7 @@ def read_variables(path, names):
             attrs = {k: (a.decode() if isinstance(a, bytes) else a) for k, a in v._attributes.items()}
             arr = np.array(v[:])
             arr = arr.astype(arr.dtype.newbyteorder('='), copy=False)      # NetCDF-3 is big-endian on disk
-            if 'scale_factor' in attrs or 'add_offset' in attrs:      # CF packing, as xarray / netCDF4 decode it
-                arr = arr * np.float64(attrs.get('scale_factor', 1.0)) + np.float64(attrs.get('add_offset', 0.0))
-            out[name] = (arr, tuple(v.dimensions), attrs)
+            out[name] = (_cf_decode(arr, attrs), tuple(v.dimensions), attrs)
     return out
 
 

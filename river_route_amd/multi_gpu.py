@@ -229,38 +229,51 @@ def run_in_process(engines, specs, T: int, nsub: int, chunk_rows: int) -> None:
             raise RuntimeError('run_in_process: parts are deadlocked (no message can be delivered)')
 
 
-def roofline_from_profile(prof: dict, nsub: int, traffic, peak_gbs: float = 8000.0, traffic_per_reach_tick=None):
-    """`roofline` object of bench.py from Plan.profile(): algorithmic bytes of SURVEY section 8(d) (72 B per reach
-    sub-step + 16 B per reach row) over the HIP-event time of the bracketed routing launches.  Every eighth launch
-    is bracketed, fill and drain launches included, so `avg_launch_us` is the average rocprofv3 reports for the
-    kernel and the bytes are those of the average launch.  `traffic` = measured HBM bytes per launch, given directly
-    or as bytes per reach-tick (PMC passes over full launches) times the reach-ticks of the average launch."""
+TILE_STATE_BYTES = 72.0      # per position and task: lag, first upstream, counts, ghost link (16), ss, sq, c1, c2, c3 read (40), sq, ss written (16)
+
+
+def roofline_from_profile(prof: dict, nsub: int, peak_gbs: float = 8000.0, traffic_per_position_tick=None, traffic_source=None,
+                          copy_gbs=None, unit: bool = False):
+    """`roofline` object of bench.py from Plan.profile() for the dominant kernel.
+
+    Time-tiled kernel (k_tile; a launch advances its tiles by K ticks): ALGORITHMIC bytes of a launch = positions x
+    (16 B x K: the record of every position read once and written once, a ghost's by the tile that owns its reach) +
+    positions x 72 B (80 with the channel state of UnitMuskingum) of state and coefficients once per task; `frac` =
+    those bytes / HIP-event time of the sampled launches / peak, a fraction of the roofline by construction.
+    Every fourth launch is sampled, fill and drain launches included, so `avg_launch_us` is the average rocprofv3
+    reports for the kernel.  `traffic` = HBM bytes per launch measured by separate rocprofv3 --pmc passes (bytes per
+    position-tick of full launches x the position-ticks of the average launch), with the file it came from.
+    `streaming_model_*` prices the same launches at SURVEY section 8(d)'s contract figure (72 B per reach sub-step + 16 B
+    per reach row: what a kernel that keeps nothing on chip between ticks would move); a time-tiled kernel undercuts
+    it, so that figure may exceed the peak and is NOT the roofline fraction."""
     if prof['sampled'] <= 0 or prof['sampled_ms'] <= 0:
         return None
-    bytes_per_reach_tick = 72.0 + 16.0 / nsub
     tpl = max(1, prof['ticks_per_launch'])
     launches = prof['sampled'] / tpl
     avg_ms = prof['sampled_ms'] / launches
-    reach_ticks = prof['sampled_reaches'] / launches
-    if traffic is None and traffic_per_reach_tick is not None:
-        traffic = round(traffic_per_reach_tick * reach_ticks)
-    alg_bytes = bytes_per_reach_tick * reach_ticks
-    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    return {'bound': 'hbm', 'achieved': round(achieved, 1), 'peak': peak_gbs, 'unit': 'GB/s',
-            'frac': round(achieved / peak_gbs, 4), 'traffic': traffic,
-            'kernel': 'k_wave (time-tiled routing)' if tpl > 1 else 'k_tick (streaming routing)',
-            'ticks_per_launch': tpl, 'avg_launch_us': round(avg_ms * 1e3, 3),
-            'algorithmic_bytes_per_launch': round(alg_bytes),
-            'compulsory_bytes_per_launch': round(16.0 / nsub * reach_ticks),
-            'compulsory_gbps': round(16.0 / nsub * reach_ticks / (avg_ms * 1e-3) / 1e9, 1),
-            'frac_compulsory': round(16.0 / nsub * reach_ticks / (avg_ms * 1e-3) / 1e9 / peak_gbs, 4),
-            'measured_hbm_gbps': None if traffic is None else round(traffic / (avg_ms * 1e-3) / 1e9, 1),
-            'frac_measured': None if traffic is None else round(traffic / (avg_ms * 1e-3) / 1e9 / peak_gbs, 4),
-            'note': 'achieved/frac price a launch at the streaming model of SURVEY 8(d) (88 B per reach-step at one '
-                    'sub-step), which a time-tiled kernel undercuts, hence frac > 1; frac_measured uses the HBM bytes '
-                    'the kernel really moved (traffic), frac_compulsory the 16 B per reach-step no schedule avoids',
-            'launches_per_pass': prof['launches'], 'launches_sampled': int(launches),
-            'pass_region_ms': round(prof['region_ms'], 3)}
+    pos_ticks = prof['sampled_reaches'] / launches          # position-ticks (time-tiled) or reach-ticks (streaming) per launch
+    streaming = (72.0 + 16.0 / nsub) * pos_ticks
+    if tpl > 1:
+        alg = pos_ticks * (16.0 + (TILE_STATE_BYTES + (8.0 if unit else 0.0)) / tpl)
+        kernel = f'k_tile (time-tiled routing over subtree tiles, {tpl} ticks per task)'
+    else:
+        alg = streaming
+        kernel = 'k_tick (streaming routing)'
+    sec = avg_ms * 1e-3
+    traffic = None if traffic_per_position_tick is None else round(traffic_per_position_tick * pos_ticks)
+    out = {'bound': 'hbm', 'achieved': round(alg / sec / 1e9, 1), 'peak': peak_gbs, 'unit': 'GB/s',
+           'frac': round(alg / sec / 1e9 / peak_gbs, 4), 'traffic': traffic, 'traffic_source': traffic_source,
+           'kernel': kernel, 'ticks_per_launch': tpl, 'avg_launch_us': round(avg_ms * 1e3, 3),
+           'algorithmic_bytes_per_launch': round(alg),
+           'algorithmic_bytes_per_position_tick': round(alg / pos_ticks, 3),
+           'measured_hbm_gbps': None if traffic is None else round(traffic / sec / 1e9, 1),
+           'frac_measured_traffic': None if traffic is None else round(traffic / sec / 1e9 / peak_gbs, 4),
+           'peak_measured_copy': None if copy_gbs is None else round(copy_gbs, 1),
+           'frac_of_measured_copy': None if copy_gbs is None else round(alg / sec / 1e9 / copy_gbs, 4),
+           'streaming_model_gbps': round(streaming / sec / 1e9, 1),
+           'launches_per_pass': prof['launches'], 'launches_sampled': int(launches),
+           'pass_region_ms': round(prof['region_ms'], 3)}
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ bench.py --gpus N
@@ -275,7 +288,7 @@ def bench_main(args, rank: int, local_rank: int, world: int) -> None:
     from . import synth
     from .engine import partition_forest
 
-    n, T, nsub, dt = args.reaches * world, args.runoff_steps, args.substeps, 900.0
+    n, T, nsub, dt = args.reaches * world, args.runoff_steps, args.substeps, 900.0      # 1.25M per GPU by default: 10M on 8 GPUs (BASELINE config 5)
     net = synth.synth_network(n, order=args.order)
     has = net.down_index >= 0
     indptr = np.concatenate([[0], np.cumsum(has)]).astype(np.int32)
@@ -315,7 +328,7 @@ def bench_main(args, rank: int, local_rank: int, world: int) -> None:
     gathered = [torch.zeros_like(info) for _ in range(world)]
     dist.all_gather(gathered, info)
     if rank == 0:
-        roofline = roofline_from_profile(prof, nsub, None)
+        roofline = roofline_from_profile(prof, nsub)
         line = {
             'metric': 'reach-steps/sec', 'value': float(n) * T * nsub * args.steps / elapsed,
             'unit': 'reach-steps/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,

@@ -11,32 +11,30 @@ __all__ = ['RapidMuskingum']
 class RapidMuskingum(TransformMuskingum):
     _as_volumes = True   # qlateral is a volume (m3) per runoff step
 
+    def _lateral_coefficient(self) -> None:
+        """c4 / dt_runoff turns a volume per runoff step into the discharge term of the routing step (RapidMuskingum.py:24)."""
+        self._upload_coefficients(self.c4 / self.dt_runoff, ('rapid', int(self.dt_runoff)))
+
     def _router(self, qlateral: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
-        n = self.A.shape[0]
-        discharge_array = np.zeros((self.num_runoff_steps, n), dtype=np.float64)
-        q_t = np.array(self.channel_state, dtype=np.float64, order='C')
-        c4_dt = self.c4 / self.dt_runoff
-        self._upload_coefficients(c4_dt, ('rapid', int(self.dt_runoff)))
-        self._plan.rapid_route(q_t, qlateral, discharge_array, self.num_routing_steps_per_runoff)
-        return q_t, discharge_array
+        state = np.array(self.channel_state, dtype=np.float64, order='C')
+        routed = np.zeros((self.num_runoff_steps, state.shape[0]), dtype=np.float64)
+        self._lateral_coefficient()
+        self._plan.rapid_route(state, qlateral, routed, self.num_routing_steps_per_runoff)
+        return state, routed
+
+    _engine_router = _router
 
     def _router_device(self, qlateral: np.ndarray, rows_per_output: int) -> tuple[np.ndarray, np.ndarray]:
-        from ..engine import DeviceBuffer, resample_cast_dev
+        from ._device import Arena, float32_rows
         ql = self._check_lateral(qlateral)
         T, n = ql.shape
-        dev = self.cfg.device
-        self._upload_coefficients(self.c4 / self.dt_runoff, ('rapid', int(self.dt_runoff)))
-        bufs = []
-        try:
-            d_ql = DeviceBuffer(ql.nbytes, dev).upload(ql); bufs.append(d_ql)
-            d_out = DeviceBuffer(ql.nbytes, dev); bufs.append(d_out)
-            d_q = DeviceBuffer(n * 8, dev).upload(np.array(self.channel_state, dtype=np.float64, order='C')); bufs.append(d_q)
-            d_f32 = DeviceBuffer((T // rows_per_output) * n * 4, dev); bufs.append(d_f32)
-            self._plan.rapid_route_dev(d_q, d_ql, T, d_out, T, T, self.num_routing_steps_per_runoff)
-            resample_cast_dev(d_out, T, n, rows_per_output, d_f32, dev)
-            q_array = d_f32.download(np.float32, (T // rows_per_output, n))
-            q_t = d_q.download(np.float64, (n,))
-        finally:
-            for b in bufs:
-                b.free()
-        return q_t, q_array
+        nsub = self.num_routing_steps_per_runoff
+        self._lateral_coefficient()
+        with Arena(self.cfg.device) as arena:
+            d_ql = arena.put(ql)
+            d_q = arena.put(np.array(self.channel_state, dtype=np.float64, order='C'))
+            q_array = float32_rows(
+                arena, T, n, rows_per_output,
+                fused=lambda d32: self._plan.rapid_route_f32_dev(d_q, d_ql, T, d32, T, nsub, rows_per_output),
+                plain=lambda d64: self._plan.rapid_route_dev(d_q, d_ql, T, d64, T, T, nsub))
+            return d_q.download(np.float64, (n,)), q_array

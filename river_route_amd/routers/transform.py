@@ -9,7 +9,7 @@ from abc import ABC, abstractmethod
 
 import numpy as np
 
-from .muskingum import Muskingum
+from .muskingum import PROGRESS, Muskingum
 
 __all__ = ['TransformMuskingum']
 
@@ -42,78 +42,93 @@ class TransformMuskingum(Muskingum, ABC):
                        ds['qlateral'].values.astype(np.float64, copy=False), runoff_file, discharge_file)
 
     def _validate_router_configs(self) -> None:
-        qlateral = self.cfg.qlateral_files
-        grids = self.cfg.grid_runoff_files and self.cfg.grid_weights_file
-        if qlateral and grids:
+        laterals = list(self.cfg.qlateral_files or [])
+        grids = list(self.cfg.grid_runoff_files or []) if self.cfg.grid_weights_file else []
+        if laterals and self.cfg.grid_runoff_files and self.cfg.grid_weights_file:
             raise ValueError('Provide qlateral_files or grid_runoff_files with grid_weights_file, not both')
-        if not qlateral and not grids:
+        if not laterals and not grids:
             raise ValueError('Provide qlateral_files or grid_runoff_files with grid_weights_file')
-        n_inputs = len(qlateral) + len(self.cfg.grid_runoff_files or [])
-        if len(self.cfg.discharge_files) != n_inputs:
+        if len(self.cfg.discharge_files) != len(laterals) + len(self.cfg.grid_runoff_files or []):
             raise ValueError('Number of resolved discharge output files must match number of input files')
 
-    def _set_network_and_time_dependent_vectors(self, dates: np.ndarray) -> None:
-        """Time-step defaults and rules of docs/references/time-options.md (TransformMuskingum.py:66-106)."""
-        self.logger.debug('Setting and validating time parameters')
-        self.dt_runoff = self.cfg.dt_runoff or (dates[1] - dates[0]).astype('timedelta64[s]').astype(int)
-        self.dt_discharge = self.cfg.dt_discharge or self.dt_runoff
-        self.dt_total = self.cfg.dt_total or self.dt_runoff * dates.shape[0]
-        if not self.cfg.dt_routing:
-            self.logger.warning('dt_routing was not provided or is Null/False, defaulting to dt_runoff')
-        self.dt_routing = self.cfg.dt_routing or self.dt_runoff
+    # the four time steps, coarsest first, and the rule each adjacent pair obeys (docs/references/time-options.md:32-50)
+    _STEP_PAIRS = (('dt_total', 'dt_runoff'), ('dt_total', 'dt_discharge'), ('dt_discharge', 'dt_runoff'), ('dt_runoff', 'dt_routing'))
 
-        signature = (self.dt_total, self.dt_runoff, self.dt_discharge, self.dt_routing)
-        if self._network_time_signature == signature:
-            return
-        for big, small in (('dt_total', 'dt_runoff'), ('dt_total', 'dt_discharge'), ('dt_discharge', 'dt_runoff'),
-                           ('dt_runoff', 'dt_routing')):
-            if getattr(self, big) < getattr(self, small):
-                raise ValueError(f'{big} must be >= {small}')
-        for big, small in (('dt_total', 'dt_runoff'), ('dt_total', 'dt_discharge'), ('dt_discharge', 'dt_runoff'),
-                           ('dt_runoff', 'dt_routing')):
-            if getattr(self, big) % getattr(self, small) != 0:
-                raise ValueError(f'{big} must be an integer multiple of {small}')
-        self.num_runoff_steps = int(self.dt_total / self.dt_runoff)
-        self.num_runoff_steps_per_discharge = int(self.dt_discharge / self.dt_runoff)
-        self.num_routing_steps_per_runoff = int(self.dt_runoff / self.dt_routing)
+    def _set_network_and_time_dependent_vectors(self, dates: np.ndarray) -> None:
+        """Time-step defaults and rules (river_route/routers/TransformMuskingum.py:66-106), then the coefficients."""
+        self.logger.debug('Setting and validating time parameters')
+        cfg = self.cfg
+        from_dates = int((dates[1] - dates[0]).astype('timedelta64[s]').astype(int)) if not cfg.dt_runoff else None
+        self.dt_runoff = cfg.dt_runoff or from_dates
+        self.dt_discharge = cfg.dt_discharge or self.dt_runoff
+        self.dt_total = cfg.dt_total or self.dt_runoff * dates.shape[0]
+        if not cfg.dt_routing:
+            self.logger.warning('dt_routing was not provided or is Null/False, defaulting to dt_runoff')
+        self.dt_routing = cfg.dt_routing or self.dt_runoff
+
+        steps = (self.dt_total, self.dt_runoff, self.dt_discharge, self.dt_routing)
+        if steps == self._network_time_signature:
+            return      # same grid as the previous file: counts and coefficients stand
+        value = dict(zip(('dt_total', 'dt_runoff', 'dt_discharge', 'dt_routing'), steps))
+        for rule, message in ((lambda a, b: a >= b, '{} must be >= {}'), (lambda a, b: a % b == 0, '{} must be an integer multiple of {}')):
+            for coarse, fine in self._STEP_PAIRS:
+                if not rule(value[coarse], value[fine]):
+                    raise ValueError(message.format(coarse, fine))
+        self.num_runoff_steps = self.dt_total // self.dt_runoff
+        self.num_runoff_steps_per_discharge = self.dt_discharge // self.dt_runoff
+        self.num_routing_steps_per_runoff = self.dt_runoff // self.dt_routing
         self._set_muskingum_coefficients(self.dt_routing)
         self.c4 = self.c1 + self.c2
-        self._network_time_signature = signature
+        self._network_time_signature = steps
+
+    def _route_one_file(self, qlateral: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        """(final state, float32 discharge at dt_discharge) of one file.  The file stays on the GPU from the lateral
+        upload to the float32 rows unless a subclass brings its own `_router` (the reference's extension point), the
+        engine is not the HIP plan, or the file does not fit on the card: then `_router` + the post-processing of
+        TransformMuskingum.py:128-142 on the host."""
+        per = self.num_runoff_steps_per_discharge
+        own_router = type(self)._router is getattr(type(self), '_engine_router', None)
+        if self._device_postprocess and own_router and hasattr(self._plan, 'rapid_route_dev'):
+            from ._device import DeviceOutOfMemory
+            try:
+                return self._router_device(qlateral, per)
+            except DeviceOutOfMemory as e:
+                self.logger.warning(f'file does not fit on the device ({e}); routing it in chunks from host memory')
+        q_t, q_array = self._router(qlateral)
+        if per > 1:
+            q_array = q_array.reshape((-1, per, q_array.shape[1])).mean(axis=1)
+        return q_t, q_array.astype(np.float32, copy=False)
 
     def _execute_routing(self) -> None:
-        self._ensemble_member_states = []
-        total_files = len(self.cfg.qlateral_files or self.cfg.grid_runoff_files)
-        file_iter = self._qlateral_generator()
+        import time
+        members: list[np.ndarray] = []
+        files = self._qlateral_generator()
         if self.cfg.progress_bar:
             from tqdm import tqdm
-            file_iter = tqdm(file_iter, total=total_files, desc='Files Routed')
-
-        for dates, qlateral, runoff_file, discharge_file in file_iter:
+            files = tqdm(files, total=len(self.cfg.qlateral_files or self.cfg.grid_runoff_files), desc='Files Routed')
+        sequential = self.cfg.runoff_processing_mode == 'sequential'
+        for dates, qlateral, runoff_file, discharge_file in files:
             self.logger.info(f'Routing qlateral: {runoff_file}')
             self._set_network_and_time_dependent_vectors(dates)
             self.logger.debug('Starting routing computation')
-            per = int(self.dt_discharge / self.dt_runoff) if self.dt_discharge > self.dt_runoff else 1
-            if self._device_postprocess and hasattr(self._plan, 'rapid_route_dev'):
-                # device-resident file: lateral in once, resample-mean + float32 cast on the GPU, float32 out
-                q_t, q_array = self._router_device(qlateral, per)
-            else:
-                q_t, q_array = self._router(qlateral)
-                if per > 1:
-                    q_array = q_array.reshape((int(self.dt_total / self.dt_discharge), per, self.A.shape[0])).mean(axis=1)
-                q_array = q_array.astype(np.float32, copy=False)
-            if self.cfg.runoff_processing_mode == 'sequential':
+            t0 = time.perf_counter()
+            q_t, q_array = self._route_one_file(qlateral)
+            seconds = time.perf_counter() - t0
+            reach_steps = self.A.shape[0] * self.num_runoff_steps * self.num_routing_steps_per_runoff
+            self.logger.log(PROGRESS, f'{reach_steps / max(seconds, 1e-9):.3e} reach-steps/s '
+                                      f'({reach_steps * 16 / max(seconds, 1e-9) / 1e9:.1f} GB/s of lateral + discharge rows) for {runoff_file}')
+            if sequential:
                 self.channel_state = q_t
-            elif self.cfg.runoff_processing_mode == 'ensemble':
-                self._ensemble_member_states.append(q_t.copy())
-            if per > 1:
+            else:
+                members.append(np.array(q_t, copy=True))
+            if self.num_runoff_steps_per_discharge > 1:
                 self.logger.debug('Resampling dates and discharges to specified timestep')
                 dates = dates[::self.num_runoff_steps_per_discharge]
-
             self.logger.debug('Writing Discharge Array to File')
             self._write_discharges(dates, q_array, discharge_file, runoff_file)
-
-        if self.cfg.runoff_processing_mode == 'ensemble':
-            self.channel_state = np.array(self._ensemble_member_states).mean(axis=0)
+        if not sequential:
+            self._ensemble_member_states = members
+            self.channel_state = np.mean(np.array(members), axis=0)
         self.logger.info('-' * 60)
 
     @abstractmethod

@@ -31,50 +31,59 @@ class UnitMuskingum(TransformMuskingum):
                 f'Headwater split: {len(self.hw_idx)} headwater, {len(self.inner_idx)} inner '
                 f'({len(self.hw_idx) / self.A.shape[0] * 100:.0f}% excluded from solve)')
 
+    def _check_kernel(self) -> None:
+        """The kernel file must describe this network: one column of taps per reach (scipy's fftconvolve raises in the
+        reference; raw device addresses would not)."""
+        n = self.A.shape[0]
+        if self._uh.kernel.ndim != 2 or self._uh.kernel.shape[1] != n or np.shape(self._uh.state) != self._uh.kernel.shape:
+            raise ValueError(f'unit-hydrograph kernel {self._uh.kernel.shape} / state {np.shape(self._uh.state)} do not match '
+                             f'the network: expected (n_kernel_steps, {n})')
+
+    def _seed(self) -> np.ndarray:
+        """Channel and full discharge of the inner reaches both restart from channel_state at every file (UnitMuskingum.py:78-79)."""
+        return np.array(self.channel_state[self.inner_idx], dtype=np.float64, order='C')
+
     def _router(self, qlateral: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
-        convolved = self._uh.convolve(qlateral)                       # rr_uh_convolve
+        self._check_kernel()
+        lateral = self._uh.convolve(qlateral)                       # rr_uh_convolve
         n = self.river_ids.shape[0]
-        discharge_array = np.zeros((self.num_runoff_steps, n), dtype=np.float64)
-        # both channel and full discharge are re-seeded from channel_state at every file (UnitMuskingum.py:78-79)
-        q_ch = np.array(self.channel_state[self.inner_idx], dtype=np.float64, order='C')
+        routed = np.zeros((self.num_runoff_steps, n), dtype=np.float64)
+        q_ch = self._seed()
         q_full = q_ch.copy()
         self._upload_coefficients(None, ('unit',))
-        self._plan.unit_route(q_ch, q_full, convolved, discharge_array, self.num_routing_steps_per_runoff)
-        q_final = np.empty(n, dtype=np.float64)
-        q_final[self.hw_idx] = convolved[-1][self.hw_idx]
-        q_final[self.inner_idx] = q_full
-        return q_final, discharge_array
+        self._plan.unit_route(q_ch, q_full, lateral, routed, self.num_routing_steps_per_runoff)
+        state = np.empty(n, dtype=np.float64)
+        state[self.hw_idx] = lateral[-1][self.hw_idx]       # a headwater's state is its last lateral inflow
+        state[self.inner_idx] = q_full
+        return state, routed
+
+    _engine_router = _router
 
     def _router_device(self, qlateral: np.ndarray, rows_per_output: int) -> tuple[np.ndarray, np.ndarray]:
-        from ..engine import DeviceBuffer, resample_cast_dev, uh_convolve_dev
+        from ..engine import uh_convolve_dev
+        from ._device import Arena, float32_rows
+        self._check_kernel()
         depth = self._check_lateral(qlateral)
         T, n = depth.shape
-        dev = self.cfg.device
-        n_ks = self._uh.kernel.shape[0]
+        n_ks, nsub = self._uh.kernel.shape[0], self.num_routing_steps_per_runoff
         self._upload_coefficients(None, ('unit',))
-        bufs = []
-        try:
-            d_depth = DeviceBuffer(depth.nbytes, dev).upload(depth); bufs.append(d_depth)
-            d_kern = DeviceBuffer(self._uh.kernel.nbytes, dev).upload(self._uh.kernel); bufs.append(d_kern)
-            d_state = DeviceBuffer(self._uh.kernel.nbytes, dev).upload(np.ascontiguousarray(self._uh.state)); bufs.append(d_state)
-            d_conv = DeviceBuffer(depth.nbytes, dev); bufs.append(d_conv)
-            uh_convolve_dev(d_kern, d_state, d_depth, d_conv, T, n_ks, n, device=dev)
+        with Arena(self.cfg.device) as arena:
+            d_depth = arena.put(depth)
+            d_kern = arena.put(self._uh.kernel)
+            d_state = arena.put(np.ascontiguousarray(self._uh.state, dtype=np.float64))
+            d_conv = arena.empty(depth.nbytes)
+            uh_convolve_dev(d_kern, d_state, d_depth, d_conv, T, n_ks, n, device=self.cfg.device)
             self._uh.state = d_state.download(np.float64, self._uh.kernel.shape)
-            d_depth.free()
-            q_ch = np.array(self.channel_state[self.inner_idx], dtype=np.float64, order='C')
-            d_qch = DeviceBuffer(max(q_ch.nbytes, 8), dev).upload(q_ch); bufs.append(d_qch)
-            d_qfull = DeviceBuffer(max(q_ch.nbytes, 8), dev).upload(q_ch); bufs.append(d_qfull)
-            d_out = DeviceBuffer(depth.nbytes, dev); bufs.append(d_out)
-            d_f32 = DeviceBuffer((T // rows_per_output) * n * 4, dev); bufs.append(d_f32)
-            self._plan.unit_route_dev(d_qch, d_qfull, d_conv, T, d_out, T, T, self.num_routing_steps_per_runoff)
-            resample_cast_dev(d_out, T, n, rows_per_output, d_f32, dev)
-            q_array = d_f32.download(np.float32, (T // rows_per_output, n))
-            q_final = d_conv.download(np.float64, (n,), offset=(T - 1) * n * 8)    # headwaters keep the last lateral row
-            q_final[self.inner_idx] = d_qfull.download(np.float64, q_ch.shape)
-        finally:
-            for b in bufs:
-                b.free()
-        return q_final, q_array
+            arena.release(d_depth)
+            seed = self._seed()
+            d_qch, d_qfull = arena.put(seed), arena.put(seed)
+            q_array = float32_rows(
+                arena, T, n, rows_per_output,
+                fused=lambda d32: self._plan.unit_route_f32_dev(d_qch, d_qfull, d_conv, T, d32, T, nsub, rows_per_output),
+                plain=lambda d64: self._plan.unit_route_dev(d_qch, d_qfull, d_conv, T, d64, T, T, nsub))
+            state = d_conv.download(np.float64, (n,), offset=(T - 1) * n * 8)    # headwaters keep the last lateral row
+            state[self.inner_idx] = d_qfull.download(np.float64, seed.shape)
+        return state, q_array
 
     def _write_final_state(self) -> None:
         super()._write_final_state()

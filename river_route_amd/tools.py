@@ -1,12 +1,13 @@
 """
-Network structure helpers on the hot path (river_route/tools.py:75-109) plus the engine-order helper.
+Network structure helpers: `adjacency_matrix` on the hot path (river_route/tools.py:75-109), the engine-order helper,
+and the reference's offline network-editing utilities (river_route/tools.py:20-72) on plain arrays.
 """
 from __future__ import annotations
 
 import numpy as np
 import scipy.sparse
 
-__all__ = ['adjacency_matrix', 'engine_order']
+__all__ = ['adjacency_matrix', 'engine_order', 'connectivity_to_digraph', 'upstream_of', 'subset_configs_to_river']
 
 
 def adjacency_matrix(river_ids: np.ndarray, downstream_ids: np.ndarray) -> scipy.sparse.csc_matrix:
@@ -51,3 +52,66 @@ def engine_order(river_ids: np.ndarray, downstream_ids: np.ndarray) -> np.ndarra
     A = adjacency_matrix(river_ids, downstream_ids)
     with Plan(A.indptr, A.indices, device=_lib.RR_DEVICE_NONE) as plan:
         return plan.layout()[0].astype(np.int64)
+
+
+def connectivity_to_digraph(river_ids: np.ndarray, downstream_ids: np.ndarray):
+    """networkx.DiGraph with one edge per reach, river -> downstream river, the -1 outlet sentinel included as a node
+    (river_route/tools.py:57-72).  networkx is imported here: nothing on the routing path needs it."""
+    import networkx as nx
+    graph = nx.DiGraph()
+    graph.add_edges_from(zip(np.asarray(river_ids).tolist(), np.asarray(downstream_ids).tolist()))
+    return graph
+
+
+def upstream_of(target_river: int, river_ids: np.ndarray, downstream_ids: np.ndarray) -> np.ndarray:
+    """Boolean mask of `target_river` and every reach that drains into it, for ids in ANY order: a breadth-first walk up
+    the network over a sorted edge list (what the reference gets from networkx.ancestors, river_route/tools.py:42-44)."""
+    rid = np.asarray(river_ids).astype(np.int64, copy=False).ravel()
+    did = np.asarray(downstream_ids).astype(np.int64, copy=False).ravel()
+    if not (rid == target_river).any():
+        raise ValueError(f'river {target_river} is not in river_ids')
+    by_down = np.argsort(did, kind='stable')
+    keys = did[by_down]
+    keep = np.zeros(rid.shape[0], dtype=bool)
+    frontier = np.flatnonzero(rid == target_river)
+    while frontier.size:
+        keep[frontier] = True
+        lo, hi = np.searchsorted(keys, rid[frontier], 'left'), np.searchsorted(keys, rid[frontier], 'right')
+        nxt = np.concatenate([by_down[a:b] for a, b in zip(lo, hi)]) if frontier.size else frontier
+        frontier = nxt[~keep[nxt]]
+    return keep
+
+
+def subset_configs_to_river(target_river: int, params, out_params, weights=None, out_weights=None) -> None:
+    """Routing parameters (and, when both weight paths are given, the grid weight table) of `target_river` and everything
+    upstream of it; the target becomes the outlet of the subset, downstream_river_id = -1 (river_route/tools.py:20-54).
+    Row order is kept, so a topologically sorted file stays sorted."""
+    import pandas as pd
+    table = pd.read_parquet(params)
+    keep = upstream_of(target_river, table['river_id'].to_numpy(), table['downstream_river_id'].to_numpy())
+    subset = table.loc[keep].copy()
+    subset.loc[subset['river_id'] == target_river, 'downstream_river_id'] = -1
+    subset.to_parquet(out_params)
+    if weights is None or out_weights is None:
+        return
+    kept_ids = subset['river_id'].to_numpy()
+    try:
+        import xarray as xr
+        with xr.open_dataset(weights) as ds:
+            ds.isel(index=np.isin(ds['river_id'].values, kept_ids)).to_netcdf(out_weights)
+        return
+    except ImportError:
+        pass
+    from scipy.io import netcdf_file      # NetCDF-3 stand-in where xarray is absent: every variable along `index` is filtered
+    with netcdf_file(str(weights), 'r', mmap=False) as src, netcdf_file(str(out_weights), 'w', version=2) as dst:
+        mask = np.isin(np.array(src.variables['river_id'][:]), kept_ids)
+        for name, size in src.dimensions.items():
+            dst.createDimension(name, int(mask.sum()) if name == 'index' else size)
+        for name, var in src.variables.items():
+            data = np.array(var[:])
+            if 'index' in var.dimensions:
+                data = np.compress(mask, data, axis=var.dimensions.index('index'))
+            out = dst.createVariable(name, data.dtype.newbyteorder('='), var.dimensions)
+            out[:] = data
+            for k, v in var._attributes.items():
+                setattr(out, k, v)

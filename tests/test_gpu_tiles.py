@@ -287,3 +287,34 @@ def test_uhkernels_convolve_equals_incremental_on_the_gpu():
     whole = b.convolve(depth)
     np.testing.assert_allclose(np.vstack([first, second]), whole, rtol=1e-12, atol=1e-12 * np.abs(whole).max())
     np.testing.assert_allclose(a.state, b.state, rtol=1e-12, atol=1e-12 * np.abs(whole).max())
+
+
+@pytest.mark.parametrize('n,T,nsub,factor', [(60_000, 256, 1, 1), (60_000, 256, 1, 4), (60_000, 96, 2, 2), (300_000, 384, 1, 8)])
+def test_float32_output_fused_into_the_record_pass(monkeypatch, n, T, nsub, factor):
+    """rr_rapid_route_f32_dev == float64 routing, then mean over `factor` rows, then the float32 cast
+    (river_route/routers/TransformMuskingum.py:128-142), bit for bit; a factor that does not divide a batch is refused."""
+    from river_route_amd._lib import RR_E_UNSUPPORTED, RRError
+    set_env(monkeypatch, {})
+    net = synth.synth_network(n, seed=17)
+    indptr, indices = csc_from_down(net.down_index)
+    dt = 900.0
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, dt)
+    c4_dt = (c1 + c2) / (dt * nsub)
+    ql = synth.synth_qlateral(n, 0, T, dt=dt * nsub)
+    q0 = 2.0 * synth.u01(3, np.arange(n))
+    with Plan(indptr, indices) as plan:
+        plan.set_coeffs(-c1[indices], c2, c3, c4_dt)
+        d_ql, d_q = DeviceBuffer(ql.nbytes).upload(ql), DeviceBuffer(n * 8).upload(q0)
+        d_64, d_32 = DeviceBuffer(T * n * 8), DeviceBuffer((T // factor) * n * 4)
+        plan.rapid_route_dev(d_q, d_ql, T, d_64, T, T, nsub)
+        q_a = d_q.download(np.float64, (n,))
+        want = d_64.download(np.float64, (T, n)).reshape(T // factor, factor, n).mean(axis=1).astype(np.float32)
+        d_q.upload(q0)
+        plan.rapid_route_f32_dev(d_q, d_ql, T, d_32, T, nsub, factor)
+        np.testing.assert_array_equal(d_32.download(np.float32, (T // factor, n)), want)
+        np.testing.assert_array_equal(d_q.download(np.float64, (n,)), q_a)
+        with pytest.raises(RRError) as e:
+            plan.rapid_route_f32_dev(d_q, d_ql, T, d_32, T - T % 3, nsub, 3)
+        assert e.value.code == RR_E_UNSUPPORTED
+        for b in (d_ql, d_q, d_64, d_32):
+            b.free()

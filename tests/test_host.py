@@ -96,3 +96,52 @@ def test_product_does_not_import_oracle():
             if f.endswith(('.py', '.cpp', '.hip', '.hpp', '.h')):
                 text = open(os.path.join(root, f)).read()
                 assert 'import oracle' not in text and 'from oracle' not in text and 'rr_oracle' not in text, f
+
+
+def test_network_tools_digraph_and_subset(tmp_path):
+    """river_route/tools.py:20-72: connectivity_to_digraph keeps the -1 sentinel edge (tests/test_tools.py:71-77 of the
+    reference); subset_configs_to_river keeps the target and everything upstream and makes the target the outlet."""
+    import pandas as pd
+    from river_route_amd import synth, tools
+    ids = np.array([10, 20, 30, 40], dtype=np.int64)
+    down = np.array([30, 30, 40, -1], dtype=np.int64)
+    g = tools.connectivity_to_digraph(ids, down)
+    assert set(g.edges()) == {(10, 30), (20, 30), (30, 40), (40, -1)} and -1 in g.nodes
+    net = synth.synth_network(2000, seed=12)
+    table = pd.DataFrame({'river_id': net.river_ids, 'downstream_river_id': net.downstream_ids, 'k': net.k, 'x': net.x})
+    params, out = tmp_path / 'params.parquet', tmp_path / 'subset.parquet'
+    table.to_parquet(params)
+    target = int(net.river_ids[1500])
+    tools.subset_configs_to_river(target, params, out)
+    sub = pd.read_parquet(out)
+    import networkx as nx
+    want = set(nx.ancestors(tools.connectivity_to_digraph(net.river_ids, net.downstream_ids), target)) | {target}
+    assert set(sub['river_id']) == want
+    assert int(sub.loc[sub['river_id'] == target, 'downstream_river_id'].iloc[0]) == -1
+    assert (sub['downstream_river_id'][sub['river_id'] != target].isin(sub['river_id'])).all()
+    tools.adjacency_matrix(sub['river_id'].to_numpy(), sub['downstream_river_id'].to_numpy())      # still sorted upstream -> downstream
+
+
+def test_packed_runoff_with_fill_values_is_masked(tmp_path):
+    """CF packing with a _FillValue (how ERA5-style runoff files store no-data cells): the reference reads through
+    xarray's mask_and_scale, so fill cells are NaN (and end up as zero inflow), never fill * scale."""
+    from scipy.io import netcdf_file
+    from river_route_amd.io import read_variables
+    path = tmp_path / 'packed.nc'
+    raw = np.array([[100, -32767, 300], [-32767, 500, 600]], dtype=np.int16)
+    with netcdf_file(str(path), 'w', version=2) as ds:
+        ds.createDimension('time', 2)
+        ds.createDimension('x', 3)
+        v = ds.createVariable('ro', 'i2', ('time', 'x'))
+        v[:] = raw
+        v.scale_factor, v.add_offset, v._FillValue = 0.5, 10.0, np.int16(-32767)
+        w = ds.createVariable('plain', 'f4', ('time', 'x'))
+        w[:] = raw.astype(np.float32)
+        w.missing_value = np.float32(-32767.0)
+    got = read_variables(path, ['ro', 'plain'])
+    ro, plain = got['ro'][0], got['plain'][0]
+    want = np.where(raw == -32767, np.nan, raw * 0.5 + 10.0)
+    np.testing.assert_array_equal(np.isnan(ro), raw == -32767)
+    np.testing.assert_allclose(ro[~np.isnan(ro)], want[~np.isnan(want)])
+    np.testing.assert_array_equal(np.isnan(plain), raw == -32767)
+    assert plain.dtype == np.float32 and plain[0, 0] == 100.0
