@@ -1,11 +1,12 @@
 """Times the host-pointer entry point rr_rapid_route (numpy arrays in/out, what river_route_amd.kernels.rapid_route
-calls) at 1M reaches: the PCIe-inclusive rate noted in DESIGN.md."""
+calls): the PCIe-inclusive rate noted in DESIGN.md.    python host_path.py [rows] [reaches]"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from river_route_amd import synth
 from river_route_amd.engine import Plan
-n, T = 1_000_000, int(sys.argv[1]) if len(sys.argv) > 1 else 192
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 192
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 1_000_000
 net = synth.synth_network(n)
 has = net.down_index >= 0
 indptr = np.concatenate([[0], np.cumsum(has)]).astype(np.int32); indices = net.down_index[has].astype(np.int32)

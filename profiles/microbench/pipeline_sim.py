@@ -1,17 +1,26 @@
 """Lock-step simulation of the multi-GPU pipeline (no GPU needed): the bench network is partitioned as `bench.py --gpus N`
 does, every part gets a host-only plan, and the executor's readiness rules (river_route_amd/csrc/rr_engine.hip:
-session_advance_wave -- a diagonal of the time-tiled schedule may launch once the boundary sub-steps it reads have
-arrived; exports become final `wave_export_skew` ticks behind the schedule; batches of 128 sub-steps are shipped) are
-stepped with one launch per part per step.  Prints, per part, the launches it needs alone and the step at which it
-finishes: the ratio is the pipeline's fill cost on top of a perfectly parallel run."""
-import numpy as np, sys, time
+session_advance_tile -- a batch of 128 tick-rows becomes records once the lateral rows AND the boundary sub-steps behind it
+have arrived; launch d runs once the ticks below (d + 1) K are records and the boundary sub-steps below (d + 1) K - slack are; an export reach in a tile of level l at lag L is
+final (d - l) K - L sub-steps into the schedule; finished sub-steps are shipped in batches of `exchange_rows`) are stepped
+with one launch per part per step (parts are the same size, so launches take the same time).  Prints, per part, the
+launches it needs alone and the step at which it finishes: the ratio is the pipeline's fill cost on top of a perfectly
+parallel run.
+
+    python profiles/microbench/pipeline_sim.py [reaches per GPU] > profiles/r02_pipeline_sim.txt
+"""
+import sys
+import numpy as np
 sys.path.insert(0, '.')
 from river_route_amd import synth
-from river_route_amd.engine import partition_forest, Plan
-from river_route_amd.multi_gpu import split_network
 from river_route_amd._lib import RR_DEVICE_NONE
+from river_route_amd.engine import Plan, partition_forest
+from river_route_amd.multi_gpu import split_network
 
-def simulate(n, parts, T=35040, K=16, BS=2048, batch=128):
+MASK = (1 << 27) - 1
+
+
+def simulate(n, parts, T=35040, K=64, batch=128, exchange=128):
     net = synth.synth_network(n, order='random')
     has = net.down_index >= 0
     indptr = np.concatenate([[0], np.cumsum(has)]).astype(np.int32)
@@ -20,56 +29,56 @@ def simulate(n, parts, T=35040, K=16, BS=2048, batch=128):
     info = []
     for p in range(parts):
         spec = split_network(net.down_index, part_of, p, parts)
-        plan = Plan(spec.indptr, spec.indices, device=RR_DEVICE_NONE)
-        perm, lag, child_ptr = plan.layout()
-        inv = np.empty_like(perm); inv[perm] = np.arange(perm.size)
-        n_loc = perm.size
-        ng = spec.n_ghost
-        nb = (n_loc + BS - 1) // BS
-        ghost_pos = inv[np.arange(ng)]
-        export_local = ng + np.searchsorted(spec.real_global, spec.export_global)
-        exp_pos = inv[export_local]
-        slack = int(np.min(ghost_pos // BS * K + lag[ghost_pos])) if ng else 0
-        # per upstream part slack (min over its ghosts)
-        ups = {}
-        for src, cols in spec.upstream_parts:
-            gp = ghost_pos[cols]
-            ups[src] = int(np.min(gp // BS * K + lag[gp]))
-        skew = int(np.max(exp_pos // BS * K + lag[exp_pos])) if export_local.size else 0
-        depth = int(lag.max()) + 1
-        n_chunks = (T + depth - 1 + K - 1) // K
-        info.append(dict(nb=nb, slack=slack, ups=ups, skew=skew, depth=depth, n_diags=n_chunks + nb - 1, n=n_loc))
-        plan.close()
-    # lockstep simulation in launch units
-    d = [0] * parts
-    sent = [0] * parts      # export sub-steps shipped (batched)
-    t = 0
-    done = [False] * parts
-    finish = [0] * parts
-    while not all(done) and t < 100000:
-        t += 1
-        export_ready = [T if d[p] >= info[p]['n_diags'] else max(0, d[p] * K - info[p]['skew']) for p in range(parts)]
-        for p in range(parts):
-            r = min(export_ready[p], T)
-            while r - sent[p] >= batch or (r >= T and sent[p] < T):
-                sent[p] = min(sent[p] + batch, r, T)
-        nd = list(d)
-        for p in range(parts):
-            if done[p]: continue
-            ok = True
-            for q, sl in info[p]['ups'].items():
-                need = min((d[p] + 1) * K - info[p]['slack'], T)     # engine uses the part-wide minimum slack
-                if sent[q] < need: ok = False
-            if ok:
-                nd[p] = d[p] + 1
-                if nd[p] >= info[p]['n_diags']:
-                    done[p] = True; finish[p] = t
-        d = nd
-    base = max(i['n_diags'] for i in info)
-    return info, finish, base
+        with Plan(spec.indptr, spec.indices, device=RR_DEVICE_NONE) as plan:
+            ti, L = plan.tile_info(), plan.tile_layout()
+            depth = plan.depth
+        real = (L['lag'] & (1 << 28)) == 0
+        inv = np.empty(spec.n_local, np.int64)
+        inv[L['perm'][real]] = np.flatnonzero(real)
+        tile_of = np.repeat(np.arange(ti['tiles']), np.diff(L['tile_ptr']))
+        export_local = spec.n_ghost + np.searchsorted(spec.real_global, spec.export_global)
+        pos = inv[export_local]
+        skew = int(np.max(L['tile_level'][tile_of[pos]] * K + (L['lag'][pos] & MASK))) if pos.size else 0
+        gpos = inv[np.arange(spec.n_ghost)]
+        slack = int(np.min(L['tile_level'][tile_of[gpos]] * K + (L['lag'][gpos] & MASK))) if gpos.size else 0
+        n_macro = -(-(T + depth - 1) // K)
+        info.append(dict(p=p, n=int(spec.real_global.size), ghosts=spec.n_ghost, exports=int(pos.size), depth=depth, levels=ti['levels'],
+                         tiles=ti['tiles'], skew=skew, slack=slack, n_diags=n_macro + ti['levels'] - 1, ups=[s for s, _ in spec.upstream_parts]))
+    sent = [0] * parts        # sub-steps of each part's export series shipped downstream
+    diag = [0] * parts
+    done_step = [None] * parts
+    step = 0
+    while any(d is None for d in done_step):
+        step += 1
+        new_sent = list(sent)
+        for i in info:
+            p = i['p']
+            if done_step[p] is not None:
+                continue
+            ghost_ready = min([sent[s] for s in i['ups']], default=T)
+            # boundary sub-steps that are records: whole batches of the ghost series (lateral rows are all resident); a
+            # ghost is first read `slack` ticks into the schedule
+            batches = T // batch + 1 if ghost_ready >= T else ghost_ready // batch
+            have = T if batches * batch >= T else max(0, batches * batch - 15)
+            if have >= min(max(0, (diag[p] + 1) * K - i['slack']), T):
+                diag[p] += 1
+            if diag[p] >= i['n_diags']:
+                done_step[p] = step
+                ready = T
+            else:
+                ready = max(0, min(T, diag[p] * K - i['skew']))
+            new_sent[p] = T if ready >= T else (ready // exchange) * exchange
+        sent = new_sent
+    print(f'{n} reaches, {parts} parts, T={T}, K={K}:')
+    for i in info:
+        print(f"  part {i['p']}: {i['n']} reaches, {i['ghosts']} boundary inflows from parts {i['ups']}, {i['exports']} exports, depth {i['depth']}, "
+              f"{i['tiles']} tiles in {i['levels']} levels, export skew {i['skew']} / ghost slack {i['slack']} ticks: {i['n_diags']} launches alone, "
+              f"finishes at step {done_step[i['p']]} ({done_step[i['p']] / i['n_diags']:.3f}x)")
+    first, last = min(done_step), max(done_step)
+    print(f'  last part finishes {last / first:.3f}x after the first; the slowest part alone needs {max(i["n_diags"] for i in info)} launches')
 
-for n, parts in ((2_000_000, 2), (4_000_000, 4), (8_000_000, 8)):
-    t0 = time.time()
-    info, finish, base = simulate(n, parts)
-    print(n, parts, 'launches alone', [i['n_diags'] for i in info], 'finish', finish, 'ratio %.2f' % (max(finish) / base),
-          'slack', [i['slack'] for i in info], 'skew', [i['skew'] for i in info], 'depth', [i['depth'] for i in info], f'{time.time()-t0:.0f}s')
+
+if __name__ == '__main__':
+    per = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000
+    for parts in (2, 4, 8):
+        simulate(per * parts, parts)

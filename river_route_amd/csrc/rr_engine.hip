@@ -17,7 +17,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rr_hip.h"
@@ -361,7 +363,7 @@ struct TileArgs {
 #ifdef RR_WAVE_TRACE
     long long *trace; int32_t trace_diag;   // development build: per-block timestamps of one launch (profiles/microbench/wave_dbg.py)
 #endif
-    int32_t np, t_last, KC, diag, n_macro, total, has_lat;
+    int32_t np, t_first, t_last, KC, diag, n_macro, total, has_lat;
     Div32 nsub;
     double inv_nsub;
 };
@@ -432,32 +434,43 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int32_t tile = a.t_last - (int32_t)blockIdx.x;      // highest level first: the few tiles with ghosts start in the first round
-    const int32_t m = a.diag - a.tile_level[tile];
-    if (m < 0 || m >= a.n_macro) return;
-    const int32_t total = a.total, tau_begin = m * a.KC * kRec;
-    // a tile none of whose positions is active during the task has nothing to do (pipeline fill and drain); a ghost has
-    // the lag of the reach it mirrors, so it is idle exactly when its owner did not write its record
-    if (tau_begin >= a.tile_lag_hi[tile] + total || tau_begin + a.KC * kRec <= a.tile_lag_lo[tile]) return;
-    const int32_t b0 = a.tile_ptr[tile], b1 = a.tile_ptr[tile + 1];
+    const int32_t total = a.total, K = a.KC * kRec;
     double *stage = lds + 2 * TH + (size_t)(tid >> 6) * (kStageLanes * kStageStride);   // this wave's transpose area
+    auto ring = [&](int32_t chunk) { return make_rsrc(a.rec + (int64_t)a.rec_chunks.mod((uint32_t)chunk) * a.np * kRec, (uint32_t)a.np * 128u); };   // np < 2^25
+
+    // A workgroup takes the tiles t_last - blockIdx.x - g * gridDim.x, g = 0, 1, ... of this launch (highest level first:
+    // the few tiles with ghosts start in the first round), so that the first record and the state of its NEXT tile are
+    // requested while the current one still ticks.  A tile none of whose positions is active during its task has nothing
+    // to do (pipeline fill and drain; a ghost has the lag of the reach it mirrors, so it is idle exactly when its owner
+    // did not write its record) and is skipped.
+    struct Task { int32_t tile, m, b0, b1; };
+    auto select = [&](int32_t from, Task &t) {
+        for (int32_t c = from; c >= a.t_first; c -= (int32_t)gridDim.x) {
+            const int32_t m = a.diag - a.tile_level[c];
+            if (m < 0 || m >= a.n_macro) continue;
+            if (m * K >= a.tile_lag_hi[c] + total || (m + 1) * K <= a.tile_lag_lo[c]) continue;
+            t.tile = c; t.m = m; t.b0 = a.tile_ptr[c]; t.b1 = a.tile_ptr[c + 1];
+            return true;
+        }
+        return false;
+    };
+    Task cur;
+    if (!select(a.t_last - (int32_t)blockIdx.x, cur)) return;
 #ifdef RR_WAVE_TRACE
-    const bool trace = a.trace && a.diag == a.trace_diag && tid == 0;
-    long long *tq = a.trace + (int64_t)tile * 16;
+    bool trace = a.trace && a.diag == a.trace_diag && tid == 0;
+    long long *tq = a.trace + (int64_t)cur.tile * 16;
 #define RR_TRACE(i) do { if (trace) tq[i] = wall_clock64(); } while (0)
 #else
 #define RR_TRACE(i) do { } while (0)
 #endif
     RR_TRACE(0);
-    auto ring = [&](int32_t chunk) { return make_rsrc(a.rec + (int64_t)a.rec_chunks.mod((uint32_t)chunk) * a.np * kRec, (uint32_t)a.np * 128u); };   // np < 2^25
-    __amdgpu_buffer_rsrc_t rec_cur = ring(m * a.KC);
 
     // Four lanes fetch (store) the four 16-byte pieces of one 64-byte sector: in flight a lane's N[] holds OTHER
     // positions' pieces; receive() hands them to their owners through the wave's staging area.
     double R[kRec], N[kRec];
     // load j of a record: (i = j / 2: half wave and group of 16 positions, half = j % 2: which 64-byte sector), so the two
     // sectors of a 128-byte line are requested by consecutive loads
-    auto issue_load = [&](__amdgpu_buffer_rsrc_t src, int j, bool real) {
+    auto issue_load = [&](__amdgpu_buffer_rsrc_t src, int32_t b0, int32_t b1, int j, bool real) {
         const int32_t t = fresh(tid), ln = t & 63;      // addresses are rebuilt at every use, not kept in registers across the task
         const int i = j >> 1, half = j & 1;
         const int32_t pos = min(b0 + (t - ln) + (i >> 1) * kStageLanes + 16 * (i & 1) + (ln >> 2), b1 - 1);
@@ -483,154 +496,171 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
             }
     };
 
-    // A slot past the end of the tile keeps lag -1: no upstream range, never active, publishes 0.0 to nobody.
-    // up: LDS slot of the first upstream value (low 16 bits) and the number of upstream positions (high 16 bits)
-    int32_t lg = -1, up = 0, xp = 0, uh = 0, sub = 0;
-    double c1 = 0.0, c2 = 0.0, c3 = 0.0, s_prev = 0.0, qch = 0.0, isum = 0.0, st_q = 0.0;
-    double *first_buf = lds + (size_t)((tau_begin + 1) & 1) * TH;     // tick tau_begin reads the buffer of tick tau_begin - 1
-    // State and coefficients are requested BEFORE the records: memory operations retire in order, so the wait for
-    // them below leaves the (much larger) record loads in flight.
-    {
-        const int32_t p = b0 + tid;
-        if (p < b1) {
+    // State of a position.  A slot past the end of the tile keeps lag -1: no upstream range, never active, publishes 0.0
+    // to nobody.  up: LDS slot of the first upstream value (low 16 bits), number of upstream positions (high 16 bits).
+    struct State { int32_t lg, up, xp, uh; double c1, c2, c3, s_prev, qch, isum, q; };
+    auto load_state = [&](const Task &t, State &s) {
+        s.lg = -1; s.up = 0; s.xp = 0; s.uh = 0;
+        s.c1 = s.c2 = s.c3 = s.s_prev = s.qch = s.isum = s.q = 0.0;
+        const int32_t p = t.b0 + tid;
+        if (p < t.b1) {
             const uint32_t cc = a.ccnt[p];
-            const int32_t first_up = a.cfirst[p] - b0;
-            lg = a.lag[p]; up = first_up | (int32_t)((cc & 0xFFFFu) << 16);
-            xp = a.xpos[p];
-            if (UNIT) { uh = first_up + (int32_t)(cc >> 16); qch = a.sqch[p]; }
-            if (SUB) isum = a.si[p];
-            s_prev = a.ss[p];
-            st_q = a.sq[p]; c1 = a.c1row[p]; c2 = a.c2[p]; c3 = a.c3[p];
+            const int32_t first_up = a.cfirst[p] - t.b0;
+            s.lg = a.lag[p]; s.up = first_up | (int32_t)((cc & 0xFFFFu) << 16);
+            s.xp = a.xpos[p];
+            if (UNIT) { s.uh = first_up + (int32_t)(cc >> 16); s.qch = a.sqch[p]; }
+            if (SUB) s.isum = a.si[p];
+            s.s_prev = a.ss[p];
+            s.q = a.sq[p]; s.c1 = a.c1row[p]; s.c2 = a.c2[p]; s.c3 = a.c3[p];
         }
-    }
+    };
+    // The first tile: state and coefficients are requested BEFORE the record: memory operations retire in order, so the
+    // wait for them leaves the (much larger) record load in flight.
+    State st;
+    load_state(cur, st);
+    __amdgpu_buffer_rsrc_t rec_cur = ring(cur.m * a.KC);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) issue_load(rec_cur, j, true);
+    for (int j = 0; j < 8; ++j) issue_load(rec_cur, cur.b0, cur.b1, j, true);
     // everything but the 8 record loads has arrived (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 |
     // vmcnt[5:4] << 14); a real s_waitcnt, so hipcc knows that no state register is pending inside the tick loop
     __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
-    first_buf[tid] = st_q;
-    if (SUB && lg >= 0) {      // phase of the position's sub-step counter at the first tick of the task
-        const int32_t ts0 = tau_begin - (lg & kLagMask);
-        const uint32_t r = a.nsub.mod((uint32_t)(ts0 < 0 ? -ts0 : ts0));
-        sub = ts0 >= 0 ? (int32_t)r : (r ? (int32_t)(a.nsub.d - r) : 0);
-    }
+    RR_TRACE(1);
+    receive();          // the first tile's first record: the only record load nothing overlaps
+    RR_TRACE(2);
     const bool has_lat = a.has_lat != 0;   // channel-only routing: the records only carry discharge
 
-    // Eight slots of the record are final: write that 64-byte sector.  Half a wave at a time parks its sectors in
-    // the wave's staging area, then all 64 lanes store them, four lanes per sector.
-    auto store_half = [&](__amdgpu_buffer_rsrc_t dst, int half) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (lane / kStageLanes == h) {
-                double2 *mine = reinterpret_cast<double2 *>(stage + (lane % kStageLanes) * kStageStride);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) mine[j] = make_double2(R[8 * half + 2 * j], R[8 * half + 2 * j + 1]);
-                reinterpret_cast<int32_t *>(mine + 4)[0] = (lg < 0 || (lg & (kGhostBit | kTileGhostBit))) ? 1 : 0;   // not this tile's to write
-            }
-            wave_lds_fence();
-            const int32_t t = fresh(tid), ln = t & 63;
-            const uint32_t first = (uint32_t)(b0 + (t - ln) + h * kStageLanes) * 128u + (uint32_t)half * 64u;
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {       // lanes 4i .. 4i+3: the four 16-byte pieces of position 16 g + i
-                const int pm = 16 * g + (ln >> 2), piece = ln & 3;
-                const double2 *theirs = reinterpret_cast<const double2 *>(stage + pm * kStageStride);
-                const double2 v = theirs[piece];
-                const bool skip = reinterpret_cast<const int32_t *>(theirs + 4)[0] != 0;
-                store_f64x2(dst, skip ? kDropAccess : first + (uint32_t)pm * 128u + (uint32_t)piece * 16u, v);
-            }
-            wave_lds_fence();
+    for (;;) {
+        int32_t lg = st.lg, up = st.up, xp = st.xp, uh = st.uh, sub = 0;
+        double c1 = st.c1, c2 = st.c2, c3 = st.c3, s_prev = st.s_prev, qch = st.qch, isum = st.isum;
+        const int32_t b0 = cur.b0, tau_begin = cur.m * K;
+        lds[(size_t)((tau_begin + 1) & 1) * TH + tid] = st.q;       // tick tau_begin reads the buffer of tick tau_begin - 1
+        if (SUB && lg >= 0) {      // phase of the position's sub-step counter at the first tick of the task
+            const int32_t ts0 = tau_begin - (lg & kLagMask);
+            const uint32_t r = a.nsub.mod((uint32_t)(ts0 < 0 ? -ts0 : ts0));
+            sub = ts0 >= 0 ? (int32_t)r : (r ? (int32_t)(a.nsub.d - r) : 0);
         }
-    };
-    auto ticks = [&](int32_t tau0, int half, __amdgpu_buffer_rsrc_t rec_next, bool more) {
-#pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8) {
-            const int s = 8 * half + s8;
-            // the next chunk's record is requested one load per tick: a CU accepts only so many requests at a time, and a
-            // wave that waits to issue its loads cannot tick
-            if (half == 0) issue_load(rec_next, s8, more);
-            const int32_t tau = tau0 + s;
-            const double *rd = lds + (size_t)((tau + 1) & 1) * TH;
-            double *wr = lds + (size_t)(tau & 1) * TH;
-            const int32_t t = fresh(tid), lgk = fresh(lg), upk = fresh(up);
-            const int32_t u0 = upk & 0xFFFF, u1 = u0 + (int32_t)((uint32_t)upk >> 16);
-            double qk = rd[t];       // own discharge one tick back
-            double s_cur = 0.0, s_hw = 0.0;
-            if (UNIT) {   // headwater tributaries come first in the upstream range
-                for (int32_t u = u0; u < uh; ++u) s_hw += rd[u];
-                for (int32_t u = uh; u < u1; ++u) s_cur += rd[u];
-            } else {
-                for (int32_t u = u0; u < u1; ++u) s_cur += rd[u];
-            }
-            const int32_t ts = tau - (lgk & kLagMask);
-            if (ts >= 0 && ts < total) {
-                const double lat = has_lat ? R[s] : 0.0;
-                double outv = 0.0;
-                bool routed = false;
-                if (lgk & (kGhostBit | kTileGhostBit)) {
-                    qk = R[s];        // a ghost republishes what its owner computed
-                } else if (UNIT) {
-                    if (u0 == u1) {
-                        qk = lat;        // headwater: discharge = lateral, the record slot already holds it (unclamped, un-averaged)
-                    } else {
-                        const double r = __builtin_fma(c1, s_hw + s_cur, __builtin_fma(c2, s_hw + s_prev, c3 * qch));
-                        qch = r;
-                        qk = r + lat;
-                        outv = qk; routed = true;
-                    }
-                } else {
-                    // explicit fma: every copy of this tick must round identically (split run == joint run)
-                    qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev, __builtin_fma(c3, qk, lat)));
-                    outv = qk; routed = true;
-                    if (lgk & kExportBit) a.exports[(int64_t)ts * a.n_export + a.bidx[b0 + t]] = qk;
-                }
-                if (routed) {
-                    if (SUB) {      // mean over the sub-steps of a row, written to the slot of the row's last sub-step
-                        const double acc = (sub == 0 ? 0.0 : isum) + outv;
-                        isum = acc;
-                        if (sub + 1 == (int32_t)a.nsub.d) { const double v = acc * a.inv_nsub; R[s] = v > 0.0 ? v : 0.0; }
-                    } else {
-                        R[s] = outv > 0.0 ? outv : 0.0;
-                    }
-                }
-            }
-            if (SUB) sub = sub + 1 == (int32_t)a.nsub.d ? 0 : sub + 1;
-            s_prev = s_cur;
-            wr[t] = qk;
-            // a reach mirrored by a ghost of another tile: 8 bytes into the ghost's record, always issued (see store_f64)
-            store_f64(rec_cur, (lgk >= 0 && (lgk & kTileExportBit)) ? (uint32_t)fresh(xp) * 128u + (uint32_t)s * 8u : kDropAccess, qk);
-            barrier_lds();
-        }
-    };
+        Task nxt;
+        const bool has_next = select(cur.tile - (int32_t)gridDim.x, nxt);
 
-    barrier_lds();      // first_buf is in place
-    RR_TRACE(1);
-    receive();          // the first chunk's record: the only load nothing overlaps
-    RR_TRACE(2);
-    for (int32_t cc = 0; cc < a.KC; ++cc) {
-        const int32_t chunk = m * a.KC + cc, tau0 = chunk * kRec;
-        const __amdgpu_buffer_rsrc_t rec_next = ring(chunk + 1);
-        ticks(tau0, 0, rec_next, cc + 1 < a.KC);
-        if (cc == 0) RR_TRACE(3);
-        if (cc == 1) RR_TRACE(9);
-        store_half(rec_cur, 0);
-        if (cc == 0) RR_TRACE(4);
-        ticks(tau0, 1, rec_next, false);
-        if (cc == 0) RR_TRACE(6);
-        if (cc == 1) RR_TRACE(11);
-        store_half(rec_cur, 1);
-        if (cc == 0) RR_TRACE(7);
-        receive();      // the next chunk's record has had 16 ticks to arrive (zeros after the last chunk)
-        if (cc == 0) RR_TRACE(8);
-        rec_cur = rec_next;
+        // Eight slots of the record are final: write that 64-byte sector.  Half a wave at a time parks its sectors in
+        // the wave's staging area, then all 64 lanes store them, four lanes per sector.
+        auto store_half = [&](__amdgpu_buffer_rsrc_t dst, int half) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (lane / kStageLanes == h) {
+                    double2 *mine = reinterpret_cast<double2 *>(stage + (lane % kStageLanes) * kStageStride);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mine[j] = make_double2(R[8 * half + 2 * j], R[8 * half + 2 * j + 1]);
+                    reinterpret_cast<int32_t *>(mine + 4)[0] = (lg < 0 || (lg & (kGhostBit | kTileGhostBit))) ? 1 : 0;   // not this tile's to write
+                }
+                wave_lds_fence();
+                const int32_t t = fresh(tid), ln = t & 63;
+                const uint32_t first = (uint32_t)(b0 + (t - ln) + h * kStageLanes) * 128u + (uint32_t)half * 64u;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {       // lanes 4i .. 4i+3: the four 16-byte pieces of position 16 g + i
+                    const int pm = 16 * g + (ln >> 2), piece = ln & 3;
+                    const double2 *theirs = reinterpret_cast<const double2 *>(stage + pm * kStageStride);
+                    const double2 v = theirs[piece];
+                    const bool skip = reinterpret_cast<const int32_t *>(theirs + 4)[0] != 0;
+                    store_f64x2(dst, skip ? kDropAccess : first + (uint32_t)pm * 128u + (uint32_t)piece * 16u, v);
+                }
+                wave_lds_fence();
+            }
+        };
+        auto ticks = [&](int32_t tau0, int half, __amdgpu_buffer_rsrc_t rec_next, int32_t nb0, int32_t nb1, bool more) {
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                const int s = 8 * half + s8;
+                // the next record (this tile's next chunk, or the next tile's first) is requested one load per tick: a CU
+                // accepts only so many requests at a time, and a wave that waits to issue its loads cannot tick
+                if (half == 0) issue_load(rec_next, nb0, nb1, s8, more);
+                const int32_t tau = tau0 + s;
+                const double *rd = lds + (size_t)((tau + 1) & 1) * TH;
+                double *wr = lds + (size_t)(tau & 1) * TH;
+                const int32_t t = fresh(tid), lgk = fresh(lg), upk = fresh(up);
+                const int32_t u0 = upk & 0xFFFF, u1 = u0 + (int32_t)((uint32_t)upk >> 16);
+                double qk = rd[t];       // own discharge one tick back
+                double s_cur = 0.0, s_hw = 0.0;
+                if (UNIT) {   // headwater tributaries come first in the upstream range
+                    for (int32_t u = u0; u < uh; ++u) s_hw += rd[u];
+                    for (int32_t u = uh; u < u1; ++u) s_cur += rd[u];
+                } else {
+                    for (int32_t u = u0; u < u1; ++u) s_cur += rd[u];
+                }
+                const int32_t ts = tau - (lgk & kLagMask);
+                if (ts >= 0 && ts < total) {
+                    const double lat = has_lat ? R[s] : 0.0;
+                    double outv = 0.0;
+                    bool routed = false;
+                    if (lgk & (kGhostBit | kTileGhostBit)) {
+                        qk = R[s];        // a ghost republishes what its owner computed
+                    } else if (UNIT) {
+                        if (u0 == u1) {
+                            qk = lat;        // headwater: discharge = lateral, the record slot already holds it (unclamped, un-averaged)
+                        } else {
+                            const double r = __builtin_fma(c1, s_hw + s_cur, __builtin_fma(c2, s_hw + s_prev, c3 * qch));
+                            qch = r;
+                            qk = r + lat;
+                            outv = qk; routed = true;
+                        }
+                    } else {
+                        // explicit fma: every copy of this tick must round identically (split run == joint run)
+                        qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev, __builtin_fma(c3, qk, lat)));
+                        outv = qk; routed = true;
+                        if (lgk & kExportBit) a.exports[(int64_t)ts * a.n_export + a.bidx[b0 + t]] = qk;
+                    }
+                    if (routed) {
+                        if (SUB) {      // mean over the sub-steps of a row, written to the slot of the row's last sub-step
+                            const double acc = (sub == 0 ? 0.0 : isum) + outv;
+                            isum = acc;
+                            if (sub + 1 == (int32_t)a.nsub.d) { const double v = acc * a.inv_nsub; R[s] = v > 0.0 ? v : 0.0; }
+                        } else {
+                            R[s] = outv > 0.0 ? outv : 0.0;
+                        }
+                    }
+                }
+                if (SUB) sub = sub + 1 == (int32_t)a.nsub.d ? 0 : sub + 1;
+                s_prev = s_cur;
+                wr[t] = qk;
+                // a reach mirrored by a ghost of another tile: 8 bytes into the ghost's record, always issued (see store_f64)
+                store_f64(rec_cur, (lgk >= 0 && (lgk & kTileExportBit)) ? (uint32_t)fresh(xp) * 128u + (uint32_t)s * 8u : kDropAccess, qk);
+                barrier_lds();
+            }
+        };
+
+        barrier_lds();      // the buffer of tick tau_begin - 1 is in place (and every wave has left the previous tile)
+        for (int32_t cc = 0; cc < a.KC; ++cc) {
+            const int32_t chunk = cur.m * a.KC + cc, tau0 = chunk * kRec;
+            const bool last = cc + 1 == a.KC;
+            // what arrives during this chunk: the tile's next chunk, or -- in its last one -- the first chunk of the next tile
+            const __amdgpu_buffer_rsrc_t rec_next = ring(last ? nxt.m * a.KC : chunk + 1);
+            const int32_t nb0 = last ? nxt.b0 : b0, nb1 = last ? nxt.b1 : cur.b1;
+            ticks(tau0, 0, rec_next, nb0, nb1, !last || has_next);
+            if (cc == 0) RR_TRACE(3);
+            store_half(rec_cur, 0);
+            ticks(tau0, 1, rec_next, nb0, nb1, false);
+            if (cc == 0) RR_TRACE(6);
+            store_half(rec_cur, 1);
+            if (cc == 0) RR_TRACE(7);
+            if (last && has_next) load_state(nxt, st);      // small, and only the wait for it is exposed between two tiles
+            receive();      // the record that has had 16 ticks to arrive (zeros after the last chunk of the last tile)
+            if (cc == 0) RR_TRACE(8);
+            rec_cur = rec_next;
+        }
+        RR_TRACE(12);
+        if (lg >= 0) {
+            const int32_t p = b0 + tid;
+            a.sq[p] = lds[(size_t)((tau_begin + K - 1) & 1) * TH + tid]; a.ss[p] = s_prev;
+            if (UNIT) a.sqch[p] = qch;
+            if (SUB) a.si[p] = isum;
+        }
+        RR_TRACE(13);
+#ifdef RR_WAVE_TRACE
+        trace = false;      // the first tile of the workgroup only
+#endif
+        if (!has_next) break;
+        cur = nxt;
     }
-    RR_TRACE(12);
-    if (lg >= 0) {
-        const int32_t p = b0 + tid;
-        a.sq[p] = lds[(size_t)((tau_begin + a.KC * kRec - 1) & 1) * TH + tid]; a.ss[p] = s_prev;
-        if (UNIT) a.sqch[p] = qch;
-        if (SUB) a.si[p] = isum;
-    }
-    RR_TRACE(13);
 #undef RR_TRACE
 }
 
@@ -1189,12 +1219,44 @@ struct Session {
     int64_t KC = 1;               // record chunks per task: K = 16 * KC ticks
     int64_t rec_chunks = 0, in_batches = 0, n_in_batches = 0, out_batches = 0, n_out_batches = 0;
     int64_t ticks_stored = 0;     // tick-rows that have left the record ring
+    int64_t out_limit = std::numeric_limits<int64_t>::max();   // rows the caller's output ring can take (host pipeline)
     int64_t diag = 0, n_diags = 0, n_macro = 0;
-    int64_t export_skew = 0;      // export reaches of a partitioned network in the time-tiled schedule (level skew included)
+    int64_t ghost_batches = 0;    // batches of the boundary (ghost) series turned into records
+    int64_t ghost_slack = 0, export_skew = 0;      // boundary reaches of a partitioned network in the time-tiled schedule (level skew included)
     TileArgs ta{};
     bool bracket_open = false;
     int64_t bracket_reaches = 0;
     size_t max_samples = 0;
+};
+
+// ---- host-pointer calls: PCIe pipeline around the time-tiled kernel ----
+//
+// The reference's kernel boundary hands over numpy arrays in pageable host memory.  hipMemcpy from pageable memory moves
+// 22 GB/s here, and one direction at a time; registering the caller's arrays costs 43 ms per GB; pinned memory moves
+// 49 GB/s each way at once (profiles/microbench/host_copy.hip).  So rows travel in chunks of 64 through three pinned
+// buffers per direction, filled and emptied by eight copy threads each, while the DMA engines move the neighbouring
+// chunks and the GPU routes what has arrived: caller -> pinned -> device staging ring -> records -> tiles -> records ->
+// device staging ring -> pinned -> caller, every stage overlapping the others.  The open routing call is the streaming
+// session the partitioned path uses (rows become ready chunk by chunk).
+struct HostPipe {
+    static constexpr int kPinned = 3, kCopyThreads = 8;
+    int64_t chunk_rows = 64, ring_chunks = 8;
+    double *pin_in[kPinned] = {nullptr, nullptr, nullptr}, *pin_out[kPinned] = {nullptr, nullptr, nullptr};
+    double *dev_in = nullptr, *dev_out = nullptr;
+    int64_t pin_cap = 0, dev_cap = 0;      // doubles per pinned buffer / per device ring
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    std::vector<hipEvent_t> ev_h2d, ev_d2h, ev_adv;
+    void destroy()
+    {
+        for (int k = 0; k < kPinned; ++k) { if (pin_in[k]) (void)hipHostFree(pin_in[k]); if (pin_out[k]) (void)hipHostFree(pin_out[k]); pin_in[k] = pin_out[k] = nullptr; }
+        if (dev_in) (void)hipFree(dev_in);
+        if (dev_out) (void)hipFree(dev_out);
+        dev_in = dev_out = nullptr; pin_cap = dev_cap = 0;
+        for (auto *v : {&ev_h2d, &ev_d2h, &ev_adv}) { for (hipEvent_t e : *v) (void)hipEventDestroy(e); v->clear(); }
+        if (s_h2d) (void)hipStreamDestroy(s_h2d);
+        if (s_d2h) (void)hipStreamDestroy(s_d2h);
+        s_h2d = s_d2h = nullptr;
+    }
 };
 
 struct rr_plan {
@@ -1236,6 +1298,7 @@ struct rr_plan {
     int2 *d_ghostmeta = nullptr; // the same per boundary ghost (column of the ghost series)
     double *d_c4_params = nullptr;   // c4dt in params order (scale of the record permutation)
     size_t dev_total_bytes = 0;
+    int cu_count = 256;
 
     // boundary reaches of a partitioned network
     int64_t n_ghost = 0, n_export = 0;
@@ -1243,6 +1306,7 @@ struct rr_plan {
     std::vector<int32_t> ghost_reach, export_reach;   // params indices, in the caller's order
 
     Session ses;
+    HostPipe pipe;      // staging of the host-pointer entry points (allocated at first use)
 
     // profile of the last route call
     std::vector<hipEvent_t> ev;
@@ -1376,10 +1440,13 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         const int64_t K = S.KC * kRec;
         S.n_macro = (S.total_ticks + K - 1) / K;
         S.n_diags = S.n_macro + TP.n_levels - 1;
-        S.n_in_batches = (S.has_in || P->n_ghost > 0) ? (S.total + 14) / kRecRows + 1 : 0;
+        S.n_in_batches = (S.total + 14) / kRecRows + 1;      // of the lateral rows (if any) and of the boundary series (if any)
         S.n_out_batches = (S.total + kRecRows - 1) / kRecRows;
-        // external boundary reaches: an export reach in a tile of level l at lag L has produced the sub-steps below (diag - l) K - L
+        // external boundary reaches: a ghost in a tile of level l at lag L is read for sub-steps below (diag - l + 1) K - L,
+        // an export reach there has produced the sub-steps below (diag - l) K - L
         S.export_skew = 0;
+        S.ghost_slack = P->ghost_reach.empty() ? 0 : S.total_ticks + (int64_t)TP.n_levels * K;
+        for (int32_t i : P->ghost_reach) { const int32_t p = TP.inv[i]; S.ghost_slack = std::min<int64_t>(S.ghost_slack, (int64_t)TP.tile_level[TP.tile_of[p]] * K + (TP.lag[p] & kLagMask)); }
         for (int32_t i : P->export_reach) { const int32_t p = TP.inv[i]; S.export_skew = std::max<int64_t>(S.export_skew, (int64_t)TP.tile_level[TP.tile_of[p]] * K + (TP.lag[p] & kLagMask)); }
         if (io.dev_out32) {
             const int64_t step = io.out_factor * nsub;
@@ -1581,13 +1648,14 @@ int session_launch_diag(rr_plan *P, int64_t d)
     }
     if (t_hi <= t_lo) { ++P->prof_launches; return RR_OK; }
     TileArgs &w = S.ta;
-    w.diag = (int32_t)d; w.t_last = (int32_t)t_hi - 1;
+    w.diag = (int32_t)d; w.t_first = (int32_t)t_lo; w.t_last = (int32_t)t_hi - 1;
     // every fourth launch is bracketed by HIP events, full or not (fill and drain launches run fewer tiles), so the
     // sampled average is the average rocprofv3 reports for the kernel; the reach-ticks of a sample are those of the
     // tiles it launched
     const bool sample = S.max_samples > 0 && (P->prof_launches % 4) == 0 && (size_t)P->prof_brackets < S.max_samples;
     if (sample) HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets], S.stream));
-    const dim3 g((unsigned)(t_hi - t_lo));
+    // one workgroup per resident slot (16 waves per CU); each walks its share of the launch's tiles
+    const dim3 g((unsigned)std::min<int64_t>(t_hi - t_lo, (int64_t)P->cu_count * (1024 / P->wave_threads)));
     const size_t lds_bytes = tile_lds_bytes(P->wave_threads);
     hipLaunchKernelGGL(tile_kernel(P->wave_threads, S.mode == Mode::Unit, S.nsub > 1), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
     if (sample) {
@@ -1649,22 +1717,26 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
     const int64_t ticks_ready = std::min(rows_ready, S.T) * S.nsub;
     for (;;) {
         bool progressed = false;
-        // one batch of 128 tick-rows -> records; a record slot is recycled only after every tick-row it can hold has left
-        if (S.in_batches < S.n_in_batches) {
-            const int64_t j = S.in_batches;
+        // one batch of 128 tick-rows -> records; a record slot is recycled only after every tick-row it can hold has left.
+        // Lateral rows and boundary sub-steps (the ghost series of a partitioned network) advance separately: a ghost in a
+        // tile of level l at lag L is first read (l K + L) ticks into the schedule, so the boundary may trail the rows.
+        auto slot_free = [&](int64_t j) {
             const int64_t hi = kRecBatch * j + (dmax >> 4) + kRecBatch - 1;
-            const bool rows_here = (!S.has_in || ticks_ready >= std::min(kRecRows * (j + 1), S.total)) &&
-                                   (P->n_ghost == 0 || ghost_ready >= std::min(kRecRows * (j + 1), S.total));
-            const bool slot_free = hi < S.rec_chunks || S.ticks_stored >= std::min(S.total, kRec * (hi - S.rec_chunks + 1));
-            if (rows_here && slot_free) {
-                if (S.has_in) launch_rec_permute(P, true, j);
-                if (P->n_ghost > 0) launch_ghost_permute(P, j);
-                ++S.in_batches;
-                progressed = true;
-            }
+            return hi < S.rec_chunks || S.ticks_stored >= std::min(S.total, kRec * (hi - S.rec_chunks + 1));
+        };
+        if (S.has_in && S.in_batches < S.n_in_batches && ticks_ready >= std::min(kRecRows * (S.in_batches + 1), S.total) && slot_free(S.in_batches)) {
+            launch_rec_permute(P, true, S.in_batches);
+            ++S.in_batches;
+            progressed = true;
         }
-        const int64_t loaded = S.in_batches >= S.n_in_batches ? S.total : std::max<int64_t>(0, kRecRows * S.in_batches - 15);
-        const int64_t have = (S.has_in || P->n_ghost > 0) ? loaded : S.total;
+        if (P->n_ghost > 0 && S.ghost_batches < S.n_in_batches && ghost_ready >= std::min(kRecRows * (S.ghost_batches + 1), S.total) && slot_free(S.ghost_batches)) {
+            launch_ghost_permute(P, S.ghost_batches);
+            ++S.ghost_batches;
+            progressed = true;
+        }
+        auto loaded_ticks = [&](int64_t batches) { return batches >= S.n_in_batches ? S.total : std::max<int64_t>(0, kRecRows * batches - 15); };
+        const int64_t have = S.has_in ? loaded_ticks(S.in_batches) : S.total;
+        const int64_t have_ghost = P->n_ghost > 0 ? loaded_ticks(S.ghost_batches) : S.total;
         S.rows_loaded = have / S.nsub;
         // launch d runs macro-chunk d of the tiles of level 0: ticks below (d + 1) K need the tick-rows below that
         int64_t launched = 0;
@@ -1672,6 +1744,7 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
         while (S.diag < S.n_diags && launched < batch) {
             const int64_t need_ticks = std::min((S.diag + 1) * K, S.total);
             if (have < need_ticks) break;
+            if (have_ghost < std::min(std::max<int64_t>(0, (S.diag + 1) * K - S.ghost_slack), S.total)) break;
             // the tasks of this launch overwrite records in place: nothing they write may still be waiting to leave from
             // one ring revolution earlier (their chunks are at most (d + 1) KC - 1)
             const int64_t top = std::min(S.diag + 1, S.n_macro) * S.KC - 1;
@@ -1687,7 +1760,8 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
         if (S.diag >= S.n_diags) done = S.total;
         else if (m_done >= 0) done = std::max<int64_t>(0, (m_done + 1) * K - dmax);
         done = std::min(done, S.total);
-        while (S.out_batches < S.n_out_batches && done >= std::min(kRecRows * (S.out_batches + 1), S.total)) {
+        while (S.out_batches < S.n_out_batches && done >= std::min(kRecRows * (S.out_batches + 1), S.total) &&
+               (std::min(kRecRows * (S.out_batches + 1), S.total) + S.nsub - 1) / S.nsub <= S.out_limit) {
             launch_rec_permute(P, false, S.out_batches);
             ++S.out_batches;
             S.ticks_stored = std::min(S.total, kRecRows * S.out_batches);
@@ -1831,44 +1905,151 @@ void launch_state_out(rr_plan *P, Mode mode, double *d_q, int64_t total, hipStre
                        P->d_lag, P->d_inv, (int32_t)n, total);
 }
 
-// Host-pointer calls whose rows fit on the card are routed as device calls on whole staged arrays (the time-tiled
-// kernel works on device rows); larger ones go through the streaming kernel chunk by chunk.
-struct StagedRows {
-    double *d_in = nullptr, *d_out = nullptr;
-    Rows io;
-    bool active = false;
-    void release() { if (d_in) (void)hipFree(d_in); if (d_out) (void)hipFree(d_out); d_in = d_out = nullptr; }
-};
-
-int stage_host_rows(rr_plan *P, const Rows &io, int64_t T, StagedRows &st, hipStream_t stream)
+void parallel_copy(double *dst, const double *src, size_t count, int threads, std::vector<std::thread> &pool)
 {
-    st.io = io;
-    if (!io.host_in && !io.host_out) return RR_OK;
+    const size_t per = ((count + threads - 1) / threads + 511) / 512 * 512;
+    for (int t = 0; t < threads; ++t) {
+        const size_t o = (size_t)t * per;
+        if (o >= count) break;
+        pool.emplace_back([=] { std::memcpy(dst + o, src + o, std::min(per, count - o) * sizeof(double)); });
+    }
+}
+
+int host_pipe_prepare(rr_plan *P)
+{
+    HostPipe &H = P->pipe;
     const int64_t n = P->h.n;
-    const size_t row_bytes = (size_t)n * sizeof(double), need = (size_t)T * row_bytes * (io.host_in ? 2 : 1);
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || need > free_b / 2) return RR_OK;      // chunked path
-    if (io.host_in && hipMalloc((void **)&st.d_in, (size_t)T * row_bytes) != hipSuccess) { (void)hipGetLastError(); return RR_OK; }
-    if (hipMalloc((void **)&st.d_out, (size_t)T * row_bytes) != hipSuccess) { (void)hipGetLastError(); st.release(); return RR_OK; }
-    if (io.host_in) HIPCHK(hipMemcpyAsync(st.d_in, io.host_in, (size_t)T * row_bytes, hipMemcpyHostToDevice, stream));
-    st.io = Rows();
-    st.io.dev_in = st.d_in; st.io.rows_in = T; st.io.dev_out = st.d_out; st.io.rows_out = T;
-    st.active = true;
+    // chunks of about half a gigabyte: long enough for the DMA engines to reach their rate, short enough to pipeline
+    H.chunk_rows = std::max<int64_t>(16, std::min<int64_t>(4096, ((int64_t{1} << 29) / (n * 8) + 15) / 16 * 16));
+    if (n * 8 * 64 <= (int64_t{1} << 30)) H.chunk_rows = std::max<int64_t>(H.chunk_rows, 64);
+    H.ring_chunks = std::max<int64_t>(8, (2 * kRecRows + 15) / H.chunk_rows + 6);      // a batch of 128 rows + its 15-row overlap stays readable
+    const int64_t pin_need = H.chunk_rows * n, dev_need = H.ring_chunks * H.chunk_rows * n;
+    if (H.pin_cap < pin_need || H.dev_cap < dev_need) {
+        H.destroy();
+        for (int k = 0; k < HostPipe::kPinned; ++k) {
+            if (hipHostMalloc((void **)&H.pin_in[k], (size_t)pin_need * 8, hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc((void **)&H.pin_out[k], (size_t)pin_need * 8, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError(); H.destroy();
+                return fail(RR_E_ALLOC, "host pipeline: pinned staging buffers could not be allocated");
+            }
+        }
+        if (hipMalloc((void **)&H.dev_in, (size_t)dev_need * 8) != hipSuccess || hipMalloc((void **)&H.dev_out, (size_t)dev_need * 8) != hipSuccess) {
+            (void)hipGetLastError(); H.destroy();
+            return fail(RR_E_ALLOC, "host pipeline: device staging rings could not be allocated");
+        }
+        H.pin_cap = pin_need; H.dev_cap = dev_need;
+    }
+    if (!H.s_h2d) { HIPCHK(hipStreamCreateWithFlags(&H.s_h2d, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&H.s_d2h, hipStreamNonBlocking)); }
     return RR_OK;
 }
 
-int unstage_host_rows(rr_plan *P, const Rows &io, int64_t T, StagedRows &st, hipStream_t stream, int rc)
+// Routes T rows between host arrays (host_in may be NULL: channel-only) through the pipeline above.  State arrays are
+// already on the device and the tile state is loaded; returns when host_out is complete.
+int route_host_pipelined(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const double *host_in, double *host_out, hipStream_t stream)
 {
-    if (!st.active) return rc;
-    if (rc == RR_OK) {
-        hipError_t e = hipMemcpyAsync(io.host_out, st.d_out, (size_t)T * P->h.n * sizeof(double), hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) rc = fail(RR_E_HIP, hipGetErrorString(e));
-    } else {
-        (void)hipStreamSynchronize(stream);
+    int rc = host_pipe_prepare(P);
+    if (rc) return rc;
+    HostPipe &H = P->pipe;
+    constexpr int kPinned = HostPipe::kPinned;
+    const int64_t n = P->h.n, C = H.chunk_rows, NR = H.ring_chunks, nchunks = (T + C - 1) / C;
+    auto grow = [&](std::vector<hipEvent_t> &v, size_t count) {
+        while (v.size() < count) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false; v.push_back(e); }
+        return true;
+    };
+    if (!grow(H.ev_h2d, (size_t)nchunks) || !grow(H.ev_d2h, (size_t)nchunks) || !grow(H.ev_adv, (size_t)4 * nchunks + 64))
+        return fail(RR_E_HIP, "host pipeline: event creation failed");
+    Rows io;
+    io.dev_in = host_in ? H.dev_in : nullptr; io.rows_in = NR * C; io.dev_out = H.dev_out; io.rows_out = NR * C;
+    rc = session_begin(P, mode, T, nsub, io, stream, nullptr, nullptr);
+    if (rc) return rc;
+    Session &S = P->ses;
+    auto rows_of = [&](int64_t c) { return std::min(C, T - c * C); };
+    std::vector<int64_t> adv_loaded;      // rows that were records after the a-th advance (ev_adv[a] marks it on the stream)
+    int64_t filled = 0, h2d_issued = 0, d2h_issued = 0, copied_out = 0;      // chunks through each stage
+    std::vector<std::thread> pool;
+    auto bail = [&](int code, const std::string &msg) {
+        for (auto &t : pool) t.join();
+        (void)hipStreamSynchronize(H.s_h2d); (void)hipStreamSynchronize(H.s_d2h); (void)hipStreamSynchronize(stream);
+        P->ses.open = false;
+        return fail(code, msg);
+    };
+#define RR_PIPE(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return bail(RR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
+    // One iteration: the copy threads fill the next pinned input chunk and empty the oldest downloaded output chunk while
+    // this thread enqueues the upload of the chunk filled last time, the routing it enables and the downloads it completes.
+    while (copied_out < nchunks) {
+        pool.clear();
+        bool progressed = false;
+        const bool fill = host_in && filled < nchunks && filled < h2d_issued + kPinned;
+        if (fill) {
+            if (filled >= kPinned) RR_PIPE(hipEventSynchronize(H.ev_h2d[filled - kPinned]));      // the buffer's previous chunk has left
+            parallel_copy(H.pin_in[filled % kPinned], host_in + filled * C * n, (size_t)(rows_of(filled) * n), HostPipe::kCopyThreads, pool);
+        }
+        bool empty = false;
+        if (copied_out < d2h_issued) {      // only a download that HAS arrived: waiting for one here would stall the uploads behind it
+            const hipError_t q = hipEventQuery(H.ev_d2h[copied_out]);
+            if (q == hipSuccess) empty = true;
+            else if (q != hipErrorNotReady) return bail(RR_E_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+        }
+        if (empty) {
+            parallel_copy(host_out + copied_out * C * n, H.pin_out[copied_out % kPinned], (size_t)(rows_of(copied_out) * n), HostPipe::kCopyThreads, pool);
+        }
+        // upload of a chunk filled earlier, into the ring slot whose previous occupant has become records
+        if (host_in && h2d_issued < filled) {
+            const int64_t c = h2d_issued;
+            bool slot_ready = true;
+            if (c >= NR) {
+                const int64_t need = std::min(T, (c - NR + 1) * C);
+                size_t a = 0;
+                while (a < adv_loaded.size() && adv_loaded[a] < need) ++a;
+                if (a < adv_loaded.size()) RR_PIPE(hipStreamWaitEvent(H.s_h2d, H.ev_adv[a], 0));
+                else slot_ready = false;      // the routing has to get further first (see the advance below)
+            }
+            if (slot_ready) {
+                RR_PIPE(hipMemcpyAsync(H.dev_in + (c % NR) * C * n, H.pin_in[c % kPinned], (size_t)(rows_of(c) * n) * 8, hipMemcpyHostToDevice, H.s_h2d));
+                RR_PIPE(hipEventRecord(H.ev_h2d[c], H.s_h2d));
+                RR_PIPE(hipStreamWaitEvent(stream, H.ev_h2d[c], 0));
+                ++h2d_issued;
+                progressed = true;
+            }
+        }
+        // route what has arrived; output rows land in the device ring at row % (NR * C), so no batch may be written before
+        // the rows it overwrites are on their way to the host
+        if (S.tau < S.total_ticks || S.rows_stored < T) {
+            const int64_t ready = host_in ? std::min(T, h2d_issued * C) : T;
+            S.out_limit = std::min(T, d2h_issued * C) + NR * C;
+            if (d2h_issued > 0) RR_PIPE(hipStreamWaitEvent(stream, H.ev_d2h[d2h_issued - 1], 0));
+            const int64_t before_diag = S.diag, before_in = S.in_batches, before_out = S.out_batches;
+            rc = session_advance(P, ready, S.total, nullptr);
+            if (rc) { for (auto &t : pool) t.join(); P->ses.open = false; return rc; }
+            if (S.diag != before_diag || S.in_batches != before_in || S.out_batches != before_out) {
+                progressed = true;
+                if (adv_loaded.size() < H.ev_adv.size() - 1) {
+                    RR_PIPE(hipEventRecord(H.ev_adv[adv_loaded.size()], stream));
+                    adv_loaded.push_back(S.rows_loaded);
+                }
+            }
+        }
+        // downloads of the output chunks that are complete; a pinned buffer is free once the copy threads have emptied it
+        while (d2h_issued < nchunks && std::min(T, (d2h_issued + 1) * C) <= S.rows_stored && d2h_issued < copied_out + kPinned) {
+            const int64_t k = d2h_issued;
+            RR_PIPE(hipEventRecord(H.ev_adv.back(), stream));      // everything enqueued so far on the routing stream
+            RR_PIPE(hipStreamWaitEvent(H.s_d2h, H.ev_adv.back(), 0));
+            RR_PIPE(hipMemcpyAsync(H.pin_out[k % kPinned], H.dev_out + (k % NR) * C * n, (size_t)(rows_of(k) * n) * 8, hipMemcpyDeviceToHost, H.s_d2h));
+            RR_PIPE(hipEventRecord(H.ev_d2h[k], H.s_d2h));
+            ++d2h_issued;
+            progressed = true;
+        }
+        for (auto &t : pool) t.join();
+        if (fill) ++filled;
+        if (empty) ++copied_out;
+        if (!progressed && !fill && !empty) {
+            if (copied_out < d2h_issued) RR_PIPE(hipEventSynchronize(H.ev_d2h[copied_out]));      // nothing else to do but wait for it
+            else return bail(RR_E_STATE, "host pipeline: no stage can make progress");
+        }
     }
-    st.release();
-    return rc;
+#undef RR_PIPE
+    S.out_limit = std::numeric_limits<int64_t>::max();
+    return session_end(P);
 }
 
 int rapid_like(rr_plan *P, Mode mode, double *q_t, const Rows &io_in, int64_t T, int64_t nsub, hipStream_t stream,
@@ -1876,22 +2057,23 @@ int rapid_like(rr_plan *P, Mode mode, double *q_t, const Rows &io_in, int64_t T,
 {
     const int64_t n = P->h.n;
     if (n == 0 || T == 0) return RR_OK;
-    StagedRows st;
-    int rc0 = stage_host_rows(P, io_in, T, st, stream);
-    if (rc0) return rc0;
-    const Rows &io = st.io;
-    decide_wave(P, mode, T * nsub, io.host_in != nullptr || io.host_out != nullptr);
+    const Rows &io = io_in;
+    const bool host_rows = io.host_in != nullptr || io.host_out != nullptr;
+    // host rows reach the time-tiled kernel through the PCIe pipeline's device rings; where it does not apply they are
+    // routed chunk by chunk by the streaming kernel
+    if (!decide_wave(P, mode, T * nsub, false) && host_rows) decide_wave(P, mode, T * nsub, true);
+    const bool piped = host_rows && P->wave_now;
     double *d_q = q_t;
     double *tmp = nullptr;
     if (q_on_host) {
         int rc = dev_alloc(&tmp, n);
-        if (rc) { st.release(); return rc; }
+        if (rc) return rc;
         d_q = tmp;
         hipError_t e = hipMemcpyAsync(d_q, q_t, n * sizeof(double), hipMemcpyHostToDevice, stream);
-        if (e != hipSuccess) { (void)hipFree(tmp); st.release(); return fail(RR_E_HIP, hipGetErrorString(e)); }
+        if (e != hipSuccess) { (void)hipFree(tmp); return fail(RR_E_HIP, hipGetErrorString(e)); }
     }
     int rc = launch_state_in(P, mode, d_q, stream);
-    if (rc == RR_OK) rc = route_core(P, mode, T, nsub, io, stream);
+    if (rc == RR_OK) rc = piped ? route_host_pipelined(P, mode, T, nsub, io.host_in, io.host_out, stream) : route_core(P, mode, T, nsub, io, stream);
     if (rc == RR_OK) {
         launch_state_out(P, mode, d_q, T * nsub, stream);
         if (q_on_host) {
@@ -1900,7 +2082,6 @@ int rapid_like(rr_plan *P, Mode mode, double *q_t, const Rows &io_in, int64_t T,
             if (e != hipSuccess) rc = fail(RR_E_HIP, hipGetErrorString(e));
         }
     }
-    rc = unstage_host_rows(P, io_in, T, st, stream, rc);
     if (tmp) { (void)hipStreamSynchronize(stream); (void)hipFree(tmp); }
     return rc;
 }
@@ -1910,19 +2091,18 @@ int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io_in, int64
 {
     const int64_t n = P->h.n, ni = (int64_t)P->h.inner_pos.size();
     if (n == 0 || T == 0) return RR_OK;
-    StagedRows st;
-    int rc0 = stage_host_rows(P, io_in, T, st, stream);
-    if (rc0) return rc0;
-    const Rows &io = st.io;
-    decide_wave(P, Mode::Unit, T * nsub, io.host_in != nullptr || io.host_out != nullptr);
+    const Rows &io = io_in;
+    const bool host_rows = io.host_in != nullptr || io.host_out != nullptr;
+    if (!decide_wave(P, Mode::Unit, T * nsub, false) && host_rows) decide_wave(P, Mode::Unit, T * nsub, true);
+    const bool piped = host_rows && P->wave_now;
     double *d_qch = q_ch, *d_qfull = q_full, *tmp = nullptr;
     if (q_on_host) {
         int rc = dev_alloc(&tmp, 2 * std::max<int64_t>(ni, 1));
-        if (rc) { st.release(); return rc; }
+        if (rc) return rc;
         d_qch = tmp; d_qfull = tmp + std::max<int64_t>(ni, 1);
         hipError_t e = hipMemcpyAsync(d_qch, q_ch, ni * sizeof(double), hipMemcpyHostToDevice, stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_qfull, q_full, ni * sizeof(double), hipMemcpyHostToDevice, stream);
-        if (e != hipSuccess) { (void)hipFree(tmp); st.release(); return fail(RR_E_HIP, hipGetErrorString(e)); }
+        if (e != hipSuccess) { (void)hipFree(tmp); return fail(RR_E_HIP, hipGetErrorString(e)); }
     }
     const bool wave = use_wave(P, Mode::Unit);
     int rc = RR_OK;
@@ -1942,8 +2122,8 @@ int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io_in, int64
             hipLaunchKernelGGL(k_unit_state_in, grid1(ni), dim3(kBlock), 0, stream, P->d_x, P->d_x + n, P->d_x + 2 * n,
                                P->d_qch, (const double *)d_qch, (const double *)d_qfull, P->d_inner_pos, (int32_t)ni);
     }
-    if (e0 != hipSuccess) { if (tmp) (void)hipFree(tmp); st.release(); return fail(RR_E_HIP, hipGetErrorString(e0)); }
-    if (rc == RR_OK) rc = route_core(P, Mode::Unit, T, nsub, io, stream);
+    if (e0 != hipSuccess) { if (tmp) (void)hipFree(tmp); return fail(RR_E_HIP, hipGetErrorString(e0)); }
+    if (rc == RR_OK) rc = piped ? route_host_pipelined(P, Mode::Unit, T, nsub, io.host_in, io.host_out, stream) : route_core(P, Mode::Unit, T, nsub, io, stream);
     if (rc == RR_OK && ni > 0) {
         if (wave)
             hipLaunchKernelGGL(k_tile_unit_state_out, grid1(ni), dim3(kBlock), 0, stream, d_qch, d_qfull,
@@ -1959,7 +2139,6 @@ int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io_in, int64
             if (e != hipSuccess) rc = fail(RR_E_HIP, hipGetErrorString(e));
         }
     }
-    rc = unstage_host_rows(P, io_in, T, st, stream, rc);
     if (tmp) { (void)hipStreamSynchronize(stream); (void)hipFree(tmp); }
     return rc;
 }
@@ -2038,6 +2217,7 @@ void rr_plan_destroy(rr_plan *P)
                         P->d_c3, P->d_c4, P->d_x, P->d_isum, P->d_qch, P->d_ring, P->d_stage, P->d_mrows,
                         P->d_slot_a[0], P->d_slot_a[1], P->d_slot_b[0], P->d_slot_b[1], P->d_m_index[0], P->d_m_index[1]};
         for (void *p : ptrs) if (p) (void)hipFree(p);
+        P->pipe.destroy();
         for (hipEvent_t e : P->ev) (void)hipEventDestroy(e);
         if (P->ev_first) (void)hipEventDestroy(P->ev_first);
         if (P->ev_last) (void)hipEventDestroy(P->ev_last);
@@ -2083,6 +2263,9 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) P->dev_total_bytes = total_b;
+            int cus = 0;
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) P->cu_count = cus;
+            if (const char *e2 = getenv("RR_TILE_SLOTS")) P->cu_count = std::max(1, atoi(e2));      // tests: few workgroups, many tiles each
         }
         for (int v = 0; v < 4; ++v)    // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
             if (hipFuncSetAttribute((const void *)tile_kernel(P->wave_threads, (v & 1) != 0, (v & 2) != 0), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2734,6 +2917,15 @@ int rr_copy_bandwidth(int device, int64_t bytes, int reps, double *gbps)
             if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
             if (e == hipSuccess) e = hipEventSynchronize(e1);
             if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            // the runtime's own device-to-device copy: whichever of the two is faster is "the achievable rate"
+            float ms2 = 0.f;
+            if (e == hipSuccess) e = hipMemcpyAsync(b, a, (size_t)count * 16, hipMemcpyDeviceToDevice, nullptr);
+            if (e == hipSuccess) e = hipEventRecord(e0, nullptr);
+            for (int r = 0; r < reps && e == hipSuccess; ++r) e = hipMemcpyAsync(b, a, (size_t)count * 16, hipMemcpyDeviceToDevice, nullptr);
+            if (e == hipSuccess) e = hipEventRecord(e1, nullptr);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms2, e0, e1);
+            if (e == hipSuccess && ms2 > 0.f && ms2 < ms) ms = ms2;
         }
         if (e != hipSuccess) rc = fail(RR_E_HIP, hipGetErrorString(e));
     }

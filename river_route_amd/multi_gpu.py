@@ -336,8 +336,8 @@ def bench_main(args, rank: int, local_rank: int, world: int) -> None:
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'RapidMuskingum, ONE {n}-reach synthetic random-topology network graph-partitioned '
                                    f'over {world} MI355X ({args.reaches} reaches per GPU), {T} runoff steps @ 900 s, '
-                                   f'{nsub} sub-step(s), fp64, boundary discharge exchanged over RCCL every '
-                                   f'{chunk_rows} steps',
+                                   f'{nsub} sub-step(s), fp64, boundary discharge exchanged over '
+                                   f'{"RCCL (xGMI)" if dist.get_backend() == "nccl" else dist.get_backend()} every {chunk_rows} steps',
                        'reaches': n, 'runoff_steps': T, 'substeps': nsub, 'params_order': args.order,
                        'part_reaches': [int(g[0].item()) for g in gathered],
                        'part_ghosts': [int(g[1].item()) for g in gathered],

@@ -95,3 +95,32 @@ def gloo_worker(rank, world, port, n, T, chunk_rows, out_dir):
              state=eng.final_state())
     dist.barrier()
     dist.destroy_process_group()
+
+
+def hip_worker(rank, world, port, n, T, chunk_rows, out_dir, backend):
+    """One rank of the real partitioned run: HipPartEngine on GPU `rank % device_count`, boundary series over `backend`
+    ('nccl' = RCCL, one GPU per rank; 'gloo' lets the ranks of a rehearsal share one card)."""
+    import torch
+    import torch.distributed as dist
+    from river_route_amd import synth
+    from river_route_amd.engine import partition_forest
+    from river_route_amd.multi_gpu import HipPartEngine, run_distributed, split_network
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    device = rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', device))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    net, indptr, indices, c1, c2, c3, q0 = setup_case(n)
+    part_of, _ = partition_forest(indptr, indices, world)
+    spec = split_network(net.down_index, part_of, rank, world)
+    ql = synth.synth_qlateral(n, 0, T)
+    eng = HipPartEngine(spec, c1, c2, c3, (c1 + c2) / 900.0, q0, ql[:, spec.real_global], T, 1, device, out_rows=T)
+    for _ in range(2):          # bench.py reuses the engines pass after pass
+        run_distributed(eng, spec, T, 1, chunk_rows, dist)
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, f'rank{rank}.npz'), real=spec.real_global, state=eng.final_state(),
+             discharge=eng.discharge.cpu().numpy()[:, spec.n_ghost:])
+    dist.barrier()
+    dist.destroy_process_group()

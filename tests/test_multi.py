@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from conftest import assert_close
-from multi_helpers import OraclePartEngine, gloo_worker, setup_case
+from multi_helpers import OraclePartEngine, gloo_worker, hip_worker, setup_case
 from river_route_amd import synth
 from river_route_amd.engine import partition_forest
 from river_route_amd.multi_gpu import run_in_process, split_network
@@ -142,3 +142,31 @@ def test_hip_parts_on_one_gpu_match_single_plan(monkeypatch, wave, n, T, nsub, p
     run_in_process(engines, specs, T, nsub, chunk)
     for s, e in zip(specs, engines):
         np.testing.assert_array_equal(e.final_state(), q[s.real_global])
+
+
+def _ranks_vs_oracle(tmp_path, world, backend, n=120_000, T=200, chunk=32):
+    import torch.multiprocessing as mp
+    mp.spawn(hip_worker, args=(world, free_port(), n, T, chunk, str(tmp_path), backend), nprocs=world, join=True)
+    q_ref, d_ref = single_domain(n, T)
+    q, d = np.zeros(n), np.zeros((T, n))
+    for r in range(world):
+        z = np.load(tmp_path / f'rank{r}.npz')
+        q[z['real']], d[:, z['real']] = z['state'], z['discharge']
+    assert_close(q, q_ref, 'state')
+    assert_close(d, d_ref, 'discharge')
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_one_gpu_over_gloo_vs_oracle(tmp_path):
+    """The distributed driver with the real engine: two processes, one card, boundary series over gloo (what a 1-GPU
+    box can run of `bench.py --gpus 2`), against the oracle on the undivided network."""
+    _ranks_vs_oracle(tmp_path, 2, 'gloo')
+
+
+@pytest.mark.gpu
+def test_two_ranks_rccl_vs_oracle(tmp_path):
+    """The same over RCCL (backend 'nccl'), one GPU per rank: needs two GPUs, skipped on a 1-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs 2 GPUs (RCCL refuses two ranks on one device)')
+    _ranks_vs_oracle(tmp_path, 2, 'nccl')
