@@ -42,10 +42,10 @@ def adjacency_matrix(river_ids: np.ndarray, downstream_ids: np.ndarray) -> scipy
 
 def engine_order(river_ids: np.ndarray, downstream_ids: np.ndarray) -> np.ndarray:
     """
-    Row order in which the HIP engine lays reaches out (farthest-from-outlet level first, each level in the
-    order of its downstream reaches).  It is a valid topological order, so a params file (and its qlateral /
-    state files) re-sorted with it is accepted by the reference unchanged and lets the engine skip its
-    params-order <-> engine-order permutation passes.
+    Row order of the streaming kernel's lag-ordered layout (farthest-from-outlet level first, each level in the order of
+    its downstream reaches).  It is a valid topological order, so a params file (and its qlateral / state files)
+    re-sorted with it is accepted by the reference unchanged; the streaming kernel then reads the caller's arrays in
+    place.  (The time-tiled kernel, which routes all but very short calls, always goes through its record passes.)
     """
     from . import _lib
     from .engine import Plan
