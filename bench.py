@@ -144,7 +144,7 @@ def bench_unit(args, device_index):
     convolution, 28 GB at 1M reaches)."""
     import torch
     from river_route_amd import synth
-    from river_route_amd.engine import Plan, uh_convolve_dev
+    from river_route_amd.engine import Plan
     n, nsub, dt, n_ks = args.reaches, args.substeps, 900.0, args.uh_steps
     T = args.runoff_steps if args.runoff_steps != 35_040 else 3_504
     dev = torch.device('cuda', device_index)
@@ -160,18 +160,15 @@ def bench_unit(args, device_index):
     g = torch.Generator(device=dev)
     g.manual_seed(1234)
     depth = torch.rand((T, n), dtype=torch.float64, device=dev, generator=g) * 1e-3
-    conv = torch.empty_like(depth)
-    out_rows = 96
-    out = torch.zeros((out_rows, n), dtype=torch.float64, device=dev)
+    out = torch.zeros((T, n), dtype=torch.float64, device=dev)
     n_inner = plan.n_inner
     q_ch = torch.zeros(n_inner, dtype=torch.float64, device=dev)
     q_full = torch.zeros(n_inner, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def one_pass():
+    def one_pass():      # UnitMuskingum._router of one file: convolution fused into the in-pass, routing, state bookkeeping
         state.zero_(); q_ch.zero_(); q_full.zero_()
-        uh_convolve_dev(kern, state, depth, conv, T, n_ks, n, device=device_index, stream=stream)
-        plan.unit_route_dev(q_ch, q_full, conv, T, out, out_rows, T, nsub, stream)
+        plan.unit_route_uh_dev(q_ch, q_full, None, kern, state, n_ks, depth, T, nsub, discharge=out, stream=stream)
 
     base = None
     if not args.no_cpu_baseline:
@@ -196,15 +193,13 @@ def bench_unit(args, device_index):
                 'sample': f'{n} reaches x {Tc} runoff steps, direct-form convolution + unit_route, {dt_s:.2f} s, 1 thread'}
         chk = torch.zeros((Tc, n), dtype=torch.float64, device=dev)
         state.zero_(); q_ch.zero_(); q_full.zero_()
-        conv_c = torch.empty((Tc, n), dtype=torch.float64, device=dev)
-        uh_convolve_dev(kern, state, depth[:Tc].contiguous(), conv_c, Tc, n_ks, n, device=device_index, stream=stream)
-        plan.unit_route_dev(q_ch, q_full, conv_c, Tc, chk, Tc, Tc, nsub, stream)
+        plan.unit_route_uh_dev(q_ch, q_full, None, kern, state, n_ks, depth[:Tc].contiguous(), Tc, nsub, discharge=chk, stream=stream)
         torch.cuda.synchronize()
         got = chk.cpu().numpy()
         chk_kernel = plan.profile()['ticks_per_launch']
         if not np.allclose(got, dd, rtol=1e-10, atol=1e-10 * np.abs(dd).max()):
             raise SystemExit('bench.py: GPU UnitMuskingum result differs from the oracle; refusing to report a number')
-        base['parity_gate'] = (f'{Tc} rows x {n} reaches, convolution + routing by the timed kernels '
+        base['parity_gate'] = (f'{Tc} rows x {n} reaches, fused convolution + routing by the timed kernels '
                                f'({"k_tile, " + str(chk_kernel) + " ticks per task" if chk_kernel > 1 else "k_tick"}) == oracle, '
                                f'rtol 1e-10, max |diff| {float(np.abs(got - dd).max()):.3e}')
 
@@ -226,7 +221,7 @@ def bench_unit(args, device_index):
             'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'UnitMuskingum, {n}-reach synthetic network + {n_ks}-step UH kernel, {T} runoff steps, '
-                                   f'{nsub} sub-step(s), fp64, 1xMI355X (BASELINE config 4; convolution + routing)',
+                                   f'{nsub} sub-step(s), fp64, 1xMI355X (BASELINE config 4; convolution fused into the record in-pass + routing)',
                        'reaches': n, 'runoff_steps': T, 'uh_steps': n_ks, 'headwaters': plan.n_headwaters},
             'roofline': roofline, 'cpu_baseline': base}
     print(json.dumps(line))

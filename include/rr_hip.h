@@ -155,6 +155,16 @@ int rr_muskingum_route_f32_dev(rr_plan *plan, double *q_t, float *discharge32, i
 int rr_unit_route_f32_dev(rr_plan *plan, double *q_ch, double *q_full, const double *convolved_lateral, int64_t conv_rows,
                           float *discharge32, int64_t num_runoff_steps, int64_t num_substeps, int64_t factor, void *stream);
 
+/* UnitMuskingum with the unit-hydrograph convolution fused into the pass that turns rows into the engine's records
+ * (river_route/routers/UnitMuskingum.py:72-98 in one call): depth[T*n] runoff depths, uh_kernel[n_ks*n], uh_state[n_ks*n]
+ * in/out (carry-over, updated in place), n_ks <= 64.  Exactly one of discharge (float64, T rows) / discharge32 (float32,
+ * T / factor rows, `factor` rows averaged) is non-NULL.  q_final[n] (may be NULL) receives the state the router keeps: the
+ * last lateral inflow on headwaters, q_full on inner reaches.  The convolved lateral never exists as rows in memory.
+ * RR_E_UNSUPPORTED where the call is not time-tiled (use rr_uh_convolve_dev + rr_unit_route_dev). */
+int rr_unit_route_uh_dev(rr_plan *plan, double *q_ch, double *q_full, double *q_final, const double *uh_kernel, double *uh_state,
+                         int64_t n_ks, const double *depth, double *discharge, float *discharge32, int64_t factor,
+                         int64_t num_runoff_steps, int64_t num_substeps, void *stream);
+
 /* ---- partitioned networks (multi-GPU): boundary reaches and streaming calls ----
  *
  * A network cut into parts (rr_partition_forest) is routed one part per GPU.  In the part that holds the

@@ -964,11 +964,58 @@ struct RecPermArgs {
     Div32 factor;
 };
 
+constexpr int kRecTileRows = 16 * kRecBatch + 15;      // tick-rows behind one batch of records
+constexpr int kRecTileLd = kRecCols + 1;
+
+// Second half of the in-pass: the LDS tile (row = runoff row - row_first, kRecTileLd doubles per row) becomes records.
+template <bool SUB, int THREADS = kRecThreads>
+__device__ __forceinline__ void write_records(const RecPermArgs &a, const double *tile, int64_t col0, int64_t tick_first, int64_t row_first)
+{
+    constexpr int R = kRecTileRows;
+    const int tid = threadIdx.x;
+    constexpr int IT = kRecCols * kRecBatch * 8 / THREADS;
+    int2 meta[IT];
+    double f[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {     // all metadata loads first: they are independent
+        const int64_t i = col0 + (it * THREADS + tid) / (8 * kRecBatch);
+        meta[it] = i < a.n ? a.colmeta[i] : make_int2(-1, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int64_t i = col0 + (it * THREADS + tid) / (8 * kRecBatch);
+        f[it] = (a.scale && i < a.n) ? a.scale[i] : 1.0;
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int piece = it * THREADS + tid;       // (column, record, 16-byte part): 8 consecutive lanes = one record
+        const int c = piece / (8 * kRecBatch), k = (piece >> 3) % kRecBatch, part = piece & 7;
+        const int32_t p = meta[it].x;
+        if (p < 0) continue;
+        const int32_t lag = meta[it].y;
+        const int o = lag & 15;
+        const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)(lag >> 4) + k;
+        const int r = 15 - o + 16 * k + 2 * part;       // tick-row tick_first + r
+        double v0, v1;
+        if (SUB) {
+            const int64_t t0 = tick_first + r, t1 = t0 + 1;
+            uint32_t s;
+            const int r0 = t0 < 0 ? 0 : (int)((int64_t)a.nsub.div((uint32_t)t0, s) - row_first);
+            const int r1 = t1 < 0 ? 0 : (int)((int64_t)a.nsub.div((uint32_t)t1, s) - row_first);
+            v0 = tile[min(r0, R - 1) * kRecTileLd + c] * f[it]; v1 = tile[min(r1, R - 1) * kRecTileLd + c] * f[it];
+        } else {
+            v0 = tile[r * kRecTileLd + c] * f[it]; v1 = tile[(r + 1) * kRecTileLd + c] * f[it];
+        }
+        double2 *dst = reinterpret_cast<double2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.np + p) * kRec) + part;
+        *dst = make_double2(v0, v1);
+    }
+}
+
 template <bool SUB>
 __global__ __launch_bounds__(kRecThreads) void k_rec_in(const RecPermArgs a)
 {
-    constexpr int R = 16 * kRecBatch + 15;
-    __shared__ double tile[R][kRecCols + 1];
+    constexpr int R = kRecTileRows;
+    __shared__ double tile[R * kRecTileLd];
     const int tid = threadIdx.x;
     const int64_t col0 = (int64_t)blockIdx.x * kRecCols;
     const int64_t tick_first = kRecRows * a.batch - 15;                 // may be negative in the first batch
@@ -989,46 +1036,90 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_in(const RecPermArgs a)
         for (int q = 0; q < RPT; ++q) {
             const int r = r0 + q * (kRecThreads / kRecCols);
             const int64_t t = row_first + r;
-            if (r < R) tile[r][c] = (t >= 0 && t < a.T && col0 + c < a.n) ? v[q] : 0.0;
+            if (r < R) tile[r * kRecTileLd + c] = (t >= 0 && t < a.T && col0 + c < a.n) ? v[q] : 0.0;
         }
     }
     __syncthreads();
-    constexpr int IT = kRecCols * kRecBatch * 8 / kRecThreads;
-    int2 meta[IT];
-    double f[IT];
+    write_records<SUB>(a, tile, col0, tick_first, row_first);
+}
+
+// The in-pass with the unit-hydrograph convolution fused in (UnitHydrograph.py:93-107, direct form): the tile is COMPUTED
+// from the runoff-depth rows instead of loaded, so the convolved lateral never exists as (T, n) rows in HBM (written by the
+// convolution kernel, read again by k_rec_in: 16 B per value).  The block loads the depth rows behind its 143 tick-rows plus
+// the n_ks - 1 before them and the kernel's taps into LDS; thread (column, group of 18 rows) pulls its window of 18 + NK - 1
+// depth values into registers and accumulates 18 outputs x NK taps with static indices (NK = n_ks padded with zero taps);
+// the outputs replace the depth tile in LDS and leave as records.  out[t] = [t < n_ks] state[t] + sum_k kernel[k] depth[t - k].
+struct UhArgs {
+    const double *kernel, *state;     // (n_ks, n) taps and carried-in state, params order
+    int32_t n_ks;
+};
+constexpr int kUhInThreads = 256;       // 8 groups of rows x 32 columns: 18 outputs per thread, windows of 18 + NK - 1 depth values (512 threads x 9 rows: 20 % slower)
+constexpr int kUhRowsPerThread = (kRecTileRows + kUhInThreads / kRecCols - 1) / (kUhInThreads / kRecCols);
+constexpr size_t rec_in_uh_lds_bytes(int nk) { return (size_t)((kRecTileRows + nk - 1) + nk) * kRecTileLd * sizeof(double); }
+
+template <bool SUB, int NK>
+__global__ __launch_bounds__(kUhInThreads) void k_rec_in_uh(const RecPermArgs a, const UhArgs u)
+{
+    constexpr int R = kRecTileRows, G = kUhInThreads / kRecCols, RP = kUhRowsPerThread, W = RP + NK - 1;
+    extern __shared__ __attribute__((aligned(16))) double uh_lds[];
+    double *dt = uh_lds;                                   // [R + NK - 1][kRecTileLd] depth rows row_first - (NK - 1) ...
+    double *tp = uh_lds + (R + NK - 1) * kRecTileLd;       // [NK][kRecTileLd] taps
+    const int tid = threadIdx.x, c = tid % kRecCols, g = tid / kRecCols;
+    const int64_t col0 = (int64_t)blockIdx.x * kRecCols;
+    const int64_t tick_first = kRecRows * a.batch - 15;
+    uint32_t sub_unused;
+    const int64_t row_first = SUB ? (int64_t)a.nsub.div((uint32_t)(tick_first < 0 ? 0 : tick_first), sub_unused) : tick_first;
+    const int need = SUB ? (int)((uint32_t)(R - 1) / a.nsub.d) + 2 : R;
+    const int64_t i = min(col0 + c, a.n - 1);
+    const bool live = col0 + c < a.n;
+    {   // all loads in flight first (branch-free: out-of-range rows/columns are clamped and zeroed afterwards)
+        constexpr int DPT = (R + NK - 1 + G - 1) / G, TPT = (NK + G - 1) / G;
+        double dv[DPT], tv[TPT];
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {     // all metadata loads first: they are independent
-        const int64_t i = col0 + (it * kRecThreads + tid) / (8 * kRecBatch);
-        meta[it] = i < a.n ? a.colmeta[i] : make_int2(-1, 0);
-    }
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int64_t i = col0 + (it * kRecThreads + tid) / (8 * kRecBatch);
-        f[it] = (a.scale && i < a.n) ? a.scale[i] : 1.0;
-    }
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int piece = it * kRecThreads + tid;       // (column, record, 16-byte part): 8 consecutive lanes = one record
-        const int c = piece / (8 * kRecBatch), k = (piece >> 3) % kRecBatch, part = piece & 7;
-        const int32_t p = meta[it].x;
-        if (p < 0) continue;
-        const int32_t lag = meta[it].y;
-        const int o = lag & 15;
-        const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)(lag >> 4) + k;
-        const int r = 15 - o + 16 * k + 2 * part;       // tick-row tick_first + r
-        double v0, v1;
-        if (SUB) {
-            const int64_t t0 = tick_first + r, t1 = t0 + 1;
-            uint32_t s;
-            const int r0 = t0 < 0 ? 0 : (int)((int64_t)a.nsub.div((uint32_t)t0, s) - row_first);
-            const int r1 = t1 < 0 ? 0 : (int)((int64_t)a.nsub.div((uint32_t)t1, s) - row_first);
-            v0 = tile[min(r0, R - 1)][c] * f[it]; v1 = tile[min(r1, R - 1)][c] * f[it];
-        } else {
-            v0 = tile[r][c] * f[it]; v1 = tile[r + 1][c] * f[it];
+        for (int q = 0; q < DPT; ++q) {
+            const int64_t t = row_first - (NK - 1) + min(g + q * G, need + NK - 2);
+            dv[q] = a.rows.row(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t))[i];
         }
-        double2 *dst = reinterpret_cast<double2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.np + p) * kRec) + part;
-        *dst = make_double2(v0, v1);
+#pragma unroll
+        for (int q = 0; q < TPT; ++q) tv[q] = u.kernel[(int64_t)min(g + q * G, u.n_ks - 1) * a.n + i];
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) {
+            const int r = g + q * G;
+            const int64_t t = row_first - (NK - 1) + r;
+            if (r < R + NK - 1) dt[r * kRecTileLd + c] = (live && t >= 0 && t < a.T) ? dv[q] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < TPT; ++q) {
+            const int k = g + q * G;
+            if (k < NK) tp[k * kRecTileLd + c] = (live && k < u.n_ks) ? tv[q] : 0.0;
+        }
     }
+    __syncthreads();
+    const int rb = g * RP;      // first output row of this thread
+    double acc[RP];
+    if (rb < need) {
+        double win[W];
+#pragma unroll
+        for (int q = 0; q < W; ++q) win[q] = dt[min(rb + q, R + NK - 2) * kRecTileLd + c];      // depth row (row_first + rb + q - (NK - 1))
+#pragma unroll
+        for (int j = 0; j < RP; ++j) {
+            const int64_t t = row_first + rb + j;
+            acc[j] = (live && t >= 0 && t < u.n_ks && t < a.T) ? u.state[t * a.n + i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const double tap = tp[k * kRecTileLd + c];
+#pragma unroll
+            for (int j = 0; j < RP; ++j) acc[j] = __builtin_fma(tap, win[j + (NK - 1) - k], acc[j]);
+        }
+    }
+    __syncthreads();      // every window is in registers: the depth tile's space now takes the outputs
+    if (rb < need) {
+#pragma unroll
+        for (int j = 0; j < RP; ++j) if (rb + j < R) dt[(rb + j) * kRecTileLd + c] = acc[j];
+    }
+    __syncthreads();
+    write_records<SUB, kUhInThreads>(a, dt, col0, tick_first, row_first);
 }
 
 // OUT32: the router's post-processing fused in (TransformMuskingum.py:128-142): mean over `factor` consecutive rows
@@ -1198,6 +1289,10 @@ struct Rows {
     int64_t rows_out = 0;
     float *dev_out32 = nullptr;       // instead of dev_out: float32 rows, each the mean of out_factor routed rows
     int64_t out_factor = 1;
+    // UnitMuskingum with the convolution fused into the in-pass: dev_in holds runoff DEPTH rows, the lateral inflow is
+    // computed on the way into the records (k_rec_in_uh)
+    const double *uh_kernel = nullptr, *uh_state = nullptr;
+    int64_t uh_nks = 0;
 };
 
 // One routing call in flight: rows enter (permutation in), ticks run, finished rows leave (permutation out).
@@ -1681,6 +1776,17 @@ void launch_ghost_permute(rr_plan *P, int64_t batch)
     hipLaunchKernelGGL(k_rec_in<false>, dim3((unsigned)((P->n_ghost + kRecCols - 1) / kRecCols)), dim3(kRecThreads), 0, S.stream, ra);
 }
 
+typedef void (*rec_in_uh_t)(const RecPermArgs, const UhArgs);
+constexpr int kUhFusedMaxTaps = 64;
+int uh_padded_taps(int64_t n_ks) { return n_ks <= 16 ? 16 : (n_ks <= 48 ? 48 : 64); }
+rec_in_uh_t rec_in_uh_kernel(bool sub, int64_t n_ks)
+{
+    const int nk = uh_padded_taps(n_ks);
+#define RR_UHIN_PICK(NK_) (sub ? (rec_in_uh_t)k_rec_in_uh<true, NK_> : (rec_in_uh_t)k_rec_in_uh<false, NK_>)
+    return nk == 16 ? RR_UHIN_PICK(16) : (nk == 48 ? RR_UHIN_PICK(48) : RR_UHIN_PICK(64));
+#undef RR_UHIN_PICK
+}
+
 void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
 {
     Session &S = P->ses;
@@ -1696,7 +1802,10 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
     ra.factor = Div32((uint32_t)std::max<int64_t>(1, S.io.out_factor));
     const dim3 g((unsigned)((n + kRecCols - 1) / kRecCols));
     const bool sub = S.nsub > 1;
-    if (in) {
+    if (in && S.io.uh_kernel) {
+        UhArgs ua{S.io.uh_kernel, S.io.uh_state, (int32_t)S.io.uh_nks};
+        hipLaunchKernelGGL(rec_in_uh_kernel(sub, S.io.uh_nks), g, dim3(kUhInThreads), rec_in_uh_lds_bytes(uh_padded_taps(S.io.uh_nks)), S.stream, ra, ua);
+    } else if (in) {
         if (sub) hipLaunchKernelGGL(k_rec_in<true>, g, dim3(kRecThreads), 0, S.stream, ra);
         else hipLaunchKernelGGL(k_rec_in<false>, g, dim3(kRecThreads), 0, S.stream, ra);
     } else if (ra.rows32) {
@@ -2087,7 +2196,7 @@ int rapid_like(rr_plan *P, Mode mode, double *q_t, const Rows &io_in, int64_t T,
 }
 
 int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io_in, int64_t T, int64_t nsub,
-              hipStream_t stream, bool q_on_host)
+              hipStream_t stream, bool q_on_host, double *d_q_final = nullptr, double *uh_state_inout = nullptr)
 {
     const int64_t n = P->h.n, ni = (int64_t)P->h.inner_pos.size();
     if (n == 0 || T == 0) return RR_OK;
@@ -2124,6 +2233,15 @@ int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io_in, int64
     }
     if (e0 != hipSuccess) { if (tmp) (void)hipFree(tmp); return fail(RR_E_HIP, hipGetErrorString(e0)); }
     if (rc == RR_OK) rc = piped ? route_host_pipelined(P, Mode::Unit, T, nsub, io.host_in, io.host_out, stream) : route_core(P, Mode::Unit, T, nsub, io, stream);
+    if (rc == RR_OK && wave && d_q_final)      // every reach: a headwater's state is its last lateral inflow, an inner reach's q_full
+        hipLaunchKernelGGL(k_tile_state_out, grid1(n), dim3(kBlock), 0, stream, d_q_final, (const double *)P->d_sq, P->d_tinv, (int32_t)n);
+    if (rc == RR_OK && io.uh_kernel && uh_state_inout) {      // carry-over state of the fused convolution, in place, after every batch has read the old one
+        const dim3 gt((unsigned)((n + kUhTailThreads - 1) / kUhTailThreads));
+        const int32_t nks = (int32_t)io.uh_nks;
+        if (nks <= 16) hipLaunchKernelGGL(k_uh_tail<16>, gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in, T, nks, n);
+        else if (nks <= 48) hipLaunchKernelGGL(k_uh_tail<48>, gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in, T, nks, n);
+        else hipLaunchKernelGGL(k_uh_tail<0>, gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in, T, nks, n);
+    }
     if (rc == RR_OK && ni > 0) {
         if (wave)
             hipLaunchKernelGGL(k_tile_unit_state_out, grid1(ni), dim3(kBlock), 0, stream, d_qch, d_qfull,
@@ -2273,6 +2391,9 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
                 (void)hipGetLastError();
                 P->wave_enabled = false;
             }
+        for (int v = 0; v < 2; ++v)
+            (void)hipFuncSetAttribute((const void *)rec_in_uh_kernel(v != 0, 64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rec_in_uh_lds_bytes(64));
+        (void)hipGetLastError();
         const rr::HostPlan &H = P->h;
         const int64_t ni = (int64_t)H.inner_pos.size();
         rc = dev_alloc(&P->d_child_ptr, n + 1);
@@ -2684,6 +2805,27 @@ int rr_unit_route_f32_dev(rr_plan *P, double *q_ch, double *q_full, const double
     if (rc) return rc;
     Rows io; io.dev_in = conv; io.rows_in = conv_rows; io.dev_out32 = discharge32; io.out_factor = factor; io.rows_out = T / factor;
     return unit_like(P, q_ch, q_full, io, T, nsub, (hipStream_t)stream, false);
+}
+
+int rr_unit_route_uh_dev(rr_plan *P, double *q_ch, double *q_full, double *q_final, const double *uh_kernel, double *uh_state,
+                         int64_t n_ks, const double *depth, double *discharge, float *discharge32, int64_t factor, int64_t T,
+                         int64_t nsub, void *stream)
+{
+    int rc = check_route_args(P, false, T, nsub);
+    if (rc) return rc;
+    const bool f32 = discharge32 != nullptr;
+    if (P->h.n > 0 && T > 0 && (!depth || !uh_kernel || !uh_state || (!discharge && !discharge32) || (discharge && discharge32) || n_ks < 1 ||
+                                (!P->h.inner_pos.empty() && (!q_ch || !q_full))))
+        return fail(RR_E_INVALID, "rr_unit_route_uh_dev: null array, both or neither output, or n_ks < 1");
+    if (P->h.n == 0 || T == 0) return RR_OK;
+    if (n_ks > kUhFusedMaxTaps) return fail(RR_E_UNSUPPORTED, "rr_unit_route_uh_dev: more than 64 kernel steps: convolve with rr_uh_convolve_dev, then rr_unit_route_dev");
+    if (f32) { rc = f32_output_applies(P, Mode::Unit, T, nsub, factor); if (rc) return rc; }
+    else if (!decide_wave(P, Mode::Unit, T * nsub, false)) return fail(RR_E_UNSUPPORTED, "rr_unit_route_uh_dev needs the time-tiled kernel, which this call does not get");
+    Rows io; io.dev_in = depth; io.rows_in = T;
+    if (f32) { io.dev_out32 = discharge32; io.out_factor = factor; io.rows_out = T / factor; }
+    else { io.dev_out = discharge; io.rows_out = T; }
+    io.uh_kernel = uh_kernel; io.uh_state = uh_state; io.uh_nks = n_ks;
+    return unit_like(P, q_ch, q_full, io, T, nsub, (hipStream_t)stream, false, q_final, uh_state);
 }
 
 int rr_uh_convolve_dev(int device, const double *kernel, double *state, const double *lateral, double *out,

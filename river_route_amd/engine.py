@@ -177,6 +177,13 @@ class Plan:
         check(_lib.lib().rr_unit_route_f32_dev(self._h, ptr(q_ch), ptr(q_full), ptr(convolved), int(conv_rows),
                                                ptr(discharge32), int(T), int(num_substeps), int(factor), stream))
 
+    def unit_route_uh_dev(self, q_ch, q_full, q_final, uh_kernel, uh_state, n_ks, depth, T, num_substeps, discharge=None,
+                          discharge32=None, factor=1, stream=None) -> None:
+        """Convolution + routing of one file in one call (rr_unit_route_uh_dev); exactly one of discharge / discharge32."""
+        check(_lib.lib().rr_unit_route_uh_dev(self._h, ptr(q_ch), ptr(q_full), ptr(q_final), ptr(uh_kernel), ptr(uh_state),
+                                              int(n_ks), ptr(depth), ptr(discharge), ptr(discharge32), int(factor), int(T),
+                                              int(num_substeps), stream))
+
     # -- partitioned networks: boundary reaches + streaming calls (include/rr_hip.h) --
     def set_boundary(self, ghost_reaches, export_reaches) -> None:
         g = np.ascontiguousarray(ghost_reaches, dtype=np.int64)

@@ -318,3 +318,51 @@ def test_float32_output_fused_into_the_record_pass(monkeypatch, n, T, nsub, fact
         assert e.value.code == RR_E_UNSUPPORTED
         for b in (d_ql, d_q, d_64, d_32):
             b.free()
+
+
+@pytest.mark.parametrize('n,T,nsub,n_ks', [(60_000, 200, 1, 48), (300_000, 150, 1, 48), (60_000, 70, 3, 12), (60_000, 40, 1, 60),
+                                           (60_000, 33, 1, 1)])
+def test_unit_route_with_fused_convolution_vs_oracle(monkeypatch, n, T, nsub, n_ks):
+    """rr_unit_route_uh_dev: UnitHydrograph.convolve + unit_route + the router's state bookkeeping
+    (river_route/routers/UnitMuskingum.py:72-98) in one call, the convolved lateral never written as rows; two files, so
+    the UH carry-over state (including T < n_ks leftovers) and the channel state both cross a file boundary."""
+    set_env(monkeypatch, {})
+    net = synth.synth_network(n, seed=23)
+    indptr, indices = csc_from_down(net.down_index)
+    hw_idx, inner_idx, A_in, A_hw = unit_split(indptr, indices, n)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0 / nsub)
+    c1i, c2i, c3i = c1[inner_idx], c2[inner_idx], c3[inner_idx]
+    args = (A_in.indptr, A_in.indices, -c1i[A_in.indices], A_in.indptr, A_in.indices, A_in.data,
+            A_hw.indptr, A_hw.indices, A_hw.data, c1i, c2i, c3i, hw_idx, inner_idx)
+    kern = synth.synth_uh_kernel(n, n_ks)
+    uh = oracle.UnitHydrograph(kern)
+    state_ref = 3.0 * synth.u01(7, np.arange(n))
+    ni = inner_idx.size
+    with Plan(indptr, indices) as plan:
+        plan.set_coeffs(-c1[indices], c2, c3, None)
+        d_kern, d_state = DeviceBuffer(kern.nbytes).upload(kern), DeviceBuffer(kern.nbytes).upload(np.zeros_like(kern))
+        d_depth, d_out, d_fin = DeviceBuffer(T * n * 8), DeviceBuffer(T * n * 8), DeviceBuffer(n * 8)
+        d_qc, d_qf = DeviceBuffer(ni * 8), DeviceBuffer(ni * 8)
+        state = state_ref.copy()
+        for f, Tf in enumerate((T, max(2, n_ks // 2))):       # the second file is shorter than the kernel
+            depth = synth.synth_runoff_depth(n, f * T, f * T + Tf)
+            conv_ref = uh.convolve(depth)
+            qc_ref, qf_ref, d_ref = state_ref[inner_idx].copy(), state_ref[inner_idx].copy(), np.zeros((Tf, n))
+            oracle.unit_route(*args, qc_ref, qf_ref, conv_ref, d_ref, nsub)
+            state_ref[hw_idx], state_ref[inner_idx] = conv_ref[-1][hw_idx], qf_ref
+            d_depth.upload(depth)
+            d_qc.upload(state[inner_idx].copy()); d_qf.upload(state[inner_idx].copy())
+            try:
+                plan.unit_route_uh_dev(d_qc, d_qf, d_fin, d_kern, d_state, n_ks, d_depth, Tf, nsub, discharge=d_out)
+            except Exception as e:      # a call too short for the time-tiled kernel is refused: the two-call form then
+                from river_route_amd._lib import RR_E_UNSUPPORTED
+                assert getattr(e, 'code', None) == RR_E_UNSUPPORTED and Tf * nsub < 32
+                break
+            d = d_out.download(np.float64, (Tf, n))
+            state = d_fin.download(np.float64, (n,))
+            assert_close(d, d_ref, f'file {f} discharge')
+            assert_close(state, state_ref, f'file {f} router state')
+            assert_close(d_qc.download(np.float64, (ni,)), qc_ref, f'file {f} q_ch')
+            assert_close(d_state.download(np.float64, kern.shape), uh.state, f'file {f} UH state')
+        for b in (d_kern, d_state, d_depth, d_out, d_fin, d_qc, d_qf):
+            b.free()
