@@ -155,6 +155,16 @@ int rr_muskingum_route_f32_dev(rr_plan *plan, double *q_t, float *discharge32, i
 int rr_unit_route_f32_dev(rr_plan *plan, double *q_ch, double *q_full, const double *convolved_lateral, int64_t conv_rows,
                           float *discharge32, int64_t num_runoff_steps, int64_t num_substeps, int64_t factor, void *stream);
 
+/* RapidMuskingum fed by gridded runoff (river_route/routers/TransformMuskingum.py:38-51 -> runoff.py:288-332 -> RapidMuskingum.py:
+ * 19-33 in one call, one sub-step per row): the weights product of rr_runoff_to_qlateral_dev (same arguments, device arrays;
+ * pass area: the routers route volumes) runs inside the pass that builds the engine's records, so the catchment inflow never
+ * exists as (T, n) rows.  Exactly one of discharge (float64, T rows) / discharge32 (float32, T / factor rows) is non-NULL.
+ * RR_E_UNSUPPORTED where the call is not time-tiled (use rr_runoff_to_qlateral_dev + rr_rapid_route_dev). */
+int rr_rapid_route_runoff_dev(rr_plan *plan, double *q_t, int64_t n_points, const int32_t *indptr, const int32_t *indices,
+                              const double *weights, const void *runoff, int runoff_is_f32, int64_t stride_t, int64_t stride_p,
+                              const double *area, int flags, double *discharge, float *discharge32, int64_t factor,
+                              int64_t num_runoff_steps, void *stream);
+
 /* UnitMuskingum with the unit-hydrograph convolution fused into the pass that turns rows into the engine's records
  * (river_route/routers/UnitMuskingum.py:72-98 in one call): depth[T*n] runoff depths, uh_kernel[n_ks*n], uh_state[n_ks*n]
  * in/out (carry-over, updated in place), n_ks <= 64.  Exactly one of discharge (float64, T rows) / discharge32 (float32,

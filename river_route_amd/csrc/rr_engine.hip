@@ -1257,6 +1257,71 @@ __global__ __launch_bounds__(kBlock) void k_runoff_to_qlateral(const int32_t *__
     }
 }
 
+// The in-pass with the gridded-runoff aggregation fused in (one sub-step per row): thread (river i, record k of the batch)
+// computes the 16 rows of ONE record of river i -- rows [128 j + 16 k - o, + 16), o = lag % 16: the record boundaries of a
+// river follow its lag -- exactly as k_runoff_to_qlateral computes its 16-row chunks (same gather, same rounding, same
+// post-processing), times c4dt, and the block's 256 records leave through LDS eight lanes per record.  The catchment
+// inflow never exists as (T, n) rows in HBM.
+struct RunoffArgs {
+    const int32_t *indptr, *indices;
+    const double *weights, *area;
+    const void *runoff;
+    int64_t stride_t, stride_p;
+    int32_t flags, is_f32;
+};
+constexpr int kRunoffInThreads = 256;
+
+template <typename RT>
+__global__ __launch_bounds__(kRunoffInThreads) void k_rec_in_runoff(const RecPermArgs a, const RunoffArgs g)
+{
+    __shared__ double stage[kRunoffInThreads][kRec + 1];
+    __shared__ int64_t slot[kRunoffInThreads];      // record index (chunk % chunks) * np + position, -1: no record
+    const int tid = threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * kRunoffInThreads + tid;
+    const int k = blockIdx.y;
+    const bool cumulative = g.flags & RR_RUNOFF_CUMULATIVE, force_positive = g.flags & RR_RUNOFF_FORCE_POSITIVE,
+               keep_nan = g.flags & RR_RUNOFF_KEEP_NAN;
+    slot[tid] = -1;
+    if (i < a.n) {
+        const int2 meta = a.colmeta[i];
+        const int32_t lag = meta.y, o = lag & 15;
+        const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)(lag >> 4) + (uint32_t)k;
+        const int64_t t0 = kRecRows * a.batch + 16 * k - o;      // first row of the record; rows outside [0, T) hold zeros
+        double acc[kRec + 1];        // slot 0: row t0 - 1 (cumulative input only)
+#pragma unroll
+        for (int j = 0; j <= kRec; ++j) acc[j] = 0.0;
+        const RT *base = static_cast<const RT *>(g.runoff);
+        for (int32_t e = g.indptr[i]; e < g.indptr[i + 1]; ++e) {
+            const double w = g.weights[e];
+            const RT *src = base + (int64_t)g.indices[e] * g.stride_p;
+#pragma unroll
+            for (int j = 0; j <= kRec; ++j) {
+                const int64_t t = t0 - 1 + j;
+                if (t >= 0 && t < a.T && (j > 0 || cumulative)) acc[j] = __dadd_rn(acc[j], __dmul_rn(w, (double)src[t * g.stride_t]));
+            }
+        }
+        const double area = g.area ? g.area[i] : 1.0, f = a.scale ? a.scale[i] : 1.0;
+#pragma unroll
+        for (int j = 1; j <= kRec; ++j) {
+            const int64_t t = t0 - 1 + j;
+            double v = (cumulative && t > 0) ? acc[j] - acc[j - 1] : acc[j];
+            if (force_positive) v = v < 0.0 ? 0.0 : v;      // np.clip leaves NaN alone, as does this comparison
+            if (v != v && !keep_nan) v = 0.0;
+            if (g.area) v = v * area;
+            stage[tid][j - 1] = (t >= 0 && t < a.T) ? v * f : 0.0;
+        }
+        slot[tid] = (int64_t)a.rec_chunks.mod(chunk) * a.np + meta.x;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int piece = it * kRunoffInThreads + tid, r = piece >> 3, part = piece & 7;      // 8 consecutive lanes = one record
+        const int64_t sl = slot[r];
+        if (sl < 0) continue;
+        reinterpret_cast<double2 *>(a.rec + sl * kRec)[part] = make_double2(stage[r][2 * part], stage[r][2 * part + 1]);
+    }
+}
+
 // Device copy rate probe (bench.py reports it beside the nominal HBM peak): 16 bytes per lane, grid-stride.
 __global__ __launch_bounds__(kBlock) void k_copy16(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t count)
 {
@@ -1293,6 +1358,8 @@ struct Rows {
     // computed on the way into the records (k_rec_in_uh)
     const double *uh_kernel = nullptr, *uh_state = nullptr;
     int64_t uh_nks = 0;
+    // RapidMuskingum fed by gridded runoff: no lateral rows at all, the weights product runs in the in-pass (k_rec_in_runoff)
+    const RunoffArgs *runoff = nullptr;
 };
 
 // One routing call in flight: rows enter (permutation in), ticks run, finished rows leave (permutation out).
@@ -1802,7 +1869,11 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
     ra.factor = Div32((uint32_t)std::max<int64_t>(1, S.io.out_factor));
     const dim3 g((unsigned)((n + kRecCols - 1) / kRecCols));
     const bool sub = S.nsub > 1;
-    if (in && S.io.uh_kernel) {
+    if (in && S.io.runoff) {
+        const dim3 gr((unsigned)((n + kRunoffInThreads - 1) / kRunoffInThreads), (unsigned)kRecBatch);
+        if (S.io.runoff->is_f32) hipLaunchKernelGGL(k_rec_in_runoff<float>, gr, dim3(kRunoffInThreads), 0, S.stream, ra, *S.io.runoff);
+        else hipLaunchKernelGGL(k_rec_in_runoff<double>, gr, dim3(kRunoffInThreads), 0, S.stream, ra, *S.io.runoff);
+    } else if (in && S.io.uh_kernel) {
         UhArgs ua{S.io.uh_kernel, S.io.uh_state, (int32_t)S.io.uh_nks};
         hipLaunchKernelGGL(rec_in_uh_kernel(sub, S.io.uh_nks), g, dim3(kUhInThreads), rec_in_uh_lds_bytes(uh_padded_taps(S.io.uh_nks)), S.stream, ra, ua);
     } else if (in) {
@@ -2805,6 +2876,28 @@ int rr_unit_route_f32_dev(rr_plan *P, double *q_ch, double *q_full, const double
     if (rc) return rc;
     Rows io; io.dev_in = conv; io.rows_in = conv_rows; io.dev_out32 = discharge32; io.out_factor = factor; io.rows_out = T / factor;
     return unit_like(P, q_ch, q_full, io, T, nsub, (hipStream_t)stream, false);
+}
+
+int rr_rapid_route_runoff_dev(rr_plan *P, double *q_t, int64_t n_points, const int32_t *indptr, const int32_t *indices,
+                              const double *weights, const void *runoff, int runoff_is_f32, int64_t stride_t, int64_t stride_p,
+                              const double *area, int flags, double *discharge, float *discharge32, int64_t factor, int64_t T,
+                              void *stream)
+{
+    int rc = check_route_args(P, true, T, 1);
+    if (rc) return rc;
+    const bool f32 = discharge32 != nullptr;
+    if (P->h.n > 0 && T > 0 && (!q_t || !indptr || !indices || !weights || !runoff || (!discharge && !discharge32) || (discharge && discharge32)))
+        return fail(RR_E_INVALID, "rr_rapid_route_runoff_dev: null array, or both or neither output");
+    if (n_points < 0 || stride_t < 0 || stride_p < 0) return fail(RR_E_INVALID, "rr_rapid_route_runoff_dev: negative size or stride");
+    if (P->h.n == 0 || T == 0) return RR_OK;
+    if (f32) { rc = f32_output_applies(P, Mode::Rapid, T, 1, factor); if (rc) return rc; }
+    else if (!decide_wave(P, Mode::Rapid, T, false)) return fail(RR_E_UNSUPPORTED, "rr_rapid_route_runoff_dev needs the time-tiled kernel, which this call does not get");
+    RunoffArgs ga{indptr, indices, weights, area, runoff, stride_t, stride_p, (int32_t)flags, runoff_is_f32 ? 1 : 0};
+    Rows io; io.dev_in = P->d_c4_params; io.rows_in = 1;      // (no lateral rows: dev_in only has to be non-NULL for the executor)
+    if (f32) { io.dev_out32 = discharge32; io.out_factor = factor; io.rows_out = T / factor; }
+    else { io.dev_out = discharge; io.rows_out = T; }
+    io.runoff = &ga;
+    return rapid_like(P, Mode::Rapid, q_t, io, T, 1, (hipStream_t)stream, false);
 }
 
 int rr_unit_route_uh_dev(rr_plan *P, double *q_ch, double *q_full, double *q_final, const double *uh_kernel, double *uh_state,

@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import RRError, check, ptr
 
 __all__ = ['Plan', 'RRError', 'uh_convolve', 'uh_convolve_dev', 'runoff_to_qlateral', 'DeviceBuffer', 'partition_forest', 'synchronize',
-           'resample_cast_dev', 'copy_bandwidth']
+           'resample_cast_dev', 'copy_bandwidth', 'runoff_to_qlateral_dev']
 
 
 def _f64(a, name):
@@ -177,6 +177,13 @@ class Plan:
         check(_lib.lib().rr_unit_route_f32_dev(self._h, ptr(q_ch), ptr(q_full), ptr(convolved), int(conv_rows),
                                                ptr(discharge32), int(T), int(num_substeps), int(factor), stream))
 
+    def rapid_route_runoff_dev(self, q_t, n_points, indptr, indices, weights, runoff, runoff_is_f32, stride_t, stride_p, area, flags, T,
+                               discharge=None, discharge32=None, factor=1, stream=None) -> None:
+        """Gridded runoff -> records -> routing in one call (rr_rapid_route_runoff_dev); exactly one of discharge / discharge32."""
+        check(_lib.lib().rr_rapid_route_runoff_dev(self._h, ptr(q_t), int(n_points), ptr(indptr), ptr(indices), ptr(weights), ptr(runoff),
+                                                   int(bool(runoff_is_f32)), int(stride_t), int(stride_p), ptr(area), int(flags),
+                                                   ptr(discharge), ptr(discharge32), int(factor), int(T), stream))
+
     def unit_route_uh_dev(self, q_ch, q_full, q_final, uh_kernel, uh_state, n_ks, depth, T, num_substeps, discharge=None,
                           discharge32=None, factor=1, stream=None) -> None:
         """Convolution + routing of one file in one call (rr_unit_route_uh_dev); exactly one of discharge / discharge32."""
@@ -269,6 +276,14 @@ def runoff_to_qlateral(indptr, indices, weights, runoff_tp, area=None, flags: in
                                            ptr(point_major), int(point_major.dtype == np.float32), 1, t_pad,
                                            ptr(area) if area is not None else None, int(flags), ptr(out)))
     return out
+
+
+def runoff_to_qlateral_dev(n_rivers, n_points, T, indptr, indices, weights, runoff, runoff_is_f32, stride_t, stride_p, area, flags, out,
+                           device: int = 0, stream=None) -> None:
+    """rr_runoff_to_qlateral_dev: device arrays in, (T, n_rivers) float64 device rows out; only enqueues."""
+    check(_lib.lib().rr_runoff_to_qlateral_dev(int(device), int(n_rivers), int(n_points), int(T), ptr(indptr), ptr(indices), ptr(weights),
+                                               ptr(runoff), int(bool(runoff_is_f32)), int(stride_t), int(stride_p),
+                                               ptr(area) if area is not None else None, int(flags), ptr(out), stream))
 
 
 def resample_cast_dev(discharge, num_rows, n, factor, out, device: int = 0, stream=None) -> None:

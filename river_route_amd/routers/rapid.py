@@ -25,16 +25,19 @@ class RapidMuskingum(TransformMuskingum):
     _engine_router = _router
 
     def _router_device(self, qlateral: np.ndarray, rows_per_output: int) -> tuple[np.ndarray, np.ndarray]:
-        from ._device import Arena, float32_rows
+        from ._device import Arena
         ql = self._check_lateral(qlateral)
-        T, n = ql.shape
-        nsub = self.num_routing_steps_per_runoff
-        self._lateral_coefficient()
         with Arena(self.cfg.device) as arena:
-            d_ql = arena.put(ql)
-            d_q = arena.put(np.array(self.channel_state, dtype=np.float64, order='C'))
-            q_array = float32_rows(
-                arena, T, n, rows_per_output,
-                fused=lambda d32: self._plan.rapid_route_f32_dev(d_q, d_ql, T, d32, T, nsub, rows_per_output),
-                plain=lambda d64: self._plan.rapid_route_dev(d_q, d_ql, T, d64, T, T, nsub))
-            return d_q.download(np.float64, (n,)), q_array
+            return self._route_on_device(arena, arena.put(ql), ql.shape[0], rows_per_output)
+
+    def _route_on_device(self, arena, d_ql, T: int, rows_per_output: int) -> tuple[np.ndarray, np.ndarray]:
+        """Lateral volumes already on the device, (T, n) float64 rows -> (final state, float32 discharge rows)."""
+        from ._device import float32_rows
+        n, nsub = self.A.shape[0], self.num_routing_steps_per_runoff
+        self._lateral_coefficient()
+        d_q = arena.put(np.array(self.channel_state, dtype=np.float64, order='C'))
+        q_array = float32_rows(
+            arena, T, n, rows_per_output,
+            fused=lambda d32: self._plan.rapid_route_f32_dev(d_q, d_ql, T, d32, T, nsub, rows_per_output),
+            plain=lambda d64: self._plan.rapid_route_dev(d_q, d_ql, T, d64, T, T, nsub))
+        return d_q.download(np.float64, (n,)), q_array

@@ -28,18 +28,51 @@ class TransformMuskingum(Muskingum, ABC):
                 dates, array = read_qlateral(lateral_file, self.cfg.var_t)
                 yield dates, array, lateral_file, discharge_file
         elif self.cfg.grid_runoff_files and self.cfg.grid_weights_file:
-            # gridded runoff -> catchment inflow on the device (TransformMuskingum.py:38-51 -> runoff.runoff_to_qlateral)
-            from ..runoff import runoff_to_qlateral
+            # gridded runoff -> catchment inflow on the device (TransformMuskingum.py:38-51 -> runoff.runoff_to_qlateral).  A
+            # router that can take the runoff itself (`_router_device_runoff`) gets the prepared source instead of the
+            # (time, river) array, so the inflow is computed on its way into the engine's records
+            from ..runoff import prepare_runoff, runoff_to_qlateral
+            kw = dict(grid_weights_file=self.cfg.grid_weights_file, var_runoff=self.cfg.var_grid_runoff, var_x=self.cfg.var_x,
+                      var_y=self.cfg.var_y, var_t=self.cfg.var_t, var_river_id=self.cfg.var_river_id,
+                      cumulative=self.cfg.grid_accumulation_type == 'cumulative', device=self.cfg.device)
             for runoff_file, discharge_file in zip(self.cfg.grid_runoff_files, self.cfg.discharge_files):
                 self.logger.info('-' * 60)
                 self.logger.debug(f'Calculating qlateral: {runoff_file}')
-                ds = runoff_to_qlateral(runoff_file, grid_weights_file=self.cfg.grid_weights_file,
-                                        var_runoff=self.cfg.var_grid_runoff, var_x=self.cfg.var_x, var_y=self.cfg.var_y,
-                                        var_t=self.cfg.var_t, var_river_id=self.cfg.var_river_id,
-                                        cumulative=self.cfg.grid_accumulation_type == 'cumulative',
-                                        as_volumes=self._as_volumes, device=self.cfg.device)
+                if self._takes_runoff_source():
+                    src = prepare_runoff(runoff_file, **kw)
+                    if not src.irregular:
+                        yield src.time_index.astype('datetime64[s]'), src, runoff_file, discharge_file
+                        continue
+                ds = runoff_to_qlateral(runoff_file, as_volumes=self._as_volumes, **kw)
                 yield (ds['time'].values.astype('datetime64[s]'),
                        ds['qlateral'].values.astype(np.float64, copy=False), runoff_file, discharge_file)
+
+    def _takes_runoff_source(self) -> bool:
+        return (self._device_postprocess and hasattr(self, '_route_on_device') and hasattr(self._plan, 'rapid_route_dev')
+                and type(self)._router is getattr(type(self), '_engine_router', None))
+
+    def _router_device_runoff(self, source, rows_per_output: int) -> tuple[np.ndarray, np.ndarray]:
+        """Gridded runoff of one file routed without leaving the GPU: the runoff block and the weight table go up once,
+        rr_runoff_to_qlateral_dev writes the catchment inflow as device rows (volumes for RapidMuskingum, depths for
+        UnitMuskingum), and the router's device path takes it from there.  (rr_rapid_route_runoff_dev computes the inflow
+        inside the record pass instead and saves the (T, n) array; its per-river row offsets defeat the aligned 16-byte
+        gathers, so at 1M reaches x 744 steps it takes 20.6 ms against 16.4 ms for the two calls: profiles/r02_runoff_path.txt.)"""
+        from ..engine import runoff_to_qlateral_dev
+        from ._device import Arena
+        T, n = source.runoff_tp.shape[0], self.A.shape[0]
+        if source.river_ids.shape[0] != n or T != self.num_runoff_steps:
+            raise ValueError(f'gridded runoff covers {source.river_ids.shape[0]} rivers x {T} steps, the network and time options '
+                             f'expect {n} x {self.num_runoff_steps}')
+        block = source.point_major()
+        with Arena(self.cfg.device) as arena:
+            d_block, d_ptr, d_idx = arena.put(block), arena.put(source.indptr), arena.put(source.indices)
+            d_w = arena.put(source.weights)
+            d_area = arena.put(source.area) if self._as_volumes else None
+            d_lat = arena.empty(T * n * 8)
+            runoff_to_qlateral_dev(n, block.shape[0], T, d_ptr, d_idx, d_w, d_block, block.dtype == np.float32, 1, block.shape[1], d_area,
+                                   source.flags, d_lat, device=self.cfg.device)
+            arena.release(d_block)
+            return self._route_on_device(arena, d_lat, T, rows_per_output)
 
     def _validate_router_configs(self) -> None:
         laterals = list(self.cfg.qlateral_files or [])
@@ -87,6 +120,16 @@ class TransformMuskingum(Muskingum, ABC):
         engine is not the HIP plan, or the file does not fit on the card: then `_router` + the post-processing of
         TransformMuskingum.py:128-142 on the host."""
         per = self.num_runoff_steps_per_discharge
+        from ..runoff import RunoffSource
+        if isinstance(qlateral, RunoffSource):
+            from .._lib import RR_E_UNSUPPORTED, RRError
+            from ._device import DeviceOutOfMemory
+            try:
+                return self._router_device_runoff(qlateral, per)
+            except (DeviceOutOfMemory, RRError) as e:
+                if isinstance(e, RRError) and e.code != RR_E_UNSUPPORTED:
+                    raise
+                qlateral = qlateral.to_array(self._as_volumes)      # the two-step form: (time, river) rows, then the routing call
         own_router = type(self)._router is getattr(type(self), '_engine_router', None)
         if self._device_postprocess and own_router and hasattr(self._plan, 'rapid_route_dev'):
             from ._device import DeviceOutOfMemory

@@ -60,43 +60,47 @@ class UnitMuskingum(TransformMuskingum):
     _engine_router = _router
 
     def _router_device(self, qlateral: np.ndarray, rows_per_output: int) -> tuple[np.ndarray, np.ndarray]:
-        """One file on the device.  Where the engine takes it (time-tiled call, at most 64 kernel steps) the convolution is
-        fused into the pass that turns rows into records (rr_unit_route_uh_dev): the convolved lateral never exists as
-        rows; otherwise rr_uh_convolve_dev, then the routing call."""
-        from .._lib import RR_E_UNSUPPORTED, RRError
-        from ..engine import uh_convolve_dev
-        from ._device import Arena, float32_rows
+        from ._device import Arena
         self._check_kernel()
         depth = self._check_lateral(qlateral)
-        T, n = depth.shape
+        with Arena(self.cfg.device) as arena:
+            return self._route_on_device(arena, arena.put(depth), depth.shape[0], rows_per_output)
+
+    def _route_on_device(self, arena, d_depth, T: int, rows_per_output: int) -> tuple[np.ndarray, np.ndarray]:
+        """Runoff depths already on the device, (T, n) float64 rows -> (router state, float32 discharge rows).  Where the
+        engine takes it (time-tiled call, at most 64 kernel steps) the convolution is fused into the pass that turns rows
+        into records (rr_unit_route_uh_dev): the convolved lateral never exists as rows; otherwise rr_uh_convolve_dev, then
+        the routing call."""
+        from .._lib import RR_E_UNSUPPORTED, RRError
+        from ..engine import uh_convolve_dev
+        from ._device import float32_rows
+        self._check_kernel()
+        n = self.A.shape[0]
         n_ks, nsub = self._uh.kernel.shape[0], self.num_routing_steps_per_runoff
         self._upload_coefficients(None, ('unit',))
         seed = self._seed()
-        with Arena(self.cfg.device) as arena:
-            d_depth = arena.put(depth)
-            d_kern = arena.put(self._uh.kernel)
-            d_state = arena.put(np.ascontiguousarray(self._uh.state, dtype=np.float64))
-            d_qch, d_qfull, d_final = arena.put(seed), arena.put(seed), arena.empty(n * 8)
-            d_f32 = arena.empty((T // rows_per_output) * n * 4)
-            try:
-                self._plan.unit_route_uh_dev(d_qch, d_qfull, d_final, d_kern, d_state, n_ks, d_depth, T, nsub,
-                                             discharge32=d_f32, factor=rows_per_output)
-                q_array = d_f32.download(np.float32, (T // rows_per_output, n))
-                state = d_final.download(np.float64, (n,))
-            except RRError as e:
-                if e.code != RR_E_UNSUPPORTED:
-                    raise
-                arena.release(d_f32)
-                d_conv = arena.empty(depth.nbytes)
-                uh_convolve_dev(d_kern, d_state, d_depth, d_conv, T, n_ks, n, device=self.cfg.device)
-                arena.release(d_depth)
-                q_array = float32_rows(
-                    arena, T, n, rows_per_output,
-                    fused=lambda d32: self._plan.unit_route_f32_dev(d_qch, d_qfull, d_conv, T, d32, T, nsub, rows_per_output),
-                    plain=lambda d64: self._plan.unit_route_dev(d_qch, d_qfull, d_conv, T, d64, T, T, nsub))
-                state = d_conv.download(np.float64, (n,), offset=(T - 1) * n * 8)    # headwaters keep the last lateral row
-                state[self.inner_idx] = d_qfull.download(np.float64, seed.shape)
-            self._uh.state = d_state.download(np.float64, self._uh.kernel.shape)
+        d_kern = arena.put(self._uh.kernel)
+        d_state = arena.put(np.ascontiguousarray(self._uh.state, dtype=np.float64))
+        d_qch, d_qfull, d_final = arena.put(seed), arena.put(seed), arena.empty(n * 8)
+        d_f32 = arena.empty((T // rows_per_output) * n * 4)
+        try:
+            self._plan.unit_route_uh_dev(d_qch, d_qfull, d_final, d_kern, d_state, n_ks, d_depth, T, nsub,
+                                         discharge32=d_f32, factor=rows_per_output)
+            q_array = d_f32.download(np.float32, (T // rows_per_output, n))
+            state = d_final.download(np.float64, (n,))
+        except RRError as e:
+            if e.code != RR_E_UNSUPPORTED:
+                raise
+            arena.release(d_f32)
+            d_conv = arena.empty(T * n * 8)
+            uh_convolve_dev(d_kern, d_state, d_depth, d_conv, T, n_ks, n, device=self.cfg.device)
+            q_array = float32_rows(
+                arena, T, n, rows_per_output,
+                fused=lambda d32: self._plan.unit_route_f32_dev(d_qch, d_qfull, d_conv, T, d32, T, nsub, rows_per_output),
+                plain=lambda d64: self._plan.unit_route_dev(d_qch, d_qfull, d_conv, T, d64, T, T, nsub))
+            state = d_conv.download(np.float64, (n,), offset=(T - 1) * n * 8)    # headwaters keep the last lateral row
+            state[self.inner_idx] = d_qfull.download(np.float64, seed.shape)
+        self._uh.state = d_state.download(np.float64, self._uh.kernel.shape)
         return state, q_array
 
     def _write_final_state(self) -> None:

@@ -20,7 +20,7 @@ import numpy as np
 from . import engine
 from .io import _decode_cf_time, read_variables
 
-__all__ = ['runoff_to_qlateral', 'QlateralDataset']
+__all__ = ['runoff_to_qlateral', 'QlateralDataset', 'RunoffSource', 'prepare_runoff']
 
 logger = logging.getLogger(__name__)
 
@@ -91,12 +91,43 @@ def _read_runoff_points(paths, var_runoff, var_x, var_y, var_t, x_index, y_index
     return block, units, time_index
 
 
-def runoff_to_qlateral(runoff_data, grid_weights_file, *, var_runoff: str = 'ro', var_x: str = 'lon', var_y: str = 'lat',
-                       var_t: str = 'time', var_river_id: str = 'river_id', runoff_depth_unit: str | None = None,
-                       cumulative: bool = False, force_positive_runoff: bool = False,
-                       force_uniform_timesteps: bool = True, as_volumes: bool = False, device: int = 0) -> QlateralDataset:
-    """Area-weighted aggregation of gridded runoff depths to per-catchment lateral inflow (depths in m, or volumes
-    in m3 with `as_volumes`), river_route/runoff.py:218-352.  `device` (HIP ordinal) is the only extra argument."""
+@dataclass
+class RunoffSource:
+    """Everything rr_runoff_to_qlateral needs for one set of runoff files, before any arithmetic of the path: the
+    (time, points) runoff block, the CSR weights (proportion x unit conversion, duplicates summed, ascending point order
+    as the reference's csr_matrix), catchment areas, flags, the time axis and the river ids in column order.  The routers
+    upload it as it is, so that the catchment inflow is computed on the GPU and routed from there without a trip through host
+    memory (TransformMuskingum._router_device_runoff; rr_rapid_route_runoff_dev takes the same pieces and computes the inflow
+    on the way into the engine's records); `to_array()` is the reference's (time, river) array."""
+    runoff_tp: np.ndarray
+    indptr: np.ndarray
+    indices: np.ndarray
+    weights: np.ndarray
+    area: np.ndarray
+    flags: int
+    time_index: np.ndarray
+    river_ids: np.ndarray
+    irregular: bool
+    device: int = 0
+
+    def point_major(self):
+        """(points, padded time) copy of the block, rows padded to whole 16-step chunks, float32 or float64 as read."""
+        block = self.runoff_tp if self.runoff_tp.dtype in (np.float32, np.float64) else self.runoff_tp.astype(np.float64)
+        T, n_points = block.shape
+        t_pad = -(-T // 16) * 16
+        out = np.zeros((n_points, t_pad), dtype=block.dtype)
+        out[:, :T] = block.T
+        return out
+
+    def to_array(self, as_volumes: bool, keep_nan: bool = False) -> np.ndarray:
+        return engine.runoff_to_qlateral(self.indptr, self.indices, self.weights, self.runoff_tp, self.area if as_volumes else None,
+                                         self.flags | (engine.RUNOFF_KEEP_NAN if keep_nan else 0), self.device)
+
+
+def prepare_runoff(runoff_data, grid_weights_file, *, var_runoff: str = 'ro', var_x: str = 'lon', var_y: str = 'lat', var_t: str = 'time',
+                   var_river_id: str = 'river_id', runoff_depth_unit: str | None = None, cumulative: bool = False,
+                   force_positive_runoff: bool = False, force_uniform_timesteps: bool = True, device: int = 0) -> RunoffSource:
+    """File reading and index bookkeeping of runoff_to_qlateral (river_route/runoff.py:255-298), no arithmetic of the path."""
     import pandas as pd
     import scipy.sparse
 
@@ -122,15 +153,29 @@ def runoff_to_qlateral(runoff_data, grid_weights_file, *, var_runoff: str = 'ro'
     catchment_area = weight_df.groupby(var_river_id)['area_sqm'].sum().reindex(river_ids_ordered).to_numpy()
 
     time_diff = np.diff(time_index)
-    irregular = time_index.shape[0] > 2 and not np.all(time_diff == time_index[1] - time_index[0]) and force_uniform_timesteps
+    irregular = bool(time_index.shape[0] > 2 and not np.all(time_diff == time_index[1] - time_index[0]) and force_uniform_timesteps)
     flags = (engine.RUNOFF_CUMULATIVE if cumulative else 0) | (engine.RUNOFF_FORCE_POSITIVE if force_positive_runoff else 0)
-    if not irregular:
-        qlateral = engine.runoff_to_qlateral(weights.indptr, weights.indices, weights.data, runoff_raw,
-                                             catchment_area if as_volumes else None, flags, device)
+    return RunoffSource(runoff_raw, weights.indptr.astype(np.int32), weights.indices.astype(np.int32), np.ascontiguousarray(weights.data, dtype=np.float64),
+                        np.ascontiguousarray(catchment_area, dtype=np.float64), flags, time_index, river_ids_ordered.astype(np.int64, copy=False),
+                        irregular, device)
+
+
+def runoff_to_qlateral(runoff_data, grid_weights_file, *, var_runoff: str = 'ro', var_x: str = 'lon', var_y: str = 'lat',
+                       var_t: str = 'time', var_river_id: str = 'river_id', runoff_depth_unit: str | None = None,
+                       cumulative: bool = False, force_positive_runoff: bool = False,
+                       force_uniform_timesteps: bool = True, as_volumes: bool = False, device: int = 0) -> QlateralDataset:
+    """Area-weighted aggregation of gridded runoff depths to per-catchment lateral inflow (depths in m, or volumes
+    in m3 with `as_volumes`), river_route/runoff.py:218-352.  `device` (HIP ordinal) is the only extra argument."""
+    import pandas as pd
+    src = prepare_runoff(runoff_data, grid_weights_file, var_runoff=var_runoff, var_x=var_x, var_y=var_y, var_t=var_t,
+                         var_river_id=var_river_id, runoff_depth_unit=runoff_depth_unit, cumulative=cumulative,
+                         force_positive_runoff=force_positive_runoff, force_uniform_timesteps=force_uniform_timesteps, device=device)
+    time_index, river_ids_ordered, catchment_area = src.time_index, src.river_ids, src.area
+    if not src.irregular:
+        qlateral = src.to_array(as_volumes)
     else:
         # runoff.py:311-330: the resampling sits between the clip and the NaN fill, so the device stops before the fill
-        qlateral = engine.runoff_to_qlateral(weights.indptr, weights.indices, weights.data, runoff_raw, None,
-                                             flags | engine.RUNOFF_KEEP_NAN, device)
+        qlateral = src.to_array(False, keep_nan=True)
         timestep = int((time_index[1] - time_index[0]) / np.timedelta64(1, 's'))
         logger.warning(f'Time steps are not uniform, resampling to the first timestep: {timestep} seconds')
         df = pd.DataFrame(qlateral, index=time_index, columns=river_ids_ordered)

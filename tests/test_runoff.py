@@ -246,10 +246,17 @@ from test_routers import backend, case, drive  # noqa: E402,F401  (fixtures)
 import river_route_amd as rr  # noqa: E402
 
 
-def test_router_with_grid_runoff_files(backend, case, tmp_path, monkeypatch):
-    """RapidMuskingum configured with grid_runoff_files + grid_weights_file routes exactly what it routes when handed
-    the oracle's catchment volumes for the same grids."""
+@pytest.mark.parametrize('router', ['rapid', 'unit'])
+def test_router_with_grid_runoff_files(backend, case, tmp_path, monkeypatch, router):
+    """RapidMuskingum (UnitMuskingum) configured with grid_runoff_files + grid_weights_file routes exactly what it routes
+    when handed the oracle's catchment volumes (depths) for the same grids."""
     from river_route_amd import engine
+    from test_routers import _unit_files
+    cls = rr.RapidMuskingum if router == 'rapid' else rr.UnitMuskingum
+    extra = dict(dt_routing=900)
+    if router == 'unit':
+        kp, us = _unit_files(case)
+        extra = dict(dt_routing=1200, uh_kernel_file=kp, uh_state_init_file=us)
     if backend == 'oracle_injected':
         def fake(indptr, indices, weights, runoff_tp, area=None, flags=0, device=0):
             W = scipy.sparse.csr_matrix((weights, indices, indptr), shape=(len(indptr) - 1, runoff_tp.shape[1]))
@@ -278,15 +285,15 @@ def test_router_with_grid_runoff_files(backend, case, tmp_path, monkeypatch):
             'time': (('time',), secs, {'units': 'seconds since 1970-01-01 00:00:00'}),
             'ro': (('time', 'y', 'x'), grid, {'units': 'm'})})
         files.append(str(p))
-        _, vol = brute_force(tab, grid, 1.0, False, False, True)
+        _, vol = brute_force(tab, grid, 1.0, False, False, router == 'rapid')
         series.append(vol)
 
     got = []
-    r = rr.RapidMuskingum(params_file=case['params'], grid_runoff_files=files, grid_weights_file=str(wfile),
-                          discharge_dir=str(tmp_path), channel_state_init_file=case['init'], dt_routing=900, log=False)
+    r = cls(params_file=case['params'], grid_runoff_files=files, grid_weights_file=str(wfile),
+            discharge_dir=str(tmp_path), channel_state_init_file=case['init'], log=False, **extra)
     r.set_write_discharges(lambda d, q, f_, rf='': got.append((np.asarray(d), np.asarray(q), f_, rf)))
     r.route()
-    r_ref, want = drive(rr.RapidMuskingum, case, series, channel_state_init_file=case['init'], dt_routing=900)
+    r_ref, want = drive(cls, case, series, channel_state_init_file=case['init'], **extra)
     assert len(got) == 2
     for (d, q, f_, rf), (dw, qw, _, _) in zip(got, want):
         np.testing.assert_array_equal(d, dw)
