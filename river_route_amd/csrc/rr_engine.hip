@@ -1535,10 +1535,12 @@ int64_t pick_KC(const rr_plan *P, int64_t total_ticks)
 // the streaming kernel's, a few launches, so only calls of a handful of sub-steps stream.  RR_WAVE=1 forces it where it
 // applies, RR_WAVE=0 forbids it.
 //
-// Records are indexed by tick = tick-row + lag.  Rows enter for all columns at once and leave for all columns at once,
-// so a record lives from (its first tick - depth) until every tile has passed (its last tick + depth): the ring spans
-// 2 depth + levels * K ticks plus the batching of the two permutation passes.  It may take five eighths of the card; a
-// deep network that does not fit gets shorter tasks, then the streaming kernel.
+// Records are indexed by tick = tick-row + lag, modulo the ring, per position: a position's slots never hold another
+// position's data, so what the ring must cover is one position's tick-rows in flight.  Rows enter for all columns at once
+// (ahead of the level-0 tiles) and leave for all columns at once (after the last level has passed their tick + depth), so
+// every position keeps depth + levels * K tick-rows plus the batching of the two permutation passes; that its window sits
+// lag ticks later than a headwater's does not widen it.  The ring may take five eighths of the card; a deep network that
+// does not fit gets shorter tasks, then the streaming kernel.
 bool decide_wave(rr_plan *P, Mode mode, int64_t total, bool host_rows)
 {
     bool ok = P->wave_enabled && P->tp.ok && P->weights_uniform && P->h.n > 0 && !host_rows && P->tp.np < (int64_t{1} << 25) &&
@@ -1549,7 +1551,7 @@ bool decide_wave(rr_plan *P, Mode mode, int64_t total, bool host_rows)
         const int64_t all_chunks = kRecBatch * ((total + 14) / kRecRows + 2) + (dmax >> 4) + 2;
         ok = false;
         for (int64_t KC = pick_KC(P, total + dmax); KC >= 1; KC /= 2) {
-            const int64_t chunks = std::min<int64_t>(all_chunks, (2 * dmax + levels * KC * kRec) / kRec + 4 * kRecBatch);
+            const int64_t chunks = std::min<int64_t>(all_chunks, (dmax + levels * KC * kRec) / kRec + 4 * kRecBatch);
             const int64_t bytes = chunks * kRec * np * (int64_t)sizeof(double);
             if (P->dev_total_bytes > 0 && bytes > (int64_t)(P->dev_total_bytes / 8 * 5)) continue;
             if (ensure_cap(&P->d_ring, &P->ring_cap, chunks * kRec * np) != RR_OK) { (void)hipGetLastError(); continue; }
@@ -1900,9 +1902,12 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
         // one batch of 128 tick-rows -> records; a record slot is recycled only after every tick-row it can hold has left.
         // Lateral rows and boundary sub-steps (the ghost series of a partitioned network) advance separately: a ghost in a
         // tile of level l at lag L is first read (l K + L) ticks into the schedule, so the boundary may trail the rows.
+        // Batch j writes, for a position of lag L, the records whose last tick-row lies in the batch: chunks up to
+        // (128 (j + 1) + L) / 16.  One ring revolution earlier that slot held the same position's tick-rows up to
+        // 128 (j + 1) - 16 rec_chunks + 15, whatever L is: those must have left.
         auto slot_free = [&](int64_t j) {
-            const int64_t hi = kRecBatch * j + (dmax >> 4) + kRecBatch - 1;
-            return hi < S.rec_chunks || S.ticks_stored >= std::min(S.total, kRec * (hi - S.rec_chunks + 1));
+            const int64_t must_have_left = kRecRows * (j + 1) + kRec - kRec * S.rec_chunks;
+            return must_have_left <= 0 || S.ticks_stored >= std::min(S.total, must_have_left);
         };
         if (S.has_in && S.in_batches < S.n_in_batches && ticks_ready >= std::min(kRecRows * (S.in_batches + 1), S.total) && slot_free(S.in_batches)) {
             launch_rec_permute(P, true, S.in_batches);
