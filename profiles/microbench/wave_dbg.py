@@ -30,3 +30,9 @@ for grp, m in (('R1', first), ('R2', ~first)):
         d = (cur - prev)[ok]
         print(f"  {names[k]:22s} mean {d.mean():8.2f} p10 {np.percentile(d, 10):8.2f} p90 {np.percentile(d, 90):8.2f} max {d.max():8.2f}   (at {cur[ok].mean():8.2f})")
         prev = np.where(ok, cur, prev)
+
+if a.shape[1] >= 16:      # persistent workgroups: when each one left, relative to the first start of the launch
+    end = (a[:, 15] - t0) / 100.0
+    end = end[a[:, 15] > 0]
+    print(f'workgroups {len(end)}: leave at mean {end.mean():.1f} us, p10 {np.percentile(end, 10):.1f}, p50 {np.percentile(end, 50):.1f}, '
+          f'p90 {np.percentile(end, 90):.1f}, max {end.max():.1f}  -> the launch waits {end.max() - end.mean():.1f} us for its slowest workgroup')

@@ -458,6 +458,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
     if (!select(a.t_last - (int32_t)blockIdx.x, cur)) return;
 #ifdef RR_WAVE_TRACE
     bool trace = a.trace && a.diag == a.trace_diag && tid == 0;
+    const bool trace_wg = trace;
     long long *tq = a.trace + (int64_t)cur.tile * 16;
 #define RR_TRACE(i) do { if (trace) tq[i] = wall_clock64(); } while (0)
 #else
@@ -657,6 +658,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
         RR_TRACE(13);
 #ifdef RR_WAVE_TRACE
         trace = false;      // the first tile of the workgroup only
+        if (!has_next && trace_wg) tq[14] = wall_clock64();     // ... and when the workgroup leaves
 #endif
         if (!has_next) break;
         cur = nxt;
@@ -2033,7 +2035,7 @@ int session_end(rr_plan *P)
         (void)hipMemcpy(hbuf.data(), S.ta.trace, hbuf.size() * 8, hipMemcpyDeviceToHost);
         if (FILE *f = fopen(getenv("RR_WAVE_TRACE_FILE") ? getenv("RR_WAVE_TRACE_FILE") : "/tmp/wave_trace.txt", "w")) {
             for (int b = 0; b < 4096; ++b)
-                if (hbuf[16 * b]) { fprintf(f, "%d", b); for (int k = 0; k < 14; ++k) fprintf(f, " %lld", hbuf[16 * b + k]); fprintf(f, "\n"); }
+                if (hbuf[16 * b]) { fprintf(f, "%d", b); for (int k = 0; k < 15; ++k) fprintf(f, " %lld", hbuf[16 * b + k]); fprintf(f, "\n"); }
             fclose(f);
         }
     }
