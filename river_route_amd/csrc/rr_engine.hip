@@ -1293,13 +1293,30 @@ __global__ __launch_bounds__(kRunoffInThreads) void k_rec_in_runoff(const RecPer
 #pragma unroll
         for (int j = 0; j <= kRec; ++j) acc[j] = 0.0;
         const RT *base = static_cast<const RT *>(g.runoff);
+        // A record's 16 rows start wherever the river's lag puts them, so the gather cannot be 16-byte aligned; with the
+        // block point-major the window is still one run of memory and gfx950 takes 16-byte loads at element alignment.
+        // Records that stick out of the grid point's (padded) row -- the first of a river, the last -- go row by row.
+        constexpr int VL = 16 / (int)sizeof(RT);
+        typedef RT VecU __attribute__((ext_vector_type(VL), aligned(sizeof(RT))));
+        const bool inside = g.stride_t == 1 && t0 >= 1 && t0 + kRec <= g.stride_p;
         for (int32_t e = g.indptr[i]; e < g.indptr[i + 1]; ++e) {
             const double w = g.weights[e];
             const RT *src = base + (int64_t)g.indices[e] * g.stride_p;
+            if (inside) {
+                if (cumulative) acc[0] = __dadd_rn(acc[0], __dmul_rn(w, (double)src[t0 - 1]));
+                VecU x[kRec / VL];
 #pragma unroll
-            for (int j = 0; j <= kRec; ++j) {
-                const int64_t t = t0 - 1 + j;
-                if (t >= 0 && t < a.T && (j > 0 || cumulative)) acc[j] = __dadd_rn(acc[j], __dmul_rn(w, (double)src[t * g.stride_t]));
+                for (int q = 0; q < kRec / VL; ++q) x[q] = *reinterpret_cast<const VecU *>(src + t0 + q * VL);      // rows past T: padding, zeroed below
+#pragma unroll
+                for (int q = 0; q < kRec / VL; ++q)
+#pragma unroll
+                    for (int v = 0; v < VL; ++v) acc[1 + q * VL + v] = __dadd_rn(acc[1 + q * VL + v], __dmul_rn(w, (double)x[q][v]));
+            } else {
+#pragma unroll
+                for (int j = 0; j <= kRec; ++j) {
+                    const int64_t t = t0 - 1 + j;
+                    if (t >= 0 && t < a.T && (j > 0 || cumulative)) acc[j] = __dadd_rn(acc[j], __dmul_rn(w, (double)src[t * g.stride_t]));
+                }
             }
         }
         const double area = g.area ? g.area[i] : 1.0, f = a.scale ? a.scale[i] : 1.0;

@@ -54,9 +54,8 @@ class TransformMuskingum(Muskingum, ABC):
     def _router_device_runoff(self, source, rows_per_output: int) -> tuple[np.ndarray, np.ndarray]:
         """Gridded runoff of one file routed without leaving the GPU: the runoff block and the weight table go up once,
         rr_runoff_to_qlateral_dev writes the catchment inflow as device rows (volumes for RapidMuskingum, depths for
-        UnitMuskingum), and the router's device path takes it from there.  (rr_rapid_route_runoff_dev computes the inflow
-        inside the record pass instead and saves the (T, n) array; its per-river row offsets defeat the aligned 16-byte
-        gathers, so at 1M reaches x 744 steps it takes 20.6 ms against 16.4 ms for the two calls: profiles/r02_runoff_path.txt.)"""
+        UnitMuskingum), and the router's device path takes it from there.  RapidMuskingum overrides this with the call that
+        computes the inflow inside the record pass (rr_rapid_route_runoff_dev) where that applies."""
         from ..engine import runoff_to_qlateral_dev
         from ._device import Arena
         T, n = source.runoff_tp.shape[0], self.A.shape[0]

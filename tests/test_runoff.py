@@ -246,14 +246,14 @@ from test_routers import backend, case, drive  # noqa: E402,F401  (fixtures)
 import river_route_amd as rr  # noqa: E402
 
 
-@pytest.mark.parametrize('router', ['rapid', 'unit'])
+@pytest.mark.parametrize('router', ['rapid', 'rapid_one_step', 'unit'])
 def test_router_with_grid_runoff_files(backend, case, tmp_path, monkeypatch, router):
     """RapidMuskingum (UnitMuskingum) configured with grid_runoff_files + grid_weights_file routes exactly what it routes
     when handed the oracle's catchment volumes (depths) for the same grids."""
     from river_route_amd import engine
     from test_routers import _unit_files
-    cls = rr.RapidMuskingum if router == 'rapid' else rr.UnitMuskingum
-    extra = dict(dt_routing=900)
+    cls = rr.UnitMuskingum if router == 'unit' else rr.RapidMuskingum
+    extra = dict(dt_routing=900) if router == 'rapid' else {}      # one routing step per runoff step: the fused in-pass on the GPU
     if router == 'unit':
         kp, us = _unit_files(case)
         extra = dict(dt_routing=1200, uh_kernel_file=kp, uh_state_init_file=us)
@@ -285,7 +285,7 @@ def test_router_with_grid_runoff_files(backend, case, tmp_path, monkeypatch, rou
             'time': (('time',), secs, {'units': 'seconds since 1970-01-01 00:00:00'}),
             'ro': (('time', 'y', 'x'), grid, {'units': 'm'})})
         files.append(str(p))
-        _, vol = brute_force(tab, grid, 1.0, False, False, router == 'rapid')
+        _, vol = brute_force(tab, grid, 1.0, False, False, router != 'unit')
         series.append(vol)
 
     got = []
