@@ -184,7 +184,11 @@ int rr_unit_route_uh_dev(rr_plan *plan, double *q_ch, double *q_full, double *q_
  * are device arrays of shape (T * nsub, n_ghost) / (T * nsub, n_export), row = sub-step.  The streaming
  * calls keep the lag pipeline full while series arrive in batches (no drain between batches). */
 
-/* Reaches are LOCAL params indices of this plan.  Ghosts must be headwaters of the local network. */
+/* Reaches are LOCAL params indices of this plan.  A ghost's value is prescribed, so whatever the local network puts upstream
+ * of it is ignored.  UnitMuskingum distinguishes headwater tributaries from the others (_numba_kernels.py:150-156): a ghost
+ * that mirrors a reach WITH upstream reaches must itself have one in the local network (a dummy headwater whose lateral
+ * column is zero does), so that it falls on the same side of that distinction as the reach it mirrors, and it then has an
+ * entry in the q_ch / q_full arrays, whose q_full is the mirrored reach's. */
 int rr_plan_set_boundary(rr_plan *plan, int64_t n_ghost, const int64_t *ghost_reaches, int64_t n_export,
                          const int64_t *export_reaches);
 
@@ -200,6 +204,16 @@ int rr_stream_advance(rr_plan *plan, int64_t lateral_rows_ready, int64_t ghost_s
                       int64_t *export_substeps_ready);
 /* Closes the call (all T steps must have been routed) and writes the final state to q_t[n] (may be NULL). */
 int rr_stream_end(rr_plan *plan, double *q_t);
+
+/* The same for UnitMuskingum (river_route/routers/_numba_kernels.py:88-171 on one part of a cut network): lateral = the
+ * convolved runoff depths of this part's columns (rr_uh_convolve_dev; ghost columns are not read), q_ch / q_full over the
+ * local reaches that have upstream reaches, ascending local index.  Export series hold the discharge a reach publishes
+ * (q_full; the lateral inflow on a headwater).  Advance with rr_stream_advance. */
+int rr_stream_begin_unit(rr_plan *plan, const double *q_ch, const double *q_full, const double *lateral, int64_t lat_rows,
+                         double *discharge, int64_t out_rows, int64_t T, int64_t nsub, const double *ghost_series,
+                         double *export_series, void *stream);
+/* Closes the call and writes the final q_ch / q_full (both may be NULL). */
+int rr_stream_end_unit(rr_plan *plan, double *q_ch, double *q_full);
 
 /* Cuts a forest into at most n_parts balanced parts whose part graph is acyclic (boundary discharge flows one way):
  * main stems + the tributaries joining them farthest upstream in the last part, the other subtrees spread over the

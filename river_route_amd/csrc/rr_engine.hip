@@ -163,8 +163,13 @@ __global__ __launch_bounds__(kBlock) void k_tick_unit(const UnitTickArgs ua)
     const TickArgs &a = ua.t;
     const int32_t p = a.p_lo + (int32_t)(blockIdx.x * kBlock + threadIdx.x);
     if (p >= a.p_hi) return;
-    const int32_t ts = (int32_t)a.tau - (a.lag[p] & kLagMask);
+    const int32_t lag_bits = a.lag[p];
+    const int32_t ts = (int32_t)a.tau - (lag_bits & kLagMask);
     if (ts < 0 || ts >= (int32_t)a.total_substeps) return;
+    if (lag_bits & kGhostBit) {   // boundary inflow: the discharge another GPU published for this sub-step
+        a.xc[p] = a.ghost[(int64_t)ts * a.n_ghost + a.bidx[p]];
+        return;
+    }
     uint32_t t, s;
     if (SINGLE_SUBSTEP) { t = (uint32_t)ts; s = 0; }
     else t = a.nsub.div((uint32_t)ts, s);
@@ -173,6 +178,7 @@ __global__ __launch_bounds__(kBlock) void k_tick_unit(const UnitTickArgs ua)
     const int32_t u0 = a.child_ptr[p], u1 = a.child_ptr[p + 1];
     if (u0 == u1) {  // headwater: discharge is the lateral inflow, unclamped and un-averaged (lines 122-123)
         a.xc[p] = lat;
+        if (lag_bits & kExportBit) a.exports[(int64_t)ts * a.n_export + a.bidx[p]] = lat;
         if (s == 0) a.out[(int64_t)a.out_rows.mod(t) * a.out_ld + p] = lat;
         return;
     }
@@ -193,6 +199,7 @@ __global__ __launch_bounds__(kBlock) void k_tick_unit(const UnitTickArgs ua)
     ua.qch[p] = r;
     const double qfull = r + lat;
     a.xc[p] = qfull;
+    if (lag_bits & kExportBit) a.exports[(int64_t)ts * a.n_export + a.bidx[p]] = qfull;
 
     if (SINGLE_SUBSTEP) {
         a.out[(int64_t)a.out_rows.mod(t) * a.out_ld + p] = qfull > 0.0 ? qfull : 0.0;
@@ -604,6 +611,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                             qk = r + lat;
                             outv = qk; routed = true;
                         }
+                        if (lgk & kExportBit) a.exports[(int64_t)ts * a.n_export + a.bidx[b0 + t]] = qk;
                     } else {
                         // explicit fma: every copy of this tick must round identically (split run == joint run)
                         qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev, __builtin_fma(c3, qk, lat)));
@@ -1562,8 +1570,7 @@ int64_t pick_KC(const rr_plan *P, int64_t total_ticks)
 // does not fit gets shorter tasks, then the streaming kernel.
 bool decide_wave(rr_plan *P, Mode mode, int64_t total, bool host_rows)
 {
-    bool ok = P->wave_enabled && P->tp.ok && P->weights_uniform && P->h.n > 0 && !host_rows && P->tp.np < (int64_t{1} << 25) &&
-              (mode != Mode::Unit || (P->n_ghost == 0 && P->n_export == 0));
+    bool ok = P->wave_enabled && P->tp.ok && P->weights_uniform && P->h.n > 0 && !host_rows && P->tp.np < (int64_t{1} << 25);
     if (ok && !P->wave_forced) ok = total >= 32;
     if (ok) {
         const int64_t dmax = P->h.depth - 1, np = P->tp.np, levels = P->tp.n_levels;
@@ -1933,7 +1940,8 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
             ++S.in_batches;
             progressed = true;
         }
-        if (P->n_ghost > 0 && S.ghost_batches < S.n_in_batches && ghost_ready >= std::min(kRecRows * (S.ghost_batches + 1), S.total) && slot_free(S.ghost_batches)) {
+        if (P->n_ghost > 0 && S.ghost_batches < S.n_in_batches && (!S.has_in || S.ghost_batches < S.in_batches) &&      // after the lateral batch: that one writes zeros into the ghosts' records
+            ghost_ready >= std::min(kRecRows * (S.ghost_batches + 1), S.total) && slot_free(S.ghost_batches)) {
             launch_ghost_permute(P, S.ghost_batches);
             ++S.ghost_batches;
             progressed = true;
@@ -2290,6 +2298,41 @@ int rapid_like(rr_plan *P, Mode mode, double *q_t, const Rows &io_in, int64_t T,
     return rc;
 }
 
+// UnitMuskingum state (channel discharge and full discharge of the reaches that have upstream reaches) into the layout of the
+// kernel this call runs, and back.
+int unit_state_in(rr_plan *P, const double *d_qch, const double *d_qfull, hipStream_t stream)
+{
+    const int64_t n = P->h.n, ni = (int64_t)P->h.inner_pos.size();
+    hipError_t e0 = hipSuccess;
+    if (use_wave(P, Mode::Unit)) {   // q_full / q_ch scattered to params order (zeros on headwaters), then gathered position by position
+        e0 = hipMemsetAsync(P->d_full, 0, n * sizeof(double), stream);
+        if (e0 == hipSuccess) e0 = hipMemsetAsync(P->d_chan, 0, n * sizeof(double), stream);
+        if (e0 == hipSuccess && ni > 0)
+            hipLaunchKernelGGL(k_unit_scatter, grid1(ni), dim3(kBlock), 0, stream, P->d_full, P->d_chan, d_qfull, d_qch, P->d_inner_idx, (int32_t)ni);
+        if (e0 == hipSuccess)
+            hipLaunchKernelGGL(k_tile_unit_state_in, grid1(P->tp.np), dim3(kBlock), 0, stream, P->d_sq, P->d_ss, P->d_si, P->d_sqch,
+                               (const double *)P->d_full, (const double *)P->d_chan, P->d_tperm, P->d_cfirst, P->d_ccnt, (int32_t)P->tp.np);
+    } else {
+        e0 = hipMemsetAsync(P->d_x, 0, 3 * n * sizeof(double), stream);
+        if (e0 == hipSuccess && ni > 0)
+            hipLaunchKernelGGL(k_unit_state_in, grid1(ni), dim3(kBlock), 0, stream, P->d_x, P->d_x + n, P->d_x + 2 * n,
+                               P->d_qch, d_qch, d_qfull, P->d_inner_pos, (int32_t)ni);
+    }
+    return e0 == hipSuccess ? RR_OK : fail(RR_E_HIP, hipGetErrorString(e0));
+}
+
+void unit_state_out(rr_plan *P, double *d_qch, double *d_qfull, int64_t total, hipStream_t stream)
+{
+    const int64_t n = P->h.n, ni = (int64_t)P->h.inner_pos.size();
+    if (ni == 0) return;
+    if (use_wave(P, Mode::Unit))
+        hipLaunchKernelGGL(k_tile_unit_state_out, grid1(ni), dim3(kBlock), 0, stream, d_qch, d_qfull,
+                           (const double *)P->d_sq, (const double *)P->d_sqch, P->d_inner_idx, P->d_tinv, (int32_t)ni);
+    else
+        hipLaunchKernelGGL(k_unit_state_out, grid1(ni), dim3(kBlock), 0, stream, d_qch, d_qfull,
+                           (const double *)P->d_x, n, (const double *)P->d_qch, P->d_lag, P->d_inner_pos, (int32_t)ni, total);
+}
+
 int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io_in, int64_t T, int64_t nsub,
               hipStream_t stream, bool q_on_host, double *d_q_final = nullptr, double *uh_state_inout = nullptr)
 {
@@ -2309,24 +2352,8 @@ int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io_in, int64
         if (e != hipSuccess) { (void)hipFree(tmp); return fail(RR_E_HIP, hipGetErrorString(e)); }
     }
     const bool wave = use_wave(P, Mode::Unit);
-    int rc = RR_OK;
-    hipError_t e0 = hipSuccess;
-    if (wave) {   // q_full / q_ch scattered to params order (zeros on headwaters), then gathered position by position
-        e0 = hipMemsetAsync(P->d_full, 0, n * sizeof(double), stream);
-        if (e0 == hipSuccess) e0 = hipMemsetAsync(P->d_chan, 0, n * sizeof(double), stream);
-        if (e0 == hipSuccess && ni > 0)
-            hipLaunchKernelGGL(k_unit_scatter, grid1(ni), dim3(kBlock), 0, stream, P->d_full, P->d_chan, (const double *)d_qfull,
-                               (const double *)d_qch, P->d_inner_idx, (int32_t)ni);
-        if (e0 == hipSuccess)
-            hipLaunchKernelGGL(k_tile_unit_state_in, grid1(P->tp.np), dim3(kBlock), 0, stream, P->d_sq, P->d_ss, P->d_si, P->d_sqch,
-                               (const double *)P->d_full, (const double *)P->d_chan, P->d_tperm, P->d_cfirst, P->d_ccnt, (int32_t)P->tp.np);
-    } else {
-        e0 = hipMemsetAsync(P->d_x, 0, 3 * n * sizeof(double), stream);
-        if (e0 == hipSuccess && ni > 0)
-            hipLaunchKernelGGL(k_unit_state_in, grid1(ni), dim3(kBlock), 0, stream, P->d_x, P->d_x + n, P->d_x + 2 * n,
-                               P->d_qch, (const double *)d_qch, (const double *)d_qfull, P->d_inner_pos, (int32_t)ni);
-    }
-    if (e0 != hipSuccess) { if (tmp) (void)hipFree(tmp); return fail(RR_E_HIP, hipGetErrorString(e0)); }
+    int rc = unit_state_in(P, d_qch, d_qfull, stream);
+    if (rc) { if (tmp) (void)hipFree(tmp); return rc; }
     if (rc == RR_OK) rc = piped ? route_host_pipelined(P, Mode::Unit, T, nsub, io.host_in, io.host_out, stream) : route_core(P, Mode::Unit, T, nsub, io, stream);
     if (rc == RR_OK && wave && d_q_final)      // every reach: a headwater's state is its last lateral inflow, an inner reach's q_full
         hipLaunchKernelGGL(k_tile_state_out, grid1(n), dim3(kBlock), 0, stream, d_q_final, (const double *)P->d_sq, P->d_tinv, (int32_t)n);
@@ -2338,13 +2365,7 @@ int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io_in, int64
         else hipLaunchKernelGGL(k_uh_tail<0>, gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in, T, nks, n);
     }
     if (rc == RR_OK && ni > 0) {
-        if (wave)
-            hipLaunchKernelGGL(k_tile_unit_state_out, grid1(ni), dim3(kBlock), 0, stream, d_qch, d_qfull,
-                               (const double *)P->d_sq, (const double *)P->d_sqch, P->d_inner_idx, P->d_tinv, (int32_t)ni);
-        else
-            hipLaunchKernelGGL(k_unit_state_out, grid1(ni), dim3(kBlock), 0, stream, d_qch, d_qfull,
-                               (const double *)P->d_x, n, (const double *)P->d_qch, P->d_lag, P->d_inner_pos,
-                               (int32_t)ni, T * nsub);
+        unit_state_out(P, d_qch, d_qfull, T * nsub, stream);
         if (q_on_host) {
             hipError_t e = hipMemcpyAsync(q_ch, d_qch, ni * sizeof(double), hipMemcpyDeviceToHost, stream);
             if (e == hipSuccess) e = hipMemcpyAsync(q_full, d_qfull, ni * sizeof(double), hipMemcpyDeviceToHost, stream);
@@ -2720,8 +2741,7 @@ int rr_plan_set_boundary(rr_plan *P, int64_t n_ghost, const int64_t *ghost_reach
         const int64_t i = ghost_reaches[g];
         if (i < 0 || i >= n) return fail(RR_E_INVALID, "rr_plan_set_boundary: ghost reach out of range");
         const int32_t p = H.inv[i];
-        if (H.child_ptr[p + 1] != H.child_ptr[p] || (lag[p] & kGhostBit))
-            return fail(RR_E_INVALID, "rr_plan_set_boundary: a ghost reach must be a headwater of this part, listed once");
+        if (lag[p] & kGhostBit) return fail(RR_E_INVALID, "rr_plan_set_boundary: a ghost reach is listed twice");
         lag[p] |= kGhostBit;
         bidx[p] = (int32_t)g;
         gmin = std::min<int64_t>(gmin, H.lag[p]);
@@ -2779,6 +2799,38 @@ int rr_stream_begin(rr_plan *P, int has_lateral, const double *q_t, const double
         if (rc) return rc;
     }
     return session_begin(P, mode, T, nsub, io, (hipStream_t)stream, ghost_series, export_series);
+}
+
+int rr_stream_begin_unit(rr_plan *P, const double *q_ch, const double *q_full, const double *lateral, int64_t lat_rows,
+                         double *discharge, int64_t out_rows, int64_t T, int64_t nsub, const double *ghost_series,
+                         double *export_series, void *stream)
+{
+    int rc = check_route_args(P, false, T, nsub);
+    if (rc) return rc;
+    const int64_t ni = (int64_t)P->h.inner_pos.size();
+    if (P->h.n > 0 && T > 0 && (!lateral || !discharge || lat_rows < 1 || out_rows < 1 || (ni > 0 && (!q_ch || !q_full))))
+        return fail(RR_E_INVALID, "rr_stream_begin_unit: null array or empty row count");
+    Rows io; io.dev_in = lateral; io.rows_in = lat_rows; io.dev_out = discharge; io.rows_out = out_rows;
+    if (P->ses.open) return fail(RR_E_STATE, "a routing call is already open on this plan (rr_stream_end_unit it first)");
+    decide_wave(P, Mode::Unit, T * nsub, false);
+    if (P->h.n > 0 && T > 0) {
+        rc = unit_state_in(P, q_ch, q_full, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return session_begin(P, Mode::Unit, T, nsub, io, (hipStream_t)stream, ghost_series, export_series);
+}
+
+int rr_stream_end_unit(rr_plan *P, double *q_ch, double *q_full)
+{
+    int rc = need_device(P);
+    if (rc) return rc;
+    if (P->ses.open && P->ses.mode != Mode::Unit) return fail(RR_E_STATE, "rr_stream_end_unit: the open call is not a UnitMuskingum call");
+    const int64_t total = P->ses.total;
+    hipStream_t stream = P->ses.stream;
+    rc = session_end(P);
+    if (rc) return rc;
+    if (P->h.n > 0 && total > 0 && q_ch && q_full) unit_state_out(P, q_ch, q_full, total, stream);
+    return RR_OK;
 }
 
 int rr_stream_advance(rr_plan *P, int64_t lateral_rows_ready, int64_t ghost_substeps_ready, int64_t *export_substeps_ready)

@@ -213,6 +213,14 @@ class Plan:
     def stream_end(self, q_t=None) -> None:
         check(_lib.lib().rr_stream_end(self._h, ptr(q_t)))
 
+    def stream_begin_unit(self, q_ch, q_full, lateral, lat_rows, discharge, out_rows, T, num_substeps, ghost_series=None,
+                          export_series=None, stream=None) -> None:
+        check(_lib.lib().rr_stream_begin_unit(self._h, ptr(q_ch), ptr(q_full), ptr(lateral), int(lat_rows), ptr(discharge),
+                                              int(out_rows), int(T), int(num_substeps), ptr(ghost_series), ptr(export_series), stream))
+
+    def stream_end_unit(self, q_ch=None, q_full=None) -> None:
+        check(_lib.lib().rr_stream_end_unit(self._h, ptr(q_ch), ptr(q_full)))
+
 
 def partition_forest(csc_indptr, csc_indices, n_parts: int):
     """(part_of int32[n], part_sizes int64[n_parts]) -- rr_partition_forest; host-only."""

@@ -12,8 +12,11 @@ gloo in the CPU tests): a few KB per batch, so the exchange is latency-bound and
 GPU keeps its lag pipeline open across batches (`rr_stream_begin/advance/end`), so a downstream part simply
 runs a fixed number of ticks behind its upstream parts and all GPUs compute concurrently.
 
-RapidMuskingum / Muskingum only (UnitMuskingum needs the headwater-as-old-value quirk across the cut and is
-single-GPU for now).
+UnitMuskingum crosses the cut the same way (`HipUnitPartEngine`): what travels is the discharge a reach publishes
+(q_full; the convolved lateral on a headwater).  Its kernel treats headwater tributaries differently from the others
+(river_route/routers/_numba_kernels.py:150-156), so a ghost that mirrors a reach WITH upstream reaches gets a dummy
+headwater above it in the local network (zero lateral, value never used): the ghost then counts as an inner tributary,
+exactly as the reach it mirrors does in the uncut network, while a ghost that mirrors a headwater stays a headwater.
 """
 from __future__ import annotations
 
@@ -21,7 +24,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-__all__ = ['PartSpec', 'split_network', 'HipPartEngine', 'part_driver', 'run_distributed', 'run_in_process',
+__all__ = ['PartSpec', 'split_network', 'HipPartEngine', 'HipUnitPartEngine', 'part_driver', 'run_distributed', 'run_in_process',
            'bench_main']
 
 
@@ -39,19 +42,31 @@ class PartSpec:
     down_local: np.ndarray           # local downstream index, -1 at local outlets
     upstream_parts: list = field(default_factory=list)    # [(part, ghost column slice)]
     downstream_parts: list = field(default_factory=list)  # [(part, export column slice)]
+    dummy_ghost: np.ndarray = field(default_factory=lambda: np.zeros(0, dtype=np.int64))   # UnitMuskingum: ghost (by number) below each dummy headwater
 
     @property
     def n_ghost(self) -> int:
         return int(self.ghost_global.size)
 
     @property
+    def n_dummy(self) -> int:
+        return int(self.dummy_ghost.size)
+
+    @property
+    def n_lead(self) -> int:
+        """Local columns before the part's own reaches: dummies, then ghosts."""
+        return self.n_dummy + self.n_ghost
+
+    @property
     def n_local(self) -> int:
-        return int(self.ghost_global.size + self.real_global.size)
+        return int(self.n_lead + self.real_global.size)
 
 
-def split_network(down_index: np.ndarray, part_of: np.ndarray, part: int, n_parts: int) -> PartSpec:
+def split_network(down_index: np.ndarray, part_of: np.ndarray, part: int, n_parts: int, inner_global=None) -> PartSpec:
     """Local network of one part.  Local index order: ghosts (grouped by owning part, ascending global index)
-    first, then the part's reaches in ascending global index -- still upstream before downstream."""
+    first, then the part's reaches in ascending global index -- still upstream before downstream.  With `inner_global`
+    (UnitMuskingum: True where a reach of the uncut network has upstream reaches) every ghost that mirrors such a reach
+    gets a dummy headwater above it; the dummies come before the ghosts."""
     down_index = np.asarray(down_index, dtype=np.int64)
     part_of = np.asarray(part_of)
     real = np.flatnonzero(part_of == part)
@@ -62,17 +77,19 @@ def split_network(down_index: np.ndarray, part_of: np.ndarray, part: int, n_part
     cut_out = np.flatnonzero(has_down & (part_of == part) & (dpart != part))
     cut_out = cut_out[np.lexsort((cut_out, dpart[cut_out]))]
     ng = cut_in.size
+    dummy_ghost = np.flatnonzero(np.asarray(inner_global, dtype=bool)[cut_in]) if inner_global is not None else np.zeros(0, dtype=np.int64)
+    nd = dummy_ghost.size
     local_of = np.full(down_index.size, -1, dtype=np.int64)
-    local_of[cut_in] = np.arange(ng)
-    local_of[real] = ng + np.arange(real.size)
+    local_of[cut_in] = nd + np.arange(ng)
+    local_of[real] = nd + ng + np.arange(real.size)
     members = np.concatenate([cut_in, real])
-    down_local = np.where(has_down[members], local_of[np.maximum(down_index[members], 0)], -1)
-    down_local[ng:][np.isin(real, cut_out)] = -1          # exports are outlets of the local network
+    down_local = np.concatenate([nd + dummy_ghost, np.where(has_down[members], local_of[np.maximum(down_index[members], 0)], -1)])
+    down_local[nd + ng:][np.isin(real, cut_out)] = -1          # exports are outlets of the local network
     has = down_local >= 0
     indptr = np.concatenate([[0], np.cumsum(has)]).astype(np.int32)
     indices = down_local[has].astype(np.int32)
     spec = PartSpec(part, n_parts, real, cut_in, part_of[cut_in].astype(np.int64), cut_out,
-                    dpart[cut_out].astype(np.int64), indptr, indices, down_local)
+                    dpart[cut_out].astype(np.int64), indptr, indices, down_local, dummy_ghost=dummy_ghost.astype(np.int64))
     for owners, out in ((spec.ghost_owner, spec.upstream_parts), (spec.export_consumer, spec.downstream_parts)):
         for p in np.unique(owners):
             cols = np.flatnonzero(owners == p)
@@ -137,6 +154,74 @@ class HipPartEngine:
 
     def final_state(self) -> np.ndarray:
         return self.q_t.cpu().numpy()[self.spec.n_ghost:]
+
+
+class HipUnitPartEngine:
+    """One part of a UnitMuskingum run on one GPU (river_route/routers/UnitMuskingum.py:72-98 over a cut network): the
+    part convolves its own columns (the convolution is column-wise, rr_uh_convolve_dev) and routes them with
+    rr_stream_begin_unit / rr_stream_advance / rr_stream_end_unit; ghosts carry the discharge their reaches publish.
+
+    `inner_global`: True where a reach of the uncut network has upstream reaches; q_ch / q_full: state over those reaches
+    (ascending global index), as the reference's router keeps it."""
+
+    def __init__(self, spec: PartSpec, c1, c2, c3, inner_global, q_ch, q_full, uh_kernel, uh_state, depth_rows, T, nsub, device):
+        import torch
+        from .engine import Plan, uh_convolve_dev
+        self.torch = torch
+        self.spec, self.T, self.nsub = spec, int(T), int(nsub)
+        self.dev = torch.device('cuda', device)
+        nd, ng, lead = spec.n_dummy, spec.n_ghost, spec.n_lead
+        inner_global = np.asarray(inner_global, dtype=bool)
+        members = np.concatenate([spec.ghost_global[spec.dummy_ghost], spec.ghost_global, spec.real_global])   # a dummy borrows its ghost's reach
+        n_loc = members.size
+        self.plan = Plan(spec.indptr, spec.indices, device=device)
+        has = spec.down_local >= 0
+        c1_loc = np.asarray(c1, dtype=np.float64)[members]
+        self.plan.set_coeffs(-c1_loc[spec.down_local[has]], np.asarray(c2, dtype=np.float64)[members],
+                             np.asarray(c3, dtype=np.float64)[members], None)
+        self.plan.set_boundary(nd + np.arange(ng), lead + np.searchsorted(spec.real_global, spec.export_global))
+        # state over the local reaches that have upstream reaches: ghosts below a dummy (q_full = their reach's), then real ones
+        self.inner_local = np.flatnonzero(np.bincount(spec.down_local[has], minlength=n_loc) > 0)
+        assert self.inner_local.size == self.plan.n_inner
+        rank = np.cumsum(inner_global) - 1
+        self.inner_rank = rank[members[self.inner_local]]
+        self.q_ch0 = torch.from_numpy(np.asarray(q_ch, dtype=np.float64)[self.inner_rank]).to(self.dev)
+        self.q_full0 = torch.from_numpy(np.asarray(q_full, dtype=np.float64)[self.inner_rank]).to(self.dev)
+        self.q_ch, self.q_full = torch.empty_like(self.q_ch0), torch.empty_like(self.q_full0)
+        # convolution of this part's columns on the device; dummy and ghost columns of the lateral rows are zero and unread
+        rows, n_real = depth_rows.shape
+        n_ks = uh_kernel.shape[0]
+        d_depth = torch.from_numpy(np.ascontiguousarray(depth_rows, dtype=np.float64)).to(self.dev)
+        d_kernel = torch.from_numpy(np.ascontiguousarray(uh_kernel, dtype=np.float64)).to(self.dev)
+        self.uh_state = torch.from_numpy(np.ascontiguousarray(uh_state, dtype=np.float64)).to(self.dev)
+        conv = torch.empty_like(d_depth)
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        uh_convolve_dev(d_kernel, self.uh_state, d_depth, conv, rows, n_ks, n_real, device=device, stream=stream)
+        self.lateral = torch.zeros((rows, n_loc), dtype=torch.float64, device=self.dev)
+        self.lateral[:, lead:] = conv
+        self.lat_rows = rows
+        self.discharge = torch.zeros((rows, n_loc), dtype=torch.float64, device=self.dev)
+        S = self.T * self.nsub
+        self.ghost_series = torch.zeros((S, max(ng, 1)), dtype=torch.float64, device=self.dev)
+        self.export_series = torch.zeros((S, max(spec.export_global.size, 1)), dtype=torch.float64, device=self.dev)
+
+    def begin(self) -> None:
+        self.q_ch.copy_(self.q_ch0)
+        self.q_full.copy_(self.q_full0)
+        stream = self.torch.cuda.current_stream(self.dev).cuda_stream
+        self.plan.stream_begin_unit(self.q_ch, self.q_full, self.lateral, self.lat_rows, self.discharge, self.lat_rows, self.T,
+                                    self.nsub, self.ghost_series, self.export_series, stream)
+
+    def advance(self, rows_ready: int, ghost_ready: int) -> int:
+        return self.plan.stream_advance(rows_ready, ghost_ready)
+
+    def end(self) -> None:
+        self.plan.stream_end_unit(self.q_ch, self.q_full)
+
+    def final_state(self):
+        """(global inner rank, q_ch, q_full) of this part's own reaches."""
+        own = self.inner_local >= self.spec.n_lead
+        return self.inner_rank[own], self.q_ch.cpu().numpy()[own], self.q_full.cpu().numpy()[own]
 
 
 def part_driver(engine, spec: PartSpec, T: int, nsub: int, chunk_rows: int):

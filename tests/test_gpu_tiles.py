@@ -366,3 +366,54 @@ def test_unit_route_with_fused_convolution_vs_oracle(monkeypatch, n, T, nsub, n_
             assert_close(d_state.download(np.float64, kern.shape), uh.state, f'file {f} UH state')
         for b in (d_kern, d_state, d_depth, d_out, d_fin, d_qc, d_qf):
             b.free()
+
+
+@pytest.mark.parametrize('wave,n,parts,T,nsub,chunk', [('1', 120_000, 4, 96, 1, 32), ('1', 60_000, 3, 40, 2, 16), ('0', 20_000, 5, 12, 2, 4),
+                                                       ('1', 200_000, 8, 150, 1, 32)])
+def test_unit_muskingum_on_a_cut_network_vs_oracle(monkeypatch, wave, n, parts, T, nsub, chunk):
+    """UnitMuskingum with the network cut into parts (river_route/routers/_numba_kernels.py:88-171 on the undivided network
+    is the oracle): ghosts of inner reaches and -- by moving one headwater across the cut -- a ghost of a headwater, carried
+    state, each part convolving its own columns."""
+    from river_route_amd.multi_gpu import HipUnitPartEngine, run_in_process, split_network
+    set_env(monkeypatch, {'RR_WAVE': wave})
+    net = synth.synth_network(n, seed=17)
+    indptr, indices = csc_from_down(net.down_index)
+    hw_idx, inner_idx, A_in, A_hw = unit_split(indptr, indices, n)
+    dt = 3600.0 / nsub
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, dt)
+    c1i, c2i, c3i = c1[inner_idx], c2[inner_idx], c3[inner_idx]
+    args = (A_in.indptr, A_in.indices, -c1i[A_in.indices], A_in.indptr, A_in.indices, A_in.data,
+            A_hw.indptr, A_hw.indices, A_hw.data, c1i, c2i, c3i, hw_idx, inner_idx)
+    n_ks = 9
+    kern = synth.synth_uh_kernel(n, n_ks)
+    uh_state0 = 0.1 * synth.u01(3, np.arange(n_ks * n)).reshape(n_ks, n)
+    depth = synth.synth_runoff_depth(n, 0, T)
+    uh = oracle.UnitHydrograph(kern)
+    uh.state = uh_state0.copy()
+    conv_ref = uh.convolve(depth)
+    q0 = 3.0 * synth.u01(7, np.arange(n))
+    qc_ref, qf_ref, d_ref = 0.5 * q0[inner_idx], q0[inner_idx].copy(), np.zeros((T, n))
+    oracle.unit_route(*args, qc_ref, qf_ref, conv_ref, d_ref, nsub)
+
+    inner = np.zeros(n, dtype=bool)
+    inner[inner_idx] = True
+    part_of, _ = partition_forest(indptr, indices, parts)
+    part_of = part_of.copy()
+    last = np.flatnonzero(~inner & (net.down_index >= 0) & (part_of == parts - 1))
+    part_of[last[0]] = 0                                   # a cut directly below a headwater
+    specs = [split_network(net.down_index, part_of, p, parts, inner_global=inner) for p in range(parts)]
+    assert sum(s.n_dummy for s in specs) > 0 and sum(s.n_ghost - s.n_dummy for s in specs) > 0
+    engines = [HipUnitPartEngine(s, c1, c2, c3, inner, 0.5 * q0[inner_idx], q0[inner_idx], kern[:, s.real_global],
+                                 uh_state0[:, s.real_global], depth[:, s.real_global], T, nsub, 0) for s in specs]
+    run_in_process(engines, specs, T, nsub, chunk)
+    if wave == '1':
+        assert all(e.plan.profile()['ticks_per_launch'] >= 16 for e in engines)      # the time-tiled kernel ran
+    qc, qf = np.full(inner_idx.size, np.nan), np.full(inner_idx.size, np.nan)
+    for s, e in zip(specs, engines):
+        d = e.discharge.cpu().numpy()[:, s.n_lead:]
+        assert_close(d, d_ref[:, s.real_global], f'part {s.part} discharge')
+        rank, a, b = e.final_state()
+        qc[rank], qf[rank] = a, b
+        np.testing.assert_allclose(e.uh_state.cpu().numpy(), uh.state[:, s.real_global], rtol=0, atol=1e-12 * np.abs(uh.state).max())
+    assert_close(qc, qc_ref, 'q_ch')
+    assert_close(qf, qf_ref, 'q_full')

@@ -170,3 +170,35 @@ def test_two_ranks_rccl_vs_oracle(tmp_path):
     if torch.cuda.device_count() < 2:
         pytest.skip('needs 2 GPUs (RCCL refuses two ranks on one device)')
     _ranks_vs_oracle(tmp_path, 2, 'nccl')
+
+
+def test_unit_split_gives_inner_ghosts_a_dummy_headwater():
+    """UnitMuskingum on a cut network: a ghost falls on the same side of the headwater / inner distinction
+    (river_route/routers/_numba_kernels.py:150-156) as the reach it mirrors."""
+    from river_route_amd.multi_gpu import split_network
+    n, parts = 20_000, 5
+    net = synth.synth_network(n, seed=4)
+    has = net.down_index >= 0
+    indptr = np.concatenate([[0], np.cumsum(has)]).astype(np.int32)
+    indices = net.down_index[has].astype(np.int32)
+    part_of, _ = partition_forest(indptr, indices, parts)
+    inner = np.bincount(net.down_index[has], minlength=n) > 0
+    # move one headwater away from the reach it flows into, to an upstream part: a cut directly below a headwater
+    hw = np.flatnonzero(~inner & has & (part_of == parts - 1))
+    part_of = part_of.copy()
+    part_of[hw[0]] = 0
+    seen_hw_ghost = False
+    for p in range(parts):
+        spec = split_network(net.down_index, part_of, p, parts, inner_global=inner)
+        nd, ng = spec.n_dummy, spec.n_ghost
+        assert nd == int(inner[spec.ghost_global].sum())
+        local_inner = np.bincount(spec.down_local[spec.down_local >= 0], minlength=spec.n_local) > 0
+        np.testing.assert_array_equal(local_inner[nd:nd + ng], inner[spec.ghost_global])       # ghosts: as their reaches
+        np.testing.assert_array_equal(local_inner[nd + ng:], inner[spec.real_global])           # own reaches: unchanged
+        assert not local_inner[:nd].any()                                                       # dummies are headwaters
+        np.testing.assert_array_equal(spec.down_local[:nd], nd + spec.dummy_ghost)
+        assert (spec.down_local[nd:nd + ng] >= nd + ng).all()                                   # a ghost flows into an own reach
+        seen_hw_ghost |= bool((~inner[spec.ghost_global]).any())
+        plain = split_network(net.down_index, part_of, p, parts)
+        assert plain.n_dummy == 0 and plain.n_local == spec.n_local - nd
+    assert seen_hw_ghost
