@@ -1577,7 +1577,8 @@ bool decide_wave(rr_plan *P, Mode mode, int64_t total, bool host_rows)
         const int64_t all_chunks = kRecBatch * ((total + 14) / kRecRows + 2) + (dmax >> 4) + 2;
         ok = false;
         for (int64_t KC = pick_KC(P, total + dmax); KC >= 1; KC /= 2) {
-            const int64_t chunks = std::min<int64_t>(all_chunks, (dmax + levels * KC * kRec) / kRec + 4 * kRecBatch);
+            static const int64_t extra = getenv("RR_RING_EXTRA") ? atoll(getenv("RR_RING_EXTRA")) : 0;      // measurements: a larger ring than needed
+            const int64_t chunks = std::min<int64_t>(all_chunks, (dmax + levels * KC * kRec) / kRec + 4 * kRecBatch + extra);
             const int64_t bytes = chunks * kRec * np * (int64_t)sizeof(double);
             if (P->dev_total_bytes > 0 && bytes > (int64_t)(P->dev_total_bytes / 8 * 5)) continue;
             if (ensure_cap(&P->d_ring, &P->ring_cap, chunks * kRec * np) != RR_OK) { (void)hipGetLastError(); continue; }
