@@ -344,8 +344,9 @@ def main():
 def engine_sha16():
     import hashlib
     h = hashlib.sha256()
-    for name in ('rr_engine.hip', 'rr_plan.cpp', 'rr_plan.hpp'):
-        with open(os.path.join(REPO, 'river_route_amd', 'csrc', name), 'rb') as f:
+    csrc = os.path.join(REPO, 'river_route_amd', 'csrc')
+    for name in sorted(f for f in os.listdir(csrc) if f.endswith(('.hip', '.hpp', '.cpp'))):      # every source of librr_hip.so
+        with open(os.path.join(csrc, name), 'rb') as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 

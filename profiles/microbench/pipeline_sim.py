@@ -1,5 +1,5 @@
 """Lock-step simulation of the multi-GPU pipeline (no GPU needed): the bench network is partitioned as `bench.py --gpus N`
-does, every part gets a host-only plan, and the executor's readiness rules (river_route_amd/csrc/rr_engine.hip:
+does, every part gets a host-only plan, and the executor's readiness rules (river_route_amd/csrc/rr_exec.hpp:
 session_advance_tile -- a batch of 128 tick-rows becomes records once the lateral rows AND the boundary sub-steps behind it
 have arrived; launch d runs once the ticks below (d + 1) K are records and the boundary sub-steps below (d + 1) K - slack are; an export reach in a tile of level l at lag L is
 final (d - l) K - L sub-steps into the schedule; finished sub-steps are shipped in batches of `exchange_rows`) are stepped

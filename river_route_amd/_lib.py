@@ -32,7 +32,7 @@ class RRError(RuntimeError):
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile librr_hip.so for gfx950 with hipcc (cross-compiles without a GPU). Returns the path."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
-    deps = srcs + [os.path.join(CSRC, 'rr_plan.hpp'), os.path.join(os.path.dirname(_HERE), 'include', 'rr_hip.h')]
+    deps = srcs + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.hpp')] + [os.path.join(os.path.dirname(_HERE), 'include', 'rr_hip.h')]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
     hipcc = os.environ.get('HIPCC') or ('/opt/rocm/bin/hipcc' if os.path.exists('/opt/rocm/bin/hipcc') else 'hipcc')

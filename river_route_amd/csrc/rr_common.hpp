@@ -1,0 +1,76 @@
+// rr_common.hpp -- includes, error helper, constants and index helpers shared by the kernels and the executor.
+// Part of the one translation unit rr_engine.hip builds (included from there first).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/rr_hip.h"
+#include "rr_plan.hpp"
+
+#define RR_VERSION_NUM 100
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return fail(RR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));                 \
+    } while (0)
+
+constexpr int kBlock = 256;
+constexpr int kSampleGroup = 16;   // routing-tick launches per HIP-event bracket
+// lag[] carries two flag bits for the boundary reaches of a partitioned network
+constexpr int32_t kGhostBit = 1 << 30;    // value prescribed from the ghost series (an upstream reach owned by another GPU)
+constexpr int32_t kExportBit = 1 << 29;   // value also copied to the export series (feeds another GPU)
+constexpr int32_t kTileGhostBit = rr::kTileGhost;     // tile layout only: position mirrors a reach another tile owns
+constexpr int32_t kTileExportBit = rr::kTileExport;   // tile layout only: reach is mirrored by a ghost, values also go to the export ring
+constexpr int32_t kLagMask = kTileExportBit - 1;
+
+// Index arithmetic: every tick, row and chunk index of a call is below 2^31 (checked in session_begin), and the
+// hardware has no integer divide -- a 64-bit `%` is a ~100-instruction emulation.  Division by a run-time constant
+// goes through a host-computed double reciprocal instead: floor(x * (1/d)) is exact or one too small (only when d
+// divides x), which the single fix-up repairs.
+struct Div32 {
+    uint32_t d;
+    double inv;
+    Div32() = default;
+    __host__ __device__ explicit Div32(uint32_t d_) : d(d_ ? d_ : 1u), inv(1.0 / (double)(d_ ? d_ : 1u)) {}
+    __device__ __forceinline__ uint32_t div(uint32_t x, uint32_t &rem) const
+    {
+        uint32_t q = (uint32_t)((double)x * inv);
+        uint32_t r = x - q * d;
+        if (r >= d) { r -= d; ++q; }
+        rem = r;
+        return q;
+    }
+    __device__ __forceinline__ uint32_t mod(uint32_t x) const { uint32_t r; div(x, r); return r; }
+};
+
+// Row addressing of a (rows, ld) array read or written cyclically: row of step t is (t - t0) % rows.
+struct RowView {
+    double *base;
+    int64_t ld;
+    int64_t t0;
+    Div32 rows;
+    RowView() = default;
+    RowView(double *base_, int64_t ld_, int64_t t0_, uint32_t rows_) : base(base_), ld(ld_), t0(t0_), rows(rows_) {}
+    __device__ __forceinline__ double *row(int64_t t) const { return base + (int64_t)rows.mod((uint32_t)(t - t0)) * ld; }
+};
+
+inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+}  // namespace

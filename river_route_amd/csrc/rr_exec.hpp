@@ -1,0 +1,1062 @@
+// rr_exec.hpp -- the plan object and the executor: schedule choice, record ring, streaming session, host PCIe pipeline,
+// the route cores behind the C ABI.  Part of the one translation unit rr_engine.hip builds.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// plan object
+// ------------------------------------------------------------------------------------------------
+
+enum class Mode { Rapid, Muskingum, Unit };
+
+// Where the (time, reach) rows in params order come from / go to.
+struct Rows {
+    const double *dev_in = nullptr;   // device array, rows_in rows
+    const double *host_in = nullptr;  // host array, T rows
+    int64_t rows_in = 0;
+    double *dev_out = nullptr;
+    double *host_out = nullptr;
+    int64_t rows_out = 0;
+    float *dev_out32 = nullptr;       // instead of dev_out: float32 rows, each the mean of out_factor routed rows
+    int64_t out_factor = 1;
+    // UnitMuskingum with the convolution fused into the in-pass: dev_in holds runoff DEPTH rows, the lateral inflow is
+    // computed on the way into the records (k_rec_in_uh)
+    const double *uh_kernel = nullptr, *uh_state = nullptr;
+    int64_t uh_nks = 0;
+    // RapidMuskingum fed by gridded runoff: no lateral rows at all, the weights product runs in the in-pass (k_rec_in_runoff)
+    const RunoffArgs *runoff = nullptr;
+};
+
+// One routing call in flight: rows enter (permutation in), ticks run, finished rows leave (permutation out).
+// route_core() runs a session start to finish; the rr_stream_* entry points keep it open between calls so the
+// lag pipeline is never drained while forcing or boundary series arrive in chunks (multi-GPU).
+struct Session {
+    bool open = false;
+    Mode mode = Mode::Rapid;
+    int64_t T = 0, nsub = 1, total = 0, total_ticks = 0;
+    Rows io;
+    hipStream_t stream = nullptr;
+    bool direct = false, has_in = true;
+    int64_t ring_rows = 0;
+    int64_t rows_loaded = 0, rows_stored = 0, tau = 0;
+    const double *ghost_series = nullptr;
+    double *export_series = nullptr;
+    TickArgs a{};
+    bool wave = false;            // time-tiled k_tile over records instead of per-tick k_tick over rows
+    int64_t KC = 1;               // record chunks per task: K = 16 * KC ticks
+    int64_t rec_chunks = 0, in_batches = 0, n_in_batches = 0, out_batches = 0, n_out_batches = 0;
+    int64_t ticks_stored = 0;     // tick-rows that have left the record ring
+    int64_t out_limit = std::numeric_limits<int64_t>::max();   // rows the caller's output ring can take (host pipeline)
+    int64_t diag = 0, n_diags = 0, n_macro = 0;
+    int64_t ghost_batches = 0;    // batches of the boundary (ghost) series turned into records
+    int64_t ghost_slack = 0, export_skew = 0;      // boundary reaches of a partitioned network in the time-tiled schedule (level skew included)
+    TileArgs ta{};
+    bool bracket_open = false;
+    int64_t bracket_reaches = 0;
+    size_t max_samples = 0;
+};
+
+// ---- host-pointer calls: PCIe pipeline around the time-tiled kernel ----
+//
+// The reference's kernel boundary hands over numpy arrays in pageable host memory.  hipMemcpy from pageable memory moves
+// 22 GB/s here, and one direction at a time; registering the caller's arrays costs 43 ms per GB; pinned memory moves
+// 49 GB/s each way at once (profiles/microbench/host_copy.hip).  So rows travel in chunks of 64 through three pinned
+// buffers per direction, filled and emptied by eight copy threads each, while the DMA engines move the neighbouring
+// chunks and the GPU routes what has arrived: caller -> pinned -> device staging ring -> records -> tiles -> records ->
+// device staging ring -> pinned -> caller, every stage overlapping the others.  The open routing call is the streaming
+// session the partitioned path uses (rows become ready chunk by chunk).
+struct HostPipe {
+    static constexpr int kPinned = 3, kCopyThreads = 8;
+    int64_t chunk_rows = 64, ring_chunks = 8;
+    double *pin_in[kPinned] = {nullptr, nullptr, nullptr}, *pin_out[kPinned] = {nullptr, nullptr, nullptr};
+    double *dev_in = nullptr, *dev_out = nullptr;
+    int64_t pin_cap = 0, dev_cap = 0;      // doubles per pinned buffer / per device ring
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    std::vector<hipEvent_t> ev_h2d, ev_d2h, ev_adv;
+    void destroy()
+    {
+        for (int k = 0; k < kPinned; ++k) { if (pin_in[k]) (void)hipHostFree(pin_in[k]); if (pin_out[k]) (void)hipHostFree(pin_out[k]); pin_in[k] = pin_out[k] = nullptr; }
+        if (dev_in) (void)hipFree(dev_in);
+        if (dev_out) (void)hipFree(dev_out);
+        dev_in = dev_out = nullptr; pin_cap = dev_cap = 0;
+        for (auto *v : {&ev_h2d, &ev_d2h, &ev_adv}) { for (hipEvent_t e : *v) (void)hipEventDestroy(e); v->clear(); }
+        if (s_h2d) (void)hipStreamDestroy(s_h2d);
+        if (s_d2h) (void)hipStreamDestroy(s_d2h);
+        s_h2d = s_d2h = nullptr;
+    }
+};
+
+struct rr_plan {
+    rr::HostPlan h;
+    int device = RR_DEVICE_NONE;
+    bool coeffs_set = false, has_c4 = false;
+    int64_t chunk_rows = 16, sample_every = 0;
+
+    // streaming kernel (k_tick): lag-ordered layout of rr::HostPlan
+    int32_t *d_child_ptr = nullptr, *d_lag = nullptr, *d_perm = nullptr, *d_inv = nullptr, *d_inner_pos = nullptr;
+    int32_t *d_bidx = nullptr;   // ghost / export slot of flagged positions
+    uint16_t *d_hwc = nullptr;
+    double *d_w = nullptr, *d_c1row_h = nullptr, *d_c2 = nullptr, *d_c3 = nullptr, *d_c4 = nullptr;
+    double *d_x = nullptr, *d_isum = nullptr, *d_qch = nullptr;
+    double *d_ring = nullptr;
+    int64_t ring_cap = 0;  // doubles
+    double *d_stage = nullptr;
+    int64_t stage_cap = 0;
+    double *d_mrows = nullptr;   // intermediate rows of the tiled permutation
+    int64_t mrows_cap = 0;
+    // tiled permutations: [0] params order -> engine order (pi = perm), [1] engine -> params (pi = inv)
+    uint16_t *d_slot_a[2] = {nullptr, nullptr}, *d_slot_b[2] = {nullptr, nullptr};
+    int32_t *d_m_index[2] = {nullptr, nullptr};
+    int64_t perm_rows_per_block = 2;
+
+    // time-tiled routing (k_tile): subtree tiles of rr::TilePlan
+    rr::TilePlan tp;
+    bool wave_enabled = true, wave_forced = false, wave_now = false, weights_uniform = false;
+    int wave_threads = 1024, wave_ppt = 2;
+    int64_t wave_K = 0;          // ticks per task (multiple of 16); 0 = chosen per call
+    int64_t next_KC = 1, next_chunks = 0;   // decide_wave: task length and record ring of the call about to start
+    int32_t *d_tile_ptr = nullptr, *d_tile_level = nullptr, *d_tile_lag_lo = nullptr, *d_tile_lag_hi = nullptr;
+    int32_t *d_tlag = nullptr, *d_cfirst = nullptr, *d_xpos = nullptr, *d_tperm = nullptr, *d_tinv = nullptr;
+    int32_t *d_tbidx = nullptr, *d_inner_idx = nullptr;
+    uint32_t *d_ccnt = nullptr;
+    double *d_c1row = nullptr, *d_tc2 = nullptr, *d_tc3 = nullptr, *d_sq = nullptr, *d_ss = nullptr, *d_si = nullptr, *d_sqch = nullptr;
+    double *d_full = nullptr, *d_chan = nullptr;   // UnitMuskingum state scattered to params order
+    int2 *d_colmeta = nullptr;   // per params column {position, lag}
+    int2 *d_ghostmeta = nullptr; // the same per boundary ghost (column of the ghost series)
+    double *d_c4_params = nullptr;   // c4dt in params order (scale of the record permutation)
+    size_t dev_total_bytes = 0;
+    int cu_count = 256;
+
+    // boundary reaches of a partitioned network
+    int64_t n_ghost = 0, n_export = 0;
+    int64_t ghost_min_lag = 0, export_max_lag = 0;
+    std::vector<int32_t> ghost_reach, export_reach;   // params indices, in the caller's order
+
+    Session ses;
+    HostPipe pipe;      // staging of the host-pointer entry points (allocated at first use)
+
+    // profile of the last route call
+    std::vector<hipEvent_t> ev;
+    std::vector<int64_t> ev_reaches;
+    hipEvent_t ev_first = nullptr, ev_last = nullptr;
+    int64_t prof_launches = 0, prof_samples = 0, prof_brackets = 0, prof_reach_steps = 0;
+    hipStream_t last_stream = nullptr;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(T **p, int64_t count)
+{
+    *p = nullptr;
+    if (count <= 0) count = 1;
+    hipError_t e = hipMalloc((void **)p, (size_t)count * sizeof(T));
+    if (e != hipSuccess)
+        return fail(RR_E_ALLOC, std::string("hipMalloc of ") + std::to_string((size_t)count * sizeof(T)) +
+                                    " bytes failed: " + hipGetErrorString(e));
+    return RR_OK;
+}
+
+template <typename T>
+int dev_upload(T *dst, const std::vector<T> &src)
+{
+    if (src.empty()) return RR_OK;
+    HIPCHK(hipMemcpy(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RR_OK;
+}
+
+int need_device(const rr_plan *plan)
+{
+    if (!plan) return fail(RR_E_INVALID, "null plan");
+    if (plan->device < 0)
+        return fail(RR_E_NO_DEVICE, "this plan is host-only (RR_DEVICE_NONE): the HIP engine has no CPU fallback");
+    HIPCHK(hipSetDevice(plan->device));
+    return RR_OK;
+}
+
+template <typename T>
+int ensure_cap(T **buf, int64_t *cap, int64_t count)
+{
+    if (*cap >= count) return RR_OK;
+    if (*buf) { (void)hipFree(*buf); *buf = nullptr; *cap = 0; }
+    int rc = dev_alloc(buf, count);
+    if (rc) return rc;
+    *cap = count;
+    return RR_OK;
+}
+
+// ---- session -------------------------------------------------------------------------------------
+
+// Record chunks per task.  A longer task amortises the load of the tile's state and of its first half chunk, which
+// nothing overlaps; every tile level adds one task of skew to the pipeline and to the record ring.
+int64_t pick_KC(const rr_plan *P, int64_t total_ticks)
+{
+    if (P->wave_K > 0) return std::max<int64_t>(1, P->wave_K / kRec);
+    return total_ticks >= 4096 ? 4 : (total_ticks >= 512 ? 2 : 1);
+}
+
+// Which routing kernel a call uses.  The time-tiled schedule needs device rows, one upstream weight per reach, a
+// network that tiles (rr::TilePlan) and room for its record ring; its fill and drain cost (levels x K) ticks more than
+// the streaming kernel's, a few launches, so only calls of a handful of sub-steps stream.  RR_WAVE=1 forces it where it
+// applies, RR_WAVE=0 forbids it.
+//
+// Records are indexed by tick = tick-row + lag, modulo the ring, per position: a position's slots never hold another
+// position's data, so what the ring must cover is one position's tick-rows in flight.  Rows enter for all columns at once
+// (ahead of the level-0 tiles) and leave for all columns at once (after the last level has passed their tick + depth), so
+// every position keeps depth + levels * K tick-rows plus the batching of the two permutation passes; that its window sits
+// lag ticks later than a headwater's does not widen it.  The ring may take five eighths of the card; a deep network that
+// does not fit gets shorter tasks, then the streaming kernel.
+bool decide_wave(rr_plan *P, Mode mode, int64_t total, bool host_rows)
+{
+    bool ok = P->wave_enabled && P->tp.ok && P->weights_uniform && P->h.n > 0 && !host_rows && P->tp.np < (int64_t{1} << 25);
+    if (ok && !P->wave_forced) ok = total >= 32;
+    if (ok) {
+        const int64_t dmax = P->h.depth - 1, np = P->tp.np, levels = P->tp.n_levels;
+        const int64_t all_chunks = kRecBatch * ((total + 14) / kRecRows + 2) + (dmax >> 4) + 2;
+        ok = false;
+        for (int64_t KC = pick_KC(P, total + dmax); KC >= 1; KC /= 2) {
+            static const int64_t extra = getenv("RR_RING_EXTRA") ? atoll(getenv("RR_RING_EXTRA")) : 0;      // measurements: a larger ring than needed
+            const int64_t chunks = std::min<int64_t>(all_chunks, (dmax + levels * KC * kRec) / kRec + 4 * kRecBatch + extra);
+            const int64_t bytes = chunks * kRec * np * (int64_t)sizeof(double);
+            if (P->dev_total_bytes > 0 && bytes > (int64_t)(P->dev_total_bytes / 8 * 5)) continue;
+            if (ensure_cap(&P->d_ring, &P->ring_cap, chunks * kRec * np) != RR_OK) { (void)hipGetLastError(); continue; }
+            P->next_KC = KC; P->next_chunks = chunks;
+            ok = true;
+            break;
+        }
+    }
+    P->wave_now = ok;
+    return ok;
+}
+
+bool use_wave(const rr_plan *P, Mode) { return P->wave_now; }
+
+int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io, hipStream_t stream,
+                  const double *ghost_series, double *export_series)
+{
+    const rr::HostPlan &H = P->h;
+    const int64_t n = H.n;
+    Session &S = P->ses;
+    if (S.open) return fail(RR_E_STATE, "a routing call is already open on this plan (rr_stream_end it first)");
+    S = Session();
+    S.mode = mode; S.T = T; S.nsub = nsub; S.total = T * nsub; S.io = io; S.stream = stream;
+    S.ghost_series = ghost_series; S.export_series = export_series;
+    const int64_t dmax = H.depth - 1;
+    S.total_ticks = S.total + dmax;
+    // the kernels index ticks, rows and chunks in 32 bits (Div32)
+    if (S.total_ticks >= (int64_t{1} << 31) - (int64_t{1} << 20) || io.rows_in >= (int64_t{1} << 31) || io.rows_out >= (int64_t{1} << 31))
+        return fail(RR_E_UNSUPPORTED, "more than 2^31 routing ticks or rows in one call: split it into several calls");
+    S.has_in = mode != Mode::Muskingum;
+    const bool host_io = io.host_out != nullptr || io.host_in != nullptr;
+    S.wave = use_wave(P, mode);
+    S.direct = H.identity && !host_io && !S.wave;   // engine order == params order: the streaming kernel reads the caller's arrays
+    const int64_t C = std::max<int64_t>(1, P->chunk_rows);
+
+    P->prof_launches = P->prof_samples = P->prof_brackets = 0;
+    P->prof_reach_steps = n * S.total;
+    P->ev_reaches.clear();
+    P->last_stream = stream;
+    S.open = true;
+    if (n == 0 || S.total == 0) return RR_OK;
+    if (P->n_ghost > 0 && !ghost_series) { S.open = false; return fail(RR_E_INVALID, "plan has ghost reaches but no ghost series was given"); }
+    if (P->n_export > 0 && !export_series) { S.open = false; return fail(RR_E_INVALID, "plan has export reaches but no export series was given"); }
+    if (io.dev_out32 && !S.wave) { S.open = false; return fail(RR_E_UNSUPPORTED, "float32 output needs the time-tiled kernel"); }
+
+    int rc = RR_OK;
+    if (S.wave) { S.KC = P->next_KC; S.rec_chunks = P->next_chunks; }     // ring sized and allocated by decide_wave
+    if (S.wave) {
+        const rr::TilePlan &TP = P->tp;
+        const int64_t K = S.KC * kRec;
+        S.n_macro = (S.total_ticks + K - 1) / K;
+        S.n_diags = S.n_macro + TP.n_levels - 1;
+        S.n_in_batches = (S.total + 14) / kRecRows + 1;      // of the lateral rows (if any) and of the boundary series (if any)
+        S.n_out_batches = (S.total + kRecRows - 1) / kRecRows;
+        // external boundary reaches: a ghost in a tile of level l at lag L is read for sub-steps below (diag - l + 1) K - L,
+        // an export reach there has produced the sub-steps below (diag - l) K - L
+        S.export_skew = 0;
+        S.ghost_slack = P->ghost_reach.empty() ? 0 : S.total_ticks + (int64_t)TP.n_levels * K;
+        for (int32_t i : P->ghost_reach) { const int32_t p = TP.inv[i]; S.ghost_slack = std::min<int64_t>(S.ghost_slack, (int64_t)TP.tile_level[TP.tile_of[p]] * K + (TP.lag[p] & kLagMask)); }
+        for (int32_t i : P->export_reach) { const int32_t p = TP.inv[i]; S.export_skew = std::max<int64_t>(S.export_skew, (int64_t)TP.tile_level[TP.tile_of[p]] * K + (TP.lag[p] & kLagMask)); }
+        if (io.dev_out32) {
+            const int64_t step = io.out_factor * nsub;
+            if (io.out_factor < 1 || kRecRows % step != 0 || T % io.out_factor != 0) { S.open = false; return fail(RR_E_UNSUPPORTED, "float32 output: factor * sub-steps must divide 128 and factor the number of rows"); }
+        }
+        TileArgs &w = S.ta;
+        w.tile_ptr = P->d_tile_ptr; w.tile_level = P->d_tile_level; w.tile_lag_lo = P->d_tile_lag_lo; w.tile_lag_hi = P->d_tile_lag_hi;
+        w.lag = P->d_tlag; w.cfirst = P->d_cfirst; w.xpos = P->d_xpos; w.ccnt = P->d_ccnt;
+        w.c1row = P->d_c1row; w.c2 = P->d_tc2; w.c3 = P->d_tc3;
+        w.sq = P->d_sq; w.ss = P->d_ss; w.si = P->d_si; w.sqch = P->d_sqch;
+        w.bidx = P->d_tbidx; w.exports = export_series; w.n_export = (int32_t)P->n_export;
+        w.rec = P->d_ring; w.rec_chunks = Div32((uint32_t)S.rec_chunks);
+#ifdef RR_WAVE_TRACE
+        w.trace = nullptr; w.trace_diag = -1;
+        if (getenv("RR_WAVE_TRACE_DIAG")) {
+            static long long *tbuf = nullptr;
+            if (!tbuf) (void)hipMalloc(&tbuf, 8 * 16 * 4096);
+            (void)hipMemset(tbuf, 0, 8 * 16 * 4096);
+            w.trace = tbuf; w.trace_diag = atoi(getenv("RR_WAVE_TRACE_DIAG"));
+        }
+#endif
+        w.np = (int32_t)TP.np; w.KC = (int32_t)S.KC; w.n_macro = (int32_t)S.n_macro; w.total = (int32_t)S.total;
+        w.has_lat = S.has_in ? 1 : 0; w.nsub = Div32((uint32_t)nsub); w.inv_nsub = 1.0 / (double)nsub;
+    }
+    if (getenv("RR_VERBOSE"))
+        fprintf(stderr, "rr: n=%lld T=%lld nsub=%lld tiled=%d K=%lld tiles=%d levels=%d block=%d ghosts=%lld ring_chunks=%lld (%.1f GB) lds=%zu\n",
+                (long long)n, (long long)T, (long long)nsub, (int)S.wave, (long long)(S.KC * kRec), P->tp.n_tiles, P->tp.n_levels, P->tp.block,
+                (long long)P->tp.n_ghost, (long long)S.rec_chunks, S.wave ? (double)S.rec_chunks * kRec * P->tp.np * 8 / 1e9 : 0.0,
+                tile_lds_bytes(P->wave_threads));
+    if (!S.wave) {
+        // work ring in engine order: lateral rows come in, discharge rows overwrite them in place; rows stay until the
+        // outlet-most reaches have passed them
+        const int64_t lag_rows = (dmax + nsub - 1) / nsub;
+        S.ring_rows = S.direct ? 0 : std::min<int64_t>(T, lag_rows + 2 * C + 2);
+        if (S.ring_rows > 0xFFFFFFFFLL || T > 0x7FFFFFFFLL) { S.open = false; return fail(RR_E_INVALID, "route: too many time rows"); }
+        rc = RR_OK;
+        if (!S.direct) rc = ensure_cap(&P->d_ring, &P->ring_cap, S.ring_rows * n);
+        if (!rc && !S.direct) rc = ensure_cap(&P->d_mrows, &P->mrows_cap, C * n);
+        if (!rc && host_io) rc = ensure_cap(&P->d_stage, &P->stage_cap, C * n);
+        if (rc) { S.open = false; return rc; }
+        TickArgs &a = S.a;
+        a.child_ptr = P->d_child_ptr; a.lag = P->d_lag; a.w = P->d_w; a.c2 = P->d_c2; a.c3 = P->d_c3; a.c4 = P->d_c4;
+        a.c1row = P->weights_uniform ? P->d_c1row_h : nullptr;
+        a.isum = P->d_isum; a.bidx = P->d_bidx;
+        a.ghost = ghost_series; a.exports = export_series; a.n_ghost = (int32_t)P->n_ghost; a.n_export = (int32_t)P->n_export;
+        a.total_substeps = S.total; a.nsub = Div32((uint32_t)nsub); a.inv_nsub = 1.0 / (double)nsub;
+        if (S.direct) {
+            a.in = io.dev_in; a.in_ld = n; a.in_rows = Div32((uint32_t)std::max<int64_t>(1, io.rows_in));
+            a.out = io.dev_out; a.out_ld = n; a.out_rows = Div32((uint32_t)io.rows_out);
+        } else {
+            a.in = S.has_in ? P->d_ring : nullptr; a.in_ld = n; a.in_rows = Div32((uint32_t)S.ring_rows);
+            a.out = P->d_ring; a.out_ld = n; a.out_rows = Div32((uint32_t)S.ring_rows);
+        }
+    }
+    S.max_samples = P->sample_every >= kSampleGroup ? (size_t)std::min<int64_t>(4096, S.total_ticks / P->sample_every + 1) : 0;
+    if (S.wave && S.max_samples > 0) S.max_samples = (size_t)std::min<int64_t>(4096, S.n_diags / 4 + 1);     // every fourth launch
+    while (P->ev.size() < 2 * S.max_samples) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        P->ev.push_back(e);
+    }
+    if (!P->ev_first) { HIPCHK(hipEventCreate(&P->ev_first)); HIPCHK(hipEventCreate(&P->ev_last)); }
+    HIPCHK(hipEventRecord(P->ev_first, stream));
+    return RR_OK;
+}
+
+// params order <-> engine order through the two-phase tiled permutation (k_perm_a / k_perm_b)
+void permute_rows(rr_plan *P, int which, const RowView &src, const RowView &dst, int64_t t0, int nrows)
+{
+    const int64_t n = P->h.n;
+    constexpr int E = kPermE;
+    const int64_t tile = (int64_t)E * kPermThreads;
+    const int rpb = (int)std::max<int64_t>(1, P->perm_rows_per_block);
+    dim3 g((unsigned)((n + tile - 1) / tile), (unsigned)((nrows + rpb - 1) / rpb));
+    const size_t lds_bytes = (size_t)tile * sizeof(double);
+    hipStream_t stream = P->ses.stream;
+    hipLaunchKernelGGL(k_perm_a<E>, g, dim3(kPermThreads), lds_bytes, stream, src, P->d_mrows, n,
+                       (const uint16_t *)P->d_slot_a[which], (const int32_t *)P->d_m_index[which], t0, nrows, rpb);
+    hipLaunchKernelGGL(k_perm_b<E>, g, dim3(kPermThreads), lds_bytes, stream, dst, (const double *)P->d_mrows, n,
+                       (const uint16_t *)P->d_slot_b[which], t0, nrows, rpb);
+}
+
+int session_load_rows(rr_plan *P, int64_t r0, int64_t r1)   // params order -> ring
+{
+    Session &S = P->ses;
+    if (S.direct || !S.has_in) return RR_OK;
+    const int64_t n = P->h.n, C = std::max<int64_t>(1, P->chunk_rows);
+    const int nrows = (int)(r1 - r0);
+    const RowView ring_view{P->d_ring, n, 0, (uint32_t)std::max<int64_t>(1, S.ring_rows)};
+    if (S.io.host_in) {
+        HIPCHK(hipMemcpyAsync(P->d_stage, S.io.host_in + r0 * n, (size_t)nrows * n * sizeof(double),
+                              hipMemcpyHostToDevice, S.stream));
+        permute_rows(P, 0, RowView{P->d_stage, n, r0, (uint32_t)C}, ring_view, r0, nrows);
+        HIPCHK(hipStreamSynchronize(S.stream));   // the stage is reused by the next chunk
+    } else {
+        permute_rows(P, 0, RowView{const_cast<double *>(S.io.dev_in), n, 0, (uint32_t)S.io.rows_in}, ring_view, r0, nrows);
+    }
+    return RR_OK;
+}
+
+int session_store_rows(rr_plan *P, int64_t r0, int64_t r1)   // ring -> params order
+{
+    Session &S = P->ses;
+    if (S.direct) return RR_OK;
+    const int64_t n = P->h.n, C = std::max<int64_t>(1, P->chunk_rows);
+    const RowView ring_view{P->d_ring, n, 0, (uint32_t)std::max<int64_t>(1, S.ring_rows)};
+    for (int64_t b0 = r0; b0 < r1; b0 += C) {
+        const int nrows = (int)std::min<int64_t>(C, r1 - b0);
+        if (S.io.host_out) {
+            permute_rows(P, 1, ring_view, RowView{P->d_stage, n, b0, (uint32_t)C}, b0, nrows);
+            HIPCHK(hipMemcpyAsync(S.io.host_out + b0 * n, P->d_stage, (size_t)nrows * n * sizeof(double),
+                                  hipMemcpyDeviceToHost, S.stream));
+            HIPCHK(hipStreamSynchronize(S.stream));
+        } else {
+            permute_rows(P, 1, ring_view, RowView{S.io.dev_out, n, 0, (uint32_t)S.io.rows_out}, b0, nrows);
+        }
+    }
+    return RR_OK;
+}
+
+int session_launch_tick(rr_plan *P, int64_t tau)
+{
+    Session &S = P->ses;
+    const rr::HostPlan &H = P->h;
+    const int64_t n = H.n, dmax = H.depth - 1;
+    // active lags: tau - total < lag <= tau
+    const int64_t lag_lo = std::max<int64_t>(0, tau - S.total + 1), lag_hi = std::min<int64_t>(tau, dmax);
+    const int64_t p_lo = H.lag_start[lag_lo], p_hi = H.lag_start[lag_hi + 1];
+    if (p_hi <= p_lo) return RR_OK;
+    TickArgs &a = S.a;
+    a.p_lo = (int32_t)p_lo; a.p_hi = (int32_t)p_hi; a.tau = tau;
+    a.xc = P->d_x + (tau % 3) * n;
+    a.xa = P->d_x + ((tau + 2) % 3) * n;
+    a.xb = P->d_x + ((tau + 1) % 3) * n;
+    // sampling: every sample_every-th launch opens a bracket of kSampleGroup consecutive launches, so the
+    // event overhead (~5 us per pair) is amortised and the figure is comparable with rocprofv3's per-kernel time
+    const int64_t phase = S.max_samples > 0 ? P->prof_launches % P->sample_every : -1;
+    if (phase == 0 && !S.bracket_open && (size_t)P->prof_brackets < S.max_samples) {
+        HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets], S.stream));
+        S.bracket_open = true;
+    }
+    const dim3 g = grid1(p_hi - p_lo);
+    const bool one = S.nsub == 1;
+    if (S.mode == Mode::Unit) {
+        UnitTickArgs ua{};
+        ua.t = a; ua.hw_children = P->d_hwc; ua.qch = P->d_qch;
+        if (one) hipLaunchKernelGGL(k_tick_unit<true>, g, dim3(kBlock), 0, S.stream, ua);
+        else hipLaunchKernelGGL(k_tick_unit<false>, g, dim3(kBlock), 0, S.stream, ua);
+    } else if (S.mode == Mode::Rapid) {
+        if (one) hipLaunchKernelGGL((k_tick<true, true>), g, dim3(kBlock), 0, S.stream, a);
+        else hipLaunchKernelGGL((k_tick<true, false>), g, dim3(kBlock), 0, S.stream, a);
+    } else {
+        if (one) hipLaunchKernelGGL((k_tick<false, true>), g, dim3(kBlock), 0, S.stream, a);
+        else hipLaunchKernelGGL((k_tick<false, false>), g, dim3(kBlock), 0, S.stream, a);
+    }
+    if (S.bracket_open) {
+        S.bracket_reaches += p_hi - p_lo;
+        ++P->prof_samples;
+        if (P->prof_samples % kSampleGroup == 0) {
+            HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));
+            ++P->prof_brackets;
+            P->ev_reaches.push_back(S.bracket_reaches);
+            S.bracket_reaches = 0;
+            S.bracket_open = false;
+        }
+    }
+    ++P->prof_launches;
+    return RR_OK;
+}
+
+typedef void (*tile_kernel_t)(const TileArgs);
+
+// Tile = one position per thread; 16 waves per CU whose two record buffers fill the register file, as 1, 2 or 4 workgroups.
+tile_kernel_t tile_kernel(int threads, bool unit, bool sub)
+{
+#define RR_TILE_PICK(T_) (unit ? (sub ? (tile_kernel_t)k_tile<T_, true, true> : (tile_kernel_t)k_tile<T_, true, false>)   \
+                               : (sub ? (tile_kernel_t)k_tile<T_, false, true> : (tile_kernel_t)k_tile<T_, false, false>))
+    return threads == 256 ? RR_TILE_PICK(256) : (threads == 512 ? RR_TILE_PICK(512) : RR_TILE_PICK(1024));
+#undef RR_TILE_PICK
+}
+
+// Launch d of the time-tiled schedule: the tasks (tile, macro-chunk d - level) of every tile whose macro-chunk exists.
+// Tiles are stored by level, so they are one contiguous range; a tile with no active position returns at once.
+int session_launch_diag(rr_plan *P, int64_t d)
+{
+    Session &S = P->ses;
+    const rr::TilePlan &TP = P->tp;
+    const int64_t l_lo = std::max<int64_t>(0, d - (S.n_macro - 1)), l_hi = std::min<int64_t>(TP.n_levels - 1, d);
+    if (l_hi < l_lo) { ++P->prof_launches; return RR_OK; }
+    int64_t t_lo = TP.level_start[l_lo], t_hi = TP.level_start[l_hi + 1];
+    // tiles are sorted by their smallest lag inside a level; while the pipeline fills, the tiles of level 0 that
+    // have not started yet are a suffix of it
+    const int64_t K = S.KC * kRec;
+    if (l_lo == 0) {
+        const int64_t end0 = TP.level_start[1];
+        int64_t hi = std::min<int64_t>(t_hi, end0);
+        while (hi > t_lo && (d + 1) * K <= TP.tile_lag_lo[hi - 1]) --hi;
+        if (t_hi <= end0) t_hi = hi;     // only level 0 in this launch: trim; otherwise the idle ones just return
+    }
+    if (t_hi <= t_lo) { ++P->prof_launches; return RR_OK; }
+    TileArgs &w = S.ta;
+    w.diag = (int32_t)d; w.t_first = (int32_t)t_lo; w.t_last = (int32_t)t_hi - 1;
+    // every fourth launch is bracketed by HIP events, full or not (fill and drain launches run fewer tiles), so the
+    // sampled average is the average rocprofv3 reports for the kernel; the reach-ticks of a sample are those of the
+    // tiles it launched
+    const bool sample = S.max_samples > 0 && (P->prof_launches % 4) == 0 && (size_t)P->prof_brackets < S.max_samples;
+    if (sample) HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets], S.stream));
+    // one workgroup per resident slot (16 waves per CU); each walks its share of the launch's tiles
+    const dim3 g((unsigned)std::min<int64_t>(t_hi - t_lo, (int64_t)P->cu_count * (1024 / P->wave_threads)));
+    const size_t lds_bytes = tile_lds_bytes(P->wave_threads);
+    hipLaunchKernelGGL(tile_kernel(P->wave_threads, S.mode == Mode::Unit, S.nsub > 1), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
+    if (sample) {
+        HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));
+        P->ev_reaches.push_back((int64_t)(TP.tile_ptr[t_hi] - TP.tile_ptr[t_lo]) * K);
+        P->prof_samples += K;
+        ++P->prof_brackets;
+    }
+    ++P->prof_launches;
+    return RR_OK;
+}
+
+// Boundary inflow of a partitioned network: the ghost series (total sub-steps x ghosts, row = sub-step) is a matrix of
+// tick-rows like the lateral rows, and its columns become the records of the ghost positions by the same pass.
+void launch_ghost_permute(rr_plan *P, int64_t batch)
+{
+    Session &S = P->ses;
+    RecPermArgs ra{};
+    ra.rec = P->d_ring; ra.rec_chunks = Div32((uint32_t)S.rec_chunks); ra.n = P->n_ghost; ra.np = P->tp.np; ra.T = S.total; ra.total = S.total;
+    ra.batch = batch; ra.nsub = Div32(1u); ra.colmeta = P->d_ghostmeta; ra.scale = nullptr;
+    ra.rows = RowView{const_cast<double *>(S.ghost_series), P->n_ghost, 0, (uint32_t)S.total};
+    ra.factor = Div32(1u);
+    hipLaunchKernelGGL(k_rec_in<false>, dim3((unsigned)((P->n_ghost + kRecCols - 1) / kRecCols)), dim3(kRecThreads), 0, S.stream, ra);
+}
+
+typedef void (*rec_in_uh_t)(const RecPermArgs, const UhArgs);
+constexpr int kUhFusedMaxTaps = 64;
+int uh_padded_taps(int64_t n_ks) { return n_ks <= 16 ? 16 : (n_ks <= 48 ? 48 : 64); }
+rec_in_uh_t rec_in_uh_kernel(bool sub, int64_t n_ks)
+{
+    const int nk = uh_padded_taps(n_ks);
+#define RR_UHIN_PICK(NK_) (sub ? (rec_in_uh_t)k_rec_in_uh<true, NK_> : (rec_in_uh_t)k_rec_in_uh<false, NK_>)
+    return nk == 16 ? RR_UHIN_PICK(16) : (nk == 48 ? RR_UHIN_PICK(48) : RR_UHIN_PICK(64));
+#undef RR_UHIN_PICK
+}
+
+void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
+{
+    Session &S = P->ses;
+    const int64_t n = P->h.n;
+    RecPermArgs ra{};
+    ra.rec = P->d_ring; ra.rec_chunks = Div32((uint32_t)S.rec_chunks); ra.n = n; ra.np = P->tp.np; ra.T = S.T; ra.total = S.total; ra.batch = batch;
+    ra.nsub = Div32((uint32_t)S.nsub);
+    ra.colmeta = P->d_colmeta;
+    ra.scale = (in && S.mode == Mode::Rapid) ? P->d_c4_params : nullptr;
+    ra.rows = in ? RowView{const_cast<double *>(S.io.dev_in), n, 0, (uint32_t)S.io.rows_in}
+                 : RowView{S.io.dev_out, n, 0, (uint32_t)std::max<int64_t>(1, S.io.rows_out)};
+    ra.rows32 = in ? nullptr : S.io.dev_out32;
+    ra.factor = Div32((uint32_t)std::max<int64_t>(1, S.io.out_factor));
+    const dim3 g((unsigned)((n + kRecCols - 1) / kRecCols));
+    const bool sub = S.nsub > 1;
+    if (in && S.io.runoff) {
+        const dim3 gr((unsigned)((n + kRunoffInThreads - 1) / kRunoffInThreads), (unsigned)kRecBatch);
+        if (S.io.runoff->is_f32) hipLaunchKernelGGL(k_rec_in_runoff<float>, gr, dim3(kRunoffInThreads), 0, S.stream, ra, *S.io.runoff);
+        else hipLaunchKernelGGL(k_rec_in_runoff<double>, gr, dim3(kRunoffInThreads), 0, S.stream, ra, *S.io.runoff);
+    } else if (in && S.io.uh_kernel) {
+        UhArgs ua{S.io.uh_kernel, S.io.uh_state, (int32_t)S.io.uh_nks};
+        hipLaunchKernelGGL(rec_in_uh_kernel(sub, S.io.uh_nks), g, dim3(kUhInThreads), rec_in_uh_lds_bytes(uh_padded_taps(S.io.uh_nks)), S.stream, ra, ua);
+    } else if (in) {
+        if (sub) hipLaunchKernelGGL(k_rec_in<true>, g, dim3(kRecThreads), 0, S.stream, ra);
+        else hipLaunchKernelGGL(k_rec_in<false>, g, dim3(kRecThreads), 0, S.stream, ra);
+    } else if (ra.rows32) {
+        if (sub) hipLaunchKernelGGL((k_rec_out<true, true>), g, dim3(kRecThreads), 0, S.stream, ra);
+        else hipLaunchKernelGGL((k_rec_out<false, true>), g, dim3(kRecThreads), 0, S.stream, ra);
+    } else {
+        if (sub) hipLaunchKernelGGL((k_rec_out<true, false>), g, dim3(kRecThreads), 0, S.stream, ra);
+        else hipLaunchKernelGGL((k_rec_out<false, false>), g, dim3(kRecThreads), 0, S.stream, ra);
+    }
+}
+
+// Time-tiled schedule: batches of 128 tick-rows become records as soon as their rows are there and their ring slots
+// are free, launches run while their input is present, finished batches leave.
+int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, int64_t *export_ready)
+{
+    Session &S = P->ses;
+    const int64_t dmax = P->h.depth - 1, levels = P->tp.n_levels, K = S.KC * kRec;
+    const int64_t ticks_ready = std::min(rows_ready, S.T) * S.nsub;
+    for (;;) {
+        bool progressed = false;
+        // one batch of 128 tick-rows -> records; a record slot is recycled only after every tick-row it can hold has left.
+        // Lateral rows and boundary sub-steps (the ghost series of a partitioned network) advance separately: a ghost in a
+        // tile of level l at lag L is first read (l K + L) ticks into the schedule, so the boundary may trail the rows.
+        // Batch j writes, for a position of lag L, the records whose last tick-row lies in the batch: chunks up to
+        // (128 (j + 1) + L) / 16.  One ring revolution earlier that slot held the same position's tick-rows up to
+        // 128 (j + 1) - 16 rec_chunks + 15, whatever L is: those must have left.
+        auto slot_free = [&](int64_t j) {
+            const int64_t must_have_left = kRecRows * (j + 1) + kRec - kRec * S.rec_chunks;
+            return must_have_left <= 0 || S.ticks_stored >= std::min(S.total, must_have_left);
+        };
+        if (S.has_in && S.in_batches < S.n_in_batches && ticks_ready >= std::min(kRecRows * (S.in_batches + 1), S.total) && slot_free(S.in_batches)) {
+            launch_rec_permute(P, true, S.in_batches);
+            ++S.in_batches;
+            progressed = true;
+        }
+        if (P->n_ghost > 0 && S.ghost_batches < S.n_in_batches && (!S.has_in || S.ghost_batches < S.in_batches) &&      // after the lateral batch: that one writes zeros into the ghosts' records
+            ghost_ready >= std::min(kRecRows * (S.ghost_batches + 1), S.total) && slot_free(S.ghost_batches)) {
+            launch_ghost_permute(P, S.ghost_batches);
+            ++S.ghost_batches;
+            progressed = true;
+        }
+        auto loaded_ticks = [&](int64_t batches) { return batches >= S.n_in_batches ? S.total : std::max<int64_t>(0, kRecRows * batches - 15); };
+        const int64_t have = S.has_in ? loaded_ticks(S.in_batches) : S.total;
+        const int64_t have_ghost = P->n_ghost > 0 ? loaded_ticks(S.ghost_batches) : S.total;
+        S.rows_loaded = have / S.nsub;
+        // launch d runs macro-chunk d of the tiles of level 0: ticks below (d + 1) K need the tick-rows below that
+        int64_t launched = 0;
+        const int64_t batch = std::max<int64_t>(1, kRecRows / K);
+        while (S.diag < S.n_diags && launched < batch) {
+            const int64_t need_ticks = std::min((S.diag + 1) * K, S.total);
+            if (have < need_ticks) break;
+            if (have_ghost < std::min(std::max<int64_t>(0, (S.diag + 1) * K - S.ghost_slack), S.total)) break;
+            // the tasks of this launch overwrite records in place: nothing they write may still be waiting to leave from
+            // one ring revolution earlier (their chunks are at most (d + 1) KC - 1)
+            const int64_t top = std::min(S.diag + 1, S.n_macro) * S.KC - 1;
+            if (top >= S.rec_chunks && S.ticks_stored < std::min(S.total, kRec * (top - S.rec_chunks + 1))) break;
+            int rc = session_launch_diag(P, S.diag);
+            if (rc) return rc;
+            ++S.diag; ++launched;
+            progressed = true;
+        }
+        // the tiles of the last level have finished macro-chunk diag - levels; every other tile is further along
+        const int64_t m_done = S.diag - levels;
+        int64_t done = 0;
+        if (S.diag >= S.n_diags) done = S.total;
+        else if (m_done >= 0) done = std::max<int64_t>(0, (m_done + 1) * K - dmax);
+        done = std::min(done, S.total);
+        while (S.out_batches < S.n_out_batches && done >= std::min(kRecRows * (S.out_batches + 1), S.total) &&
+               (std::min(kRecRows * (S.out_batches + 1), S.total) + S.nsub - 1) / S.nsub <= S.out_limit) {
+            launch_rec_permute(P, false, S.out_batches);
+            ++S.out_batches;
+            S.ticks_stored = std::min(S.total, kRecRows * S.out_batches);
+            progressed = true;
+        }
+        if (!progressed) break;
+    }
+    S.rows_stored = S.ticks_stored / S.nsub;
+    if (S.diag >= S.n_diags) S.tau = S.total_ticks;
+    if (export_ready) {
+        const int64_t e = S.diag >= S.n_diags ? S.total : S.diag * K - S.export_skew;
+        *export_ready = std::max<int64_t>(0, std::min(e, S.total));
+    }
+    return RR_OK;
+}
+
+// Runs every tick whose inputs are present: lateral rows [0, rows_ready) and ghost sub-steps [0, ghost_ready).
+// On return *export_ready = number of leading sub-steps of the export series that are final.
+int session_advance(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, int64_t *export_ready)
+{
+    Session &S = P->ses;
+    if (!S.open) return fail(RR_E_STATE, "no routing call is open on this plan");
+    const int64_t n = P->h.n, dmax = P->h.depth - 1, C = std::max<int64_t>(1, P->chunk_rows);
+    if (export_ready) *export_ready = 0;
+    if (n == 0 || S.total == 0) { if (export_ready) *export_ready = S.total; return RR_OK; }
+    if (S.wave) return session_advance_tile(P, rows_ready, std::min(ghost_ready, S.total), export_ready);
+    rows_ready = std::min(rows_ready, S.T);
+    ghost_ready = std::min(ghost_ready, S.total);
+    // a ghost at lag L is read at tick tau for sub-step tau - L: ticks below ghost_ready + min lag are safe
+    const int64_t ghost_limit = (P->n_ghost == 0 || ghost_ready >= S.total) ? S.total_ticks
+                                                                            : ghost_ready + P->ghost_min_lag;
+    for (;;) {
+        bool progressed = false;
+        if (S.has_in && S.rows_loaded < rows_ready) {
+            const int64_t r1 = std::min(rows_ready, S.rows_loaded + C);
+            int rc = session_load_rows(P, S.rows_loaded, r1);
+            if (rc) return rc;
+            S.rows_loaded = r1;
+            progressed = true;
+        }
+        const int64_t have_rows = S.has_in ? S.rows_loaded : rows_ready;
+        const int64_t lat_limit = have_rows < S.T ? have_rows * S.nsub : S.total_ticks;
+        // without lateral rows to pace the loop, run the ticks in chunk-sized batches so finished rows leave the ring
+        const int64_t batch_limit = S.has_in ? S.total_ticks : S.tau + C * S.nsub;
+        const int64_t tau_end = std::min(std::min(lat_limit, ghost_limit), std::min(batch_limit, S.total_ticks));
+        for (; S.tau < tau_end; ++S.tau) {
+            int rc = session_launch_tick(P, S.tau);
+            if (rc) return rc;
+            progressed = true;
+        }
+        // row t is final once the outlet-most reaches passed it: tick (t+1)*nsub - 1 + dmax
+        int64_t done = S.tau >= S.total_ticks ? S.T : (S.tau - dmax < 0 ? 0 : (S.tau - dmax) / S.nsub);
+        done = std::min(done, S.T);
+        if (done > S.rows_stored) {
+            int rc = session_store_rows(P, S.rows_stored, done);
+            if (rc) return rc;
+            S.rows_stored = done;
+            progressed = true;
+        }
+        if (!progressed) break;
+    }
+    if (export_ready) {
+        const int64_t e = S.tau >= S.total_ticks ? S.total : S.tau - P->export_max_lag;
+        *export_ready = std::max<int64_t>(0, std::min(e, S.total));
+    }
+    return RR_OK;
+}
+
+int session_end(rr_plan *P)
+{
+    Session &S = P->ses;
+    if (!S.open) return fail(RR_E_STATE, "no routing call is open on this plan");
+    const bool complete = P->h.n == 0 || S.total == 0 || (S.tau >= S.total_ticks && S.rows_stored >= S.T);
+    S.open = false;
+    if (!complete) return fail(RR_E_STATE, "routing call closed before all of its time steps were routed");
+    if (P->h.n == 0 || S.total == 0) return RR_OK;
+    if (S.bracket_open) P->prof_samples -= P->prof_samples % kSampleGroup;   // incomplete bracket: not counted
+    HIPCHK(hipEventRecord(P->ev_last, S.stream));
+    HIPCHK(hipGetLastError());
+#ifdef RR_WAVE_TRACE
+    if (S.wave && S.ta.trace) {
+        std::vector<long long> hbuf(16 * 4096);
+        (void)hipStreamSynchronize(S.stream);
+        (void)hipMemcpy(hbuf.data(), S.ta.trace, hbuf.size() * 8, hipMemcpyDeviceToHost);
+        if (FILE *f = fopen(getenv("RR_WAVE_TRACE_FILE") ? getenv("RR_WAVE_TRACE_FILE") : "/tmp/wave_trace.txt", "w")) {
+            for (int b = 0; b < 4096; ++b)
+                if (hbuf[16 * b]) { fprintf(f, "%d", b); for (int k = 0; k < 15; ++k) fprintf(f, " %lld", hbuf[16 * b + k]); fprintf(f, "\n"); }
+            fclose(f);
+        }
+    }
+#endif
+    return RR_OK;
+}
+
+// The whole call at once: what the reference's kernel boundary does.
+int route_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io, hipStream_t stream)
+{
+    if (P->n_ghost > 0 || P->n_export > 0)
+        return fail(RR_E_STATE, "plan has boundary reaches: use rr_stream_begin / rr_stream_advance / rr_stream_end");
+    int rc = session_begin(P, mode, T, nsub, io, stream, nullptr, nullptr);
+    if (rc) return rc;
+    rc = session_advance(P, T, T * nsub, nullptr);
+    if (rc) { P->ses.open = false; return rc; }
+    return session_end(P);
+}
+
+int check_route_args(rr_plan *P, bool need_c4, int64_t T, int64_t nsub)
+{
+    int rc = need_device(P);
+    if (rc) return rc;
+    if (!P->coeffs_set) return fail(RR_E_STATE, "route called before rr_plan_set_coeffs");
+    if (need_c4 && !P->has_c4) return fail(RR_E_STATE, "rr_rapid_route needs c4_dt (rr_plan_set_coeffs got NULL)");
+    if (T < 0 || nsub < 1) return fail(RR_E_INVALID, "route: need num steps >= 0 and sub-steps >= 1");
+    if (nsub > 0x7FFFFFFF) return fail(RR_E_INVALID, "route: too many sub-steps");
+    return RR_OK;
+}
+
+int launch_state_in(rr_plan *P, Mode mode, const double *d_q, hipStream_t stream)
+{
+    const int64_t n = P->h.n;
+    if (use_wave(P, mode)) {
+        const int64_t np = P->tp.np;
+        hipLaunchKernelGGL(k_tile_state_in, grid1(np), dim3(kBlock), 0, stream, P->d_sq, P->d_ss, P->d_si, d_q, P->d_tperm,
+                           P->d_cfirst, P->d_ccnt, (int32_t)np);
+        return RR_OK;
+    }
+    hipLaunchKernelGGL(k_state_in, grid1(n), dim3(kBlock), 0, stream, P->d_x, P->d_x + n, P->d_x + 2 * n, d_q,
+                       P->d_perm, (int32_t)n);
+    return RR_OK;
+}
+
+void launch_state_out(rr_plan *P, Mode mode, double *d_q, int64_t total, hipStream_t stream)
+{
+    const int64_t n = P->h.n;
+    if (use_wave(P, mode)) {
+        hipLaunchKernelGGL(k_tile_state_out, grid1(n), dim3(kBlock), 0, stream, d_q, (const double *)P->d_sq, P->d_tinv,
+                           (int32_t)n);
+        return;
+    }
+    hipLaunchKernelGGL(k_state_out, grid1(n), dim3(kBlock), 0, stream, d_q, (const double *)P->d_x, n,
+                       P->d_lag, P->d_inv, (int32_t)n, total);
+}
+
+void parallel_copy(double *dst, const double *src, size_t count, int threads, std::vector<std::thread> &pool)
+{
+    const size_t per = ((count + threads - 1) / threads + 511) / 512 * 512;
+    for (int t = 0; t < threads; ++t) {
+        const size_t o = (size_t)t * per;
+        if (o >= count) break;
+        pool.emplace_back([=] { std::memcpy(dst + o, src + o, std::min(per, count - o) * sizeof(double)); });
+    }
+}
+
+int host_pipe_prepare(rr_plan *P)
+{
+    HostPipe &H = P->pipe;
+    const int64_t n = P->h.n;
+    // chunks of about half a gigabyte: long enough for the DMA engines to reach their rate, short enough to pipeline
+    H.chunk_rows = std::max<int64_t>(16, std::min<int64_t>(4096, ((int64_t{1} << 29) / (n * 8) + 15) / 16 * 16));
+    if (n * 8 * 64 <= (int64_t{1} << 30)) H.chunk_rows = std::max<int64_t>(H.chunk_rows, 64);
+    H.ring_chunks = std::max<int64_t>(8, (2 * kRecRows + 15) / H.chunk_rows + 6);      // a batch of 128 rows + its 15-row overlap stays readable
+    const int64_t pin_need = H.chunk_rows * n, dev_need = H.ring_chunks * H.chunk_rows * n;
+    if (H.pin_cap < pin_need || H.dev_cap < dev_need) {
+        H.destroy();
+        for (int k = 0; k < HostPipe::kPinned; ++k) {
+            if (hipHostMalloc((void **)&H.pin_in[k], (size_t)pin_need * 8, hipHostMallocDefault) != hipSuccess ||
+                hipHostMalloc((void **)&H.pin_out[k], (size_t)pin_need * 8, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError(); H.destroy();
+                return fail(RR_E_ALLOC, "host pipeline: pinned staging buffers could not be allocated");
+            }
+        }
+        if (hipMalloc((void **)&H.dev_in, (size_t)dev_need * 8) != hipSuccess || hipMalloc((void **)&H.dev_out, (size_t)dev_need * 8) != hipSuccess) {
+            (void)hipGetLastError(); H.destroy();
+            return fail(RR_E_ALLOC, "host pipeline: device staging rings could not be allocated");
+        }
+        H.pin_cap = pin_need; H.dev_cap = dev_need;
+    }
+    if (!H.s_h2d) { HIPCHK(hipStreamCreateWithFlags(&H.s_h2d, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&H.s_d2h, hipStreamNonBlocking)); }
+    return RR_OK;
+}
+
+// Routes T rows between host arrays (host_in may be NULL: channel-only) through the pipeline above.  State arrays are
+// already on the device and the tile state is loaded; returns when host_out is complete.
+int route_host_pipelined(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const double *host_in, double *host_out, hipStream_t stream)
+{
+    int rc = host_pipe_prepare(P);
+    if (rc) return rc;
+    HostPipe &H = P->pipe;
+    constexpr int kPinned = HostPipe::kPinned;
+    const int64_t n = P->h.n, C = H.chunk_rows, NR = H.ring_chunks, nchunks = (T + C - 1) / C;
+    auto grow = [&](std::vector<hipEvent_t> &v, size_t count) {
+        while (v.size() < count) { hipEvent_t e; if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false; v.push_back(e); }
+        return true;
+    };
+    if (!grow(H.ev_h2d, (size_t)nchunks) || !grow(H.ev_d2h, (size_t)nchunks) || !grow(H.ev_adv, (size_t)4 * nchunks + 64))
+        return fail(RR_E_HIP, "host pipeline: event creation failed");
+    Rows io;
+    io.dev_in = host_in ? H.dev_in : nullptr; io.rows_in = NR * C; io.dev_out = H.dev_out; io.rows_out = NR * C;
+    rc = session_begin(P, mode, T, nsub, io, stream, nullptr, nullptr);
+    if (rc) return rc;
+    Session &S = P->ses;
+    auto rows_of = [&](int64_t c) { return std::min(C, T - c * C); };
+    std::vector<int64_t> adv_loaded;      // rows that were records after the a-th advance (ev_adv[a] marks it on the stream)
+    int64_t filled = 0, h2d_issued = 0, d2h_issued = 0, copied_out = 0;      // chunks through each stage
+    std::vector<std::thread> pool;
+    auto bail = [&](int code, const std::string &msg) {
+        for (auto &t : pool) t.join();
+        (void)hipStreamSynchronize(H.s_h2d); (void)hipStreamSynchronize(H.s_d2h); (void)hipStreamSynchronize(stream);
+        P->ses.open = false;
+        return fail(code, msg);
+    };
+#define RR_PIPE(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return bail(RR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
+    // One iteration: the copy threads fill the next pinned input chunk and empty the oldest downloaded output chunk while
+    // this thread enqueues the upload of the chunk filled last time, the routing it enables and the downloads it completes.
+    while (copied_out < nchunks) {
+        pool.clear();
+        bool progressed = false;
+        const bool fill = host_in && filled < nchunks && filled < h2d_issued + kPinned;
+        if (fill) {
+            if (filled >= kPinned) RR_PIPE(hipEventSynchronize(H.ev_h2d[filled - kPinned]));      // the buffer's previous chunk has left
+            parallel_copy(H.pin_in[filled % kPinned], host_in + filled * C * n, (size_t)(rows_of(filled) * n), HostPipe::kCopyThreads, pool);
+        }
+        bool empty = false;
+        if (copied_out < d2h_issued) {      // only a download that HAS arrived: waiting for one here would stall the uploads behind it
+            const hipError_t q = hipEventQuery(H.ev_d2h[copied_out]);
+            if (q == hipSuccess) empty = true;
+            else if (q != hipErrorNotReady) return bail(RR_E_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+        }
+        if (empty) {
+            parallel_copy(host_out + copied_out * C * n, H.pin_out[copied_out % kPinned], (size_t)(rows_of(copied_out) * n), HostPipe::kCopyThreads, pool);
+        }
+        // upload of a chunk filled earlier, into the ring slot whose previous occupant has become records
+        if (host_in && h2d_issued < filled) {
+            const int64_t c = h2d_issued;
+            bool slot_ready = true;
+            if (c >= NR) {
+                const int64_t need = std::min(T, (c - NR + 1) * C);
+                size_t a = 0;
+                while (a < adv_loaded.size() && adv_loaded[a] < need) ++a;
+                if (a < adv_loaded.size()) RR_PIPE(hipStreamWaitEvent(H.s_h2d, H.ev_adv[a], 0));
+                else slot_ready = false;      // the routing has to get further first (see the advance below)
+            }
+            if (slot_ready) {
+                RR_PIPE(hipMemcpyAsync(H.dev_in + (c % NR) * C * n, H.pin_in[c % kPinned], (size_t)(rows_of(c) * n) * 8, hipMemcpyHostToDevice, H.s_h2d));
+                RR_PIPE(hipEventRecord(H.ev_h2d[c], H.s_h2d));
+                RR_PIPE(hipStreamWaitEvent(stream, H.ev_h2d[c], 0));
+                ++h2d_issued;
+                progressed = true;
+            }
+        }
+        // route what has arrived; output rows land in the device ring at row % (NR * C), so no batch may be written before
+        // the rows it overwrites are on their way to the host
+        if (S.tau < S.total_ticks || S.rows_stored < T) {
+            const int64_t ready = host_in ? std::min(T, h2d_issued * C) : T;
+            S.out_limit = std::min(T, d2h_issued * C) + NR * C;
+            if (d2h_issued > 0) RR_PIPE(hipStreamWaitEvent(stream, H.ev_d2h[d2h_issued - 1], 0));
+            const int64_t before_diag = S.diag, before_in = S.in_batches, before_out = S.out_batches;
+            rc = session_advance(P, ready, S.total, nullptr);
+            if (rc) { for (auto &t : pool) t.join(); P->ses.open = false; return rc; }
+            if (S.diag != before_diag || S.in_batches != before_in || S.out_batches != before_out) {
+                progressed = true;
+                if (adv_loaded.size() < H.ev_adv.size() - 1) {
+                    RR_PIPE(hipEventRecord(H.ev_adv[adv_loaded.size()], stream));
+                    adv_loaded.push_back(S.rows_loaded);
+                }
+            }
+        }
+        // downloads of the output chunks that are complete; a pinned buffer is free once the copy threads have emptied it
+        while (d2h_issued < nchunks && std::min(T, (d2h_issued + 1) * C) <= S.rows_stored && d2h_issued < copied_out + kPinned) {
+            const int64_t k = d2h_issued;
+            RR_PIPE(hipEventRecord(H.ev_adv.back(), stream));      // everything enqueued so far on the routing stream
+            RR_PIPE(hipStreamWaitEvent(H.s_d2h, H.ev_adv.back(), 0));
+            RR_PIPE(hipMemcpyAsync(H.pin_out[k % kPinned], H.dev_out + (k % NR) * C * n, (size_t)(rows_of(k) * n) * 8, hipMemcpyDeviceToHost, H.s_d2h));
+            RR_PIPE(hipEventRecord(H.ev_d2h[k], H.s_d2h));
+            ++d2h_issued;
+            progressed = true;
+        }
+        for (auto &t : pool) t.join();
+        if (fill) ++filled;
+        if (empty) ++copied_out;
+        if (!progressed && !fill && !empty) {
+            if (copied_out < d2h_issued) RR_PIPE(hipEventSynchronize(H.ev_d2h[copied_out]));      // nothing else to do but wait for it
+            else return bail(RR_E_STATE, "host pipeline: no stage can make progress");
+        }
+    }
+#undef RR_PIPE
+    S.out_limit = std::numeric_limits<int64_t>::max();
+    return session_end(P);
+}
+
+int rapid_like(rr_plan *P, Mode mode, double *q_t, const Rows &io_in, int64_t T, int64_t nsub, hipStream_t stream,
+               bool q_on_host)
+{
+    const int64_t n = P->h.n;
+    if (n == 0 || T == 0) return RR_OK;
+    const Rows &io = io_in;
+    const bool host_rows = io.host_in != nullptr || io.host_out != nullptr;
+    // host rows reach the time-tiled kernel through the PCIe pipeline's device rings; where it does not apply they are
+    // routed chunk by chunk by the streaming kernel
+    if (!decide_wave(P, mode, T * nsub, false) && host_rows) decide_wave(P, mode, T * nsub, true);
+    const bool piped = host_rows && P->wave_now;
+    double *d_q = q_t;
+    double *tmp = nullptr;
+    if (q_on_host) {
+        int rc = dev_alloc(&tmp, n);
+        if (rc) return rc;
+        d_q = tmp;
+        hipError_t e = hipMemcpyAsync(d_q, q_t, n * sizeof(double), hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) { (void)hipFree(tmp); return fail(RR_E_HIP, hipGetErrorString(e)); }
+    }
+    int rc = launch_state_in(P, mode, d_q, stream);
+    if (rc == RR_OK) rc = piped ? route_host_pipelined(P, mode, T, nsub, io.host_in, io.host_out, stream) : route_core(P, mode, T, nsub, io, stream);
+    if (rc == RR_OK) {
+        launch_state_out(P, mode, d_q, T * nsub, stream);
+        if (q_on_host) {
+            hipError_t e = hipMemcpyAsync(q_t, d_q, n * sizeof(double), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) rc = fail(RR_E_HIP, hipGetErrorString(e));
+        }
+    }
+    if (tmp) { (void)hipStreamSynchronize(stream); (void)hipFree(tmp); }
+    return rc;
+}
+
+// UnitMuskingum state (channel discharge and full discharge of the reaches that have upstream reaches) into the layout of the
+// kernel this call runs, and back.
+int unit_state_in(rr_plan *P, const double *d_qch, const double *d_qfull, hipStream_t stream)
+{
+    const int64_t n = P->h.n, ni = (int64_t)P->h.inner_pos.size();
+    hipError_t e0 = hipSuccess;
+    if (use_wave(P, Mode::Unit)) {   // q_full / q_ch scattered to params order (zeros on headwaters), then gathered position by position
+        e0 = hipMemsetAsync(P->d_full, 0, n * sizeof(double), stream);
+        if (e0 == hipSuccess) e0 = hipMemsetAsync(P->d_chan, 0, n * sizeof(double), stream);
+        if (e0 == hipSuccess && ni > 0)
+            hipLaunchKernelGGL(k_unit_scatter, grid1(ni), dim3(kBlock), 0, stream, P->d_full, P->d_chan, d_qfull, d_qch, P->d_inner_idx, (int32_t)ni);
+        if (e0 == hipSuccess)
+            hipLaunchKernelGGL(k_tile_unit_state_in, grid1(P->tp.np), dim3(kBlock), 0, stream, P->d_sq, P->d_ss, P->d_si, P->d_sqch,
+                               (const double *)P->d_full, (const double *)P->d_chan, P->d_tperm, P->d_cfirst, P->d_ccnt, (int32_t)P->tp.np);
+    } else {
+        e0 = hipMemsetAsync(P->d_x, 0, 3 * n * sizeof(double), stream);
+        if (e0 == hipSuccess && ni > 0)
+            hipLaunchKernelGGL(k_unit_state_in, grid1(ni), dim3(kBlock), 0, stream, P->d_x, P->d_x + n, P->d_x + 2 * n,
+                               P->d_qch, d_qch, d_qfull, P->d_inner_pos, (int32_t)ni);
+    }
+    return e0 == hipSuccess ? RR_OK : fail(RR_E_HIP, hipGetErrorString(e0));
+}
+
+void unit_state_out(rr_plan *P, double *d_qch, double *d_qfull, int64_t total, hipStream_t stream)
+{
+    const int64_t n = P->h.n, ni = (int64_t)P->h.inner_pos.size();
+    if (ni == 0) return;
+    if (use_wave(P, Mode::Unit))
+        hipLaunchKernelGGL(k_tile_unit_state_out, grid1(ni), dim3(kBlock), 0, stream, d_qch, d_qfull,
+                           (const double *)P->d_sq, (const double *)P->d_sqch, P->d_inner_idx, P->d_tinv, (int32_t)ni);
+    else
+        hipLaunchKernelGGL(k_unit_state_out, grid1(ni), dim3(kBlock), 0, stream, d_qch, d_qfull,
+                           (const double *)P->d_x, n, (const double *)P->d_qch, P->d_lag, P->d_inner_pos, (int32_t)ni, total);
+}
+
+int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io_in, int64_t T, int64_t nsub,
+              hipStream_t stream, bool q_on_host, double *d_q_final = nullptr, double *uh_state_inout = nullptr)
+{
+    const int64_t n = P->h.n, ni = (int64_t)P->h.inner_pos.size();
+    if (n == 0 || T == 0) return RR_OK;
+    const Rows &io = io_in;
+    const bool host_rows = io.host_in != nullptr || io.host_out != nullptr;
+    if (!decide_wave(P, Mode::Unit, T * nsub, false) && host_rows) decide_wave(P, Mode::Unit, T * nsub, true);
+    const bool piped = host_rows && P->wave_now;
+    double *d_qch = q_ch, *d_qfull = q_full, *tmp = nullptr;
+    if (q_on_host) {
+        int rc = dev_alloc(&tmp, 2 * std::max<int64_t>(ni, 1));
+        if (rc) return rc;
+        d_qch = tmp; d_qfull = tmp + std::max<int64_t>(ni, 1);
+        hipError_t e = hipMemcpyAsync(d_qch, q_ch, ni * sizeof(double), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_qfull, q_full, ni * sizeof(double), hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) { (void)hipFree(tmp); return fail(RR_E_HIP, hipGetErrorString(e)); }
+    }
+    const bool wave = use_wave(P, Mode::Unit);
+    int rc = unit_state_in(P, d_qch, d_qfull, stream);
+    if (rc) { if (tmp) (void)hipFree(tmp); return rc; }
+    if (rc == RR_OK) rc = piped ? route_host_pipelined(P, Mode::Unit, T, nsub, io.host_in, io.host_out, stream) : route_core(P, Mode::Unit, T, nsub, io, stream);
+    if (rc == RR_OK && wave && d_q_final)      // every reach: a headwater's state is its last lateral inflow, an inner reach's q_full
+        hipLaunchKernelGGL(k_tile_state_out, grid1(n), dim3(kBlock), 0, stream, d_q_final, (const double *)P->d_sq, P->d_tinv, (int32_t)n);
+    if (rc == RR_OK && io.uh_kernel && uh_state_inout) {      // carry-over state of the fused convolution, in place, after every batch has read the old one
+        const dim3 gt((unsigned)((n + kUhTailThreads - 1) / kUhTailThreads));
+        const int32_t nks = (int32_t)io.uh_nks;
+        if (nks <= 16) hipLaunchKernelGGL(k_uh_tail<16>, gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in, T, nks, n);
+        else if (nks <= 48) hipLaunchKernelGGL(k_uh_tail<48>, gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in, T, nks, n);
+        else hipLaunchKernelGGL(k_uh_tail<0>, gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in, T, nks, n);
+    }
+    if (rc == RR_OK && ni > 0) {
+        unit_state_out(P, d_qch, d_qfull, T * nsub, stream);
+        if (q_on_host) {
+            hipError_t e = hipMemcpyAsync(q_ch, d_qch, ni * sizeof(double), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(q_full, d_qfull, ni * sizeof(double), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) rc = fail(RR_E_HIP, hipGetErrorString(e));
+        }
+    }
+    if (tmp) { (void)hipStreamSynchronize(stream); (void)hipFree(tmp); }
+    return rc;
+}
+
+int uh_convolve_core(const double *d_kernel, double *d_state, const double *d_lateral, double *d_out, int64_t T,
+                     int64_t n_ks, int64_t n, hipStream_t stream)
+{
+    if (T < 1 || n_ks < 1 || n < 0) return fail(RR_E_INVALID, "rr_uh_convolve: need T >= 1, n_ks >= 1, n >= 0");
+    if (n == 0) return RR_OK;
+    if (n_ks > 0x7FFFFFFF || T > 0x7FFFFFFFLL * 8) return fail(RR_E_INVALID, "rr_uh_convolve: sizes out of range");
+    constexpr int TB = 8;
+    if (n_ks <= 57 && T >= 64) {
+        // long series: register-resident taps + LDS window; split time only as far as needed to fill the chip
+        const int64_t blocks_x = (n + kUhThreads - 1) / kUhThreads;
+        int64_t segs = std::max<int64_t>(1, std::min<int64_t>(T / 256, (2048 + blocks_x - 1) / blocks_x));
+        const int64_t seg_rows = ((T + segs - 1) / segs + 63) / 64 * 64;      // segments start at multiples of every NK
+        segs = (T + seg_rows - 1) / seg_rows;
+        dim3 g((unsigned)blocks_x, (unsigned)segs);
+#define RR_UH_LAUNCH(NK_, NT_, R_, D_)                                                                             \
+        do {                                                                                                       \
+            const size_t lds = (size_t)NK_ * kUhThreads * sizeof(double);                                          \
+            (void)hipFuncSetAttribute((const void *)k_uh_convolve_ring<NK_, NT_, R_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_uh_convolve_ring<NK_, NT_, R_, D_>), g, dim3(kUhThreads), lds, stream, d_kernel, (const double *)d_state,     \
+                               d_lateral, d_out, T, (int32_t)n_ks, n, seg_rows);                                   \
+        } while (0)
+#define RR_UH_LAUNCH_X(...) RR_UH_LAUNCH(__VA_ARGS__)
+        if (n_ks <= 5) RR_UH_LAUNCH(8, 5, 4, 2);            // NK >= NT + R - 1 window slots
+        else if (n_ks <= 13) RR_UH_LAUNCH(16, 13, 4, 2);
+        else if (n_ks <= 24) RR_UH_LAUNCH(32, 24, 8, 2);
+        else if (n_ks <= 29) RR_UH_LAUNCH(32, 29, 4, 2);
+        else if (n_ks <= 48) RR_UH_LAUNCH_X(RR_UH48);
+        else RR_UH_LAUNCH(64, 57, 8, 2);
+#undef RR_UH_LAUNCH
+#undef RR_UH_LAUNCH_X
+    } else {
+        dim3 g((unsigned)((n + kBlock - 1) / kBlock), (unsigned)((T + TB - 1) / TB));
+        hipLaunchKernelGGL(k_uh_convolve<TB>, g, dim3(kBlock), 0, stream, d_kernel, (const double *)d_state, d_lateral,
+                           d_out, T, (int32_t)n_ks, n);
+    }
+    // carry-over state, in place, after the rows above have read the old one (same stream)
+    const dim3 gt((unsigned)((n + kUhTailThreads - 1) / kUhTailThreads));
+    if (n_ks <= 16) hipLaunchKernelGGL(k_uh_tail<16>, gt, dim3(kUhTailThreads), 0, stream, d_kernel, d_state, d_lateral, T, (int32_t)n_ks, n);
+    else if (n_ks <= 48) hipLaunchKernelGGL(k_uh_tail<48>, gt, dim3(kUhTailThreads), 0, stream, d_kernel, d_state, d_lateral, T, (int32_t)n_ks, n);
+    else hipLaunchKernelGGL(k_uh_tail<0>, gt, dim3(kUhTailThreads), 0, stream, d_kernel, d_state, d_lateral, T, (int32_t)n_ks, n);
+    HIPCHK(hipGetLastError());
+    return RR_OK;
+}
+
+}  // namespace

@@ -1,0 +1,273 @@
+// rr_kernels_rec.hpp -- the record passes: params-order rows <-> tick-indexed records, with the fused float32 / convolution forms, and the stand-alone resample-cast.
+// Part of the one translation unit rr_engine.hip builds (included from there, in order; not a stand-alone header).
+#pragma once
+
+namespace {
+
+// ---- record permutation (one pass each way), see k_tile ----
+// Column i of the params-order rows is position p = inv[i] with lag L = 16 * sh + o.  Tick-row r of that column (tick-row =
+// routing sub-step: runoff row r / nsub, sub-step r % nsub) is slot (r + L) % 16 of record (r + L) / 16, so the 128 tick-rows
+// [128 j - o, 128 j + 128 - o) are exactly the eight records 8 j + sh .. 8 j + sh + 7.  k_rec_in reads the runoff rows
+// behind the 143 tick-rows [128 j - 15, 128 j + 128) of a 32-column tile coalesced into LDS (all loads in flight before the
+// first LDS write) and writes eight whole 128-byte records per column (8 lanes x 16 B per record), every sub-step slot of a
+// row holding the row's lateral value; k_rec_out reads nine records per column the same way and writes the tile's rows of
+// the batch coalesced: the slot of a row's LAST sub-step holds the row's mean discharge.
+#ifndef RR_REC_BATCH
+#define RR_REC_BATCH 8
+#define RR_REC_COLS 32
+#endif
+#ifndef RR_REC_THREADS
+#define RR_REC_THREADS 256
+#endif
+constexpr int kRecCols = RR_REC_COLS, kRecBatch = RR_REC_BATCH, kRecThreads = RR_REC_THREADS;
+constexpr int kRecRows = 16 * kRecBatch;    // tick-rows of one batch
+
+struct RecPermArgs {
+    double *rec;
+    Div32 rec_chunks;
+    int64_t n, np, T, total, batch;   // T runoff rows, total = T * nsub tick-rows
+    Div32 nsub;
+    const int2 *colmeta;      // per params column: {position, lag}
+    const double *scale;      // c4dt in PARAMS order (RapidMuskingum: the ring holds c4dt * lateral) or NULL
+    RowView rows;             // params-order rows (source of k_rec_in, destination of k_rec_out)
+    float *rows32;            // k_rec_out: float32 destination with `factor` rows averaged (router post-processing), or NULL
+    Div32 factor;
+};
+
+constexpr int kRecTileRows = 16 * kRecBatch + 15;      // tick-rows behind one batch of records
+constexpr int kRecTileLd = kRecCols + 1;
+
+// Second half of the in-pass: the LDS tile (row = runoff row - row_first, kRecTileLd doubles per row) becomes records.
+template <bool SUB, int THREADS = kRecThreads>
+__device__ __forceinline__ void write_records(const RecPermArgs &a, const double *tile, int64_t col0, int64_t tick_first, int64_t row_first)
+{
+    constexpr int R = kRecTileRows;
+    const int tid = threadIdx.x;
+    constexpr int IT = kRecCols * kRecBatch * 8 / THREADS;
+    int2 meta[IT];
+    double f[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {     // all metadata loads first: they are independent
+        const int64_t i = col0 + (it * THREADS + tid) / (8 * kRecBatch);
+        meta[it] = i < a.n ? a.colmeta[i] : make_int2(-1, 0);
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int64_t i = col0 + (it * THREADS + tid) / (8 * kRecBatch);
+        f[it] = (a.scale && i < a.n) ? a.scale[i] : 1.0;
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int piece = it * THREADS + tid;       // (column, record, 16-byte part): 8 consecutive lanes = one record
+        const int c = piece / (8 * kRecBatch), k = (piece >> 3) % kRecBatch, part = piece & 7;
+        const int32_t p = meta[it].x;
+        if (p < 0) continue;
+        const int32_t lag = meta[it].y;
+        const int o = lag & 15;
+        const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)(lag >> 4) + k;
+        const int r = 15 - o + 16 * k + 2 * part;       // tick-row tick_first + r
+        double v0, v1;
+        if (SUB) {
+            const int64_t t0 = tick_first + r, t1 = t0 + 1;
+            uint32_t s;
+            const int r0 = t0 < 0 ? 0 : (int)((int64_t)a.nsub.div((uint32_t)t0, s) - row_first);
+            const int r1 = t1 < 0 ? 0 : (int)((int64_t)a.nsub.div((uint32_t)t1, s) - row_first);
+            v0 = tile[min(r0, R - 1) * kRecTileLd + c] * f[it]; v1 = tile[min(r1, R - 1) * kRecTileLd + c] * f[it];
+        } else {
+            v0 = tile[r * kRecTileLd + c] * f[it]; v1 = tile[(r + 1) * kRecTileLd + c] * f[it];
+        }
+        double2 *dst = reinterpret_cast<double2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.np + p) * kRec) + part;
+        *dst = make_double2(v0, v1);
+    }
+}
+
+template <bool SUB>
+__global__ __launch_bounds__(kRecThreads) void k_rec_in(const RecPermArgs a)
+{
+    constexpr int R = kRecTileRows;
+    __shared__ double tile[R * kRecTileLd];
+    const int tid = threadIdx.x;
+    const int64_t col0 = (int64_t)blockIdx.x * kRecCols;
+    const int64_t tick_first = kRecRows * a.batch - 15;                 // may be negative in the first batch
+    uint32_t sub_unused;
+    const int64_t row_first = SUB ? (int64_t)a.nsub.div((uint32_t)(tick_first < 0 ? 0 : tick_first), sub_unused) : tick_first;
+    {   // all row loads in flight first (branch-free: out-of-range rows/columns are clamped and zeroed afterwards)
+        constexpr int RPT = (R + kRecThreads / kRecCols - 1) / (kRecThreads / kRecCols);
+        const int c = tid % kRecCols, r0 = tid / kRecCols;
+        const int64_t i = min(col0 + c, a.n - 1);
+        const int need = SUB ? (int)((uint32_t)(R - 1) / a.nsub.d) + 2 : R;     // runoff rows behind the batch's tick-rows
+        double v[RPT];
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int64_t t = row_first + min(r0 + q * (kRecThreads / kRecCols), need - 1);
+            v[q] = a.rows.row(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t))[i];
+        }
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int r = r0 + q * (kRecThreads / kRecCols);
+            const int64_t t = row_first + r;
+            if (r < R) tile[r * kRecTileLd + c] = (t >= 0 && t < a.T && col0 + c < a.n) ? v[q] : 0.0;
+        }
+    }
+    __syncthreads();
+    write_records<SUB>(a, tile, col0, tick_first, row_first);
+}
+
+// The in-pass with the unit-hydrograph convolution fused in (UnitHydrograph.py:93-107, direct form): the tile is COMPUTED
+// from the runoff-depth rows instead of loaded, so the convolved lateral never exists as (T, n) rows in HBM (written by the
+// convolution kernel, read again by k_rec_in: 16 B per value).  The block loads the depth rows behind its 143 tick-rows plus
+// the n_ks - 1 before them and the kernel's taps into LDS; thread (column, group of 18 rows) pulls its window of 18 + NK - 1
+// depth values into registers and accumulates 18 outputs x NK taps with static indices (NK = n_ks padded with zero taps);
+// the outputs replace the depth tile in LDS and leave as records.  out[t] = [t < n_ks] state[t] + sum_k kernel[k] depth[t - k].
+struct UhArgs {
+    const double *kernel, *state;     // (n_ks, n) taps and carried-in state, params order
+    int32_t n_ks;
+};
+constexpr int kUhInThreads = 256;       // 8 groups of rows x 32 columns: 18 outputs per thread, windows of 18 + NK - 1 depth values (512 threads x 9 rows: 20 % slower)
+constexpr int kUhRowsPerThread = (kRecTileRows + kUhInThreads / kRecCols - 1) / (kUhInThreads / kRecCols);
+constexpr size_t rec_in_uh_lds_bytes(int nk) { return (size_t)((kRecTileRows + nk - 1) + nk) * kRecTileLd * sizeof(double); }
+
+template <bool SUB, int NK>
+__global__ __launch_bounds__(kUhInThreads) void k_rec_in_uh(const RecPermArgs a, const UhArgs u)
+{
+    constexpr int R = kRecTileRows, G = kUhInThreads / kRecCols, RP = kUhRowsPerThread, W = RP + NK - 1;
+    extern __shared__ __attribute__((aligned(16))) double uh_lds[];
+    double *dt = uh_lds;                                   // [R + NK - 1][kRecTileLd] depth rows row_first - (NK - 1) ...
+    double *tp = uh_lds + (R + NK - 1) * kRecTileLd;       // [NK][kRecTileLd] taps
+    const int tid = threadIdx.x, c = tid % kRecCols, g = tid / kRecCols;
+    const int64_t col0 = (int64_t)blockIdx.x * kRecCols;
+    const int64_t tick_first = kRecRows * a.batch - 15;
+    uint32_t sub_unused;
+    const int64_t row_first = SUB ? (int64_t)a.nsub.div((uint32_t)(tick_first < 0 ? 0 : tick_first), sub_unused) : tick_first;
+    const int need = SUB ? (int)((uint32_t)(R - 1) / a.nsub.d) + 2 : R;
+    const int64_t i = min(col0 + c, a.n - 1);
+    const bool live = col0 + c < a.n;
+    {   // all loads in flight first (branch-free: out-of-range rows/columns are clamped and zeroed afterwards)
+        constexpr int DPT = (R + NK - 1 + G - 1) / G, TPT = (NK + G - 1) / G;
+        double dv[DPT], tv[TPT];
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) {
+            const int64_t t = row_first - (NK - 1) + min(g + q * G, need + NK - 2);
+            dv[q] = a.rows.row(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t))[i];
+        }
+#pragma unroll
+        for (int q = 0; q < TPT; ++q) tv[q] = u.kernel[(int64_t)min(g + q * G, u.n_ks - 1) * a.n + i];
+#pragma unroll
+        for (int q = 0; q < DPT; ++q) {
+            const int r = g + q * G;
+            const int64_t t = row_first - (NK - 1) + r;
+            if (r < R + NK - 1) dt[r * kRecTileLd + c] = (live && t >= 0 && t < a.T) ? dv[q] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < TPT; ++q) {
+            const int k = g + q * G;
+            if (k < NK) tp[k * kRecTileLd + c] = (live && k < u.n_ks) ? tv[q] : 0.0;
+        }
+    }
+    __syncthreads();
+    const int rb = g * RP;      // first output row of this thread
+    double acc[RP];
+    if (rb < need) {
+        double win[W];
+#pragma unroll
+        for (int q = 0; q < W; ++q) win[q] = dt[min(rb + q, R + NK - 2) * kRecTileLd + c];      // depth row (row_first + rb + q - (NK - 1))
+#pragma unroll
+        for (int j = 0; j < RP; ++j) {
+            const int64_t t = row_first + rb + j;
+            acc[j] = (live && t >= 0 && t < u.n_ks && t < a.T) ? u.state[t * a.n + i] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const double tap = tp[k * kRecTileLd + c];
+#pragma unroll
+            for (int j = 0; j < RP; ++j) acc[j] = __builtin_fma(tap, win[j + (NK - 1) - k], acc[j]);
+        }
+    }
+    __syncthreads();      // every window is in registers: the depth tile's space now takes the outputs
+    if (rb < need) {
+#pragma unroll
+        for (int j = 0; j < RP; ++j) if (rb + j < R) dt[(rb + j) * kRecTileLd + c] = acc[j];
+    }
+    __syncthreads();
+    write_records<SUB, kUhInThreads>(a, dt, col0, tick_first, row_first);
+}
+
+// OUT32: the router's post-processing fused in (TransformMuskingum.py:128-142): mean over `factor` consecutive rows
+// (sequential sum, one division, as numpy reduces a strided axis) and the float32 cast; 128 % (factor * nsub) == 0.
+template <bool SUB, bool OUT32>
+__global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
+{
+    constexpr int S = 16 * (kRecBatch + 1);
+    __shared__ double recs[kRecCols][S + 1];
+    const int tid = threadIdx.x;
+    const int64_t col0 = (int64_t)blockIdx.x * kRecCols;
+    constexpr int IT = kRecCols * (kRecBatch + 1) * 8 / kRecThreads;
+    int2 meta[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int64_t i = col0 + (it * kRecThreads + tid) / ((kRecBatch + 1) * 8);
+        meta[it] = i < a.n ? a.colmeta[i] : make_int2(-1, 0);
+    }
+    double2 v[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {     // all record reads in flight before the first LDS write
+        const int piece = it * kRecThreads + tid;
+        const int k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
+        const int32_t p = meta[it].x < 0 ? 0 : meta[it].x;
+        const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)(meta[it].y >> 4) + k;
+        v[it] = *(reinterpret_cast<const double2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.np + p) * kRec) + part);
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int piece = it * kRecThreads + tid;
+        const int c = piece / ((kRecBatch + 1) * 8), k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
+        recs[c][16 * k + 2 * part] = v[it].x;
+        recs[c][16 * k + 2 * part + 1] = v[it].y;
+    }
+    __syncthreads();
+    const int c = tid % kRecCols;
+    const int64_t i = col0 + c;
+    if (i >= a.n) return;
+    const int o = a.colmeta[i].y & 15;
+    const int64_t tick0 = kRecRows * a.batch;
+    if (OUT32) {
+        // output row q averages runoff rows [q * factor, (q + 1) * factor), each the slot of its last sub-step
+        const int step = (int)(a.factor.d * (SUB ? a.nsub.d : 1u));          // tick-rows per output row, divides 128
+        const int64_t q0 = tick0 / step;
+        for (int q = tid / kRecCols; q < kRecRows / step; q += kRecThreads / kRecCols) {
+            if ((q0 + q + 1) * step > a.total) break;
+            const int nsub = SUB ? (int)a.nsub.d : 1;
+            double acc = recs[c][o + q * step + nsub - 1];
+            for (int j = 1; j < (int)a.factor.d; ++j) acc += recs[c][o + q * step + j * nsub + nsub - 1];
+            a.rows32[(q0 + q) * a.n + i] = (float)(a.factor.d > 1 ? acc / (double)a.factor.d : acc);
+        }
+        return;
+    }
+    for (int r = tid / kRecCols; r < kRecRows; r += kRecThreads / kRecCols) {
+        const int64_t tick = tick0 + r;
+        if (tick >= a.total) break;
+        if (SUB) {
+            uint32_t s;
+            const uint32_t t = a.nsub.div((uint32_t)tick, s);
+            if (s + 1 == a.nsub.d) a.rows.row(t)[i] = recs[c][o + r];
+        } else {
+            a.rows.row(tick)[i] = recs[c][o + r];
+        }
+    }
+}
+
+// Router post-processing on the device (TransformMuskingum.py:128-142): mean over `factor` consecutive rows
+// (sequential sum then one division, as numpy's reduction over a strided axis does) and the float32 cast.
+__global__ __launch_bounds__(kBlock) void k_resample_cast(const double *__restrict__ src, float *__restrict__ dst,
+                                                          int64_t n, int64_t out_rows, int32_t factor)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int64_t o = blockIdx.y;
+    if (i >= n || o >= out_rows) return;
+    const double *p = src + o * factor * n + i;
+    double acc = p[0];
+    for (int32_t j = 1; j < factor; ++j) acc += p[(int64_t)j * n];
+    dst[o * n + i] = (float)(factor > 1 ? acc / (double)factor : acc);
+}
+
+}  // namespace

@@ -1,0 +1,394 @@
+// rr_kernels_tile.hpp -- the time-tiled routing kernel over subtree tiles (k_tile) and its state kernels.
+// Part of the one translation unit rr_engine.hip builds (included from there, in order; not a stand-alone header).
+#pragma once
+
+namespace {
+
+// ---- time-tiled routing over subtree tiles ----
+//
+// k_tick streams ~88 B per reach-step because nothing survives from one tick to the next.  k_tile lets one workgroup
+// advance one TILE (rr_plan.hpp: at most TH * PPT positions, closed under "upstream", ghosts mirroring the reaches other
+// tiles own) by K = 16 * KC routing ticks: coefficients and the tile's discharges of the previous tick sit in LDS
+// (double-buffered, one LDS-only barrier per tick), so HBM sees only the lateral read and the discharge write of every
+// reach-step plus the tile's state and coefficients once per task.  Task (tile, macro-chunk m) needs (tile, m - 1) and
+// the tiles its ghosts mirror at the same macro-chunk, all of which have a lower level: launch d runs the tasks
+// (tile, d - level(tile)) and nothing inside a launch depends on anything else inside it.
+//
+// Lateral inflow and discharge travel as RECORDS indexed by tick (kRec = 16 ticks, 128 bytes):
+//     rec[(tick / 16) % chunks][position][tick % 16]
+// holding c4dt * lateral on the way in and the clamped discharge on the way out, in place (k_rec_in / k_rec_out move
+// whole records to and from params order).  A GHOST's record slot is written by the tile that owns the mirrored reach
+// (its unclamped discharge, 8 bytes per tick; a ghost has the lag of its reach, so the ticks line up), and the ghost
+// receives its record like any other position and republishes it: no load, wait or branch of its own.
+
+struct TileArgs {
+    const int32_t *tile_ptr, *tile_level, *tile_lag_lo, *tile_lag_hi;
+    const int32_t *lag, *cfirst, *xpos;
+    const uint32_t *ccnt;
+    const double *c1row, *c2, *c3;        // c1row: the (uniform) weight of a reach's upstream terms
+    double *sq, *ss, *si, *sqch;          // carried state: discharge, sum of upstream discharges one tick back, interval sum, channel discharge
+    const int32_t *bidx;                  // slot of an export reach in the boundary series another GPU reads (multi-GPU)
+    double *exports;
+    int32_t n_export;
+    double *rec;                          // record ring [rec_chunks][np][16]
+    Div32 rec_chunks;
+#ifdef RR_WAVE_TRACE
+    long long *trace; int32_t trace_diag;   // development build: per-block timestamps of one launch (profiles/microbench/wave_dbg.py)
+#endif
+    int32_t np, t_first, t_last, KC, diag, n_macro, total, has_lat;
+    Div32 nsub;
+    double inv_nsub;
+};
+
+// LDS-only workgroup barrier: waits for this wave's LDS traffic, not for its global loads/stores, so record
+// prefetches stay in flight across ticks (__syncthreads() would drain vmcnt every tick).
+__device__ __forceinline__ void barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Predicated global accesses without a branch: a raw buffer access whose byte offset is pushed past the end of the
+// buffer is dropped by the bounds check (loads return zero).  Unlike `if (cond) *ptr = v` the instruction is always
+// issued, so hipcc can count it in vmcnt and an in-order wait for an older prefetch does not have to assume the worst.
+constexpr uint32_t kBufferFlags = 0x00020000;      // gfx9 raw buffer, 32-bit data format
+constexpr uint32_t kDropAccess = 0xFFFFFFF0u;      // offset outside any buffer this file creates (< 4 GiB - 16)
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, uint32_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, (int)kBufferFlags);
+}
+__device__ __forceinline__ void store_f64(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, double v)
+{
+    u32x2 bits;
+    __builtin_memcpy(&bits, &v, sizeof bits);
+    __builtin_amdgcn_raw_buffer_store_b64(bits, r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ void store_f64x2(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, double2 v)
+{
+    u32x4 bits;
+    __builtin_memcpy(&bits, &v, sizeof bits);
+    __builtin_amdgcn_raw_buffer_store_b128(bits, r, (int)byte_off, 0, 0);
+}
+__device__ __forceinline__ void load_f64x2(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, double &x, double &y)
+{
+    const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);   // one 16-byte request per lane
+    double2 v;
+    __builtin_memcpy(&v, &bits, sizeof v);
+    x = v.x; y = v.y;
+}
+
+// The tick loops are fully unrolled (the record slots are registers), so anything derived from a per-position constant
+// is "loop invariant" and hipcc keeps every such derivative in a VGPR for the whole task.  fresh() hands the constant
+// back as an opaque value: the two-instruction unpacking is redone each tick and the registers stay free.
+__device__ __forceinline__ int32_t fresh(int32_t v) { asm volatile("" : "+v"(v)); return v; }
+
+constexpr int kRec = 16;
+// Records move between HBM and their owning lanes through a per-wave LDS transpose: a lane owns a position (its record
+// lives in registers), but a memory instruction in which every lane touches 16 bytes of a different record costs L2 one
+// request per lane.  Through the transpose four neighbouring lanes load or store the 64 contiguous bytes of one half
+// record: a quarter of the requests.
+constexpr int kStageStride = 10;   // doubles per position in the staging area: 64 bytes + 16 of padding (bank spread, skip flag)
+constexpr int kStageLanes = 32;    // positions transposed at a time: half a wave (2.5 KiB of staging per wave)
+// Lanes of one wave exchange data through its staging area without a workgroup barrier: a wave's LDS instructions
+// execute in order.  The compiler still has to be told that other lanes wrote (it would reuse earlier reads).
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// LDS in doubles: X[2][TH] | stage[waves][kStageLanes * kStageStride]: the tile's discharges of the last two ticks and the
+// per-wave transpose areas.
+constexpr size_t tile_lds_bytes(int threads)
+{
+    return (size_t)(2 * (int64_t)threads + (threads / 64) * kStageLanes * kStageStride) * sizeof(double);
+}
+
+// One task: KC record chunks of one tile, one position per thread.  R[16] is the record the ticks work on, in place
+// (lateral in, discharge out); N[16] receives the NEXT chunk's record while the 16 ticks of this one run, so inside a task
+// HBM traffic and tick arithmetic overlap and only the first chunk's load is exposed.  Whole 128-byte records are
+// requested at once (a half record would cost the fabric a full line: measured, FETCH_SIZE 1.8x).
+template <int TH, bool UNIT, bool SUB>
+__global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 waves per CU: 1,024 / TH workgroups of 128 VGPRs
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int32_t total = a.total, K = a.KC * kRec;
+    double *stage = lds + 2 * TH + (size_t)(tid >> 6) * (kStageLanes * kStageStride);   // this wave's transpose area
+    auto ring = [&](int32_t chunk) { return make_rsrc(a.rec + (int64_t)a.rec_chunks.mod((uint32_t)chunk) * a.np * kRec, (uint32_t)a.np * 128u); };   // np < 2^25
+
+    // A workgroup takes the tiles t_last - blockIdx.x - g * gridDim.x, g = 0, 1, ... of this launch (highest level first:
+    // the few tiles with ghosts start in the first round), so that the first record and the state of its NEXT tile are
+    // requested while the current one still ticks.  A tile none of whose positions is active during its task has nothing
+    // to do (pipeline fill and drain; a ghost has the lag of the reach it mirrors, so it is idle exactly when its owner
+    // did not write its record) and is skipped.
+    struct Task { int32_t tile, m, b0, b1; };
+    auto select = [&](int32_t from, Task &t) {
+        for (int32_t c = from; c >= a.t_first; c -= (int32_t)gridDim.x) {
+            const int32_t m = a.diag - a.tile_level[c];
+            if (m < 0 || m >= a.n_macro) continue;
+            if (m * K >= a.tile_lag_hi[c] + total || (m + 1) * K <= a.tile_lag_lo[c]) continue;
+            t.tile = c; t.m = m; t.b0 = a.tile_ptr[c]; t.b1 = a.tile_ptr[c + 1];
+            return true;
+        }
+        return false;
+    };
+    Task cur;
+    if (!select(a.t_last - (int32_t)blockIdx.x, cur)) return;
+#ifdef RR_WAVE_TRACE
+    bool trace = a.trace && a.diag == a.trace_diag && tid == 0;
+    const bool trace_wg = trace;
+    long long *tq = a.trace + (int64_t)cur.tile * 16;
+#define RR_TRACE(i) do { if (trace) tq[i] = wall_clock64(); } while (0)
+#else
+#define RR_TRACE(i) do { } while (0)
+#endif
+    RR_TRACE(0);
+
+    // Four lanes fetch (store) the four 16-byte pieces of one 64-byte sector: in flight a lane's N[] holds OTHER
+    // positions' pieces; receive() hands them to their owners through the wave's staging area.
+    double R[kRec], N[kRec];
+    // load j of a record: (i = j / 2: half wave and group of 16 positions, half = j % 2: which 64-byte sector), so the two
+    // sectors of a 128-byte line are requested by consecutive loads
+    auto issue_load = [&](__amdgpu_buffer_rsrc_t src, int32_t b0, int32_t b1, int j, bool real) {
+        const int32_t t = fresh(tid), ln = t & 63;      // addresses are rebuilt at every use, not kept in registers across the task
+        const int i = j >> 1, half = j & 1;
+        const int32_t pos = min(b0 + (t - ln) + (i >> 1) * kStageLanes + 16 * (i & 1) + (ln >> 2), b1 - 1);
+        load_f64x2(src, real ? (uint32_t)pos * 128u + (uint32_t)(half * 64 + (ln & 3) * 16) : kDropAccess,
+                   N[8 * half + 2 * i], N[8 * half + 2 * i + 1]);
+    };
+    auto receive = [&]() {
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+                    reinterpret_cast<double2 *>(stage + (16 * g + (lane >> 2)) * kStageStride)[lane & 3] =
+                        make_double2(N[8 * half + 2 * (2 * h + g)], N[8 * half + 2 * (2 * h + g) + 1]);
+                wave_lds_fence();
+                if (lane / kStageLanes == h) {
+                    const double2 *src = reinterpret_cast<const double2 *>(stage + (lane % kStageLanes) * kStageStride);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const double2 v = src[j]; R[8 * half + 2 * j] = v.x; R[8 * half + 2 * j + 1] = v.y; }
+                }
+                wave_lds_fence();
+            }
+    };
+
+    // State of a position.  A slot past the end of the tile keeps lag -1: no upstream range, never active, publishes 0.0
+    // to nobody.  up: LDS slot of the first upstream value (low 16 bits), number of upstream positions (high 16 bits).
+    struct State { int32_t lg, up, xp, uh; double c1, c2, c3, s_prev, qch, isum, q; };
+    auto load_state = [&](const Task &t, State &s) {
+        s.lg = -1; s.up = 0; s.xp = 0; s.uh = 0;
+        s.c1 = s.c2 = s.c3 = s.s_prev = s.qch = s.isum = s.q = 0.0;
+        const int32_t p = t.b0 + tid;
+        if (p < t.b1) {
+            const uint32_t cc = a.ccnt[p];
+            const int32_t first_up = a.cfirst[p] - t.b0;
+            s.lg = a.lag[p]; s.up = first_up | (int32_t)((cc & 0xFFFFu) << 16);
+            s.xp = a.xpos[p];
+            if (UNIT) { s.uh = first_up + (int32_t)(cc >> 16); s.qch = a.sqch[p]; }
+            if (SUB) s.isum = a.si[p];
+            s.s_prev = a.ss[p];
+            s.q = a.sq[p]; s.c1 = a.c1row[p]; s.c2 = a.c2[p]; s.c3 = a.c3[p];
+        }
+    };
+    // The first tile: state and coefficients are requested BEFORE the record: memory operations retire in order, so the
+    // wait for them leaves the (much larger) record load in flight.
+    State st;
+    load_state(cur, st);
+    __amdgpu_buffer_rsrc_t rec_cur = ring(cur.m * a.KC);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) issue_load(rec_cur, cur.b0, cur.b1, j, true);
+    // everything but the 8 record loads has arrived (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 |
+    // vmcnt[5:4] << 14); a real s_waitcnt, so hipcc knows that no state register is pending inside the tick loop
+    __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
+    RR_TRACE(1);
+    receive();          // the first tile's first record: the only record load nothing overlaps
+    RR_TRACE(2);
+    const bool has_lat = a.has_lat != 0;   // channel-only routing: the records only carry discharge
+
+    for (;;) {
+        int32_t lg = st.lg, up = st.up, xp = st.xp, uh = st.uh, sub = 0;
+        double c1 = st.c1, c2 = st.c2, c3 = st.c3, s_prev = st.s_prev, qch = st.qch, isum = st.isum;
+        const int32_t b0 = cur.b0, tau_begin = cur.m * K;
+        lds[(size_t)((tau_begin + 1) & 1) * TH + tid] = st.q;       // tick tau_begin reads the buffer of tick tau_begin - 1
+        if (SUB && lg >= 0) {      // phase of the position's sub-step counter at the first tick of the task
+            const int32_t ts0 = tau_begin - (lg & kLagMask);
+            const uint32_t r = a.nsub.mod((uint32_t)(ts0 < 0 ? -ts0 : ts0));
+            sub = ts0 >= 0 ? (int32_t)r : (r ? (int32_t)(a.nsub.d - r) : 0);
+        }
+        Task nxt;
+        const bool has_next = select(cur.tile - (int32_t)gridDim.x, nxt);
+
+        // Eight slots of the record are final: write that 64-byte sector.  Half a wave at a time parks its sectors in
+        // the wave's staging area, then all 64 lanes store them, four lanes per sector.
+        auto store_half = [&](__amdgpu_buffer_rsrc_t dst, int half) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (lane / kStageLanes == h) {
+                    double2 *mine = reinterpret_cast<double2 *>(stage + (lane % kStageLanes) * kStageStride);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mine[j] = make_double2(R[8 * half + 2 * j], R[8 * half + 2 * j + 1]);
+                    reinterpret_cast<int32_t *>(mine + 4)[0] = (lg < 0 || (lg & (kGhostBit | kTileGhostBit))) ? 1 : 0;   // not this tile's to write
+                }
+                wave_lds_fence();
+                const int32_t t = fresh(tid), ln = t & 63;
+                const uint32_t first = (uint32_t)(b0 + (t - ln) + h * kStageLanes) * 128u + (uint32_t)half * 64u;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {       // lanes 4i .. 4i+3: the four 16-byte pieces of position 16 g + i
+                    const int pm = 16 * g + (ln >> 2), piece = ln & 3;
+                    const double2 *theirs = reinterpret_cast<const double2 *>(stage + pm * kStageStride);
+                    const double2 v = theirs[piece];
+                    const bool skip = reinterpret_cast<const int32_t *>(theirs + 4)[0] != 0;
+                    store_f64x2(dst, skip ? kDropAccess : first + (uint32_t)pm * 128u + (uint32_t)piece * 16u, v);
+                }
+                wave_lds_fence();
+            }
+        };
+        auto ticks = [&](int32_t tau0, int half, __amdgpu_buffer_rsrc_t rec_next, int32_t nb0, int32_t nb1, bool more) {
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                const int s = 8 * half + s8;
+                // the next record (this tile's next chunk, or the next tile's first) is requested one load per tick: a CU
+                // accepts only so many requests at a time, and a wave that waits to issue its loads cannot tick
+                if (half == 0) issue_load(rec_next, nb0, nb1, s8, more);
+                const int32_t tau = tau0 + s;
+                const double *rd = lds + (size_t)((tau + 1) & 1) * TH;
+                double *wr = lds + (size_t)(tau & 1) * TH;
+                const int32_t t = fresh(tid), lgk = fresh(lg), upk = fresh(up);
+                const int32_t u0 = upk & 0xFFFF, u1 = u0 + (int32_t)((uint32_t)upk >> 16);
+                double qk = rd[t];       // own discharge one tick back
+                double s_cur = 0.0, s_hw = 0.0;
+                if (UNIT) {   // headwater tributaries come first in the upstream range
+                    for (int32_t u = u0; u < uh; ++u) s_hw += rd[u];
+                    for (int32_t u = uh; u < u1; ++u) s_cur += rd[u];
+                } else {
+                    for (int32_t u = u0; u < u1; ++u) s_cur += rd[u];
+                }
+                const int32_t ts = tau - (lgk & kLagMask);
+                if (ts >= 0 && ts < total) {
+                    const double lat = has_lat ? R[s] : 0.0;
+                    double outv = 0.0;
+                    bool routed = false;
+                    if (lgk & (kGhostBit | kTileGhostBit)) {
+                        qk = R[s];        // a ghost republishes what its owner computed
+                    } else if (UNIT) {
+                        if (u0 == u1) {
+                            qk = lat;        // headwater: discharge = lateral, the record slot already holds it (unclamped, un-averaged)
+                        } else {
+                            const double r = __builtin_fma(c1, s_hw + s_cur, __builtin_fma(c2, s_hw + s_prev, c3 * qch));
+                            qch = r;
+                            qk = r + lat;
+                            outv = qk; routed = true;
+                        }
+                        if (lgk & kExportBit) a.exports[(int64_t)ts * a.n_export + a.bidx[b0 + t]] = qk;
+                    } else {
+                        // explicit fma: every copy of this tick must round identically (split run == joint run)
+                        qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev, __builtin_fma(c3, qk, lat)));
+                        outv = qk; routed = true;
+                        if (lgk & kExportBit) a.exports[(int64_t)ts * a.n_export + a.bidx[b0 + t]] = qk;
+                    }
+                    if (routed) {
+                        if (SUB) {      // mean over the sub-steps of a row, written to the slot of the row's last sub-step
+                            const double acc = (sub == 0 ? 0.0 : isum) + outv;
+                            isum = acc;
+                            if (sub + 1 == (int32_t)a.nsub.d) { const double v = acc * a.inv_nsub; R[s] = v > 0.0 ? v : 0.0; }
+                        } else {
+                            R[s] = outv > 0.0 ? outv : 0.0;
+                        }
+                    }
+                }
+                if (SUB) sub = sub + 1 == (int32_t)a.nsub.d ? 0 : sub + 1;
+                s_prev = s_cur;
+                wr[t] = qk;
+                // a reach mirrored by a ghost of another tile: 8 bytes into the ghost's record, always issued (see store_f64)
+                store_f64(rec_cur, (lgk >= 0 && (lgk & kTileExportBit)) ? (uint32_t)fresh(xp) * 128u + (uint32_t)s * 8u : kDropAccess, qk);
+                barrier_lds();
+            }
+        };
+
+        barrier_lds();      // the buffer of tick tau_begin - 1 is in place (and every wave has left the previous tile)
+        for (int32_t cc = 0; cc < a.KC; ++cc) {
+            const int32_t chunk = cur.m * a.KC + cc, tau0 = chunk * kRec;
+            const bool last = cc + 1 == a.KC;
+            // what arrives during this chunk: the tile's next chunk, or -- in its last one -- the first chunk of the next tile
+            const __amdgpu_buffer_rsrc_t rec_next = ring(last ? nxt.m * a.KC : chunk + 1);
+            const int32_t nb0 = last ? nxt.b0 : b0, nb1 = last ? nxt.b1 : cur.b1;
+            ticks(tau0, 0, rec_next, nb0, nb1, !last || has_next);
+            if (cc == 0) RR_TRACE(3);
+            store_half(rec_cur, 0);
+            ticks(tau0, 1, rec_next, nb0, nb1, false);
+            if (cc == 0) RR_TRACE(6);
+            store_half(rec_cur, 1);
+            if (cc == 0) RR_TRACE(7);
+            if (last && has_next) load_state(nxt, st);      // small, and only the wait for it is exposed between two tiles
+            receive();      // the record that has had 16 ticks to arrive (zeros after the last chunk of the last tile)
+            if (cc == 0) RR_TRACE(8);
+            rec_cur = rec_next;
+        }
+        RR_TRACE(12);
+        if (lg >= 0) {
+            const int32_t p = b0 + tid;
+            a.sq[p] = lds[(size_t)((tau_begin + K - 1) & 1) * TH + tid]; a.ss[p] = s_prev;
+            if (UNIT) a.sqch[p] = qch;
+            if (SUB) a.si[p] = isum;
+        }
+        RR_TRACE(13);
+#ifdef RR_WAVE_TRACE
+        trace = false;      // the first tile of the workgroup only
+        if (!has_next && trace_wg) tq[14] = wall_clock64();     // ... and when the workgroup leaves
+#endif
+        if (!has_next) break;
+        cur = nxt;
+    }
+#undef RR_TRACE
+}
+
+// sq = q0 at every position (a ghost starts from the state of the reach it mirrors), ss = sum of the upstream q0
+__global__ __launch_bounds__(kBlock) void k_tile_state_in(double *sq, double *ss, double *si, const double *q_t, const int32_t *perm,
+                                                          const int32_t *cfirst, const uint32_t *ccnt, int32_t np)
+{
+    const int32_t p = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (p >= np) return;
+    double s = 0.0;
+    const int32_t u0 = cfirst[p], u1 = u0 + (int32_t)(ccnt[p] & 0xFFFFu);
+    for (int32_t u = u0; u < u1; ++u) s += q_t[perm[u]];
+    sq[p] = q_t[perm[p]]; ss[p] = s; si[p] = 0.0;
+}
+
+// UnitMuskingum state for the time-tiled kernel: published discharge = q_full on inner reaches (0 on headwaters until
+// their first tick), ss = sum over the INNER tributaries only (the headwater ones come first), qch = channel discharge.
+// full[i] / chan[i]: q_full / q_ch scattered to params order, zeros on headwaters (k_unit_scatter).
+__global__ __launch_bounds__(kBlock) void k_tile_unit_state_in(double *sq, double *ss, double *si, double *sqch, const double *full,
+                                                               const double *chan, const int32_t *perm, const int32_t *cfirst,
+                                                               const uint32_t *ccnt, int32_t np)
+{
+    const int32_t p = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (p >= np) return;
+    double s = 0.0;
+    const uint32_t cc = ccnt[p];
+    const int32_t u0 = cfirst[p] + (int32_t)(cc >> 16), u1 = cfirst[p] + (int32_t)(cc & 0xFFFFu);
+    for (int32_t u = u0; u < u1; ++u) s += full[perm[u]];
+    sq[p] = full[perm[p]]; ss[p] = s; si[p] = 0.0; sqch[p] = chan[perm[p]];
+}
+
+__global__ __launch_bounds__(kBlock) void k_unit_scatter(double *full, double *chan, const double *q_full, const double *q_ch,
+                                                         const int32_t *inner_idx, int32_t n_inner)
+{
+    const int32_t k = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (k >= n_inner) return;
+    full[inner_idx[k]] = q_full[k]; chan[inner_idx[k]] = q_ch[k];
+}
+
+__global__ __launch_bounds__(kBlock) void k_tile_unit_state_out(double *q_ch, double *q_full, const double *sq, const double *sqch,
+                                                                const int32_t *inner_idx, const int32_t *inv, int32_t n_inner)
+{
+    const int32_t k = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (k >= n_inner) return;
+    const int32_t p = inv[inner_idx[k]];
+    q_full[k] = sq[p];
+    q_ch[k] = sqch[p];
+}
+
+__global__ __launch_bounds__(kBlock) void k_tile_state_out(double *q_t, const double *sq, const int32_t *inv, int32_t n)
+{
+    const int32_t i = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (i < n) q_t[i] = sq[inv[i]];
+}
+
+}  // namespace

@@ -2,7 +2,7 @@
 Gridded runoff -> catchment lateral inflow: the step immediately upstream of the routing hot path
 (river_route/runoff.py:218-352).  Same function name, keyword arguments, order of
 operations and units as the reference; the weights product, the cumulative difference, the clip, the NaN fill and
-the area scaling run on the GPU (`rr_runoff_to_qlateral`, river_route_amd/csrc/rr_engine.hip:
+the area scaling run on the GPU (`rr_runoff_to_qlateral`, river_route_amd/csrc/rr_kernels_runoff.hpp:
 k_runoff_to_qlateral), the index bookkeeping (pandas) and the rare irregular-time-step resampling stay on the host
 exactly as the reference does them.
 
