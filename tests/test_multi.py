@@ -107,7 +107,8 @@ def test_in_process_runner_with_oracle_engine_three_parts():
 @pytest.mark.gpu
 @pytest.mark.parametrize('wave', ['0', '1', 'rec'])
 @pytest.mark.parametrize('n,T,nsub,parts,chunk', [(5000, 40, 1, 3, 8), (5000, 21, 3, 4, 5), (200000, 64, 1, 8, 16),
-                                                  (200000, 300, 1, 4, 32)])
+                                                  (200000, 300, 1, 4, 32),
+                                                  (20000, 4000, 1, 3, 64)])     # long enough for the record ring to go round four times
 def test_hip_parts_on_one_gpu_match_single_plan(monkeypatch, wave, n, T, nsub, parts, chunk):
     """Ghost/export reaches + rr_stream_* + the driver, on the real engine; reference = one plan over the whole
     network (itself checked against the oracle in test_gpu_kernels.py)."""
