@@ -73,4 +73,14 @@ struct RowView {
 
 inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
+// Workgroups are handed to the eight XCDs in turn (blockIdx % 8 labels the workgroups that share an XCD and its L2, cdna
+// programming guide section 5.5 T1).  Kernels whose neighbouring tiles touch the same cache lines -- column tiles of rows
+// whose pitch is not a multiple of a line -- take tile xcd_swizzle(blockIdx) instead of blockIdx, so that neighbours run on
+// one XCD at about the same time: a line two tiles share is fetched once and written back whole.  Bijective for any grid.
+__device__ __forceinline__ uint32_t xcd_swizzle(uint32_t b, uint32_t nwg)
+{
+    const uint32_t q = nwg >> 3, r = nwg & 7u, x = b & 7u;
+    return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + (b >> 3);
+}
+
 }  // namespace

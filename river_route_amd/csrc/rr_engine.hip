@@ -47,7 +47,7 @@ void rr_plan_destroy(rr_plan *P)
         void *ptrs[] = {P->d_child_ptr, P->d_lag, P->d_perm, P->d_inv, P->d_inner_pos, P->d_bidx, P->d_hwc, P->d_w, P->d_c1row_h, P->d_c2,
                         P->d_c1row, P->d_tc2, P->d_tc3, P->d_sq, P->d_ss, P->d_si, P->d_sqch, P->d_full, P->d_chan,
                         P->d_tile_ptr, P->d_tile_level, P->d_tile_lag_lo, P->d_tile_lag_hi, P->d_tlag, P->d_cfirst, P->d_xpos,
-                        P->d_tperm, P->d_tinv, P->d_tbidx, P->d_inner_idx, P->d_ccnt, P->d_colmeta, P->d_ghostmeta, P->d_c4_params,
+                        P->d_tperm, P->d_tinv, P->d_inner_idx, P->d_ccnt, P->d_colmeta, P->d_ghostmeta, P->d_c4_params,
                         P->d_c3, P->d_c4, P->d_x, P->d_isum, P->d_qch, P->d_ring, P->d_stage, P->d_mrows,
                         P->d_slot_a[0], P->d_slot_a[1], P->d_slot_b[0], P->d_slot_b[1], P->d_m_index[0], P->d_m_index[1]};
         for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -152,7 +152,6 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
             if (!rc) rc = dev_upload(P->d_tperm, TP.perm);
             if (!rc) rc = dev_alloc(&P->d_tinv, n);
             if (!rc) rc = dev_upload(P->d_tinv, TP.inv);
-            if (!rc) rc = dev_alloc(&P->d_tbidx, np);
             if (!rc) rc = dev_alloc(&P->d_c1row, np);
             if (!rc) rc = dev_alloc(&P->d_tc2, np);
             if (!rc) rc = dev_alloc(&P->d_tc3, np);
@@ -367,11 +366,19 @@ int rr_plan_set_boundary(rr_plan *P, int64_t n_ghost, const int64_t *ghost_reach
     for (int64_t e = 0; e < n_export; ++e) P->export_reach[e] = (int32_t)export_reaches[e];
     if (P->tp.ok) {      // the same flags and slots in the tile layout
         const rr::TilePlan &TP = P->tp;
-        std::vector<int32_t> tlag(TP.lag), tbidx(TP.np, 0);
-        for (int64_t g = 0; g < n_ghost; ++g) { const int32_t p = TP.inv[ghost_reaches[g]]; tlag[p] |= kGhostBit; tbidx[p] = (int32_t)g; }
-        for (int64_t e = 0; e < n_export; ++e) { const int32_t p = TP.inv[export_reaches[e]]; tlag[p] |= kExportBit; tbidx[p] = (int32_t)e; }
+        // flags in the tile layout; an export reach's slot in the export series travels in xpos[], the word a reach mirrored
+        // by another tile's ghost uses for that ghost's position -- an export is normally an outlet of its part and has no
+        // such ghost; where it has one, the plan keeps to the streaming kernel
+        std::vector<int32_t> tlag(TP.lag), txpos(TP.xpos);
+        P->export_inside = false;
+        for (int64_t g = 0; g < n_ghost; ++g) { const int32_t p = TP.inv[ghost_reaches[g]]; tlag[p] |= kGhostBit; }
+        for (int64_t e = 0; e < n_export; ++e) {
+            const int32_t p = TP.inv[export_reaches[e]];
+            if (tlag[p] & kTileExportBit) P->export_inside = true;
+            tlag[p] |= kExportBit; txpos[p] = (int32_t)e;
+        }
         rc = dev_upload(P->d_tlag, tlag);
-        if (!rc) rc = dev_upload(P->d_tbidx, tbidx);
+        if (!rc) rc = dev_upload(P->d_xpos, P->export_inside ? TP.xpos : txpos);
         if (P->d_ghostmeta) { (void)hipFree(P->d_ghostmeta); P->d_ghostmeta = nullptr; }
         std::vector<int2> gm((size_t)n_ghost);
         for (int64_t g = 0; g < n_ghost; ++g) { const int32_t p = TP.inv[ghost_reaches[g]]; gm[g] = make_int2(p, TP.lag[p] & kLagMask); }

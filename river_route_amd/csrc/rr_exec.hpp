@@ -116,7 +116,8 @@ struct rr_plan {
     int64_t next_KC = 1, next_chunks = 0;   // decide_wave: task length and record ring of the call about to start
     int32_t *d_tile_ptr = nullptr, *d_tile_level = nullptr, *d_tile_lag_lo = nullptr, *d_tile_lag_hi = nullptr;
     int32_t *d_tlag = nullptr, *d_cfirst = nullptr, *d_xpos = nullptr, *d_tperm = nullptr, *d_tinv = nullptr;
-    int32_t *d_tbidx = nullptr, *d_inner_idx = nullptr;
+    int32_t *d_inner_idx = nullptr;
+    bool export_inside = false;      // an export reach that another tile mirrors (it has a downstream reach in this plan): streaming kernel only
     uint32_t *d_ccnt = nullptr;
     double *d_c1row = nullptr, *d_tc2 = nullptr, *d_tc3 = nullptr, *d_sq = nullptr, *d_ss = nullptr, *d_si = nullptr, *d_sqch = nullptr;
     double *d_full = nullptr, *d_chan = nullptr;   // UnitMuskingum state scattered to params order
@@ -207,7 +208,8 @@ int64_t pick_KC(const rr_plan *P, int64_t total_ticks)
 // does not fit gets shorter tasks, then the streaming kernel.
 bool decide_wave(rr_plan *P, Mode mode, int64_t total, bool host_rows)
 {
-    bool ok = P->wave_enabled && P->tp.ok && P->weights_uniform && P->h.n > 0 && !host_rows && P->tp.np < (int64_t{1} << 25);
+    bool ok = P->wave_enabled && P->tp.ok && P->weights_uniform && P->h.n > 0 && !host_rows && P->tp.np < (int64_t{1} << 25) &&
+              !P->export_inside;
     if (ok && !P->wave_forced) ok = total >= 32;
     if (ok) {
         const int64_t dmax = P->h.depth - 1, np = P->tp.np, levels = P->tp.n_levels;
@@ -285,7 +287,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         w.lag = P->d_tlag; w.cfirst = P->d_cfirst; w.xpos = P->d_xpos; w.ccnt = P->d_ccnt;
         w.c1row = P->d_c1row; w.c2 = P->d_tc2; w.c3 = P->d_tc3;
         w.sq = P->d_sq; w.ss = P->d_ss; w.si = P->d_si; w.sqch = P->d_sqch;
-        w.bidx = P->d_tbidx; w.exports = export_series; w.n_export = (int32_t)P->n_export;
+        w.exports = export_series; w.n_export = (int32_t)P->n_export;
         w.rec = P->d_ring; w.rec_chunks = Div32((uint32_t)S.rec_chunks);
 #ifdef RR_WAVE_TRACE
         w.trace = nullptr; w.trace_diag = -1;
@@ -533,6 +535,13 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
                  : RowView{S.io.dev_out, n, 0, (uint32_t)std::max<int64_t>(1, S.io.rows_out)};
     ra.rows32 = in ? nullptr : S.io.dev_out32;
     ra.factor = Div32((uint32_t)std::max<int64_t>(1, S.io.out_factor));
+    {   // The out-pass walks its column tiles in XCD-contiguous order (xcd_swizzle): where the row pitch is not a whole number
+        // of 128-byte lines neighbouring tiles write parts of the same lines, and on one XCD those meet in its L2 (1.25M-reach
+        // part with an odd column count: 522 -> 473 ms per year; 1% - 2% with an aligned pitch too).  The in-pass gains
+        // nothing from it (its shared lines are reads) and the two together were slower: profiles/r02_rec_swizzle.txt.
+        static const int knob = getenv("RR_REC_SWIZZLE") ? atoi(getenv("RR_REC_SWIZZLE")) : 2;      // measurements: bit 0 in-pass, bit 1 out-pass
+        ra.swizzle = (knob >> (in ? 0 : 1)) & 1;
+    }
     const dim3 g((unsigned)((n + kRecCols - 1) / kRecCols));
     const bool sub = S.nsub > 1;
     if (in && S.io.runoff) {

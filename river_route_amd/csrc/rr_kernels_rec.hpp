@@ -32,6 +32,7 @@ struct RecPermArgs {
     RowView rows;             // params-order rows (source of k_rec_in, destination of k_rec_out)
     float *rows32;            // k_rec_out: float32 destination with `factor` rows averaged (router post-processing), or NULL
     Div32 factor;
+    int32_t swizzle;          // column tiles in XCD-contiguous order (rr_common.hpp: xcd_swizzle)
 };
 
 constexpr int kRecTileRows = 16 * kRecBatch + 15;      // tick-rows behind one batch of records
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_in(const RecPermArgs a)
     constexpr int R = kRecTileRows;
     __shared__ double tile[R * kRecTileLd];
     const int tid = threadIdx.x;
-    const int64_t col0 = (int64_t)blockIdx.x * kRecCols;
+    const int64_t col0 = (int64_t)(a.swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x) * kRecCols;
     const int64_t tick_first = kRecRows * a.batch - 15;                 // may be negative in the first batch
     uint32_t sub_unused;
     const int64_t row_first = SUB ? (int64_t)a.nsub.div((uint32_t)(tick_first < 0 ? 0 : tick_first), sub_unused) : tick_first;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(kUhInThreads) void k_rec_in_uh(const RecPermArgs a,
     double *dt = uh_lds;                                   // [R + NK - 1][kRecTileLd] depth rows row_first - (NK - 1) ...
     double *tp = uh_lds + (R + NK - 1) * kRecTileLd;       // [NK][kRecTileLd] taps
     const int tid = threadIdx.x, c = tid % kRecCols, g = tid / kRecCols;
-    const int64_t col0 = (int64_t)blockIdx.x * kRecCols;
+    const int64_t col0 = (int64_t)(a.swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x) * kRecCols;
     const int64_t tick_first = kRecRows * a.batch - 15;
     uint32_t sub_unused;
     const int64_t row_first = SUB ? (int64_t)a.nsub.div((uint32_t)(tick_first < 0 ? 0 : tick_first), sub_unused) : tick_first;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
     constexpr int S = 16 * (kRecBatch + 1);
     __shared__ double recs[kRecCols][S + 1];
     const int tid = threadIdx.x;
-    const int64_t col0 = (int64_t)blockIdx.x * kRecCols;
+    const int64_t col0 = (int64_t)(a.swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x) * kRecCols;
     constexpr int IT = kRecCols * (kRecBatch + 1) * 8 / kRecThreads;
     int2 meta[IT];
 #pragma unroll

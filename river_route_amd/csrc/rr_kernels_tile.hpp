@@ -23,12 +23,12 @@ namespace {
 
 struct TileArgs {
     const int32_t *tile_ptr, *tile_level, *tile_lag_lo, *tile_lag_hi;
-    const int32_t *lag, *cfirst, *xpos;
+    const int32_t *lag, *cfirst;
+    const int32_t *xpos;                  // kTileExportBit: position of the ghost that mirrors this reach; kExportBit: its slot in the export series (never both)
     const uint32_t *ccnt;
     const double *c1row, *c2, *c3;        // c1row: the (uniform) weight of a reach's upstream terms
     double *sq, *ss, *si, *sqch;          // carried state: discharge, sum of upstream discharges one tick back, interval sum, channel discharge
-    const int32_t *bidx;                  // slot of an export reach in the boundary series another GPU reads (multi-GPU)
-    double *exports;
+    double *exports;                      // boundary series another GPU reads (multi-GPU)
     int32_t n_export;
     double *rec;                          // record ring [rec_chunks][np][16]
     Div32 rec_chunks;
@@ -276,12 +276,12 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                             qk = r + lat;
                             outv = qk; routed = true;
                         }
-                        if (lgk & kExportBit) a.exports[(int64_t)ts * a.n_export + a.bidx[b0 + t]] = qk;
+                        if (lgk & kExportBit) a.exports[(int64_t)ts * a.n_export + fresh(xp)] = qk;      // xp: the export slot (see TileArgs::xpos)
                     } else {
                         // explicit fma: every copy of this tick must round identically (split run == joint run)
                         qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev, __builtin_fma(c3, qk, lat)));
                         outv = qk; routed = true;
-                        if (lgk & kExportBit) a.exports[(int64_t)ts * a.n_export + a.bidx[b0 + t]] = qk;
+                        if (lgk & kExportBit) a.exports[(int64_t)ts * a.n_export + fresh(xp)] = qk;      // xp: the export slot (see TileArgs::xpos)
                     }
                     if (routed) {
                         if (SUB) {      // mean over the sub-steps of a row, written to the slot of the row's last sub-step
