@@ -124,7 +124,8 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
             const rr::TilePlan &TP = P->tp;
             const int64_t np = TP.np;
             std::vector<int2> cm(n);
-            for (int64_t i = 0; i < n; ++i) cm[i] = make_int2(TP.inv[i], TP.lag[TP.inv[i]] & kLagMask);
+            for (int64_t i = 0; i < n; ++i)      // a headwater column is flagged: UnitMuskingum's out-pass leaves it unclamped
+                cm[i] = make_int2(TP.inv[i], (TP.lag[TP.inv[i]] & kLagMask) | (H.child_ptr[H.inv[i] + 1] == H.child_ptr[H.inv[i]] ? kColHeadwater : 0));
             std::vector<int32_t> inner_idx;
             inner_idx.reserve(ni);
             for (int64_t i = 0; i < n; ++i) if (H.child_ptr[H.inv[i] + 1] > H.child_ptr[H.inv[i]]) inner_idx.push_back((int32_t)i);

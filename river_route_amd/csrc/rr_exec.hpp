@@ -535,6 +535,7 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
                  : RowView{S.io.dev_out, n, 0, (uint32_t)std::max<int64_t>(1, S.io.rows_out)};
     ra.rows32 = in ? nullptr : S.io.dev_out32;
     ra.factor = Div32((uint32_t)std::max<int64_t>(1, S.io.out_factor));
+    ra.clamp = S.nsub > 1 ? 0 : (S.mode == Mode::Unit ? 2 : 1);
     {   // The out-pass walks its column tiles in XCD-contiguous order (xcd_swizzle): where the row pitch is not a whole number
         // of 128-byte lines neighbouring tiles write parts of the same lines, and on one XCD those meet in its L2 (1.25M-reach
         // part with an odd column count: 522 -> 473 ms per year; 1% - 2% with an aligned pitch too).  The in-pass gains

@@ -33,7 +33,9 @@ struct RecPermArgs {
     float *rows32;            // k_rec_out: float32 destination with `factor` rows averaged (router post-processing), or NULL
     Div32 factor;
     int32_t swizzle;          // column tiles in XCD-contiguous order (rr_common.hpp: xcd_swizzle)
+    int32_t clamp;            // k_rec_out: 0 records hold final values (sub-steps), 1 clamp at zero, 2 clamp all but headwater columns (UnitMuskingum)
 };
+constexpr int32_t kColHeadwater = 1 << 30;      // colmeta[].y: lag | this flag
 
 constexpr int kRecTileRows = 16 * kRecBatch + 15;      // tick-rows behind one batch of records
 constexpr int kRecTileLd = kRecCols + 1;
@@ -63,7 +65,7 @@ __device__ __forceinline__ void write_records(const RecPermArgs &a, const double
         const int c = piece / (8 * kRecBatch), k = (piece >> 3) % kRecBatch, part = piece & 7;
         const int32_t p = meta[it].x;
         if (p < 0) continue;
-        const int32_t lag = meta[it].y;
+        const int32_t lag = meta[it].y & kLagMask;
         const int o = lag & 15;
         const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)(lag >> 4) + k;
         const int r = 15 - o + 16 * k + 2 * part;       // tick-row tick_first + r
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
         const int piece = it * kRecThreads + tid;
         const int k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
         const int32_t p = meta[it].x < 0 ? 0 : meta[it].x;
-        const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)(meta[it].y >> 4) + k;
+        const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)((meta[it].y & kLagMask) >> 4) + k;
         v[it] = *(reinterpret_cast<const double2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.np + p) * kRec) + part);
     }
 #pragma unroll
@@ -229,7 +231,12 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
     const int c = tid % kRecCols;
     const int64_t i = col0 + c;
     if (i >= a.n) return;
-    const int o = a.colmeta[i].y & 15;
+    const int32_t my = a.colmeta[i].y;
+    const int o = my & 15;
+    // single sub-step: the records hold the unclamped discharge (a ghost's record is a copy of its reach's); the reference's
+    // clip at zero (_numba_kernels.py:80) happens here.  UnitMuskingum leaves its headwaters' lateral inflow as it is (:122-123).
+    const bool clamp = !SUB && (a.clamp == 1 || (a.clamp == 2 && !(my & kColHeadwater)));
+    auto out = [&](double v) { return clamp && !(v > 0.0) ? 0.0 : v; };
     const int64_t tick0 = kRecRows * a.batch;
     if (OUT32) {
         // output row q averages runoff rows [q * factor, (q + 1) * factor), each the slot of its last sub-step
@@ -238,8 +245,8 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
         for (int q = tid / kRecCols; q < kRecRows / step; q += kRecThreads / kRecCols) {
             if ((q0 + q + 1) * step > a.total) break;
             const int nsub = SUB ? (int)a.nsub.d : 1;
-            double acc = recs[c][o + q * step + nsub - 1];
-            for (int j = 1; j < (int)a.factor.d; ++j) acc += recs[c][o + q * step + j * nsub + nsub - 1];
+            double acc = out(recs[c][o + q * step + nsub - 1]);
+            for (int j = 1; j < (int)a.factor.d; ++j) acc += out(recs[c][o + q * step + j * nsub + nsub - 1]);
             a.rows32[(q0 + q) * a.n + i] = (float)(a.factor.d > 1 ? acc / (double)a.factor.d : acc);
         }
         return;
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
             const uint32_t t = a.nsub.div((uint32_t)tick, s);
             if (s + 1 == a.nsub.d) a.rows.row(t)[i] = recs[c][o + r];
         } else {
-            a.rows.row(tick)[i] = recs[c][o + r];
+            a.rows.row(tick)[i] = out(recs[c][o + r]);
         }
     }
 }

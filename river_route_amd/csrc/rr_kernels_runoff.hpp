@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kRunoffInThreads) void k_rec_in_runoff(const RecPer
     slot[tid] = -1;
     if (i < a.n) {
         const int2 meta = a.colmeta[i];
-        const int32_t lag = meta.y, o = lag & 15;
+        const int32_t lag = meta.y & kLagMask, o = lag & 15;
         const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)(lag >> 4) + (uint32_t)k;
         const int64_t t0 = kRecRows * a.batch + 16 * k - o;      // first row of the record; rows outside [0, T) hold zeros
         double acc[kRec + 1];        // slot 0: row t0 - 1 (cumulative input only)

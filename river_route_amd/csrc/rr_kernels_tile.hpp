@@ -224,7 +224,9 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                     double2 *mine = reinterpret_cast<double2 *>(stage + (lane % kStageLanes) * kStageStride);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) mine[j] = make_double2(R[8 * half + 2 * j], R[8 * half + 2 * j + 1]);
-                    reinterpret_cast<int32_t *>(mine + 4)[0] = (lg < 0 || (lg & (kGhostBit | kTileGhostBit))) ? 1 : 0;   // not this tile's to write
+                    int32_t *word = reinterpret_cast<int32_t *>(mine + 4);
+                    word[0] = (lg < 0 || (lg & (kGhostBit | kTileGhostBit))) ? 1 : 0;   // not this tile's to write
+                    if (!SUB) word[1] = (lg >= 0 && (lg & kTileExportBit)) ? fresh(xp) : -1;      // position of the ghost that mirrors this reach
                 }
                 wave_lds_fence();
                 const int32_t t = fresh(tid), ln = t & 63;
@@ -236,6 +238,10 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                     const double2 v = theirs[piece];
                     const bool skip = reinterpret_cast<const int32_t *>(theirs + 4)[0] != 0;
                     store_f64x2(dst, skip ? kDropAccess : first + (uint32_t)pm * 128u + (uint32_t)piece * 16u, v);
+                    if (!SUB) {     // the same sector into the record of the ghost that mirrors the reach (always issued, see store_f64)
+                        const int32_t gx = reinterpret_cast<const int32_t *>(theirs + 4)[1];
+                        store_f64x2(dst, gx < 0 ? kDropAccess : (uint32_t)gx * 128u + (uint32_t)half * 64u + (uint32_t)piece * 16u, v);
+                    }
                 }
                 wave_lds_fence();
             }
@@ -289,15 +295,17 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                             isum = acc;
                             if (sub + 1 == (int32_t)a.nsub.d) { const double v = acc * a.inv_nsub; R[s] = v > 0.0 ? v : 0.0; }
                         } else {
-                            R[s] = outv > 0.0 ? outv : 0.0;
+                            R[s] = outv;      // unclamped: the ghost that mirrors this reach gets a copy of the record; k_rec_out clamps
                         }
                     }
                 }
                 if (SUB) sub = sub + 1 == (int32_t)a.nsub.d ? 0 : sub + 1;
                 s_prev = s_cur;
                 wr[t] = qk;
-                // a reach mirrored by a ghost of another tile: 8 bytes into the ghost's record, always issued (see store_f64)
-                store_f64(rec_cur, (lgk >= 0 && (lgk & kTileExportBit)) ? (uint32_t)fresh(xp) * 128u + (uint32_t)s * 8u : kDropAccess, qk);
+                // With sub-steps a record slot holds a row mean, not the tick's discharge: a reach mirrored by a ghost of another
+                // tile sends 8 bytes per tick into the ghost's record, always issued (see store_f64).  Without, the ghost gets a
+                // copy of the whole record in store_half.
+                if (SUB) store_f64(rec_cur, (lgk >= 0 && (lgk & kTileExportBit)) ? (uint32_t)fresh(xp) * 128u + (uint32_t)s * 8u : kDropAccess, qk);
                 barrier_lds();
             }
         };
