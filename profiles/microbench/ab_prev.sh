@@ -1,3 +1,5 @@
+# A/B of two builds of the engine on one box (boxes differ by +-3 %): river_route_amd/librr_prev.so is an earlier commit's
+# sources built with the hipcc line of river_route_amd/_lib.py (git show <commit>:river_route_amd/csrc/... into a scratch directory).
 for i in 1 2 3; do
 for lib in librr_prev.so librr_hip.so; do
   echo -n "$lib: "
