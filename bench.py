@@ -79,6 +79,17 @@ def muskingum_coefficients(k, x, dt):
     return (r - 2.0 * x) / den, (r + 2.0 * x) / den, (2.0 * (1.0 - x) - r) / den
 
 
+def host_cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown CPU'
+
+
 def cpu_baseline(net, indptr, indices, c1, c2, c3, dt, nsub, steps, seconds, replicas=0):
     """Oracle on the host: same network, first `steps` runoff steps of the same forcing."""
     from oracle import oracle
@@ -105,7 +116,7 @@ def cpu_baseline(net, indptr, indices, c1, c2, c3, dt, nsub, steps, seconds, rep
     out = {'value': n * steps * nsub * reps / dt_s, 'unit': 'reach-steps/s', 'cores': 1, 'kind': 'port',
            'sample': f'{n} reaches x {steps * reps} runoff steps ({reps} passes over {steps} forcing rows) x {nsub} '
                      f'sub-step(s), {dt_s:.2f} s, oracle/rr_oracle.c gcc -O3 -march=native -ffast-math, 1 thread '
-                     f'of {os.cpu_count()} host cores',
+                     f'of {os.cpu_count()} host cores ({host_cpu_model()})',
            'first_pass': first_pass}
     if replicas:
         out['replicas'] = cpu_replicas(replicas, indptr, indices, lhs, c2, c3, c4_dt, ql, nsub, out_dir, seconds)
