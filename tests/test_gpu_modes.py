@@ -249,3 +249,60 @@ def test_device_resident_route_record_mode(monkeypatch, env, n, T, ql_rows):
         np.testing.assert_array_equal(q2, q)
         last = np.arange(T - sink, T)
         np.testing.assert_array_equal(d2[last % sink], d[last])
+
+
+@pytest.mark.parametrize('mode,nsub', [('rapid', 3), ('muskingum', 2), ('unit', 1), ('unit', 2)])
+def test_record_ring_goes_round_with_substeps_and_other_modes(monkeypatch, mode, nsub):
+    """The record ring recycling its slots (a call several times longer than the ring) with sub-steps, without lateral rows
+    (no in-pass: the tasks write fresh records) and for UnitMuskingum -- each against the oracle, every row."""
+    from conftest import unit_split
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv('RR_WAVE', '1')
+    monkeypatch.setenv('RR_VERBOSE', '1')
+    n, T, dt = 6000, 2400 // nsub, 900.0 / nsub
+    net = synth.synth_network(n, seed=77)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, dt)
+    q0 = 3.0 * synth.u01(5, np.arange(n))
+    from river_route_amd.engine import DeviceBuffer
+    with Plan(indptr, indices) as plan:
+        if mode == 'unit':
+            hw_idx, inner_idx, A_in, A_hw = unit_split(indptr, indices, n)
+            c1i, c2i, c3i = c1[inner_idx], c2[inner_idx], c3[inner_idx]
+            args = (A_in.indptr, A_in.indices, -c1i[A_in.indices], A_in.indptr, A_in.indices, A_in.data,
+                    A_hw.indptr, A_hw.indices, A_hw.data, c1i, c2i, c3i, hw_idx, inner_idx)
+            conv = synth.synth_qlateral(n, 0, T) / 900.0 - 0.2       # some negative lateral: the clip at zero has work to do
+            qc_ref, qf_ref, d_ref = 0.5 * q0[inner_idx], q0[inner_idx].copy(), np.zeros((T, n))
+            oracle.unit_route(*args, qc_ref, qf_ref, conv, d_ref, nsub)
+            plan.set_coeffs(-c1[indices], c2, c3, None)
+            ni = inner_idx.size
+            d_qc, d_qf = DeviceBuffer(ni * 8).upload(0.5 * q0[inner_idx]), DeviceBuffer(ni * 8).upload(q0[inner_idx].copy())
+            d_conv, d_out = DeviceBuffer(conv.nbytes).upload(conv), DeviceBuffer(T * n * 8)
+            plan.unit_route_dev(d_qc, d_qf, d_conv, T, d_out, T, T, nsub)
+            assert_close(d_out.download(np.float64, (T, n)), d_ref, 'discharge')
+            assert_close(d_qc.download(np.float64, (ni,)), qc_ref, 'q_ch')
+            assert_close(d_qf.download(np.float64, (ni,)), qf_ref, 'q_full')
+            np.testing.assert_array_equal(d_out.download(np.float64, (T, n))[:, hw_idx], conv[:, hw_idx])      # headwaters: not clipped
+            for b in (d_qc, d_qf, d_conv, d_out):
+                b.free()
+        elif mode == 'rapid':
+            c4_dt = (c1 + c2) / dt
+            ql = synth.synth_qlateral(n, 0, T) - 150.0               # some negative lateral
+            q_ref, d_ref = q0.copy(), np.zeros((T, n))
+            oracle.rapid_route(indptr, indices, -c1[indices], c2, c3, c4_dt, q_ref, ql, d_ref, nsub)
+            plan.set_coeffs(-c1[indices], c2, c3, c4_dt)
+            q, d = _device_route(plan, q0, ql, T, nsub)
+            assert (d_ref == 0.0).any()
+            assert_close(q, q_ref, 'q_t')
+            assert_close(d, d_ref, 'discharge')
+        else:
+            q_ref, d_ref = q0.copy(), np.zeros((T, n))
+            oracle.muskingum_route(indptr, indices, -c1[indices], c2, c3, q_ref, d_ref, T, nsub)
+            plan.set_coeffs(-c1[indices], c2, c3, None)
+            d_q, d_out = DeviceBuffer(n * 8).upload(q0), DeviceBuffer(T * n * 8)
+            plan.muskingum_route_dev(d_q, d_out, T, T, nsub)
+            assert_close(d_q.download(np.float64, (n,)), q_ref, 'q_t')
+            assert_close(d_out.download(np.float64, (T, n)), d_ref, 'discharge')
+            d_q.free(); d_out.free()
+        assert plan.profile()['ticks_per_launch'] >= 16
