@@ -7,7 +7,7 @@ Workload at N=1 (BASELINE.json configs[2]): RapidMuskingum on the 1M-reach synth
 15-minute steps (35,040 runoff steps, dt_routing = dt_runoff = 900 s, fp64).  One bench "step" is ONE pass of
 the hot path over that year: a single rr_rapid_route_dev call.  A year of lateral inflow for 1M reaches is
 280 GB, so the forcing is a 96-row (one day) device-resident array read cyclically (row t % 96) and the
-discharge goes to a 128-row cyclic sink (the out-pass moves 128 rows at a time: no two rows of one launch share a
+discharge goes to a 256-row cyclic sink (the out-pass moves 256 rows at a time: no two rows of one launch share a
 sink row, as in a real T-row output); every routed row is still read from and written to HBM, and the
 params-order <-> engine-order permutation passes are inside the timed region.  Inputs are resident in HBM
 when the timed region starts (the PCIe-inclusive host-pointer rate is noted in DESIGN.md, never here).
@@ -291,7 +291,7 @@ def main():
     plan.set_options(rows_per_chunk=args.chunk_rows, sample_every=args.sample_every)
 
     ql = torch.from_numpy(synth.synth_qlateral(n, 0, rows, dt=dt * nsub)).to(dev)
-    sink_rows = min(T, 128)      # rows of one out-pass batch: a launch never writes a sink row twice
+    sink_rows = min(T, plan.tile_info()['batch_rows'])      # rows of one out-pass batch: a launch never writes a sink row twice
     out = torch.zeros((sink_rows, n), dtype=torch.float64, device=dev)
     q_t = torch.zeros(n, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream

@@ -80,7 +80,9 @@ int rr_plan_layout(const rr_plan *plan, int32_t *perm, int32_t *lag, int32_t *ch
 
 /* Layout of the time-tiled kernel (subtree tiles), for inspection/tests.
  * info[0]=1 if the network tiles (else the streaming kernel routes it), [1]=tile capacity in positions, [2]=positions
- * (reaches + ghosts), [3]=ghosts, [4]=tiles, [5]=tile levels, [6]=threads per workgroup.
+ * (reaches + ghosts), [3]=ghosts, [4]=tiles, [5]=tile levels, [6]=threads per workgroup, [7]=rows the passes between
+ * params-order rows and the kernel's records move per launch (a cyclic discharge array with at least that many rows is never
+ * written twice by one launch).
  * rr_plan_tile_layout (any pointer may be NULL): tile_ptr[tiles+1] first position of each tile; tile_level[tiles];
  * perm[np] params index of the reach at (or mirrored by) each position; lag[np] pipeline lag, bit 28 set on a ghost, bit 27 on
  * a reach that a ghost of another tile mirrors; cfirst[np] first upstream position; ccnt[np] upstream positions (low 16 bits)

@@ -219,7 +219,7 @@ int rr_plan_tile_info(const rr_plan *P, int64_t info[8])
     if (!P || !info) return fail(RR_E_INVALID, "rr_plan_tile_info: null argument");
     const rr::TilePlan &T = P->tp;
     info[0] = T.ok ? 1 : 0; info[1] = T.block; info[2] = T.np; info[3] = T.n_ghost; info[4] = T.n_tiles; info[5] = T.n_levels;
-    info[6] = P->wave_threads; info[7] = 0;
+    info[6] = P->wave_threads; info[7] = kRecRows;
     return RR_OK;
 }
 
@@ -513,11 +513,11 @@ int rr_unit_route_dev(rr_plan *P, double *q_ch, double *q_full, const double *co
 }
 
 // float32 output fused into the record pass (k_rec_out): applies when the call is time-tiled and factor x sub-steps divides
-// the 128 tick-rows of a batch; otherwise RR_E_UNSUPPORTED and the caller uses the float64 form + rr_resample_cast_dev.
+// the tick-rows of a batch (256); otherwise RR_E_UNSUPPORTED and the caller uses the float64 form + rr_resample_cast_dev.
 static int f32_output_applies(rr_plan *P, Mode mode, int64_t T, int64_t nsub, int64_t factor)
 {
     if (factor < 1 || T % factor != 0) return fail(RR_E_INVALID, "float32 output: the number of rows must be a multiple of factor >= 1");
-    if (kRecRows % (factor * nsub) != 0) return fail(RR_E_UNSUPPORTED, "float32 output: factor x sub-steps must divide 128");
+    if (kRecRows % (factor * nsub) != 0) return fail(RR_E_UNSUPPORTED, "float32 output: factor x sub-steps must divide the rows of a record batch (256)");
     if (!decide_wave(P, mode, T * nsub, false)) return fail(RR_E_UNSUPPORTED, "float32 output needs the time-tiled kernel, which this call does not get");
     return RR_OK;
 }

@@ -280,7 +280,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         for (int32_t i : P->export_reach) { const int32_t p = TP.inv[i]; S.export_skew = std::max<int64_t>(S.export_skew, (int64_t)TP.tile_level[TP.tile_of[p]] * K + (TP.lag[p] & kLagMask)); }
         if (io.dev_out32) {
             const int64_t step = io.out_factor * nsub;
-            if (io.out_factor < 1 || kRecRows % step != 0 || T % io.out_factor != 0) { S.open = false; return fail(RR_E_UNSUPPORTED, "float32 output: factor * sub-steps must divide 128 and factor the number of rows"); }
+            if (io.out_factor < 1 || kRecRows % step != 0 || T % io.out_factor != 0) { S.open = false; return fail(RR_E_UNSUPPORTED, "float32 output: factor * sub-steps must divide the rows of a record batch (256) and factor the number of rows"); }
         }
         TileArgs &w = S.ta;
         w.tile_ptr = P->d_tile_ptr; w.tile_level = P->d_tile_level; w.tile_lag_lo = P->d_tile_lag_lo; w.tile_lag_hi = P->d_tile_lag_hi;
@@ -551,7 +551,10 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
         else hipLaunchKernelGGL(k_rec_in_runoff<double>, gr, dim3(kRunoffInThreads), 0, S.stream, ra, *S.io.runoff);
     } else if (in && S.io.uh_kernel) {
         UhArgs ua{S.io.uh_kernel, S.io.uh_state, (int32_t)S.io.uh_nks};
-        hipLaunchKernelGGL(rec_in_uh_kernel(sub, S.io.uh_nks), g, dim3(kUhInThreads), rec_in_uh_lds_bytes(uh_padded_taps(S.io.uh_nks)), S.stream, ra, ua);
+        for (int half = 0; half < kRecBatch / kUhBatch; ++half) {      // the fused convolution's windows fit registers for 8 records at a time
+            ra.batch = batch * (kRecBatch / kUhBatch) + half;
+            hipLaunchKernelGGL(rec_in_uh_kernel(sub, S.io.uh_nks), g, dim3(kUhInThreads), rec_in_uh_lds_bytes(uh_padded_taps(S.io.uh_nks)), S.stream, ra, ua);
+        }
     } else if (in) {
         if (sub) hipLaunchKernelGGL(k_rec_in<true>, g, dim3(kRecThreads), 0, S.stream, ra);
         else hipLaunchKernelGGL(k_rec_in<false>, g, dim3(kRecThreads), 0, S.stream, ra);
@@ -564,7 +567,7 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
     }
 }
 
-// Time-tiled schedule: batches of 128 tick-rows become records as soon as their rows are there and their ring slots
+// Time-tiled schedule: batches of kRecRows (256) tick-rows become records as soon as their rows are there and their ring slots
 // are free, launches run while their input is present, finished batches leave.
 int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, int64_t *export_ready)
 {
@@ -573,12 +576,12 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
     const int64_t ticks_ready = std::min(rows_ready, S.T) * S.nsub;
     for (;;) {
         bool progressed = false;
-        // one batch of 128 tick-rows -> records; a record slot is recycled only after every tick-row it can hold has left.
+        // one batch of tick-rows -> records; a record slot is recycled only after every tick-row it can hold has left.
         // Lateral rows and boundary sub-steps (the ghost series of a partitioned network) advance separately: a ghost in a
         // tile of level l at lag L is first read (l K + L) ticks into the schedule, so the boundary may trail the rows.
         // Batch j writes, for a position of lag L, the records whose last tick-row lies in the batch: chunks up to
-        // (128 (j + 1) + L) / 16.  One ring revolution earlier that slot held the same position's tick-rows up to
-        // 128 (j + 1) - 16 rec_chunks + 15, whatever L is: those must have left.
+        // (R (j + 1) + L) / 16, R = kRecRows.  One ring revolution earlier that slot held the same position's tick-rows up to
+        // R (j + 1) - 16 rec_chunks + 15, whatever L is: those must have left.
         auto slot_free = [&](int64_t j) {
             const int64_t must_have_left = kRecRows * (j + 1) + kRec - kRec * S.rec_chunks;
             return must_have_left <= 0 || S.ticks_stored >= std::min(S.total, must_have_left);
@@ -782,7 +785,7 @@ int host_pipe_prepare(rr_plan *P)
     // chunks of about half a gigabyte: long enough for the DMA engines to reach their rate, short enough to pipeline
     H.chunk_rows = std::max<int64_t>(16, std::min<int64_t>(4096, ((int64_t{1} << 29) / (n * 8) + 15) / 16 * 16));
     if (n * 8 * 64 <= (int64_t{1} << 30)) H.chunk_rows = std::max<int64_t>(H.chunk_rows, 64);
-    H.ring_chunks = std::max<int64_t>(8, (2 * kRecRows + 15) / H.chunk_rows + 6);      // a batch of 128 rows + its 15-row overlap stays readable
+    H.ring_chunks = std::max<int64_t>(8, (2 * kRecRows + 15) / H.chunk_rows + 6);      // a batch of rows + its 15-row overlap stays readable
     const int64_t pin_need = H.chunk_rows * n, dev_need = H.ring_chunks * H.chunk_rows * n;
     if (H.pin_cap < pin_need || H.dev_cap < dev_need) {
         H.destroy();

@@ -6,14 +6,15 @@ namespace {
 
 // ---- record permutation (one pass each way), see k_tile ----
 // Column i of the params-order rows is position p = inv[i] with lag L = 16 * sh + o.  Tick-row r of that column (tick-row =
-// routing sub-step: runoff row r / nsub, sub-step r % nsub) is slot (r + L) % 16 of record (r + L) / 16, so the 128 tick-rows
-// [128 j - o, 128 j + 128 - o) are exactly the eight records 8 j + sh .. 8 j + sh + 7.  k_rec_in reads the runoff rows
-// behind the 143 tick-rows [128 j - 15, 128 j + 128) of a 32-column tile coalesced into LDS (all loads in flight before the
-// first LDS write) and writes eight whole 128-byte records per column (8 lanes x 16 B per record), every sub-step slot of a
-// row holding the row's lateral value; k_rec_out reads nine records per column the same way and writes the tile's rows of
-// the batch coalesced: the slot of a row's LAST sub-step holds the row's mean discharge.
+// routing sub-step: runoff row r / nsub, sub-step r % nsub) is slot (r + L) % 16 of record (r + L) / 16, so with B = 16 records
+// per batch the 256 tick-rows [256 j - o, 256 j + 256 - o) are exactly the records B j + sh .. B j + sh + B - 1.  k_rec_in
+// reads the runoff rows behind the 271 tick-rows [256 j - 15, 256 j + 256) of a 32-column tile coalesced into LDS (all loads
+// in flight before the first LDS write) and writes B whole 128-byte records per column (8 lanes x 16 B per record), every
+// sub-step slot of a row holding the row's lateral value; k_rec_out reads B + 1 records per column the same way and writes
+// the tile's rows of the batch coalesced: the slot of a row's LAST sub-step holds the row's mean discharge.  The 15 rows /
+// one record read twice are 6 % of a batch of 16 (12 % of a batch of 8: 366 -> 361 ms per year, profiles/r02_rec_batch.txt).
 #ifndef RR_REC_BATCH
-#define RR_REC_BATCH 8
+#define RR_REC_BATCH 16
 #define RR_REC_COLS 32
 #endif
 #ifndef RR_REC_THREADS
@@ -41,33 +42,35 @@ constexpr int kRecTileRows = 16 * kRecBatch + 15;      // tick-rows behind one b
 constexpr int kRecTileLd = kRecCols + 1;
 
 // Second half of the in-pass: the LDS tile (row = runoff row - row_first, kRecTileLd doubles per row) becomes records.
-template <bool SUB, int THREADS = kRecThreads>
+// BATCH records per column; a.batch counts launches of BATCH records (the fused convolution works in half batches).
+template <bool SUB, int THREADS = kRecThreads, int BATCH = kRecBatch>
 __device__ __forceinline__ void write_records(const RecPermArgs &a, const double *tile, int64_t col0, int64_t tick_first, int64_t row_first)
 {
-    constexpr int R = kRecTileRows;
+    constexpr int R = 16 * BATCH + 15;
     const int tid = threadIdx.x;
-    constexpr int IT = kRecCols * kRecBatch * 8 / THREADS;
+    static_assert(kRecCols * BATCH * 8 % THREADS == 0, "records of a tile must divide among the threads");
+    constexpr int IT = kRecCols * BATCH * 8 / THREADS;
     int2 meta[IT];
     double f[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {     // all metadata loads first: they are independent
-        const int64_t i = col0 + (it * THREADS + tid) / (8 * kRecBatch);
+        const int64_t i = col0 + (it * THREADS + tid) / (8 * BATCH);
         meta[it] = i < a.n ? a.colmeta[i] : make_int2(-1, 0);
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-        const int64_t i = col0 + (it * THREADS + tid) / (8 * kRecBatch);
+        const int64_t i = col0 + (it * THREADS + tid) / (8 * BATCH);
         f[it] = (a.scale && i < a.n) ? a.scale[i] : 1.0;
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int piece = it * THREADS + tid;       // (column, record, 16-byte part): 8 consecutive lanes = one record
-        const int c = piece / (8 * kRecBatch), k = (piece >> 3) % kRecBatch, part = piece & 7;
+        const int c = piece / (8 * BATCH), k = (piece >> 3) % BATCH, part = piece & 7;
         const int32_t p = meta[it].x;
         if (p < 0) continue;
         const int32_t lag = meta[it].y & kLagMask;
         const int o = lag & 15;
-        const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)(lag >> 4) + k;
+        const uint32_t chunk = (uint32_t)BATCH * (uint32_t)a.batch + (uint32_t)(lag >> 4) + k;
         const int r = 15 - o + 16 * k + 2 * part;       // tick-row tick_first + r
         double v0, v1;
         if (SUB) {
@@ -127,19 +130,22 @@ struct UhArgs {
     int32_t n_ks;
 };
 constexpr int kUhInThreads = 256;       // 8 groups of rows x 32 columns: 18 outputs per thread, windows of 18 + NK - 1 depth values (512 threads x 9 rows: 20 % slower)
-constexpr int kUhRowsPerThread = (kRecTileRows + kUhInThreads / kRecCols - 1) / (kUhInThreads / kRecCols);
-constexpr size_t rec_in_uh_lds_bytes(int nk) { return (size_t)((kRecTileRows + nk - 1) + nk) * kRecTileLd * sizeof(double); }
+constexpr int kUhBatch = 8;             // records per column and launch: two launches per batch of the plain passes (a.batch counts these half batches)
+static_assert(kRecBatch % kUhBatch == 0, "the fused convolution works in whole fractions of a record batch");
+constexpr int kUhTileRows = 16 * kUhBatch + 15;
+constexpr int kUhRowsPerThread = (kUhTileRows + kUhInThreads / kRecCols - 1) / (kUhInThreads / kRecCols);
+constexpr size_t rec_in_uh_lds_bytes(int nk) { return (size_t)((kUhTileRows + nk - 1) + nk) * kRecTileLd * sizeof(double); }
 
 template <bool SUB, int NK>
 __global__ __launch_bounds__(kUhInThreads) void k_rec_in_uh(const RecPermArgs a, const UhArgs u)
 {
-    constexpr int R = kRecTileRows, G = kUhInThreads / kRecCols, RP = kUhRowsPerThread, W = RP + NK - 1;
+    constexpr int R = kUhTileRows, G = kUhInThreads / kRecCols, RP = kUhRowsPerThread, W = RP + NK - 1;
     extern __shared__ __attribute__((aligned(16))) double uh_lds[];
     double *dt = uh_lds;                                   // [R + NK - 1][kRecTileLd] depth rows row_first - (NK - 1) ...
     double *tp = uh_lds + (R + NK - 1) * kRecTileLd;       // [NK][kRecTileLd] taps
     const int tid = threadIdx.x, c = tid % kRecCols, g = tid / kRecCols;
     const int64_t col0 = (int64_t)(a.swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x) * kRecCols;
-    const int64_t tick_first = kRecRows * a.batch - 15;
+    const int64_t tick_first = 16 * kUhBatch * a.batch - 15;
     uint32_t sub_unused;
     const int64_t row_first = SUB ? (int64_t)a.nsub.div((uint32_t)(tick_first < 0 ? 0 : tick_first), sub_unused) : tick_first;
     const int need = SUB ? (int)((uint32_t)(R - 1) / a.nsub.d) + 2 : R;
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(kUhInThreads) void k_rec_in_uh(const RecPermArgs a,
         for (int j = 0; j < RP; ++j) if (rb + j < R) dt[(rb + j) * kRecTileLd + c] = acc[j];
     }
     __syncthreads();
-    write_records<SUB, kUhInThreads>(a, dt, col0, tick_first, row_first);
+    write_records<SUB, kUhInThreads, kUhBatch>(a, dt, col0, tick_first, row_first);
 }
 
 // OUT32: the router's post-processing fused in (TransformMuskingum.py:128-142): mean over `factor` consecutive rows

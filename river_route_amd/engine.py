@@ -85,7 +85,7 @@ class Plan:
         info = np.zeros(8, dtype=np.int64)
         check(_lib.lib().rr_plan_tile_info(self._h, ptr(info)))
         return dict(ok=bool(info[0]), block=int(info[1]), positions=int(info[2]), ghosts=int(info[3]), tiles=int(info[4]),
-                    levels=int(info[5]), threads=int(info[6]))
+                    levels=int(info[5]), threads=int(info[6]), batch_rows=int(info[7]))
 
     def tile_layout(self) -> dict:
         """Arrays of the subtree-tile layout, see rr_plan_tile_layout."""
