@@ -6,9 +6,11 @@ bench.py -- reach-steps/sec of the Muskingum routing hot path on MI355X (BASELIN
 Workload at N=1 (BASELINE.json configs[2]): RapidMuskingum on the 1M-reach synthetic network, 1 year at
 15-minute steps (35,040 runoff steps, dt_routing = dt_runoff = 900 s, fp64).  One bench "step" is ONE pass of
 the hot path over that year: a single rr_rapid_route_dev call.  A year of lateral inflow for 1M reaches is
-280 GB, so the forcing is a 96-row (one day) device-resident array read cyclically (row t % 96) and the
-discharge goes to a 256-row cyclic sink (the out-pass moves 256 rows at a time: no two rows of one launch share a
-sink row, as in a real T-row output); every routed row is still read from and written to HBM, and the
+280 GB, so the forcing is a 288-row (three days) device-resident array read cyclically (row t % 288) and the
+discharge goes to a 256-row cyclic sink.  Both are at least as long as what one launch of the record passes moves (271
+rows in, 256 out), so that -- as with a real T-row array -- no launch reads or writes a row twice and finds it in a
+cache (SURVEY section 8d proposes 96-row rings; with those a quarter of the rows of every launch never reached HBM);
+every routed row is read from and written to HBM, and the
 params-order <-> engine-order permutation passes are inside the timed region.  Inputs are resident in HBM
 when the timed region starts (the PCIe-inclusive host-pointer rate is noted in DESIGN.md, never here).
 
@@ -45,7 +47,8 @@ def parse_args():
     ap.add_argument('--reaches', type=int, default=None, help='reaches per GPU (default 1,000,000 at N = 1; 1,250,000 at N > 1: BASELINE config 5 is 10M reaches on 8 GPUs)')
     ap.add_argument('--runoff-steps', type=int, default=35_040, help='runoff steps per bench step (1 yr @ 15 min)')
     ap.add_argument('--substeps', type=int, default=1)
-    ap.add_argument('--forcing-rows', type=int, default=96)
+    ap.add_argument('--forcing-rows', type=int, default=288,
+                    help='rows of the cyclic device-resident forcing (three days): more than the 271 rows one in-pass launch reads, so no launch reads a forcing row twice')
     ap.add_argument('--order', default='random', choices=['random', 'levels', 'bfs'])
     ap.add_argument('--sample-every', type=int, default=128)
     ap.add_argument('--chunk-rows', type=int, default=16)
