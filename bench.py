@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument('--substeps', type=int, default=1)
     ap.add_argument('--forcing-rows', type=int, default=288,
                     help='rows of the cyclic device-resident forcing (three days): more than the 271 rows one in-pass launch reads, so no launch reads a forcing row twice')
+    ap.add_argument('--sink-rows', type=int, default=0,
+                    help='rows of the cyclic discharge sink; 0 = one out-pass launch (256), so that no launch writes a row twice')
     ap.add_argument('--order', default='random', choices=['random', 'levels', 'bfs'])
     ap.add_argument('--sample-every', type=int, default=128)
     ap.add_argument('--chunk-rows', type=int, default=16)
@@ -294,7 +296,7 @@ def main():
     plan.set_options(rows_per_chunk=args.chunk_rows, sample_every=args.sample_every)
 
     ql = torch.from_numpy(synth.synth_qlateral(n, 0, rows, dt=dt * nsub)).to(dev)
-    sink_rows = min(T, plan.tile_info()['batch_rows'])      # rows of one out-pass batch: a launch never writes a sink row twice
+    sink_rows = min(T, args.sink_rows or plan.tile_info()['batch_rows'])      # default: rows of one out-pass batch, a launch never writes a sink row twice
     out = torch.zeros((sink_rows, n), dtype=torch.float64, device=dev)
     q_t = torch.zeros(n, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
