@@ -7,8 +7,8 @@ Workload at N=1 (BASELINE.json configs[2]): RapidMuskingum on the 1M-reach synth
 15-minute steps (35,040 runoff steps, dt_routing = dt_runoff = 900 s, fp64).  One bench "step" is ONE pass of
 the hot path over that year: a single rr_rapid_route_dev call.  A year of lateral inflow for 1M reaches is
 280 GB, so the forcing is a 288-row (three days) device-resident array read cyclically (row t % 288) and the
-discharge goes to a 256-row cyclic sink.  Both are at least as long as what one launch of the record passes moves (271
-rows in, 256 out), so that -- as with a real T-row array -- no launch reads or writes a row twice and finds it in a
+discharge goes to a 128-row cyclic sink.  Both are at least as long as what one launch of the record passes moves (143
+rows in, 128 out), so that -- as with a real T-row array -- no launch reads or writes a row twice and finds it in a
 cache (SURVEY section 8d proposes 96-row rings; with those a quarter of the rows of every launch never reached HBM);
 every routed row is read from and written to HBM, and the
 params-order <-> engine-order permutation passes are inside the timed region.  Inputs are resident in HBM
@@ -48,9 +48,9 @@ def parse_args():
     ap.add_argument('--runoff-steps', type=int, default=35_040, help='runoff steps per bench step (1 yr @ 15 min)')
     ap.add_argument('--substeps', type=int, default=1)
     ap.add_argument('--forcing-rows', type=int, default=288,
-                    help='rows of the cyclic device-resident forcing (three days): more than the 271 rows one in-pass launch reads, so no launch reads a forcing row twice')
+                    help='rows of the cyclic device-resident forcing (three days): more than the 143 rows one in-pass launch reads, so no launch reads a forcing row twice')
     ap.add_argument('--sink-rows', type=int, default=0,
-                    help='rows of the cyclic discharge sink; 0 = one out-pass launch (256), so that no launch writes a row twice')
+                    help='rows of the cyclic discharge sink; 0 = one out-pass launch (128), so that no launch writes a row twice')
     ap.add_argument('--order', default='random', choices=['random', 'levels', 'bfs'])
     ap.add_argument('--sample-every', type=int, default=128)
     ap.add_argument('--chunk-rows', type=int, default=16)

@@ -1,6 +1,6 @@
 """Lock-step simulation of the multi-GPU pipeline (no GPU needed): the bench network is partitioned as `bench.py --gpus N`
 does, every part gets a host-only plan, and the executor's readiness rules (river_route_amd/csrc/rr_exec.hpp:
-session_advance_tile -- a batch of 256 tick-rows becomes records once the lateral rows AND the boundary sub-steps behind it
+session_advance_tile -- a batch of 128 tick-rows becomes records once the lateral rows AND the boundary sub-steps behind it
 have arrived; launch d runs once the ticks below (d + 1) K are records and the boundary sub-steps below (d + 1) K - slack are; an export reach in a tile of level l at lag L is
 final (d - l) K - L sub-steps into the schedule; finished sub-steps are shipped in batches of `exchange_rows`) are stepped
 with one launch per part per step (parts are the same size, so launches take the same time).  Prints, per part, the
@@ -20,7 +20,7 @@ from river_route_amd.multi_gpu import split_network
 MASK = (1 << 27) - 1
 
 
-def simulate(n, parts, T=35040, K=64, batch=256, exchange=128):
+def simulate(n, parts, T=35040, K=64, batch=128, exchange=128):
     net = synth.synth_network(n, order='random')
     has = net.down_index >= 0
     indptr = np.concatenate([[0], np.cumsum(has)]).astype(np.int32)

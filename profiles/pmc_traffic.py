@@ -43,7 +43,7 @@ def main():
     ap.add_argument('fetch_csv'); ap.add_argument('write_csv')
     ap.add_argument('--reaches', type=int, default=1_000_000)
     ap.add_argument('--positions', type=int, required=True, help='reaches + ghost positions (bench line: reaches + ghost_positions)')
-    ap.add_argument('--rows-per-batch', type=int, default=256)
+    ap.add_argument('--rows-per-batch', type=int, default=128)
     ap.add_argument('--ticks', type=int, default=64)
     a = ap.parse_args()
     fetch, write = load(a.fetch_csv, 'FETCH_SIZE'), load(a.write_csv, 'WRITE_SIZE')

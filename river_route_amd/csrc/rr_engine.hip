@@ -513,11 +513,11 @@ int rr_unit_route_dev(rr_plan *P, double *q_ch, double *q_full, const double *co
 }
 
 // float32 output fused into the record pass (k_rec_out): applies when the call is time-tiled and factor x sub-steps divides
-// the tick-rows of a batch (256); otherwise RR_E_UNSUPPORTED and the caller uses the float64 form + rr_resample_cast_dev.
+// the tick-rows of a batch (128); otherwise RR_E_UNSUPPORTED and the caller uses the float64 form + rr_resample_cast_dev.
 static int f32_output_applies(rr_plan *P, Mode mode, int64_t T, int64_t nsub, int64_t factor)
 {
     if (factor < 1 || T % factor != 0) return fail(RR_E_INVALID, "float32 output: the number of rows must be a multiple of factor >= 1");
-    if (kRecRows % (factor * nsub) != 0) return fail(RR_E_UNSUPPORTED, "float32 output: factor x sub-steps must divide the rows of a record batch (256)");
+    if (kRecRows % (factor * nsub) != 0) return fail(RR_E_UNSUPPORTED, "float32 output: factor x sub-steps must divide the rows of a record batch (128)");
     if (!decide_wave(P, mode, T * nsub, false)) return fail(RR_E_UNSUPPORTED, "float32 output needs the time-tiled kernel, which this call does not get");
     return RR_OK;
 }

@@ -280,7 +280,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         for (int32_t i : P->export_reach) { const int32_t p = TP.inv[i]; S.export_skew = std::max<int64_t>(S.export_skew, (int64_t)TP.tile_level[TP.tile_of[p]] * K + (TP.lag[p] & kLagMask)); }
         if (io.dev_out32) {
             const int64_t step = io.out_factor * nsub;
-            if (io.out_factor < 1 || kRecRows % step != 0 || T % io.out_factor != 0) { S.open = false; return fail(RR_E_UNSUPPORTED, "float32 output: factor * sub-steps must divide the rows of a record batch (256) and factor the number of rows"); }
+            if (io.out_factor < 1 || kRecRows % step != 0 || T % io.out_factor != 0) { S.open = false; return fail(RR_E_UNSUPPORTED, "float32 output: factor * sub-steps must divide the rows of a record batch (128) and factor the number of rows"); }
         }
         TileArgs &w = S.ta;
         w.tile_ptr = P->d_tile_ptr; w.tile_level = P->d_tile_level; w.tile_lag_lo = P->d_tile_lag_lo; w.tile_lag_hi = P->d_tile_lag_hi;
@@ -567,7 +567,7 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
     }
 }
 
-// Time-tiled schedule: batches of kRecRows (256) tick-rows become records as soon as their rows are there and their ring slots
+// Time-tiled schedule: batches of kRecRows (128) tick-rows become records as soon as their rows are there and their ring slots
 // are free, launches run while their input is present, finished batches leave.
 int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, int64_t *export_ready)
 {

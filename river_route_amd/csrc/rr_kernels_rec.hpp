@@ -6,15 +6,17 @@ namespace {
 
 // ---- record permutation (one pass each way), see k_tile ----
 // Column i of the params-order rows is position p = inv[i] with lag L = 16 * sh + o.  Tick-row r of that column (tick-row =
-// routing sub-step: runoff row r / nsub, sub-step r % nsub) is slot (r + L) % 16 of record (r + L) / 16, so with B = 16 records
-// per batch the 256 tick-rows [256 j - o, 256 j + 256 - o) are exactly the records B j + sh .. B j + sh + B - 1.  k_rec_in
-// reads the runoff rows behind the 271 tick-rows [256 j - 15, 256 j + 256) of a 32-column tile coalesced into LDS (all loads
+// routing sub-step: runoff row r / nsub, sub-step r % nsub) is slot (r + L) % 16 of record (r + L) / 16, so with B = 8 records
+// per batch the 128 tick-rows [128 j - o, 128 j + 128 - o) are exactly the records B j + sh .. B j + sh + B - 1.  k_rec_in
+// reads the runoff rows behind the 143 tick-rows [128 j - 15, 128 j + 128) of a 32-column tile coalesced into LDS (all loads
 // in flight before the first LDS write) and writes B whole 128-byte records per column (8 lanes x 16 B per record), every
 // sub-step slot of a row holding the row's lateral value; k_rec_out reads B + 1 records per column the same way and writes
-// the tile's rows of the batch coalesced: the slot of a row's LAST sub-step holds the row's mean discharge.  The 15 rows /
-// one record read twice are 6 % of a batch of 16 (12 % of a batch of 8: 366 -> 361 ms per year, profiles/r02_rec_batch.txt).
+// the tile's rows of the batch coalesced: the slot of a row's LAST sub-step holds the row's mean discharge.  B = 16 halves
+// the share of rows / records read twice at a batch's edge but needs 72 KB of LDS per workgroup: 1 % slower when every row
+// comes from HBM (380 vs 384 ms per year), faster only while a short cyclic forcing array is found in a cache
+// (profiles/r02_rec_batch.txt).
 #ifndef RR_REC_BATCH
-#define RR_REC_BATCH 16
+#define RR_REC_BATCH 8
 #define RR_REC_COLS 32
 #endif
 #ifndef RR_REC_THREADS

@@ -387,7 +387,7 @@ def bench_main(args, rank: int, local_rank: int, world: int) -> None:
     idx = (np.arange(rows, dtype=np.uint64)[:, None] * np.uint64(n)) + spec.real_global.astype(np.uint64)[None, :]
     lateral = dt * nsub * synth.u01(synth.FORCING_SEED, idx)
     eng = HipPartEngine(spec, c1, c2, c3, (c1 + c2) / (dt * nsub), np.zeros(n), lateral, T, nsub, local_rank,
-                        out_rows=min(T, 256), sample_every=args.sample_every)      # sink of one out-pass batch: no row written twice by a launch
+                        out_rows=min(T, 128), sample_every=args.sample_every)      # sink of one out-pass batch: no row written twice by a launch
     chunk_rows = max(16, args.exchange_rows)
 
     def one_pass():
