@@ -88,7 +88,7 @@ def test_per_edge_weights_fall_back_to_the_streaming_kernel():
 @pytest.mark.parametrize('env', SHAPES + [{}])
 @pytest.mark.parametrize('n,T,nsub,n_ks', [(40000, 50, 1, 48), (40000, 17, 3, 5)])
 def test_unit_route_every_kernel_shape(monkeypatch, env, n, T, nsub, n_ks):
-    """UnitMuskingum through the streaming kernel (k_tick_unit) and the time-tiled kernel (k_wave, UNIT) vs the oracle,
+    """UnitMuskingum through the streaming kernel (k_tick_unit) and the time-tiled kernel (k_tile, UNIT) vs the oracle,
     two consecutive files with state hand-off as UnitMuskingum._router does it."""
     from conftest import unit_split
     from river_route_amd.engine import uh_convolve

@@ -114,8 +114,8 @@ def test_hip_parts_on_one_gpu_match_single_plan(monkeypatch, wave, n, T, nsub, p
     network (itself checked against the oracle in test_gpu_kernels.py)."""
     from river_route_amd.engine import Plan
     from river_route_amd.multi_gpu import HipPartEngine
-    # boundary reaches in the streaming kernel (k_tick), the time-tiled kernel in row mode (k_wave, K = 8) and in
-    # record mode (k_wave_rec, K = 16; one sub-step per row only)
+    # boundary reaches in the streaming kernel (k_tick) and in the time-tiled kernel (k_tile) with 16 ticks per task and with
+    # the length the engine picks
     monkeypatch.setenv('RR_WAVE', '0' if wave == '0' else '1')
     if wave == '1':
         monkeypatch.setenv('RR_WAVE_K', '16')
