@@ -295,7 +295,7 @@ def main():
     plan.set_coeffs(-c1[indices], c2, c3, (c1 + c2) / (dt * nsub))
     plan.set_options(rows_per_chunk=args.chunk_rows, sample_every=args.sample_every)
 
-    ql = torch.from_numpy(synth.synth_qlateral(n, 0, rows, dt=dt * nsub)).to(dev)
+    ql = synth.synth_qlateral_torch(n, 0, rows, dev, dt=dt * nsub)      # the same bits as synth_qlateral (tests/test_host.py), made on the device
     sink_rows = min(T, args.sink_rows or plan.tile_info()['batch_rows'])      # default: rows of one out-pass batch, a launch never writes a sink row twice
     out = torch.zeros((sink_rows, n), dtype=torch.float64, device=dev)
     q_t = torch.zeros(n, dtype=torch.float64, device=dev)

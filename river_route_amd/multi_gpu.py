@@ -127,10 +127,9 @@ class HipPartEngine:
         self.plan.set_boundary(np.arange(ng), export_local)
         self.plan.set_options(sample_every=sample_every)
         # lateral rows: (rows, n_loc) in local order; ghost columns are never read
-        lat = np.zeros((lateral_rows.shape[0], n_loc))
-        lat[:, ng:] = lateral_rows
-        self.lateral = torch.from_numpy(lat).to(self.dev)
-        self.lat_rows = lat.shape[0]
+        self.lat_rows = int(lateral_rows.shape[0])
+        self.lateral = torch.zeros((self.lat_rows, n_loc), dtype=torch.float64, device=self.dev)
+        self.lateral[:, ng:] = lateral_rows.to(self.dev) if torch.is_tensor(lateral_rows) else torch.from_numpy(np.ascontiguousarray(lateral_rows, dtype=np.float64)).to(self.dev)
         self.out_rows = int(out_rows or self.lat_rows)
         self.discharge = torch.zeros((self.out_rows, n_loc), dtype=torch.float64, device=self.dev)
         q0 = np.asarray(q0_global, dtype=np.float64)[members]      # ghosts start from their reach's own state
@@ -384,8 +383,7 @@ def bench_main(args, rank: int, local_rank: int, world: int) -> None:
     den = r + 2.0 * (1.0 - net.x)
     c1, c2, c3 = (r - 2.0 * net.x) / den, (r + 2.0 * net.x) / den, (2.0 * (1.0 - net.x) - r) / den
     rows = min(args.forcing_rows, T)
-    idx = (np.arange(rows, dtype=np.uint64)[:, None] * np.uint64(n)) + spec.real_global.astype(np.uint64)[None, :]
-    lateral = dt * nsub * synth.u01(synth.FORCING_SEED, idx)
+    lateral = synth.synth_qlateral_torch(n, 0, rows, torch.device('cuda', local_rank), columns=spec.real_global, dt=dt * nsub)
     eng = HipPartEngine(spec, c1, c2, c3, (c1 + c2) / (dt * nsub), np.zeros(n), lateral, T, nsub, local_rank,
                         out_rows=min(T, 128), sample_every=args.sample_every)      # sink of one out-pass batch: no row written twice by a launch
     chunk_rows = max(16, args.exchange_rows)

@@ -168,6 +168,37 @@ def synth_qlateral(n: int, t0: int, t1: int, seed: int = FORCING_SEED, dt: float
     return dt * u01(seed, idx)
 
 
+def _i64(v: int) -> int:
+    """The signed 64-bit integer with the bit pattern of the unsigned v."""
+    v &= 0xFFFFFFFFFFFFFFFF
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def u01_torch(seed: int, index):
+    """u01 on a torch int64 tensor (any device), bit for bit: int64 products wrap like uint64 ones, logical right shifts are
+    arithmetic ones with the sign bits masked off.  For the bench, whose forcing arrays take tens of seconds in numpy."""
+    def lsr(z, k):
+        return (z >> k) & ((1 << (64 - k)) - 1)
+    z = (index ^ _i64(int(_seed_key(seed)))) + _i64(int(_GOLD))
+    z = (z ^ lsr(z, 30)) * _i64(int(_C1))
+    z = (z ^ lsr(z, 27)) * _i64(int(_C2))
+    z = z ^ lsr(z, 31)
+    import torch
+    return lsr(z, 11).to(torch.float64) * (1.0 / 9007199254740992.0)
+
+
+def synth_qlateral_torch(n: int, t0: int, t1: int, device, columns=None, seed: int = FORCING_SEED, dt: float = 900.0, block: int = 32):
+    """synth_qlateral computed on `device` (a torch tensor, the same bits); `columns`: only these reach indices."""
+    import torch
+    cols = torch.arange(n, dtype=torch.int64, device=device) if columns is None else torch.as_tensor(np.asarray(columns, dtype=np.int64), device=device)
+    out = torch.empty((t1 - t0, cols.numel()), dtype=torch.float64, device=device)
+    for r0 in range(t0, t1, block):
+        r1 = min(t1, r0 + block)
+        idx = torch.arange(r0, r1, dtype=torch.int64, device=device)[:, None] * n + cols[None, :]
+        out[r0 - t0:r1 - t0] = dt * u01_torch(seed, idx)
+    return out
+
+
 def synth_runoff_depth(n: int, t0: int, t1: int, seed: int = FORCING_SEED) -> np.ndarray:
     """Runoff depths (m) in [0, 1e-3) for UnitMuskingum inputs."""
     idx = (np.arange(t0, t1, dtype=np.uint64)[:, None] * np.uint64(n)) + np.arange(n, dtype=np.uint64)[None, :]

@@ -145,3 +145,14 @@ def test_packed_runoff_with_fill_values_is_masked(tmp_path):
     np.testing.assert_allclose(ro[~np.isnan(ro)], want[~np.isnan(want)])
     np.testing.assert_array_equal(np.isnan(plain), raw == -32767)
     assert plain.dtype == np.float32 and plain[0, 0] == 100.0
+
+
+def test_torch_forcing_generator_matches_numpy():
+    """bench.py makes its forcing on the device (synth.synth_qlateral_torch); the oracle legs use numpy's: the same bits."""
+    from river_route_amd import synth
+    n = 12_345
+    a = synth.synth_qlateral(n, 3, 70, dt=450.0)
+    b = synth.synth_qlateral_torch(n, 3, 70, 'cpu', dt=450.0).numpy()
+    np.testing.assert_array_equal(a, b)
+    cols = np.array([0, 17, 5000, n - 1])
+    np.testing.assert_array_equal(synth.synth_qlateral_torch(n, 3, 70, 'cpu', columns=cols, dt=450.0).numpy(), a[:, cols])
