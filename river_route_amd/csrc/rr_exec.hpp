@@ -188,11 +188,14 @@ int ensure_cap(T **buf, int64_t *cap, int64_t count)
 // ---- session -------------------------------------------------------------------------------------
 
 // Record chunks per task.  A longer task amortises the load of the tile's state and of its first half chunk, which
-// nothing overlaps; every tile level adds one task of skew to the pipeline and to the record ring.
+// nothing overlaps; every tile level adds one task of skew to the pipeline and to the record ring.  Tasks of 128 and 256
+// ticks are for long calls on networks whose ring stays small (decide_wave: an eighth of the card): they are worth
+// 11 % at 100k reaches, 7 % at 250k, 3 % at 500k (profiles/microbench/k_sweep_small.sh); at 1M reaches they would
+// make the ring 50 GB for 2.5 %, and 64 ticks stay.
 int64_t pick_KC(const rr_plan *P, int64_t total_ticks)
 {
     if (P->wave_K > 0) return std::max<int64_t>(1, P->wave_K / kRec);
-    return total_ticks >= 4096 ? 4 : (total_ticks >= 512 ? 2 : 1);
+    return total_ticks >= 32768 ? 16 : (total_ticks >= 16384 ? 8 : (total_ticks >= 4096 ? 4 : (total_ticks >= 512 ? 2 : 1)));
 }
 
 // Which routing kernel a call uses.  The time-tiled schedule needs device rows, one upstream weight per reach, a
@@ -220,6 +223,7 @@ bool decide_wave(rr_plan *P, Mode mode, int64_t total, bool host_rows)
             const int64_t chunks = std::min<int64_t>(all_chunks, (dmax + levels * KC * kRec) / kRec + 4 * kRecBatch + extra);
             const int64_t bytes = chunks * kRec * np * (int64_t)sizeof(double);
             if (P->dev_total_bytes > 0 && bytes > (int64_t)(P->dev_total_bytes / 8 * 5)) continue;
+            if (KC > 4 && P->wave_K <= 0 && P->dev_total_bytes > 0 && bytes > (int64_t)(P->dev_total_bytes / 8)) continue;      // long tasks only with a small ring
             if (ensure_cap(&P->d_ring, &P->ring_cap, chunks * kRec * np) != RR_OK) { (void)hipGetLastError(); continue; }
             P->next_KC = KC; P->next_chunks = chunks;
             ok = true;

@@ -419,10 +419,11 @@ def test_unit_muskingum_on_a_cut_network_vs_oracle(monkeypatch, wave, n, parts, 
     assert_close(qf, qf_ref, 'q_full')
 
 
-@pytest.mark.parametrize('n,T', [(1_000_000, 35_040), (4_000_000, 8_760)])
+@pytest.mark.parametrize('n,T', [(1_000_000, 35_040), (4_000_000, 8_760), (250_000, 35_040), (100_000, 20_000)])
 def test_full_year_at_1m_time_tiled_equals_streaming(monkeypatch, n, T):
     """BASELINE config 3 at full length (1M reaches x 35,040 steps, the bench's cyclic forcing and sink): the record ring
-    goes round eight times; and 4M reaches, where the ring is as large as the card allows and the tasks are 16 ticks.  The time-tiled path (k_tile + record passes) and the streaming path (k_tick, no ring) evaluate
+    goes round eight times; 4M reaches, where the ring is as large as the card allows and the tasks are 16 ticks; and two smaller
+    networks, whose long calls get tasks of 256 and 128 ticks.  The time-tiled path (k_tile + record passes) and the streaming path (k_tick, no ring) evaluate
     the same expression in the same order, so the final state and the last 96 discharge rows must agree bit for bit; the
     streaming kernel is the one compared with the oracle row by row elsewhere."""
     import torch
