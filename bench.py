@@ -62,6 +62,8 @@ def parse_args():
                     help="'unit' = BASELINE config 4 (UnitMuskingum + 48-step UH kernel); secondary line, not the headline")
     ap.add_argument('--uh-steps', type=int, default=48)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help="N = 1: skip the `secondary` entries (BASELINE configs 2 and 4 behind their own oracle gates)")
     ap.add_argument('--cpu-replicas', type=int, default=-1,
                     help="also time N independent oracle replicas on N cores (the only parallelism the reference endorses, "
                          "docs/references/parallelism.md:67-114); 0 = off, -1 = one per core up to 16")
@@ -149,7 +151,7 @@ def cpu_replicas(replicas, indptr, indices, lhs, c2, c3, c4_dt, ql, nsub, out_di
     N = min(cores, 16) if replicas < 0 else min(replicas, cores)
     rows = ql[:min(ql.shape[0], 16)]
     with mp.get_context('fork').Pool(N) as pool:
-        res = pool.map(_replica_worker, [(indptr, indices, lhs, c2, c3, c4_dt, rows, nsub, out_dir, min(seconds, 8.0))] * N)
+        res = pool.map(_replica_worker, [(indptr, indices, lhs, c2, c3, c4_dt, rows, nsub, out_dir, min(seconds, 4.0))] * N)
     total = sum(r[0] for r in res) / max(r[1] for r in res)
     return {'value': total, 'unit': 'reach-steps/s', 'cores': N,
             'sample': f'{N} independent single-thread replicas of the same network, {rows.shape[0]} forcing rows each'}
@@ -241,7 +243,8 @@ def bench_unit(args, device_index):
                                    f'{nsub} sub-step(s), fp64, 1xMI355X (BASELINE config 4; convolution fused into the record in-pass + routing)',
                        'reaches': n, 'runoff_steps': T, 'uh_steps': n_ks, 'headwaters': plan.n_headwaters},
             'roofline': roofline, 'cpu_baseline': base}
-    print(json.dumps(line))
+    plan.close()
+    return line
 
 
 def main():
@@ -289,8 +292,45 @@ def main():
     local_rank = device_index
 
     if args.workload == 'unit':
-        bench_unit(args, device_index)
+        print(json.dumps(bench_unit(args, device_index)))
         return
+    line = bench_rapid(args, device_index, net, indptr, indices, c1, c2, c3, base)
+    if not args.no_secondary and n == 1_000_000 and T == 35_040 and nsub == 1:
+        line['secondary'] = secondary_lines(args, device_index)
+    print(json.dumps(line))
+
+
+def secondary_lines(args, device_index):
+    """BASELINE configs 2 and 4 in the driver's line, each behind its own oracle gate (bench_rapid / bench_unit refuse to
+    return a number that does not reproduce the oracle): `value`, `ms_per_step`, `roofline`, a short `cpu_baseline`."""
+    import copy
+    from river_route_amd import synth
+    out = []
+    a = copy.copy(args)
+    a.reaches, a.cpu_baseline_seconds, a.cpu_replicas = 100_000, 1.0, 0
+    net = synth.synth_network(a.reaches, order=a.order)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = muskingum_coefficients(net.k, net.x, 900.0)
+    base = None if a.no_cpu_baseline else cpu_baseline(net, indptr, indices, c1, c2, c3, 900.0, a.substeps, min(a.cpu_baseline_steps, a.forcing_rows), 1.0, 0)
+    line = bench_rapid(a, device_index, net, indptr, indices, c1, c2, c3, base)
+    line['config']['baseline_config'] = 2
+    out.append(line)
+    a = copy.copy(args)
+    a.workload = 'unit'
+    line = bench_unit(a, device_index)
+    line['config']['baseline_config'] = 4
+    out.append(line)
+    return out
+
+
+def bench_rapid(args, local_rank, net, indptr, indices, c1, c2, c3, base):
+    """RapidMuskingum, one year per bench step on one GPU (BASELINE config 3 at 1M reaches, config 2 at 100k): the line."""
+    import torch
+    from river_route_amd import synth
+    from river_route_amd.engine import Plan, copy_bandwidth
+    n, T, nsub, dt = net.n, args.runoff_steps, args.substeps, 900.0
+    rows = min(args.forcing_rows, T)
+    dev = torch.device('cuda', local_rank)
     plan = Plan(indptr, indices, device=local_rank)
     plan.set_coeffs(-c1[indices], c2, c3, (c1 + c2) / (dt * nsub))
     plan.set_options(rows_per_chunk=args.chunk_rows, sample_every=args.sample_every)
@@ -356,7 +396,10 @@ def main():
         'roofline': roofline,
         'cpu_baseline': base,
     }
-    print(json.dumps(line))
+    plan.close()
+    del ql, out, q_t
+    torch.cuda.empty_cache()
+    return line
 
 
 def engine_sha16():

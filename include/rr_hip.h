@@ -26,8 +26,11 @@
  *   - arrays are C-contiguous; 2-D arrays are (time, reach) row-major in PARAMS-FILE reach order,
  *     exactly as the reference passes them.  The engine keeps its own permuted device layout.
  *   - `*_dev` variants take DEVICE pointers (valid on the plan's GPU) and a hipStream_t passed as
- *     void*; they only enqueue work.  The un-suffixed variants take HOST pointers, copy in/out,
- *     and return when the results are in the caller's buffers.
+ *     void*; they only enqueue work: nothing in them allocates or synchronises (work memory comes
+ *     from rr_plan_reserve).  The record passes of a call run on a second stream of the plan, forked
+ *     from and joined to the caller's stream by events: to the caller the call is ordered on its
+ *     stream.  The un-suffixed variants take HOST pointers, copy in/out, and return when the results
+ *     are in the caller's buffers.
  *   - a plan is bound to one GPU and is not thread-safe; use one plan per thread/stream.
  *   - there is NO CPU fallback: without a usable gfx950 device every compute call fails with
  *     RR_E_NO_DEVICE.  rr_plan_create(device = RR_DEVICE_NONE) builds a host-only plan whose
@@ -96,6 +99,32 @@ int rr_plan_tile_layout(const rr_plan *plan, int32_t *tile_ptr, int32_t *tile_le
  * i.e. -c1[row(e)] (Muskingum.py:192); c2, c3 per reach; c4_dt per reach or NULL (channel-only / unit). */
 int rr_plan_set_coeffs(rr_plan *plan, const double *lhs_off_data, const double *c2, const double *c3,
                        const double *c4_dt);
+
+/* UnitMuskingum with general edge data: the reference's unit_route multiplies by a_inner_data[j] / a_hw_data[j] and
+ * subtracts lhs_off_data[j] q_ch (river_route/routers/_numba_kernels.py:126-139, 159-162); its own callers pass ones and
+ * -c1[row], which is what rr_plan_set_coeffs alone describes.  For other values: c1[n] per reach (params order, any value
+ * on headwaters) and a_data per entry of the plan's CSC structure (a_inner_data / a_hw_data of that edge);
+ * lhs_off_data of rr_plan_set_coeffs is then read for the edges between two reaches that have upstream reaches only.
+ * Such a plan routes UnitMuskingum with the streaming kernel.  (NULL, NULL) goes back to unit weights. */
+int rr_plan_set_unit_weights(rr_plan *plan, const double *c1, const double *a_data);
+
+/* Work memory of the route calls to come, allocated up front: the *_dev entry points and rr_stream_begin* only enqueue
+ * work and return RR_E_STATE (with the byte count in rr_last_error()) when a call needs more than has been reserved; the
+ * host-pointer entry points, which synchronise anyway, reserve by themselves.  Reserve once per plan for the largest
+ * call (T runoff rows x nsub sub-steps; rr_muskingum_route*: T = num_output_steps, nsub = num_routing_per_output), after
+ * rr_plan_set_coeffs and rr_plan_set_boundary / rr_plan_set_options: one call per input file is the reference's pattern
+ * (river_route/routers/TransformMuskingum.py:108-148), and the routers reserve in _hook_before_route.  Memory only
+ * grows; a smaller call fits a larger reservation.  host_rows != 0 also prepares the staging of the host-pointer entry
+ * points (pinned buffers and device rings of the PCIe pipeline).
+ * info (may be NULL): [0] 1 = time-tiled kernel, 0 = streaming kernel; [1] routing ticks per launch K; [2] chunks of the
+ * record ring (16 ticks each); [3] bytes of routing work memory now held on the device; [4] bytes of device staging and
+ * [5] of pinned host staging of the host-pointer path; [6] depth of the routing pipeline in ticks (network depth + tile
+ * levels x K: a call's first output row leaves this many ticks after its first input row entered); [7] bytes of the record
+ * ring (or streaming work rows) this shape needs. */
+#define RR_MODE_RAPID 0
+#define RR_MODE_MUSKINGUM 1
+#define RR_MODE_UNIT 2
+int rr_plan_reserve(rr_plan *plan, int mode, int64_t T, int64_t nsub, int host_rows, int64_t info[8]);
 
 /* Tuning / measurement.  rows_per_chunk: time rows moved per permutation launch of the streaming kernel (default 16).
  * sample_every >= 16: HIP-event brackets on the call's stream around sampled routing launches (every fourth launch of the

@@ -48,10 +48,12 @@ void rr_plan_destroy(rr_plan *P)
                         P->d_c1row, P->d_tc2, P->d_tc3, P->d_sq, P->d_ss, P->d_si, P->d_sqch, P->d_full, P->d_chan,
                         P->d_tile_ptr, P->d_tile_level, P->d_tile_lag_lo, P->d_tile_lag_hi, P->d_tlag, P->d_cfirst, P->d_xpos,
                         P->d_tperm, P->d_tinv, P->d_inner_idx, P->d_ccnt, P->d_colmeta, P->d_ghostmeta, P->d_c4_params,
-                        P->d_c3, P->d_c4, P->d_x, P->d_isum, P->d_qch, P->d_ring, P->d_stage, P->d_mrows,
+                        P->d_c3, P->d_c4, P->d_x, P->d_isum, P->d_qch, P->d_a2, P->d_c1own, P->d_ring, P->d_stage, P->d_mrows,
                         P->d_slot_a[0], P->d_slot_a[1], P->d_slot_b[0], P->d_slot_b[1], P->d_m_index[0], P->d_m_index[1]};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         P->pipe.destroy();
+        if (P->s_rec) (void)hipStreamDestroy(P->s_rec);
+        for (hipEvent_t e : P->ev_pool) (void)hipEventDestroy(e);
         for (hipEvent_t e : P->ev) (void)hipEventDestroy(e);
         if (P->ev_first) (void)hipEventDestroy(P->ev_first);
         if (P->ev_last) (void)hipEventDestroy(P->ev_last);
@@ -101,6 +103,8 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
             if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) P->cu_count = cus;
             if (const char *e2 = getenv("RR_TILE_SLOTS")) P->cu_count = std::max(1, atoi(e2));      // tests: few workgroups, many tiles each
         }
+        if (const char *e2 = getenv("RR_REC_STREAM")) P->rec_stream_enabled = atoi(e2) != 0;      // measurements: record passes on a second stream
+        if (P->rec_stream_enabled && hipStreamCreateWithFlags(&P->s_rec, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); P->s_rec = nullptr; }
         for (int v = 0; v < 4; ++v)    // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
             if (hipFuncSetAttribute((const void *)tile_kernel(P->wave_threads, (v & 1) != 0, (v & 2) != 0), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)tile_lds_bytes(P->wave_threads)) != hipSuccess) {
@@ -177,19 +181,6 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         if (!rc) rc = dev_upload(P->d_inv, H.inv);
         if (!rc) rc = dev_upload(P->d_inner_pos, H.inner_pos);
         if (!rc) rc = dev_upload(P->d_hwc, H.hw_children);
-        if (!rc) {
-            const int32_t *pis[2] = {H.perm.data(), H.inv.data()};
-            for (int w = 0; w < 2 && !rc; ++w) {
-                rr::TiledPermutation tp;
-                rr::build_tiled_permutation(pis[w], n, kPermE * kPermThreads, tp);
-                rc = dev_alloc(&P->d_slot_a[w], n);
-                if (!rc) rc = dev_alloc(&P->d_slot_b[w], n);
-                if (!rc) rc = dev_alloc(&P->d_m_index[w], n);
-                if (!rc) rc = dev_upload(P->d_slot_a[w], tp.slot_a);
-                if (!rc) rc = dev_upload(P->d_slot_b[w], tp.slot_b);
-                if (!rc) rc = dev_upload(P->d_m_index[w], tp.m_index);
-            }
-        }
         if (rc) { rr_plan_destroy(P); return rc; }
     }
     *out = P;
@@ -297,6 +288,56 @@ int rr_plan_set_coeffs(rr_plan *P, const double *lhs_off_data, const double *c2,
     return RR_OK;
 }
 
+int rr_plan_set_unit_weights(rr_plan *P, const double *c1, const double *a_data)
+{
+    int rc = need_device(P);
+    if (rc) return rc;
+    if (P->ses.open) return fail(RR_E_STATE, "rr_plan_set_unit_weights: a routing call is open");
+    if (!c1 && !a_data) { P->unit_general = false; return RR_OK; }
+    const rr::HostPlan &H = P->h;
+    const int64_t n = H.n;
+    if (!c1 || (H.n_edges > 0 && !a_data)) return fail(RR_E_INVALID, "rr_plan_set_unit_weights: give both arrays, or neither to go back to unit weights");
+    if (P->n_ghost > 0 || P->n_export > 0) return fail(RR_E_UNSUPPORTED, "rr_plan_set_unit_weights: general edge data on a partitioned network is not supported");
+    std::vector<double> a2(n, 0.0), own(n, 0.0);
+    for (int64_t p = 0; p < n; ++p) {
+        const int32_t i = H.perm[p], e = H.edge_of[i];
+        a2[p] = e >= 0 ? a_data[e] : 0.0;
+        own[p] = c1[i];
+    }
+    if (!P->d_a2) rc = dev_alloc(&P->d_a2, n);
+    if (!rc && !P->d_c1own) rc = dev_alloc(&P->d_c1own, n);
+    if (!rc) rc = dev_upload(P->d_a2, a2);
+    if (!rc) rc = dev_upload(P->d_c1own, own);
+    if (rc) return rc;
+    P->unit_general = true;
+    return RR_OK;
+}
+
+int rr_plan_reserve(rr_plan *P, int mode, int64_t T, int64_t nsub, int host_rows, int64_t info[8])
+{
+    int rc = need_device(P);
+    if (rc) return rc;
+    if (mode < RR_MODE_RAPID || mode > RR_MODE_UNIT || T < 0 || nsub < 1) return fail(RR_E_INVALID, "rr_plan_reserve: unknown mode, negative step count or sub-steps < 1");
+    if (!P->coeffs_set) return fail(RR_E_STATE, "rr_plan_reserve before rr_plan_set_coeffs (per-edge weights decide which kernel routes)");
+    if (P->ses.open) return fail(RR_E_STATE, "rr_plan_reserve: a routing call is open");
+    const Mode m = mode == RR_MODE_RAPID ? Mode::Rapid : (mode == RR_MODE_MUSKINGUM ? Mode::Muskingum : Mode::Unit);
+    Schedule sch;
+    // host rows reach the time-tiled kernel through the PCIe pipeline's device rings; where it does not apply they stream
+    rc = reserve_core(P, m, T, nsub, false, false, &sch);
+    if (rc == RR_OK && host_rows && !sch.tiled) rc = reserve_core(P, m, T, nsub, true, true, &sch);
+    if (rc == RR_OK && host_rows && sch.tiled) rc = host_pipe_prepare(P);
+    if (rc) return rc;
+    if (info) {
+        info[0] = sch.tiled ? 1 : 0; info[1] = sch.tiled ? sch.KC * kRec : 1; info[2] = sch.chunks;
+        info[3] = (P->ring_cap + P->mrows_cap + P->stage_cap) * (int64_t)sizeof(double);
+        info[4] = host_rows && sch.tiled ? 2 * P->pipe.dev_cap * (int64_t)sizeof(double) : 0;
+        info[5] = host_rows && sch.tiled ? 2 * HostPipe::kPinned * P->pipe.pin_cap * (int64_t)sizeof(double) : 0;
+        info[6] = sch.tiled ? P->h.depth - 1 + (int64_t)P->tp.n_levels * sch.KC * kRec : P->h.depth - 1;      // pipeline depth in ticks
+        info[7] = sch.ring * (int64_t)sizeof(double);
+    }
+    return RR_OK;
+}
+
 int rr_plan_profile(rr_plan *P, double prof[10])
 {
     if (!P || !prof) return fail(RR_E_INVALID, "rr_plan_profile: null argument");
@@ -401,7 +442,8 @@ int rr_stream_begin(rr_plan *P, int has_lateral, const double *q_t, const double
     Rows io; io.dev_in = has_lateral ? lateral : nullptr; io.rows_in = lat_rows; io.dev_out = discharge; io.rows_out = out_rows;
     const Mode mode = has_lateral ? Mode::Rapid : Mode::Muskingum;
     if (P->ses.open) return fail(RR_E_STATE, "a routing call is already open on this plan (rr_stream_end it first)");
-    decide_wave(P, mode, T * nsub, false);
+    rc = prepare_call(P, mode, T, nsub, false, false, true);
+    if (rc) return rc;
     if (P->h.n > 0 && T > 0) {
         rc = launch_state_in(P, mode, q_t, (hipStream_t)stream);
         if (rc) return rc;
@@ -420,7 +462,9 @@ int rr_stream_begin_unit(rr_plan *P, const double *q_ch, const double *q_full, c
         return fail(RR_E_INVALID, "rr_stream_begin_unit: null array or empty row count");
     Rows io; io.dev_in = lateral; io.rows_in = lat_rows; io.dev_out = discharge; io.rows_out = out_rows;
     if (P->ses.open) return fail(RR_E_STATE, "a routing call is already open on this plan (rr_stream_end_unit it first)");
-    decide_wave(P, Mode::Unit, T * nsub, false);
+    if (P->unit_general) return fail(RR_E_UNSUPPORTED, "rr_stream_begin_unit: general edge data (rr_plan_set_unit_weights) on a partitioned network is not supported");
+    rc = prepare_call(P, Mode::Unit, T, nsub, false, false, true);
+    if (rc) return rc;
     if (P->h.n > 0 && T > 0) {
         rc = unit_state_in(P, q_ch, q_full, (hipStream_t)stream);
         if (rc) return rc;
@@ -518,7 +562,7 @@ static int f32_output_applies(rr_plan *P, Mode mode, int64_t T, int64_t nsub, in
 {
     if (factor < 1 || T % factor != 0) return fail(RR_E_INVALID, "float32 output: the number of rows must be a multiple of factor >= 1");
     if (kRecRows % (factor * nsub) != 0) return fail(RR_E_UNSUPPORTED, "float32 output: factor x sub-steps must divide the rows of a record batch (128)");
-    if (!decide_wave(P, mode, T * nsub, false)) return fail(RR_E_UNSUPPORTED, "float32 output needs the time-tiled kernel, which this call does not get");
+    if (!choose_schedule(P, mode, T, nsub, false, false).tiled) return fail(RR_E_UNSUPPORTED, "float32 output needs the time-tiled kernel, which this call does not get");
     return RR_OK;
 }
 
@@ -575,7 +619,7 @@ int rr_rapid_route_runoff_dev(rr_plan *P, double *q_t, int64_t n_points, const i
     if (n_points < 0 || stride_t < 0 || stride_p < 0) return fail(RR_E_INVALID, "rr_rapid_route_runoff_dev: negative size or stride");
     if (P->h.n == 0 || T == 0) return RR_OK;
     if (f32) { rc = f32_output_applies(P, Mode::Rapid, T, 1, factor); if (rc) return rc; }
-    else if (!decide_wave(P, Mode::Rapid, T, false)) return fail(RR_E_UNSUPPORTED, "rr_rapid_route_runoff_dev needs the time-tiled kernel, which this call does not get");
+    else if (!choose_schedule(P, Mode::Rapid, T, 1, false, false).tiled) return fail(RR_E_UNSUPPORTED, "rr_rapid_route_runoff_dev needs the time-tiled kernel, which this call does not get");
     RunoffArgs ga{indptr, indices, weights, area, runoff, stride_t, stride_p, (int32_t)flags, runoff_is_f32 ? 1 : 0};
     Rows io; io.dev_in = P->d_c4_params; io.rows_in = 1;      // (no lateral rows: dev_in only has to be non-NULL for the executor)
     if (f32) { io.dev_out32 = discharge32; io.out_factor = factor; io.rows_out = T / factor; }
@@ -597,7 +641,7 @@ int rr_unit_route_uh_dev(rr_plan *P, double *q_ch, double *q_full, double *q_fin
     if (P->h.n == 0 || T == 0) return RR_OK;
     if (n_ks > kUhFusedMaxTaps) return fail(RR_E_UNSUPPORTED, "rr_unit_route_uh_dev: more than 64 kernel steps: convolve with rr_uh_convolve_dev, then rr_unit_route_dev");
     if (f32) { rc = f32_output_applies(P, Mode::Unit, T, nsub, factor); if (rc) return rc; }
-    else if (!decide_wave(P, Mode::Unit, T * nsub, false)) return fail(RR_E_UNSUPPORTED, "rr_unit_route_uh_dev needs the time-tiled kernel, which this call does not get");
+    else if (!choose_schedule(P, Mode::Unit, T, nsub, false, false).tiled) return fail(RR_E_UNSUPPORTED, "rr_unit_route_uh_dev needs the time-tiled kernel, which this call does not get");
     Rows io; io.dev_in = depth; io.rows_in = T;
     if (f32) { io.dev_out32 = discharge32; io.out_factor = factor; io.rows_out = T / factor; }
     else { io.dev_out = discharge; io.rows_out = T; }

@@ -53,6 +53,11 @@ struct Session {
     bool bracket_open = false;
     int64_t bracket_reaches = 0;
     size_t max_samples = 0;
+    // record passes on the plan's second stream (rr_plan::s_rec), ordered against the routing launches by events: see fork_*
+    bool two = false;
+    std::vector<hipEvent_t> ev_in, ev_ghost, ev_out;      // one per batch launched on the second stream
+    int64_t in_waited = 0, ghost_waited = 0, out_waited = 0;      // batches the routing stream already waits for
+    int64_t diags_marked = 0;     // routing launches covered by the last event the second stream waits for
 };
 
 // ---- host-pointer calls: PCIe pipeline around the time-tiled kernel ----
@@ -97,6 +102,8 @@ struct rr_plan {
     uint16_t *d_hwc = nullptr;
     double *d_w = nullptr, *d_c1row_h = nullptr, *d_c2 = nullptr, *d_c3 = nullptr, *d_c4 = nullptr;
     double *d_x = nullptr, *d_isum = nullptr, *d_qch = nullptr;
+    double *d_a2 = nullptr, *d_c1own = nullptr;   // UnitMuskingum with general edge data (rr_plan_set_unit_weights): streaming kernel only
+    bool unit_general = false;
     double *d_ring = nullptr;
     int64_t ring_cap = 0;  // doubles
     double *d_stage = nullptr;
@@ -113,7 +120,8 @@ struct rr_plan {
     bool wave_enabled = true, wave_forced = false, wave_now = false, weights_uniform = false;
     int wave_threads = 1024, wave_ppt = 2;
     int64_t wave_K = 0;          // ticks per task (multiple of 16); 0 = chosen per call
-    int64_t next_KC = 1, next_chunks = 0;   // decide_wave: task length and record ring of the call about to start
+    int64_t next_KC = 1, next_chunks = 0;   // prepare_call: task length and record ring of the call about to start
+    int64_t kc_cap = int64_t{1} << 20;      // longest task (record chunks) the device had room for; 0: no record ring fits, the plan streams
     int32_t *d_tile_ptr = nullptr, *d_tile_level = nullptr, *d_tile_lag_lo = nullptr, *d_tile_lag_hi = nullptr;
     int32_t *d_tlag = nullptr, *d_cfirst = nullptr, *d_xpos = nullptr, *d_tperm = nullptr, *d_tinv = nullptr;
     int32_t *d_inner_idx = nullptr;
@@ -134,6 +142,11 @@ struct rr_plan {
 
     Session ses;
     HostPipe pipe;      // staging of the host-pointer entry points (allocated at first use)
+    // second stream for the record passes of device-array calls + a pool of untimed events (created at plan creation / first use)
+    hipStream_t s_rec = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_pool_next = 0;
+    bool rec_stream_enabled = false, pipe_active = false;      // measured: no gain (profiles/r03_rec_stream.txt); RR_REC_STREAM=1 switches it on
 
     // profile of the last route call
     std::vector<hipEvent_t> ev;
@@ -185,11 +198,32 @@ int ensure_cap(T **buf, int64_t *cap, int64_t count)
     return RR_OK;
 }
 
+// The two-phase tiled permutation params order <-> lag order of the streaming kernel (k_perm_a / k_perm_b).  Built when a
+// call first streams: the time-tiled kernel, which takes almost every call, has its own record passes.
+int upload_tiled_permutations(rr_plan *P)
+{
+    const rr::HostPlan &H = P->h;
+    const int64_t n = H.n;
+    const int32_t *pis[2] = {H.perm.data(), H.inv.data()};
+    int rc = RR_OK;
+    for (int w = 0; w < 2 && !rc; ++w) {
+        rr::TiledPermutation tp;
+        rr::build_tiled_permutation(pis[w], n, kPermE * kPermThreads, tp);
+        rc = dev_alloc(&P->d_slot_a[w], n);
+        if (!rc) rc = dev_alloc(&P->d_slot_b[w], n);
+        if (!rc) rc = dev_alloc(&P->d_m_index[w], n);
+        if (!rc) rc = dev_upload(P->d_slot_a[w], tp.slot_a);
+        if (!rc) rc = dev_upload(P->d_slot_b[w], tp.slot_b);
+        if (!rc) rc = dev_upload(P->d_m_index[w], tp.m_index);
+    }
+    return rc;
+}
+
 // ---- session -------------------------------------------------------------------------------------
 
 // Record chunks per task.  A longer task amortises the load of the tile's state and of its first half chunk, which
 // nothing overlaps; every tile level adds one task of skew to the pipeline and to the record ring.  Tasks of 128 and 256
-// ticks are for long calls on networks whose ring stays small (decide_wave: an eighth of the card): they are worth
+// ticks are for long calls on networks whose ring stays small (choose_schedule: an eighth of the card): they are worth
 // 11 % at 100k reaches, 7 % at 250k, 3 % at 500k (profiles/microbench/k_sweep_small.sh); at 1M reaches they would
 // make the ring 50 GB for 2.5 %, and 64 ticks stay.
 int64_t pick_KC(const rr_plan *P, int64_t total_ticks)
@@ -198,10 +232,9 @@ int64_t pick_KC(const rr_plan *P, int64_t total_ticks)
     return total_ticks >= 32768 ? 16 : (total_ticks >= 16384 ? 8 : (total_ticks >= 4096 ? 4 : (total_ticks >= 512 ? 2 : 1)));
 }
 
-// Which routing kernel a call uses.  The time-tiled schedule needs device rows, one upstream weight per reach, a
-// network that tiles (rr::TilePlan) and room for its record ring; its fill and drain cost (levels x K) ticks more than
-// the streaming kernel's, a few launches, so only calls of a handful of sub-steps stream.  RR_WAVE=1 forces it where it
-// applies, RR_WAVE=0 forbids it.
+// Which routing kernel a call uses.  The time-tiled schedule needs one upstream weight per reach, a network that tiles
+// (rr::TilePlan) and room for its record ring; its fill and drain cost (levels x K) ticks more than the streaming kernel's, a
+// few launches, so only calls of a handful of sub-steps stream.  RR_WAVE=1 forces it where it applies, RR_WAVE=0 forbids it.
 //
 // Records are indexed by tick = tick-row + lag, modulo the ring, per position: a position's slots never hold another
 // position's data, so what the ring must cover is one position's tick-rows in flight.  Rows enter for all columns at once
@@ -209,32 +242,147 @@ int64_t pick_KC(const rr_plan *P, int64_t total_ticks)
 // every position keeps depth + levels * K tick-rows plus the batching of the two permutation passes; that its window sits
 // lag ticks later than a headwater's does not widen it.  The ring may take five eighths of the card; a deep network that
 // does not fit gets shorter tasks, then the streaming kernel.
-bool decide_wave(rr_plan *P, Mode mode, int64_t total, bool host_rows)
+//
+// The choice is a pure function of the plan, the call's shape and kc_cap (lowered only when the device refuses an
+// allocation), so rr_plan_reserve and the call it prepares for agree on it.
+struct Schedule {
+    bool tiled = false;
+    int64_t KC = 1, chunks = 0;       // time-tiled: record chunks per task, chunks of the record ring
+    int64_t ring = 0;                 // doubles of P->d_ring: record ring, or the work rows of the streaming kernel
+    int64_t mrows = 0, stage = 0;     // streaming kernel: doubles of the permutation's intermediate rows / of the host staging rows
+};
+
+Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io)
 {
-    bool ok = P->wave_enabled && P->tp.ok && P->weights_uniform && P->h.n > 0 && !host_rows && P->tp.np < (int64_t{1} << 25) &&
-              !P->export_inside;
+    Schedule sch;
+    const int64_t total = T * nsub, dmax = P->h.depth - 1, n = P->h.n;
+    bool ok = P->wave_enabled && P->tp.ok && P->weights_uniform && n > 0 && !force_streaming && P->tp.np < (int64_t{1} << 25) &&
+              !P->export_inside && P->kc_cap >= 1 && !(mode == Mode::Unit && P->unit_general);
     if (ok && !P->wave_forced) ok = total >= 32;
     if (ok) {
-        const int64_t dmax = P->h.depth - 1, np = P->tp.np, levels = P->tp.n_levels;
+        const int64_t np = P->tp.np, levels = P->tp.n_levels;
         const int64_t all_chunks = kRecBatch * ((total + 14) / kRecRows + 2) + (dmax >> 4) + 2;
         ok = false;
-        for (int64_t KC = pick_KC(P, total + dmax); KC >= 1; KC /= 2) {
+        for (int64_t KC = std::min(pick_KC(P, total + dmax), P->kc_cap); KC >= 1; KC /= 2) {
             static const int64_t extra = getenv("RR_RING_EXTRA") ? atoll(getenv("RR_RING_EXTRA")) : 0;      // measurements: a larger ring than needed
             const int64_t chunks = std::min<int64_t>(all_chunks, (dmax + levels * KC * kRec) / kRec + 4 * kRecBatch + extra);
             const int64_t bytes = chunks * kRec * np * (int64_t)sizeof(double);
             if (P->dev_total_bytes > 0 && bytes > (int64_t)(P->dev_total_bytes / 8 * 5)) continue;
             if (KC > 4 && P->wave_K <= 0 && P->dev_total_bytes > 0 && bytes > (int64_t)(P->dev_total_bytes / 8)) continue;      // long tasks only with a small ring
-            if (ensure_cap(&P->d_ring, &P->ring_cap, chunks * kRec * np) != RR_OK) { (void)hipGetLastError(); continue; }
-            P->next_KC = KC; P->next_chunks = chunks;
+            sch.tiled = true; sch.KC = KC; sch.chunks = chunks; sch.ring = chunks * kRec * np;
             ok = true;
             break;
         }
     }
-    P->wave_now = ok;
-    return ok;
+    if (!ok) {      // streaming kernel: lateral rows come in, discharge rows overwrite them in place and stay until the outlet-most reaches have passed them
+        const int64_t C = std::max<int64_t>(1, P->chunk_rows), lag_rows = (dmax + nsub - 1) / std::max<int64_t>(1, nsub);
+        const bool direct = P->h.identity && !host_io;
+        sch.ring = direct ? 0 : std::min<int64_t>(T, lag_rows + 2 * C + 2) * n;
+        sch.mrows = direct ? 0 : C * n;
+        sch.stage = host_io ? C * n : 0;
+    }
+    return sch;
+}
+
+int host_pipe_prepare(rr_plan *P);
+
+// Sizes and allocates what a call of this shape works in.  The only place on a route call's path that allocates: the
+// host-pointer entry points come here by themselves, the *_dev ones expect rr_plan_reserve to have been here.
+int reserve_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, Schedule *out)
+{
+    if (P->h.n == 0 || T <= 0) { if (out) *out = Schedule(); return RR_OK; }
+    Schedule sch;
+    for (;;) {
+        sch = choose_schedule(P, mode, T, nsub, force_streaming, host_io);
+        if (ensure_cap(&P->d_ring, &P->ring_cap, sch.ring) == RR_OK) break;
+        (void)hipGetLastError();
+        if (!sch.tiled) return fail(RR_E_ALLOC, "route: the work rows of the streaming kernel do not fit on the device");
+        P->kc_cap = sch.KC / 2;      // shorter tasks, a smaller ring; 0: this plan streams
+    }
+    int rc = ensure_cap(&P->d_mrows, &P->mrows_cap, sch.mrows);
+    if (!rc) rc = ensure_cap(&P->d_stage, &P->stage_cap, sch.stage);
+    if (!rc && !sch.tiled && !P->d_slot_a[0]) rc = upload_tiled_permutations(P);
+    if (!rc && sch.tiled && host_io) rc = host_pipe_prepare(P);
+    if (rc) return rc;
+    // events: first / last of a call, the sampled launches (rr_plan_set_options), the second stream's
+    if (!P->ev_first) { HIPCHK(hipEventCreate(&P->ev_first)); HIPCHK(hipEventCreate(&P->ev_last)); }
+    const int64_t K = sch.KC * kRec, total_ticks = T * nsub + P->h.depth - 1;
+    size_t samples = P->sample_every >= kSampleGroup ? (size_t)std::min<int64_t>(4096, total_ticks / P->sample_every + 1) : 0;
+    if (sch.tiled && samples > 0) samples = (size_t)std::min<int64_t>(4096, ((total_ticks + K - 1) / K + P->tp.n_levels) / 4 + 1);
+    while (P->ev.size() < 2 * samples) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); P->ev.push_back(e); }
+    if (sch.tiled && P->s_rec) {
+        const size_t want = (size_t)(4 * ((T * nsub + 14) / kRecRows + 2) + 16);      // in, boundary, out batches + the joins of a one-call session
+        while (P->ev_pool.size() < want) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); P->ev_pool.push_back(e); }
+    }
+    if (out) *out = sch;
+    return RR_OK;
+}
+
+// The schedule of the call about to start.  strict (the *_dev entry points, which only enqueue): everything must have been
+// reserved; otherwise it is reserved here.
+int prepare_call(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, bool strict)
+{
+    Schedule sch;
+    if (!strict) {
+        int rc = reserve_core(P, mode, T, nsub, force_streaming, host_io, &sch);
+        if (rc) return rc;
+    } else {
+        sch = choose_schedule(P, mode, T, nsub, force_streaming, host_io);
+        const size_t samples = P->sample_every >= kSampleGroup ? 1 : 0;
+        if (P->h.n > 0 && T > 0 && (sch.ring > P->ring_cap || sch.mrows > P->mrows_cap || sch.stage > P->stage_cap || !P->ev_first || P->ev.size() < 2 * samples ||
+                                    (!sch.tiled && !P->d_slot_a[0] && sch.mrows > 0)))
+            return fail(RR_E_STATE, "this call needs " + std::to_string((sch.ring + sch.mrows + sch.stage) * 8) + " bytes of work memory on the device (" +
+                                        std::to_string((P->ring_cap + P->mrows_cap + P->stage_cap) * 8) + " reserved): call rr_plan_reserve(plan, mode, " +
+                                        std::to_string(T) + ", " + std::to_string(nsub) + ", ...) first; the *_dev entry points only enqueue work");
+    }
+    P->wave_now = sch.tiled; P->next_KC = sch.KC; P->next_chunks = sch.chunks;
+    return RR_OK;
 }
 
 bool use_wave(const rr_plan *P, Mode) { return P->wave_now; }
+
+// ---- second stream -------------------------------------------------------------------------------
+// A routing launch (k_tile) ends with a tail in which half of its persistent workgroups have left, and the record passes
+// of the neighbouring batches depend on launches several steps away, not on the one running.  In device-array calls they
+// therefore run on the plan's own stream beside the caller's: the in-pass of a batch as soon as its rows are there and its
+// ring slots are free (up to four batches ahead of the routing), the out-pass once the launch that finishes its rows is
+// done.  Every dependence that stream order used to give is an event:
+//   in-pass / boundary batch j   -> the routing launch that first reads its records waits for it (fork_wait_inputs)
+//   out-pass batch j             -> waits for the last routing launch enqueued before it (fork_mark_routing); a routing
+//                                   launch that rewrites ring slots one revolution on waits for the out-pass that emptied them
+//   in-pass after out-pass       -> same stream
+//   caller's stream              -> the second stream waits for it when a call opens and whenever rows or boundary values
+//                                   are announced (rr_stream_advance); it waits for the second stream when the call closes.
+// Nothing here synchronises with the host.
+hipEvent_t pool_event(rr_plan *P)
+{
+    if (P->ev_pool_next == P->ev_pool.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        P->ev_pool.push_back(e);
+    }
+    return P->ev_pool[P->ev_pool_next++];
+}
+
+int fork_record(rr_plan *P, std::vector<hipEvent_t> &list)      // after a launch on the second stream
+{
+    hipEvent_t e = pool_event(P);
+    if (!e) return fail(RR_E_HIP, "event creation failed");
+    HIPCHK(hipEventRecord(e, P->s_rec));
+    list.push_back(e);
+    return RR_OK;
+}
+
+int fork_join_caller(rr_plan *P)      // the second stream sees everything the caller's stream has been given so far
+{
+    hipEvent_t e = pool_event(P);
+    if (!e) return fail(RR_E_HIP, "event creation failed");
+    HIPCHK(hipEventRecord(e, P->ses.stream));
+    HIPCHK(hipStreamWaitEvent(P->s_rec, e, 0));
+    return RR_OK;
+}
+
+hipStream_t rec_stream(const rr_plan *P) { return P->ses.two ? P->s_rec : P->ses.stream; }
 
 int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io, hipStream_t stream,
                   const double *ghost_series, double *export_series)
@@ -268,7 +416,10 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
     if (io.dev_out32 && !S.wave) { S.open = false; return fail(RR_E_UNSUPPORTED, "float32 output needs the time-tiled kernel"); }
 
     int rc = RR_OK;
-    if (S.wave) { S.KC = P->next_KC; S.rec_chunks = P->next_chunks; }     // ring sized and allocated by decide_wave
+    if (S.wave) { S.KC = P->next_KC; S.rec_chunks = P->next_chunks; }     // ring sized by choose_schedule, allocated by rr_plan_reserve
+    S.two = S.wave && P->rec_stream_enabled && P->s_rec != nullptr && !P->pipe_active;
+    P->ev_pool_next = 0;      // the previous call's events are all behind its closing join
+    if (S.two) { rc = fork_join_caller(P); if (rc) { S.open = false; return rc; } }
     if (S.wave) {
         const rr::TilePlan &TP = P->tp;
         const int64_t K = S.KC * kRec;
@@ -302,6 +453,9 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
             w.trace = tbuf; w.trace_diag = atoi(getenv("RR_WAVE_TRACE_DIAG"));
         }
 #endif
+#ifdef RR_DEBUG_ALIAS      // measurement builds only (wrong results): every chunk of the ring is chunk 0, so the records stay in the caches
+        if (getenv("RR_ALIAS") && (atoi(getenv("RR_ALIAS")) & 1)) w.rec_chunks = Div32(1u);
+#endif
         w.np = (int32_t)TP.np; w.KC = (int32_t)S.KC; w.n_macro = (int32_t)S.n_macro; w.total = (int32_t)S.total;
         w.has_lat = S.has_in ? 1 : 0; w.nsub = Div32((uint32_t)nsub); w.inv_nsub = 1.0 / (double)nsub;
     }
@@ -316,11 +470,10 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         const int64_t lag_rows = (dmax + nsub - 1) / nsub;
         S.ring_rows = S.direct ? 0 : std::min<int64_t>(T, lag_rows + 2 * C + 2);
         if (S.ring_rows > 0xFFFFFFFFLL || T > 0x7FFFFFFFLL) { S.open = false; return fail(RR_E_INVALID, "route: too many time rows"); }
-        rc = RR_OK;
-        if (!S.direct) rc = ensure_cap(&P->d_ring, &P->ring_cap, S.ring_rows * n);
-        if (!rc && !S.direct) rc = ensure_cap(&P->d_mrows, &P->mrows_cap, C * n);
-        if (!rc && host_io) rc = ensure_cap(&P->d_stage, &P->stage_cap, C * n);
-        if (rc) { S.open = false; return rc; }
+        if (S.ring_rows * n > P->ring_cap || (!S.direct && C * n > P->mrows_cap) || (host_io && C * n > P->stage_cap)) {      // prepare_call sized them
+            S.open = false;
+            return fail(RR_E_STATE, "route: work rows of the streaming kernel were not reserved");
+        }
         TickArgs &a = S.a;
         a.child_ptr = P->d_child_ptr; a.lag = P->d_lag; a.w = P->d_w; a.c2 = P->d_c2; a.c3 = P->d_c3; a.c4 = P->d_c4;
         a.c1row = P->weights_uniform ? P->d_c1row_h : nullptr;
@@ -337,12 +490,8 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
     }
     S.max_samples = P->sample_every >= kSampleGroup ? (size_t)std::min<int64_t>(4096, S.total_ticks / P->sample_every + 1) : 0;
     if (S.wave && S.max_samples > 0) S.max_samples = (size_t)std::min<int64_t>(4096, S.n_diags / 4 + 1);     // every fourth launch
-    while (P->ev.size() < 2 * S.max_samples) {
-        hipEvent_t e;
-        HIPCHK(hipEventCreate(&e));
-        P->ev.push_back(e);
-    }
-    if (!P->ev_first) { HIPCHK(hipEventCreate(&P->ev_first)); HIPCHK(hipEventCreate(&P->ev_last)); }
+    S.max_samples = std::min(S.max_samples, P->ev.size() / 2);      // events are made by rr_plan_reserve, never here
+    if (!P->ev_first) { S.open = false; return fail(RR_E_STATE, "route: the plan's events were not reserved"); }
     HIPCHK(hipEventRecord(P->ev_first, stream));
     return RR_OK;
 }
@@ -427,6 +576,8 @@ int session_launch_tick(rr_plan *P, int64_t tau)
     if (S.mode == Mode::Unit) {
         UnitTickArgs ua{};
         ua.t = a; ua.hw_children = P->d_hwc; ua.qch = P->d_qch;
+        ua.a2 = P->unit_general ? P->d_a2 : nullptr; ua.c1own = P->d_c1own;
+        if (P->unit_general) ua.t.c1row = nullptr;
         if (one) hipLaunchKernelGGL(k_tick_unit<true>, g, dim3(kBlock), 0, S.stream, ua);
         else hipLaunchKernelGGL(k_tick_unit<false>, g, dim3(kBlock), 0, S.stream, ua);
     } else if (S.mode == Mode::Rapid) {
@@ -512,7 +663,7 @@ void launch_ghost_permute(rr_plan *P, int64_t batch)
     ra.batch = batch; ra.nsub = Div32(1u); ra.colmeta = P->d_ghostmeta; ra.scale = nullptr;
     ra.rows = RowView{const_cast<double *>(S.ghost_series), P->n_ghost, 0, (uint32_t)S.total};
     ra.factor = Div32(1u);
-    hipLaunchKernelGGL(k_rec_in<false>, dim3((unsigned)((P->n_ghost + kRecCols - 1) / kRecCols)), dim3(kRecThreads), 0, S.stream, ra);
+    hipLaunchKernelGGL(k_rec_in<false>, dim3((unsigned)((P->n_ghost + kRecCols - 1) / kRecCols)), dim3(kRecThreads), 0, rec_stream(P), ra);
 }
 
 typedef void (*rec_in_uh_t)(const RecPermArgs, const UhArgs);
@@ -532,6 +683,9 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
     const int64_t n = P->h.n;
     RecPermArgs ra{};
     ra.rec = P->d_ring; ra.rec_chunks = Div32((uint32_t)S.rec_chunks); ra.n = n; ra.np = P->tp.np; ra.T = S.T; ra.total = S.total; ra.batch = batch;
+#ifdef RR_DEBUG_ALIAS
+    if (getenv("RR_ALIAS") && (atoi(getenv("RR_ALIAS")) & (in ? 2 : 4))) ra.rec_chunks = Div32(1u);
+#endif
     ra.nsub = Div32((uint32_t)S.nsub);
     ra.colmeta = P->d_colmeta;
     ra.scale = (in && S.mode == Mode::Rapid) ? P->d_c4_params : nullptr;
@@ -549,25 +703,26 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
     }
     const dim3 g((unsigned)((n + kRecCols - 1) / kRecCols));
     const bool sub = S.nsub > 1;
+    hipStream_t st = rec_stream(P);
     if (in && S.io.runoff) {
         const dim3 gr((unsigned)((n + kRunoffInThreads - 1) / kRunoffInThreads), (unsigned)kRecBatch);
-        if (S.io.runoff->is_f32) hipLaunchKernelGGL(k_rec_in_runoff<float>, gr, dim3(kRunoffInThreads), 0, S.stream, ra, *S.io.runoff);
-        else hipLaunchKernelGGL(k_rec_in_runoff<double>, gr, dim3(kRunoffInThreads), 0, S.stream, ra, *S.io.runoff);
+        if (S.io.runoff->is_f32) hipLaunchKernelGGL(k_rec_in_runoff<float>, gr, dim3(kRunoffInThreads), 0, st, ra, *S.io.runoff);
+        else hipLaunchKernelGGL(k_rec_in_runoff<double>, gr, dim3(kRunoffInThreads), 0, st, ra, *S.io.runoff);
     } else if (in && S.io.uh_kernel) {
         UhArgs ua{S.io.uh_kernel, S.io.uh_state, (int32_t)S.io.uh_nks};
         for (int half = 0; half < kRecBatch / kUhBatch; ++half) {      // the fused convolution's windows fit registers for 8 records at a time
             ra.batch = batch * (kRecBatch / kUhBatch) + half;
-            hipLaunchKernelGGL(rec_in_uh_kernel(sub, S.io.uh_nks), g, dim3(kUhInThreads), rec_in_uh_lds_bytes(uh_padded_taps(S.io.uh_nks)), S.stream, ra, ua);
+            hipLaunchKernelGGL(rec_in_uh_kernel(sub, S.io.uh_nks), g, dim3(kUhInThreads), rec_in_uh_lds_bytes(uh_padded_taps(S.io.uh_nks)), st, ra, ua);
         }
     } else if (in) {
-        if (sub) hipLaunchKernelGGL(k_rec_in<true>, g, dim3(kRecThreads), 0, S.stream, ra);
-        else hipLaunchKernelGGL(k_rec_in<false>, g, dim3(kRecThreads), 0, S.stream, ra);
+        if (sub) hipLaunchKernelGGL(k_rec_in<true>, g, dim3(kRecThreads), 0, st, ra);
+        else hipLaunchKernelGGL(k_rec_in<false>, g, dim3(kRecThreads), 0, st, ra);
     } else if (ra.rows32) {
-        if (sub) hipLaunchKernelGGL((k_rec_out<true, true>), g, dim3(kRecThreads), 0, S.stream, ra);
-        else hipLaunchKernelGGL((k_rec_out<false, true>), g, dim3(kRecThreads), 0, S.stream, ra);
+        if (sub) hipLaunchKernelGGL((k_rec_out<true, true>), g, dim3(kRecThreads), 0, st, ra);
+        else hipLaunchKernelGGL((k_rec_out<false, true>), g, dim3(kRecThreads), 0, st, ra);
     } else {
-        if (sub) hipLaunchKernelGGL((k_rec_out<true, false>), g, dim3(kRecThreads), 0, S.stream, ra);
-        else hipLaunchKernelGGL((k_rec_out<false, false>), g, dim3(kRecThreads), 0, S.stream, ra);
+        if (sub) hipLaunchKernelGGL((k_rec_out<true, false>), g, dim3(kRecThreads), 0, st, ra);
+        else hipLaunchKernelGGL((k_rec_out<false, false>), g, dim3(kRecThreads), 0, st, ra);
     }
 }
 
@@ -578,6 +733,14 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
     Session &S = P->ses;
     const int64_t dmax = P->h.depth - 1, levels = P->tp.n_levels, K = S.KC * kRec;
     const int64_t ticks_ready = std::min(rows_ready, S.T) * S.nsub;
+    if (S.two) { int rc = fork_join_caller(P); if (rc) return rc; }      // rows and boundary values announced by this call are in place
+    // batches whose records cover the tick-rows below `ticks` (loaded_ticks below, inverted)
+    auto batches_for = [&](int64_t ticks) { return ticks <= 0 ? int64_t{0} : (ticks >= S.total ? S.n_in_batches : std::min(S.n_in_batches, (ticks + 15 + kRecRows - 1) / kRecRows)); };
+    auto wait_for = [&](std::vector<hipEvent_t> &list, int64_t &waited, int64_t upto) -> int {      // the routing stream waits for batches [0, upto)
+        upto = std::min<int64_t>(upto, (int64_t)list.size());
+        if (upto > waited) { HIPCHK(hipStreamWaitEvent(S.stream, list[(size_t)upto - 1], 0)); waited = upto; }
+        return RR_OK;
+    };
     for (;;) {
         bool progressed = false;
         // one batch of tick-rows -> records; a record slot is recycled only after every tick-row it can hold has left.
@@ -592,12 +755,14 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
         };
         if (S.has_in && S.in_batches < S.n_in_batches && ticks_ready >= std::min(kRecRows * (S.in_batches + 1), S.total) && slot_free(S.in_batches)) {
             launch_rec_permute(P, true, S.in_batches);
+            if (S.two) { int rc = fork_record(P, S.ev_in); if (rc) return rc; }
             ++S.in_batches;
             progressed = true;
         }
         if (P->n_ghost > 0 && S.ghost_batches < S.n_in_batches && (!S.has_in || S.ghost_batches < S.in_batches) &&      // after the lateral batch: that one writes zeros into the ghosts' records
             ghost_ready >= std::min(kRecRows * (S.ghost_batches + 1), S.total) && slot_free(S.ghost_batches)) {
             launch_ghost_permute(P, S.ghost_batches);
+            if (S.two) { int rc = fork_record(P, S.ev_ghost); if (rc) return rc; }
             ++S.ghost_batches;
             progressed = true;
         }
@@ -616,6 +781,12 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
             // one ring revolution earlier (their chunks are at most (d + 1) KC - 1)
             const int64_t top = std::min(S.diag + 1, S.n_macro) * S.KC - 1;
             if (top >= S.rec_chunks && S.ticks_stored < std::min(S.total, kRec * (top - S.rec_chunks + 1))) break;
+            if (S.two) {      // the events behind the three conditions above
+                int rc = S.has_in ? wait_for(S.ev_in, S.in_waited, batches_for(need_ticks)) : RR_OK;
+                if (!rc && P->n_ghost > 0) rc = wait_for(S.ev_ghost, S.ghost_waited, batches_for(std::min(std::max<int64_t>(0, (S.diag + 1) * K - S.ghost_slack), S.total)));
+                if (!rc && top >= S.rec_chunks) rc = wait_for(S.ev_out, S.out_waited, (std::min(S.total, kRec * (top - S.rec_chunks + 1)) + kRecRows - 1) / kRecRows);
+                if (rc) return rc;
+            }
             int rc = session_launch_diag(P, S.diag);
             if (rc) return rc;
             ++S.diag; ++launched;
@@ -629,7 +800,9 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
         done = std::min(done, S.total);
         while (S.out_batches < S.n_out_batches && done >= std::min(kRecRows * (S.out_batches + 1), S.total) &&
                (std::min(kRecRows * (S.out_batches + 1), S.total) + S.nsub - 1) / S.nsub <= S.out_limit) {
+            if (S.two && S.diags_marked < S.diag) { int rc = fork_join_caller(P); if (rc) return rc; S.diags_marked = S.diag; }      // the launches that finished these rows
             launch_rec_permute(P, false, S.out_batches);
+            if (S.two) { int rc = fork_record(P, S.ev_out); if (rc) return rc; }
             ++S.out_batches;
             S.ticks_stored = std::min(S.total, kRecRows * S.out_batches);
             progressed = true;
@@ -706,6 +879,12 @@ int session_end(rr_plan *P)
     if (!complete) return fail(RR_E_STATE, "routing call closed before all of its time steps were routed");
     if (P->h.n == 0 || S.total == 0) return RR_OK;
     if (S.bracket_open) P->prof_samples -= P->prof_samples % kSampleGroup;   // incomplete bracket: not counted
+    if (S.two) {      // the caller's stream continues after the last record pass
+        hipEvent_t e = pool_event(P);
+        if (!e) return fail(RR_E_HIP, "event creation failed");
+        HIPCHK(hipEventRecord(e, P->s_rec));
+        HIPCHK(hipStreamWaitEvent(S.stream, e, 0));
+    }
     HIPCHK(hipEventRecord(P->ev_last, S.stream));
     HIPCHK(hipGetLastError());
 #ifdef RR_WAVE_TRACE
@@ -827,7 +1006,9 @@ int route_host_pipelined(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const d
         return fail(RR_E_HIP, "host pipeline: event creation failed");
     Rows io;
     io.dev_in = host_in ? H.dev_in : nullptr; io.rows_in = NR * C; io.dev_out = H.dev_out; io.rows_out = NR * C;
+    P->pipe_active = true;      // its staging rings are recycled by events on `stream`: record passes stay on it
     rc = session_begin(P, mode, T, nsub, io, stream, nullptr, nullptr);
+    P->pipe_active = false;
     if (rc) return rc;
     Session &S = P->ses;
     auto rows_of = [&](int64_t c) { return std::min(C, T - c * C); };
@@ -928,7 +1109,12 @@ int rapid_like(rr_plan *P, Mode mode, double *q_t, const Rows &io_in, int64_t T,
     const bool host_rows = io.host_in != nullptr || io.host_out != nullptr;
     // host rows reach the time-tiled kernel through the PCIe pipeline's device rings; where it does not apply they are
     // routed chunk by chunk by the streaming kernel
-    if (!decide_wave(P, mode, T * nsub, false) && host_rows) decide_wave(P, mode, T * nsub, true);
+    {   // host rows reach the time-tiled kernel through the PCIe pipeline's device rings (they are "device rows" to the schedule)
+        int rc = prepare_call(P, mode, T, nsub, false, false, !host_rows);
+        if (rc == RR_OK && host_rows && !P->wave_now) rc = prepare_call(P, mode, T, nsub, true, true, false);
+        if (rc == RR_OK && host_rows && P->wave_now) rc = host_pipe_prepare(P);
+        if (rc) return rc;
+    }
     const bool piped = host_rows && P->wave_now;
     double *d_q = q_t;
     double *tmp = nullptr;
@@ -995,7 +1181,12 @@ int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io_in, int64
     if (n == 0 || T == 0) return RR_OK;
     const Rows &io = io_in;
     const bool host_rows = io.host_in != nullptr || io.host_out != nullptr;
-    if (!decide_wave(P, Mode::Unit, T * nsub, false) && host_rows) decide_wave(P, Mode::Unit, T * nsub, true);
+    {
+        int rc = prepare_call(P, Mode::Unit, T, nsub, false, false, !host_rows);
+        if (rc == RR_OK && host_rows && !P->wave_now) rc = prepare_call(P, Mode::Unit, T, nsub, true, true, false);
+        if (rc == RR_OK && host_rows && P->wave_now) rc = host_pipe_prepare(P);
+        if (rc) return rc;
+    }
     const bool piped = host_rows && P->wave_now;
     double *d_qch = q_ch, *d_qfull = q_full, *tmp = nullptr;
     if (q_on_host) {

@@ -85,7 +85,8 @@ __device__ __forceinline__ void write_records(const RecPermArgs &a, const double
             v0 = tile[r * kRecTileLd + c] * f[it]; v1 = tile[(r + 1) * kRecTileLd + c] * f[it];
         }
         double2 *dst = reinterpret_cast<double2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.np + p) * kRec) + part;
-        *dst = make_double2(v0, v1);
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        st_site<kNtInRec>(reinterpret_cast<d2 *>(dst), d2{v0, v1});
     }
 }
 
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_in(const RecPermArgs a)
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const int64_t t = row_first + min(r0 + q * (kRecThreads / kRecCols), need - 1);
-            v[q] = a.rows.row(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t))[i];
+            v[q] = ld_site<kNtInRows>(a.rows.row(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t)) + i);
         }
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(kUhInThreads) void k_rec_in_uh(const RecPermArgs a,
 #pragma unroll
         for (int q = 0; q < DPT; ++q) {
             const int64_t t = row_first - (NK - 1) + min(g + q * G, need + NK - 2);
-            dv[q] = a.rows.row(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t))[i];
+            dv[q] = ld_site<kNtInRows>(a.rows.row(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t)) + i);
         }
 #pragma unroll
         for (int q = 0; q < TPT; ++q) tv[q] = u.kernel[(int64_t)min(g + q * G, u.n_ks - 1) * a.n + i];
@@ -226,7 +227,9 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
         const int k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
         const int32_t p = meta[it].x < 0 ? 0 : meta[it].x;
         const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)((meta[it].y & kLagMask) >> 4) + k;
-        v[it] = *(reinterpret_cast<const double2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.np + p) * kRec) + part);
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const d2 got = ld_site<kNtOutRec>(reinterpret_cast<const d2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.np + p) * kRec) + part);
+        v[it] = make_double2(got.x, got.y);
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -265,9 +268,9 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
         if (SUB) {
             uint32_t s;
             const uint32_t t = a.nsub.div((uint32_t)tick, s);
-            if (s + 1 == a.nsub.d) a.rows.row(t)[i] = recs[c][o + r];
+            if (s + 1 == a.nsub.d) st_site<kNtOutRows>(a.rows.row(t) + i, recs[c][o + r]);
         } else {
-            a.rows.row(tick)[i] = out(recs[c][o + r]);
+            st_site<kNtOutRows>(a.rows.row(tick) + i, out(recs[c][o + r]));
         }
     }
 }

@@ -83,6 +83,9 @@ struct UnitTickArgs {
     TickArgs t;
     const uint16_t *hw_children;  // [n] count of headwater tributaries (stored first among the upstream range)
     double *qch;                  // [n] channel-only discharge of inner reaches, updated in place
+    // general edge data (rr_plan_set_unit_weights; never produced by the reference's callers, whose A is all ones and whose
+    // lhs_off_data is -c1[row]): a2[u] = a_inner_data / a_hw_data of the edge leaving u, c1own[p] = c1 of the reach itself
+    const double *a2, *c1own;
 };
 
 // One routing tick for UnitMuskingum (river_route/routers/_numba_kernels.py:113-171 in gather form).
@@ -120,6 +123,17 @@ __global__ __launch_bounds__(kBlock) void k_tick_unit(const UnitTickArgs ua)
         for (int32_t u = u0; u < uh; ++u) s_hw += a.xa[u];   // headwater tributaries: "old" value is l_t too
         for (int32_t u = uh; u < u1; ++u) { s_new += a.xa[u]; s_old += a.xb[u]; }
         r = __builtin_fma(a.c1row[p], s_hw + s_new, __builtin_fma(a.c2[p], s_hw + s_old, a.c3[p] * ua.qch[p]));
+    } else if (ua.a2) {
+        // _numba_kernels.py:126-162 term by term: c1 (A_in l_in + A_hw l_hw) + c2 A_hw l_hw + c3 q_ch + c2 (structure of lhs) q_full
+        // - lhs_off q_ch+, with the upstream reach's own lateral (same row, its position) separating q_ch+ from what it published
+        r = a.c3[p] * ua.qch[p];
+        const double c1 = ua.c1own[p], c2 = a.c2[p];
+        const double *lrow = a.in + (int64_t)a.in_rows.mod(t) * a.in_ld;
+        for (int32_t u = u0; u < uh; ++u) r += (c1 + c2) * (ua.a2[u] * a.xa[u]);
+        for (int32_t u = uh; u < u1; ++u) {
+            const double lu = lrow[u];
+            r += c2 * a.xb[u] + c1 * (ua.a2[u] * lu) + a.w[u] * (a.xa[u] - lu);
+        }
     } else {
         r = a.c3[p] * ua.qch[p];
         const double c2 = a.c2[p];

@@ -65,11 +65,11 @@ __device__ __forceinline__ void store_f64x2(__amdgpu_buffer_rsrc_t r, uint32_t b
 {
     u32x4 bits;
     __builtin_memcpy(&bits, &v, sizeof bits);
-    __builtin_amdgcn_raw_buffer_store_b128(bits, r, (int)byte_off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(bits, r, (int)byte_off, 0, (RR_NT_MASK & kNtTileStore) ? 2 : 0);      // aux bit 1: nt
 }
 __device__ __forceinline__ void load_f64x2(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, double &x, double &y)
 {
-    const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);   // one 16-byte request per lane
+    const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, (RR_NT_MASK & kNtTileLoad) ? 2 : 0);   // one 16-byte request per lane
     double2 v;
     __builtin_memcpy(&v, &bits, sizeof v);
     x = v.x; y = v.y;

@@ -15,6 +15,9 @@ __all__ = ['Plan', 'RRError', 'uh_convolve', 'uh_convolve_dev', 'runoff_to_qlate
            'resample_cast_dev', 'copy_bandwidth', 'runoff_to_qlateral_dev']
 
 
+MODE_RAPID, MODE_MUSKINGUM, MODE_UNIT = 0, 1, 2      # include/rr_hip.h: RR_MODE_*
+
+
 def _f64(a, name):
     a = np.ascontiguousarray(a, dtype=np.float64)
     if not a.flags['WRITEABLE']:
@@ -121,6 +124,17 @@ class Plan:
                 raise ValueError('c4_dt must have one value per reach')
         check(_lib.lib().rr_plan_set_coeffs(self._h, ptr(lhs) if lhs.size else None, ptr(c2), ptr(c3), ptr(c4)))
 
+    def set_unit_weights(self, c1=None, a_data=None) -> None:
+        """rr_plan_set_unit_weights: general a_inner_data / a_hw_data (per CSC entry) and c1 per reach for unit_route; None, None
+        goes back to the unit weights of the reference's callers."""
+        if c1 is None and a_data is None:
+            check(_lib.lib().rr_plan_set_unit_weights(self._h, None, None))
+            return
+        c1, a = _f64(c1, 'c1'), _f64(a_data, 'a_data')
+        if c1.shape != (self.n,) or a.shape != (self.n_edges,):
+            raise ValueError('c1 must have one value per reach and a_data one per CSC entry')
+        check(_lib.lib().rr_plan_set_unit_weights(self._h, ptr(c1), ptr(a) if a.size else None))
+
     # -- host-array routing: the reference's kernel boundary --
     def rapid_route(self, q_t, qlateral, discharge_array, num_substeps: int) -> None:
         ql = np.ascontiguousarray(qlateral, dtype=np.float64)
@@ -148,38 +162,55 @@ class Plan:
         check(_lib.lib().rr_unit_route(self._h, ptr(q_ch), ptr(q_full), ptr(conv), ptr(discharge_array), T,
                                        int(num_substeps)))
 
+    # -- work memory --
+    def reserve(self, mode: int, T: int, num_substeps: int = 1, host_rows: bool = False) -> dict:
+        """rr_plan_reserve: allocate what route calls of up to T rows x num_substeps sub-steps work in (the record ring, events,
+        with host_rows the PCIe staging).  The *_dev entry points of the C ABI only enqueue and fail with RR_E_STATE when this
+        has not been done; the methods below call it for the shape they are given (no-op once large enough)."""
+        info = np.zeros(8, dtype=np.int64)
+        check(_lib.lib().rr_plan_reserve(self._h, int(mode), int(T), int(num_substeps), int(bool(host_rows)), ptr(info)))
+        return dict(tiled=bool(info[0]), ticks_per_launch=int(info[1]), ring_chunks=int(info[2]), work_bytes=int(info[3]),
+                    staging_bytes=int(info[4]), pinned_bytes=int(info[5]), pipeline_ticks=int(info[6]), ring_bytes=int(info[7]))
+
     # -- device-pointer routing (enqueue only) --
     def rapid_route_dev(self, q_t, qlateral, ql_rows, discharge, out_rows, T, num_substeps, stream=None) -> None:
+        self.reserve(MODE_RAPID, T, num_substeps)
         check(_lib.lib().rr_rapid_route_dev(self._h, ptr(q_t), ptr(qlateral), int(ql_rows), ptr(discharge),
                                             int(out_rows), int(T), int(num_substeps), stream))
 
     def muskingum_route_dev(self, q_t, discharge, out_rows, num_output_steps, num_routing_per_output,
                             stream=None) -> None:
+        self.reserve(MODE_MUSKINGUM, num_output_steps, num_routing_per_output)
         check(_lib.lib().rr_muskingum_route_dev(self._h, ptr(q_t), ptr(discharge), int(out_rows),
                                                 int(num_output_steps), int(num_routing_per_output), stream))
 
     def unit_route_dev(self, q_ch, q_full, convolved, conv_rows, discharge, out_rows, T, num_substeps,
                        stream=None) -> None:
+        self.reserve(MODE_UNIT, T, num_substeps)
         check(_lib.lib().rr_unit_route_dev(self._h, ptr(q_ch), ptr(q_full), ptr(convolved), int(conv_rows),
                                            ptr(discharge), int(out_rows), int(T), int(num_substeps), stream))
 
 
     # -- device-pointer routing with the routers' post-processing fused in: float32 rows, `factor` routed rows averaged --
     def rapid_route_f32_dev(self, q_t, qlateral, ql_rows, discharge32, T, num_substeps, factor=1, stream=None) -> None:
+        self.reserve(MODE_RAPID, T, num_substeps)
         check(_lib.lib().rr_rapid_route_f32_dev(self._h, ptr(q_t), ptr(qlateral), int(ql_rows), ptr(discharge32), int(T),
                                                 int(num_substeps), int(factor), stream))
 
     def muskingum_route_f32_dev(self, q_t, discharge32, num_output_steps, num_routing_per_output, stream=None) -> None:
+        self.reserve(MODE_MUSKINGUM, num_output_steps, num_routing_per_output)
         check(_lib.lib().rr_muskingum_route_f32_dev(self._h, ptr(q_t), ptr(discharge32), int(num_output_steps),
                                                     int(num_routing_per_output), stream))
 
     def unit_route_f32_dev(self, q_ch, q_full, convolved, conv_rows, discharge32, T, num_substeps, factor=1, stream=None) -> None:
+        self.reserve(MODE_UNIT, T, num_substeps)
         check(_lib.lib().rr_unit_route_f32_dev(self._h, ptr(q_ch), ptr(q_full), ptr(convolved), int(conv_rows),
                                                ptr(discharge32), int(T), int(num_substeps), int(factor), stream))
 
     def rapid_route_runoff_dev(self, q_t, n_points, indptr, indices, weights, runoff, runoff_is_f32, stride_t, stride_p, area, flags, T,
                                discharge=None, discharge32=None, factor=1, stream=None) -> None:
         """Gridded runoff -> records -> routing in one call (rr_rapid_route_runoff_dev); exactly one of discharge / discharge32."""
+        self.reserve(MODE_RAPID, T, 1)
         check(_lib.lib().rr_rapid_route_runoff_dev(self._h, ptr(q_t), int(n_points), ptr(indptr), ptr(indices), ptr(weights), ptr(runoff),
                                                    int(bool(runoff_is_f32)), int(stride_t), int(stride_p), ptr(area), int(flags),
                                                    ptr(discharge), ptr(discharge32), int(factor), int(T), stream))
@@ -187,6 +218,7 @@ class Plan:
     def unit_route_uh_dev(self, q_ch, q_full, q_final, uh_kernel, uh_state, n_ks, depth, T, num_substeps, discharge=None,
                           discharge32=None, factor=1, stream=None) -> None:
         """Convolution + routing of one file in one call (rr_unit_route_uh_dev); exactly one of discharge / discharge32."""
+        self.reserve(MODE_UNIT, T, num_substeps)
         check(_lib.lib().rr_unit_route_uh_dev(self._h, ptr(q_ch), ptr(q_full), ptr(q_final), ptr(uh_kernel), ptr(uh_state),
                                               int(n_ks), ptr(depth), ptr(discharge), ptr(discharge32), int(factor), int(T),
                                               int(num_substeps), stream))
@@ -201,6 +233,7 @@ class Plan:
 
     def stream_begin(self, q_t, lateral, lat_rows, discharge, out_rows, T, num_substeps, ghost_series=None,
                      export_series=None, stream=None) -> None:
+        self.reserve(MODE_MUSKINGUM if lateral is None else MODE_RAPID, T, num_substeps)
         check(_lib.lib().rr_stream_begin(self._h, 0 if lateral is None else 1, ptr(q_t), ptr(lateral), int(lat_rows),
                                          ptr(discharge), int(out_rows), int(T), int(num_substeps), ptr(ghost_series),
                                          ptr(export_series), stream))
@@ -215,6 +248,7 @@ class Plan:
 
     def stream_begin_unit(self, q_ch, q_full, lateral, lat_rows, discharge, out_rows, T, num_substeps, ghost_series=None,
                           export_series=None, stream=None) -> None:
+        self.reserve(MODE_UNIT, T, num_substeps)
         check(_lib.lib().rr_stream_begin_unit(self._h, ptr(q_ch), ptr(q_full), ptr(lateral), int(lat_rows), ptr(discharge),
                                               int(out_rows), int(T), int(num_substeps), ptr(ghost_series), ptr(export_series), stream))
 

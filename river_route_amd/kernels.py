@@ -90,9 +90,8 @@ def unit_route(lhs_indptr, lhs_indices, lhs_off_data,
                num_substeps) -> None:
     """river_route/routers/_numba_kernels.py:89-171."""
     n_total = convolved_lateral.shape[1]
-    if not (np.all(np.asarray(a_inner_data) == 1.0) and np.all(np.asarray(a_hw_data) == 1.0)):
-        raise NotImplementedError('unit_route: adjacency weights other than 1 are not supported')
     inner_idx = np.asarray(inner_idx, dtype=np.int64)
+    hw_idx = np.asarray(hw_idx, dtype=np.int64)
     indptr, indices = full_structure_from_split(lhs_indptr, lhs_indices, a_hw_indptr, a_hw_indices,
                                                 hw_idx, inner_idx, n_total)
     plan = _plan_for(indptr, indices, DEFAULT_DEVICE)
@@ -100,7 +99,23 @@ def unit_route(lhs_indptr, lhs_indices, lhs_off_data,
     c2 = np.zeros(n_total)
     c3 = np.zeros(n_total)
     c1[inner_idx], c2[inner_idx], c3[inner_idx] = c1_inner, c2_inner, c3_inner
-    if not np.array_equal(np.asarray(lhs_off_data), -np.asarray(c1_inner)[np.asarray(lhs_indices)]):
-        raise NotImplementedError('unit_route: lhs_off_data must equal -c1_inner[lhs_indices]')
-    plan.set_coeffs(-c1[indices], c2, c3, None)
+    lhs_off_data = np.asarray(lhs_off_data, dtype=np.float64)
+    unit_weights = (np.all(np.asarray(a_inner_data) == 1.0) and np.all(np.asarray(a_hw_data) == 1.0)
+                    and np.array_equal(lhs_off_data, -np.asarray(c1_inner)[np.asarray(lhs_indices)]))
+    if unit_weights:      # what UnitMuskingum passes (UnitMuskingum.py:45-70): the time-tiled kernel
+        plan.set_unit_weights(None, None)
+        plan.set_coeffs(-c1[indices], c2, c3, None)
+    else:
+        # general edge data, per entry of the full CSC structure (one entry per reach that has a downstream reach, in reach
+        # order): the streaming kernel multiplies and subtracts as _numba_kernels.py:126-139, 159-162 do
+        has_down = np.diff(indptr) == 1
+        entry_of = np.cumsum(has_down) - 1                                  # CSC entry of a reach's downstream edge
+        a_full, lhs_full = np.zeros(indices.size), np.zeros(indices.size)
+        for cols, ptr_, data, dst in ((inner_idx, a_inner_indptr, a_inner_data, a_full), (hw_idx, a_hw_indptr, a_hw_data, a_full),
+                                      (inner_idx, lhs_indptr, lhs_off_data, lhs_full)):
+            ptr_ = np.asarray(ptr_, dtype=np.int64)
+            has = np.diff(ptr_) == 1
+            dst[entry_of[cols[has]]] = np.asarray(data, dtype=np.float64)[ptr_[:-1][has]]
+        plan.set_coeffs(lhs_full, c2, c3, None)
+        plan.set_unit_weights(c1, a_full)
     plan.unit_route(q_ch, q_full, convolved_lateral, discharge_array, int(num_substeps))

@@ -226,8 +226,10 @@ class HipUnitPartEngine:
 def part_driver(engine, spec: PartSpec, T: int, nsub: int, chunk_rows: int):
     """
     Generator running one part through one routing call.  It yields requests the runner must serve:
-      ('recv', src_part, tensor_view_setter, r0, r1)   block until rows [r0, r1) of src's export block arrived
-      ('send', dst_part, tensor, r0, r1)               ship rows [r0, r1) of the export block for dst
+      ('post', k, [(src_part, ghost_view, r0, r1), ...])   rows [r0, r1) of each upstream part's export block will be needed
+                                                             for chunk k: receives may be posted now (one chunk ahead of use)
+      ('recv', src_part, ghost_view, r0, r1)               block until those rows arrived and sit in ghost_view
+      ('send', dst_part, tensor, r0, r1)                   ship rows [r0, r1) of the export block for dst
     """
     S = T * nsub
     kc = chunk_rows * nsub
@@ -244,11 +246,19 @@ def part_driver(engine, spec: PartSpec, T: int, nsub: int, chunk_rows: int):
                 yield ('send', dst, engine.export_series[sent:r1, cols], sent, r1)
             sent = r1
 
+    def wanted(k):
+        s0, s1 = k * kc, min(T, (k + 1) * chunk_rows) * nsub
+        return [(src, engine.ghost_series[s0:s1, cols], s0, s1) for src, cols in spec.upstream_parts]
+
+    if spec.upstream_parts and n_chunks:
+        yield ('post', 0, wanted(0))
     for k in range(n_chunks):
         rows1 = min(T, (k + 1) * chunk_rows)
-        s0, s1 = k * kc, rows1 * nsub
-        for src, cols in spec.upstream_parts:
-            yield ('recv', src, engine.ghost_series[s0:s1, cols], s0, s1)
+        s1 = rows1 * nsub
+        if spec.upstream_parts and k + 1 < n_chunks:
+            yield ('post', k + 1, wanted(k + 1))      # the next chunk's boundary values travel while this one is routed
+        for req in wanted(k):
+            yield ('recv',) + req
         ready = engine.advance(rows1, s1 if spec.n_ghost else S)
         if spec.downstream_parts:
             yield from flush(ready, False)
@@ -260,18 +270,33 @@ def part_driver(engine, spec: PartSpec, T: int, nsub: int, chunk_rows: int):
 
 def run_distributed(engine, spec: PartSpec, T: int, nsub: int, chunk_rows: int, dist) -> None:
     """Serve one part's driver with torch.distributed point-to-point ops (nccl = RCCL on the GPU box, gloo on CPU).
-    Rank == part.  Sends are asynchronous; their buffers are kept alive until the call ends."""
+    Rank == part.  The receives of a chunk are posted as ONE batch (one grouped RCCL call for all upstream parts) when the
+    driver announces them -- a chunk before the values are used -- so the part that collects seven boundary series never
+    stands in a queue of blocking receives; sends are asynchronous, their buffers kept alive until the call ends."""
     pending = []
+    posted = {}                                 # (src, r0, r1) -> (work, staging buffer)
     via_host = dist.get_backend() != 'nccl'     # gloo moves host memory: stage device tensors through the CPU
     for req in part_driver(engine, spec, T, nsub, chunk_rows):
-        kind, peer, view, r0, r1 = req
-        if kind == 'recv':
-            buf = view.new_empty(view.shape, device='cpu') if via_host else view.new_empty(view.shape)
-            dist.recv(buf, src=peer)
+        kind = req[0]
+        if kind == 'post':
+            ops, keys = [], []
+            for src, view, r0, r1 in req[2]:
+                buf = view.new_empty(view.shape, device='cpu') if via_host else view.new_empty(view.shape)
+                ops.append(dist.P2POp(dist.irecv, buf, src))
+                keys.append(((src, r0, r1), buf))
+            works = dist.batch_isend_irecv(ops)
+            for i, (key, buf) in enumerate(keys):
+                posted[key] = (works[i] if len(works) == len(keys) else works[-1], buf)      # RCCL returns one work for the group
+        elif kind == 'recv':
+            _, peer, view, r0, r1 = req
+            work, buf = posted.pop((peer, r0, r1))
+            work.wait()                          # RCCL: the current stream waits, the host does not
             view.copy_(buf)
         else:
+            _, peer, view, r0, r1 = req
             buf = view.cpu().contiguous() if via_host else view.contiguous()
             pending.append((dist.isend(buf, dst=peer), buf))
+    assert not posted
     for work, _ in pending:
         work.wait()
 
@@ -295,6 +320,10 @@ def run_in_process(engines, specs, T: int, nsub: int, chunk_rows: int) -> None:
                         alive.discard(p)
                         progressed = True
                         break
+                if req[0] == 'post':            # nothing to post without a network: the mailbox is the network
+                    waiting[p] = None
+                    progressed = True
+                    continue
                 kind, peer, view, r0, r1 = req
                 if kind == 'send':
                     mail.setdefault((p, peer), []).append((r0, r1, view.clone()))

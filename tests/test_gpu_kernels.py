@@ -169,6 +169,34 @@ def test_unit_vs_oracle(n, T, nsub, n_ks):
     assert_close(d, d_ref, 'discharge')
 
 
+@pytest.mark.parametrize('n,T,nsub', [(4000, 20, 1), (4000, 9, 3), (9, 6, 2)])
+def test_unit_route_general_edge_data_vs_oracle(n, T, nsub):
+    """unit_route multiplies by a_inner_data[j] / a_hw_data[j] and subtracts lhs_off_data[j] q_ch
+    (_numba_kernels.py:126-139, 159-162).  The reference's router passes ones and -c1[row]; other values are legal at the
+    kernel boundary and go through the streaming kernel's general branch; afterwards the same plan routes unit weights
+    with the time-tiled kernel again."""
+    net = synth.synth_network(n, seed=13)
+    indptr, indices = csc_from_down(net.down_index)
+    hw_idx, inner_idx, A_in, A_hw = unit_split(indptr, indices, n)
+    c1, c2, c3 = coeffs(net, 900.0 / nsub)
+    c1i, c2i, c3i = c1[inner_idx], c2[inner_idx], c3[inner_idx]
+    rng = np.random.default_rng(5)
+    a_in, a_hw = rng.uniform(0.5, 1.5, A_in.data.size), rng.uniform(0.5, 1.5, A_hw.data.size)
+    lhs_in = -c1i[A_in.indices] * rng.uniform(0.7, 1.2, A_in.data.size)
+    conv = 3.0 * synth.synth_runoff_depth(n, 0, T) * 1e3
+    q0 = 5.0 * synth.u01(17, np.arange(n))
+    for weights in ((lhs_in, a_in, a_hw), (np.ascontiguousarray(-c1i[A_in.indices]), A_in.data, A_hw.data)):
+        args = (A_in.indptr, A_in.indices, weights[0], A_in.indptr, A_in.indices, weights[1],
+                A_hw.indptr, A_hw.indices, weights[2], c1i, c2i, c3i, hw_idx, inner_idx)
+        qc_ref, qf_ref, d_ref = q0[inner_idx].copy(), 1.1 * q0[inner_idx], np.zeros((T, n))
+        oracle.unit_route(*args, qc_ref, qf_ref, conv, d_ref, nsub)
+        qc, qf, d = q0[inner_idx].copy(), 1.1 * q0[inner_idx], np.zeros((T, n))
+        kernels.unit_route(*args, qc, qf, conv, d, nsub)
+        assert_close(qc, qc_ref, 'q_ch')
+        assert_close(qf, qf_ref, 'q_full')
+        assert_close(d, d_ref, 'discharge')
+
+
 # ---------------------------------------------------------------- (c) properties the reference's tests assert
 
 def _rapid_setup(n, seed=NotImplemented):

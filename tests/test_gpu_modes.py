@@ -307,3 +307,54 @@ def test_record_ring_goes_round_with_substeps_and_other_modes(monkeypatch, mode,
             assert_close(d_out.download(np.float64, (T, n)), d_ref, 'discharge')
             d_q.free(); d_out.free()
         assert plan.profile()['ticks_per_launch'] >= 16
+
+
+@pytest.mark.parametrize('env', [{'RR_WAVE': '0'}, {}])
+def test_dev_entry_points_only_enqueue(monkeypatch, env):
+    """include/rr_hip.h: a *_dev call allocates nothing.  Through the raw ABI: without rr_plan_reserve the call is refused with
+    RR_E_STATE and a message that names the remedy; after it, the call leaves the device's free memory where it was and
+    agrees with the oracle; a larger call than reserved is refused again, a smaller one fits."""
+    import ctypes as C
+    import torch
+    from river_route_amd import _lib
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n, T, nsub = 50_000, 96, 1
+    net = synth.synth_network(n, seed=5)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0)
+    lhs, c4_dt = -c1[indices], (c1 + c2) / 900.0
+    ql = synth.synth_qlateral(n, 0, T)
+    q_ref, d_ref = np.zeros(n), np.zeros((T, n))
+    oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql, d_ref, nsub)
+    L = _lib.lib()
+    h = C.c_void_p()
+    assert L.rr_plan_create(n, _lib.ptr(indptr), _lib.ptr(indices), 0, C.byref(h)) == 0
+    try:
+        assert L.rr_plan_set_coeffs(h, _lib.ptr(lhs), _lib.ptr(c2), _lib.ptr(c3), _lib.ptr(c4_dt)) == 0
+        dev = torch.device('cuda', 0)
+        d_q = torch.zeros(n, dtype=torch.float64, device=dev)
+        d_ql = torch.from_numpy(ql).to(dev)
+        d_out = torch.zeros((2 * T, n), dtype=torch.float64, device=dev)
+        stream = torch.cuda.current_stream().cuda_stream
+        call = lambda rows: L.rr_rapid_route_dev(h, _lib.ptr(d_q), _lib.ptr(d_ql), T, _lib.ptr(d_out), 2 * T, rows, nsub, stream)  # noqa: E731
+        assert call(T) == _lib.RR_E_STATE and b'rr_plan_reserve' in L.rr_last_error()
+        info = np.zeros(8, dtype=np.int64)
+        assert L.rr_plan_reserve(h, 0, T, nsub, 0, _lib.ptr(info)) == 0
+        assert info[0] == (0 if env else 1) and info[3] >= info[7] > 0
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info(0)[0]
+        assert call(T) == 0
+        free1 = torch.cuda.mem_get_info(0)[0]      # asked while the call may still be running: nothing in it synchronised either
+        torch.cuda.synchronize()
+        assert free0 == free1 == torch.cuda.mem_get_info(0)[0]
+        assert_close(d_out[:T].cpu().numpy(), d_ref, 'discharge')
+        assert_close(d_q.cpu().numpy(), q_ref, 'q_t')
+        assert call(T // 2) == 0                                   # a smaller call fits
+        assert call(64 * T) == _lib.RR_E_STATE                     # a larger one is refused, not grown into
+        assert L.rr_plan_reserve(h, 0, 64 * T, nsub, 0, None) == 0 and call(64 * T) == 0
+        torch.cuda.synchronize()
+    finally:
+        L.rr_plan_destroy(h)

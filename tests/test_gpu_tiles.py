@@ -321,7 +321,8 @@ def test_float32_output_fused_into_the_record_pass(monkeypatch, n, T, nsub, fact
 
 
 @pytest.mark.parametrize('n,T,nsub,n_ks', [(60_000, 200, 1, 48), (300_000, 150, 1, 48), (60_000, 70, 3, 12), (60_000, 40, 1, 60),
-                                           (60_000, 33, 1, 1)])
+                                           (60_000, 33, 1, 1),
+                                           (1_000_000, 80, 1, 48)])      # BASELINE config 4's shape: the kernel bench.py times, k_rec_in_uh<false, 48>
 def test_unit_route_with_fused_convolution_vs_oracle(monkeypatch, n, T, nsub, n_ks):
     """rr_unit_route_uh_dev: UnitHydrograph.convolve + unit_route + the router's state bookkeeping
     (river_route/routers/UnitMuskingum.py:72-98) in one call, the convolved lateral never written as rows; two files, so

@@ -88,6 +88,26 @@ def test_two_ranks_gloo_match_single_domain(tmp_path):
     assert_close(d, d_ref, 'discharge')
 
 
+def test_eight_ranks_gloo_fan_in_matches_single_domain(tmp_path):
+    """BASELINE config 5's shape in miniature: eight ranks, seven of them feeding the rank that holds the main stems
+    (trunk partition), receives posted a chunk ahead as one batch per chunk -- against the oracle on the undivided network."""
+    import torch.multiprocessing as mp
+    n, T, world = 6000, 45, 8
+    net, indptr, indices, *_ = setup_case(n)
+    part_of, _ = partition_forest(indptr, indices, world)
+    has = net.down_index >= 0
+    cut = has & (part_of != part_of[np.maximum(net.down_index, 0)])
+    assert np.all(part_of[net.down_index[cut]] == world - 1) and np.unique(part_of[cut]).size == world - 1      # 7 -> 1
+    mp.spawn(gloo_worker, args=(world, free_port(), n, T, 8, str(tmp_path)), nprocs=world, join=True)
+    q_ref, d_ref = single_domain(n, T)
+    q, d = np.zeros(n), np.zeros((T, n))
+    for r in range(world):
+        z = np.load(tmp_path / f'rank{r}.npz')
+        q[z['real']], d[:, z['real']] = z['state'], z['discharge']
+    assert_close(q, q_ref, 'state')
+    assert_close(d, d_ref, 'discharge')
+
+
 def test_in_process_runner_with_oracle_engine_three_parts():
     n, T, parts = 900, 25, 3
     net, indptr, indices, c1, c2, c3, q0 = setup_case(n)
@@ -162,6 +182,14 @@ def test_two_ranks_share_one_gpu_over_gloo_vs_oracle(tmp_path):
     """The distributed driver with the real engine: two processes, one card, boundary series over gloo (what a 1-GPU
     box can run of `bench.py --gpus 2`), against the oracle on the undivided network."""
     _ranks_vs_oracle(tmp_path, 2, 'gloo')
+
+
+@pytest.mark.gpu
+def test_five_ranks_share_one_gpu_fan_in_vs_oracle(tmp_path):
+    """The shape of `bench.py --gpus 8` as far as one card allows (the GPU box admits six processes on a card, this one
+    included): five ranks with the real engine, four leaf parts feeding the trunk part of a 400k-reach network, batched
+    receives posted ahead, two passes -- against the oracle on the undivided network."""
+    _ranks_vs_oracle(tmp_path, 5, 'gloo', n=400_000, T=160, chunk=32)
 
 
 @pytest.mark.gpu

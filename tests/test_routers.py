@@ -341,7 +341,13 @@ def test_device_file_path_equals_host_path(case, monkeypatch):
             np.testing.assert_array_equal(a, b)
 
 
-def test_scs_kernel_builders(golden_kernels):
+# SURVEY section 8 row f3 on both boxes: the builders are host code (pinned by reference goldens, runs here); on the GPU
+# box (`-m gpu`) the same kernels also drive the HIP convolution against the oracle.
+BOX = pytest.mark.parametrize('box', ['host', pytest.param('gpu_box', marks=pytest.mark.gpu)])
+
+
+@BOX
+def test_scs_kernel_builders(golden_kernels, box):
     """uhkernels/_SCSBase.py: kernels equal the reference's, conserve volume (tests/test_uhkernels.py:19-42)."""
     from river_route_amd.uhkernels import SCSCurvilinear, SCSTriangular
     g = golden_kernels
@@ -353,13 +359,24 @@ def test_scs_kernel_builders(golden_kernels):
             assert uh.kernel.shape == want.shape and uh.kernel.ndim == 2
             np.testing.assert_allclose(uh.kernel, want, rtol=1e-12, atol=1e-12 * want.max())
             np.testing.assert_allclose(uh.kernel.sum(axis=0) * tr, area, rtol=1e-6)
+            if box == 'gpu_box':      # UnitHydrograph.convolve (UnitHydrograph.py:77-107) with this kernel: HIP engine vs oracle, two files
+                from oracle import oracle
+                from river_route_amd.engine import uh_convolve
+                ref, state = oracle.UnitHydrograph(uh.kernel), np.zeros_like(uh.kernel)
+                for f, T in enumerate((70, 5)):
+                    depth = 1e-3 * np.random.default_rng(f).random((T, area.shape[0]))
+                    want_rows = ref.convolve(depth)
+                    got_rows = uh_convolve(uh.kernel, state, depth)
+                    np.testing.assert_allclose(got_rows, want_rows, rtol=1e-10, atol=1e-10 * np.abs(want_rows).max())
+                    np.testing.assert_allclose(state, ref.state, rtol=1e-10, atol=1e-10 * np.abs(want_rows).max())
     with pytest.raises(ValueError, match='tr must be > 0'):
         SCSTriangular(tr=0.0, tc=tc, area=area)
     with pytest.raises(ValueError, match='same length'):
         SCSTriangular(tr=900.0, tc=tc, area=area[:2])
 
 
-def test_scs_kernel_file_round_trip(tmp_path):
+@BOX
+def test_scs_kernel_file_round_trip(tmp_path, box):
     from river_route_amd.uhkernels import SCSTriangular, UnitHydrograph
     uh = SCSTriangular(tr=900.0, tc=np.array([2000.0, 9000.0]), area=np.array([1e6, 4e6]))
     path = tmp_path / 'k.npz'
