@@ -11,6 +11,7 @@
 #include <limits>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/rr_hip.h"

@@ -45,10 +45,10 @@ void rr_plan_destroy(rr_plan *P)
     if (!P) return;
     if (P->device >= 0 && hipSetDevice(P->device) == hipSuccess) {
         void *ptrs[] = {P->d_child_ptr, P->d_lag, P->d_perm, P->d_inv, P->d_inner_pos, P->d_bidx, P->d_hwc, P->d_w, P->d_c1row_h, P->d_c2,
-                        P->d_c1row, P->d_tc2, P->d_tc3, P->d_sq, P->d_ss, P->d_si, P->d_sqch, P->d_full, P->d_chan,
-                        P->d_tile_ptr, P->d_tile_level, P->d_tile_lag_lo, P->d_tile_lag_hi, P->d_tlag, P->d_cfirst, P->d_xpos,
-                        P->d_tperm, P->d_tinv, P->d_inner_idx, P->d_ccnt, P->d_colmeta, P->d_ghostmeta, P->d_c4_params,
-                        P->d_c3, P->d_c4, P->d_x, P->d_isum, P->d_qch, P->d_a2, P->d_c1own, P->d_ring, P->d_stage, P->d_mrows,
+                        P->d_coef, P->d_sq, P->d_ss, P->d_si, P->d_sqch, P->d_full, P->d_chan,
+                        P->d_tmeta, P->d_pmeta,
+                        P->d_tperm, P->d_tinv, P->d_inner_idx, P->d_colmeta, P->d_ghostmeta, P->d_c4_params,
+                        P->d_c3, P->d_c4, P->d_x, P->d_isum, P->d_qch, P->d_a2, P->d_c1own, P->d_z, P->d_ring, P->d_stage, P->d_mrows,
                         P->d_slot_a[0], P->d_slot_a[1], P->d_slot_b[0], P->d_slot_b[1], P->d_m_index[0], P->d_m_index[1]};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         P->pipe.destroy();
@@ -74,11 +74,20 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
     std::string err;
     int rc = rr::build_host_plan(n, csc_indptr, csc_indices, P->h, err);
     if (rc) { delete P; return fail(rc, err); }
-    {   // time-tiled schedule: tiles of 512 positions, one per thread, two workgroups per CU (while the waves of one
-        // wait to issue their record loads the other one ticks: measured 368 ms per year at 1M reaches against 391 with
-        // one 1,024-thread workgroup and 382 with four 256-thread ones)
+    if (device != RR_DEVICE_NONE) {      // the tile size below depends on the card's CU count
+        int count = rr_device_count(), cus = 0;
+        if (device >= 0 && device < count && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) P->cu_count = cus;
+    }
+    if (const char *e2 = getenv("RR_TILE_SLOTS")) P->cu_count = std::max(1, atoi(e2));      // tests: few workgroups, many tiles each
+    {   // Time-tiled schedule: one position per thread, 16 waves per CU, tiles of 512 positions (two workgroups per CU: while
+        // the waves of one wait to issue their record loads the other one ticks; 368 ms per year at 1M reaches against 391
+        // with one 1,024-thread workgroup and 382 with four 256-thread ones).  Smaller tiles for smaller networks -- so that
+        // every CU has a tile: 100k reaches make 206 tiles of 512 -- were measured and do not pay: 7.5 / 7.6 / 7.4 x 10^10
+        // reach-steps/s at 100k with tiles of 128 / 256 / 512, 8.2 / 8.1 / 8.6 at 250k, 8.6 / 8.8 / 9.1 at 500k
+        // (profiles/r03_tile_size_sweep.txt): more tiles mean more ghosts and levels, and at that size the record passes, not
+        // the routing kernel, are most of the time.  RR_WAVE_THREADS picks another size.
         P->wave_threads = 512;
-        if (const char *e = getenv("RR_WAVE_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) P->wave_threads = v; }
+        if (const char *e = getenv("RR_WAVE_THREADS")) { const int v = atoi(e); if (v == 128 || v == 256 || v == 512 || v == 1024) P->wave_threads = v; }
         P->wave_ppt = 1;
         int32_t block = P->wave_threads;
         if (const char *e = getenv("RR_TILE_BLOCK")) block = std::max(8, std::min(block, atoi(e)));     // tests: many small tiles
@@ -99,14 +108,12 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         {
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) P->dev_total_bytes = total_b;
-            int cus = 0;
-            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) P->cu_count = cus;
-            if (const char *e2 = getenv("RR_TILE_SLOTS")) P->cu_count = std::max(1, atoi(e2));      // tests: few workgroups, many tiles each
         }
         if (const char *e2 = getenv("RR_REC_STREAM")) P->rec_stream_enabled = atoi(e2) != 0;      // measurements: record passes on a second stream
         if (P->rec_stream_enabled && hipStreamCreateWithFlags(&P->s_rec, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); P->s_rec = nullptr; }
-        for (int v = 0; v < 4; ++v)    // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
-            if (hipFuncSetAttribute((const void *)tile_kernel(P->wave_threads, (v & 1) != 0, (v & 2) != 0), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (const char *e2 = getenv("RR_TILE_LEAN")) P->lean_enabled = atoi(e2) != 0;      // measurements / tests: the general tick for every call
+        for (int v = 0; v < 5; ++v)    // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
+            if (hipFuncSetAttribute((const void *)tile_kernel(P->wave_threads, (v & 1) != 0, (v & 2) != 0, v == 4), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)tile_lds_bytes(P->wave_threads)) != hipSuccess) {
                 (void)hipGetLastError();
                 P->wave_enabled = false;
@@ -137,29 +144,13 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
             if (!rc) rc = dev_upload(P->d_colmeta, cm);
             if (!rc) rc = dev_alloc(&P->d_inner_idx, ni);
             if (!rc) rc = dev_upload(P->d_inner_idx, inner_idx);
-            if (!rc) rc = dev_alloc(&P->d_tile_ptr, (int64_t)TP.tile_ptr.size());
-            if (!rc) rc = dev_upload(P->d_tile_ptr, TP.tile_ptr);
-            if (!rc) rc = dev_alloc(&P->d_tile_level, TP.n_tiles);
-            if (!rc) rc = dev_upload(P->d_tile_level, TP.tile_level);
-            if (!rc) rc = dev_alloc(&P->d_tile_lag_lo, TP.n_tiles);
-            if (!rc) rc = dev_upload(P->d_tile_lag_lo, TP.tile_lag_lo);
-            if (!rc) rc = dev_alloc(&P->d_tile_lag_hi, TP.n_tiles);
-            if (!rc) rc = dev_upload(P->d_tile_lag_hi, TP.tile_lag_hi);
-            if (!rc) rc = dev_alloc(&P->d_tlag, np);
-            if (!rc) rc = dev_upload(P->d_tlag, TP.lag);
-            if (!rc) rc = dev_alloc(&P->d_cfirst, np);
-            if (!rc) rc = dev_upload(P->d_cfirst, TP.cfirst);
-            if (!rc) rc = dev_alloc(&P->d_ccnt, np);
-            if (!rc) rc = dev_upload(P->d_ccnt, TP.ccnt);
-            if (!rc) rc = dev_alloc(&P->d_xpos, np);
-            if (!rc) rc = dev_upload(P->d_xpos, TP.xpos);
+            if (!rc) rc = upload_tile_meta(P, TP.lag, TP.xpos, TP.tile_flags);
+            for (int32_t f : TP.tile_flags) P->n_wide_tiles += (f & kTileWide) ? 1 : 0;
             if (!rc) rc = dev_alloc(&P->d_tperm, np);
             if (!rc) rc = dev_upload(P->d_tperm, TP.perm);
             if (!rc) rc = dev_alloc(&P->d_tinv, n);
             if (!rc) rc = dev_upload(P->d_tinv, TP.inv);
-            if (!rc) rc = dev_alloc(&P->d_c1row, np);
-            if (!rc) rc = dev_alloc(&P->d_tc2, np);
-            if (!rc) rc = dev_alloc(&P->d_tc3, np);
+            if (!rc) rc = dev_alloc(&P->d_coef, 3 * np);
             if (!rc) rc = dev_alloc(&P->d_sq, np);
             if (!rc) rc = dev_alloc(&P->d_ss, np);
             if (!rc) rc = dev_alloc(&P->d_si, np);
@@ -265,15 +256,13 @@ int rr_plan_set_coeffs(rr_plan *P, const double *lhs_off_data, const double *c2,
     if (!rc) rc = dev_upload(P->d_c1row_h, c1row);
     if (!rc && P->tp.ok) {      // the same in tile order; a ghost computes nothing
         const rr::TilePlan &TP = P->tp;
-        std::vector<double> t1(TP.np, 0.0), t2(TP.np, 0.0), t3(TP.np, 0.0);
+        P->h_coef.assign(3 * TP.np, 0.0);
         for (int64_t p = 0; p < TP.np; ++p) {
             if (TP.lag[p] & kTileGhostBit) continue;
             const int32_t i = TP.perm[p];
-            t1[p] = c1row[H.inv[i]]; t2[p] = c2[i]; t3[p] = c3[i];
+            P->h_coef[3 * p] = c1row[H.inv[i]]; P->h_coef[3 * p + 1] = c2[i]; P->h_coef[3 * p + 2] = c3[i];
         }
-        rc = dev_upload(P->d_c1row, t1);
-        if (!rc) rc = dev_upload(P->d_tc2, t2);
-        if (!rc) rc = dev_upload(P->d_tc3, t3);
+        rc = upload_tile_coef(P);
     }
     if (!rc) rc = dev_upload(P->d_c2, a2);
     if (!rc) rc = dev_upload(P->d_c3, a3);
@@ -306,6 +295,7 @@ int rr_plan_set_unit_weights(rr_plan *P, const double *c1, const double *a_data)
     }
     if (!P->d_a2) rc = dev_alloc(&P->d_a2, n);
     if (!rc && !P->d_c1own) rc = dev_alloc(&P->d_c1own, n);
+    if (!rc && !P->d_z) rc = dev_alloc(&P->d_z, 3 * n);
     if (!rc) rc = dev_upload(P->d_a2, a2);
     if (!rc) rc = dev_upload(P->d_c1own, own);
     if (rc) return rc;
@@ -419,8 +409,10 @@ int rr_plan_set_boundary(rr_plan *P, int64_t n_ghost, const int64_t *ghost_reach
             if (tlag[p] & kTileExportBit) P->export_inside = true;
             tlag[p] |= kExportBit; txpos[p] = (int32_t)e;
         }
-        rc = dev_upload(P->d_tlag, tlag);
-        if (!rc) rc = dev_upload(P->d_xpos, P->export_inside ? TP.xpos : txpos);
+        std::vector<int32_t> tflags(TP.tile_flags);      // a tile with a boundary export stores it tick by tick
+        for (int64_t e = 0; e < n_export; ++e) tflags[TP.tile_of[TP.inv[export_reaches[e]]]] |= kTileExports;
+        rc = upload_tile_meta(P, tlag, P->export_inside ? TP.xpos : txpos, tflags);
+        if (!rc) rc = upload_tile_coef(P);      // zeros at the boundary ghosts
         if (P->d_ghostmeta) { (void)hipFree(P->d_ghostmeta); P->d_ghostmeta = nullptr; }
         std::vector<int2> gm((size_t)n_ghost);
         for (int64_t g = 0; g < n_ghost; ++g) { const int32_t p = TP.inv[ghost_reaches[g]]; gm[g] = make_int2(p, TP.lag[p] & kLagMask); }

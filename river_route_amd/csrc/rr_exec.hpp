@@ -102,7 +102,7 @@ struct rr_plan {
     uint16_t *d_hwc = nullptr;
     double *d_w = nullptr, *d_c1row_h = nullptr, *d_c2 = nullptr, *d_c3 = nullptr, *d_c4 = nullptr;
     double *d_x = nullptr, *d_isum = nullptr, *d_qch = nullptr;
-    double *d_a2 = nullptr, *d_c1own = nullptr;   // UnitMuskingum with general edge data (rr_plan_set_unit_weights): streaming kernel only
+    double *d_a2 = nullptr, *d_c1own = nullptr, *d_z = nullptr;   // UnitMuskingum with general edge data (rr_plan_set_unit_weights): streaming kernel only
     bool unit_general = false;
     double *d_ring = nullptr;
     int64_t ring_cap = 0;  // doubles
@@ -122,12 +122,15 @@ struct rr_plan {
     int64_t wave_K = 0;          // ticks per task (multiple of 16); 0 = chosen per call
     int64_t next_KC = 1, next_chunks = 0;   // prepare_call: task length and record ring of the call about to start
     int64_t kc_cap = int64_t{1} << 20;      // longest task (record chunks) the device had room for; 0: no record ring fits, the plan streams
-    int32_t *d_tile_ptr = nullptr, *d_tile_level = nullptr, *d_tile_lag_lo = nullptr, *d_tile_lag_hi = nullptr;
-    int32_t *d_tlag = nullptr, *d_cfirst = nullptr, *d_xpos = nullptr, *d_tperm = nullptr, *d_tinv = nullptr;
+    TileMeta *d_tmeta = nullptr;     // per tile (rr_kernels_tile.hpp)
+    int4 *d_pmeta = nullptr;         // per position {lag | flags, first upstream position, xpos, upstream counts}
+    int32_t *d_tperm = nullptr, *d_tinv = nullptr;
     int32_t *d_inner_idx = nullptr;
     bool export_inside = false;      // an export reach that another tile mirrors (it has a downstream reach in this plan): streaming kernel only
-    uint32_t *d_ccnt = nullptr;
-    double *d_c1row = nullptr, *d_tc2 = nullptr, *d_tc3 = nullptr, *d_sq = nullptr, *d_ss = nullptr, *d_si = nullptr, *d_sqch = nullptr;
+    double *d_coef = nullptr;        // per position {c1row, c2, c3}
+    std::vector<double> h_coef;      // the same on the host: boundary ghosts of a partitioned network get zeros (upload_tile_coef)
+    int32_t n_wide_tiles = 0;        // tiles with a reach of more than three upstream reaches: general kernel beside the LEAN one
+    double *d_sq = nullptr, *d_ss = nullptr, *d_si = nullptr, *d_sqch = nullptr;
     double *d_full = nullptr, *d_chan = nullptr;   // UnitMuskingum state scattered to params order
     int2 *d_colmeta = nullptr;   // per params column {position, lag}
     int2 *d_ghostmeta = nullptr; // the same per boundary ghost (column of the ghost series)
@@ -146,6 +149,7 @@ struct rr_plan {
     hipStream_t s_rec = nullptr;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_pool_next = 0;
+    bool lean_enabled = true;
     bool rec_stream_enabled = false, pipe_active = false;      // measured: no gain (profiles/r03_rec_stream.txt); RR_REC_STREAM=1 switches it on
 
     // profile of the last route call
@@ -196,6 +200,35 @@ int ensure_cap(T **buf, int64_t *cap, int64_t count)
     if (rc) return rc;
     *cap = count;
     return RR_OK;
+}
+
+// Tile and position constants of the time-tiled kernel, packed (TileArgs); boundary reaches of a partitioned network change
+// the lag flags, the xpos word and the tile flags (rr_plan_set_boundary).
+int upload_tile_meta(rr_plan *P, const std::vector<int32_t> &lag, const std::vector<int32_t> &xpos, const std::vector<int32_t> &flags)
+{
+    const rr::TilePlan &TP = P->tp;
+    std::vector<TileMeta> tm((size_t)TP.n_tiles);
+    for (int32_t t = 0; t < TP.n_tiles; ++t)
+        tm[t] = TileMeta{TP.tile_ptr[t], TP.tile_ptr[t + 1], TP.tile_level[t], TP.tile_lag_lo[t], TP.tile_lag_hi[t], flags[t], 0, 0};
+    std::vector<int4> pm((size_t)TP.np);
+    for (int64_t p = 0; p < TP.np; ++p) pm[p] = make_int4(lag[p], TP.cfirst[p], xpos[p], (int32_t)TP.ccnt[p]);
+    int rc = RR_OK;
+    if (!P->d_tmeta) rc = dev_alloc(&P->d_tmeta, TP.n_tiles);
+    if (!rc && !P->d_pmeta) rc = dev_alloc(&P->d_pmeta, TP.np);
+    if (!rc) rc = dev_upload(P->d_tmeta, tm);
+    if (!rc) rc = dev_upload(P->d_pmeta, pm);
+    return rc;
+}
+
+// Coefficients in tile order.  A ghost computes nothing: a tile ghost (mirror of a reach another tile owns) and a boundary
+// ghost of a partitioned network (a reach another GPU owns) both publish what arrives in their record, which is what the
+// short tick's three multiply-adds do with zero coefficients.
+int upload_tile_coef(rr_plan *P)
+{
+    if (P->h_coef.empty()) return RR_OK;
+    std::vector<double> coef(P->h_coef);
+    for (int32_t i : P->ghost_reach) { const int64_t p = P->tp.inv[i]; coef[3 * p] = coef[3 * p + 1] = coef[3 * p + 2] = 0.0; }
+    return dev_upload(P->d_coef, coef);
 }
 
 // The two-phase tiled permutation params order <-> lag order of the streaming kernel (k_perm_a / k_perm_b).  Built when a
@@ -438,9 +471,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
             if (io.out_factor < 1 || kRecRows % step != 0 || T % io.out_factor != 0) { S.open = false; return fail(RR_E_UNSUPPORTED, "float32 output: factor * sub-steps must divide the rows of a record batch (128) and factor the number of rows"); }
         }
         TileArgs &w = S.ta;
-        w.tile_ptr = P->d_tile_ptr; w.tile_level = P->d_tile_level; w.tile_lag_lo = P->d_tile_lag_lo; w.tile_lag_hi = P->d_tile_lag_hi;
-        w.lag = P->d_tlag; w.cfirst = P->d_cfirst; w.xpos = P->d_xpos; w.ccnt = P->d_ccnt;
-        w.c1row = P->d_c1row; w.c2 = P->d_tc2; w.c3 = P->d_tc3;
+        w.tiles = P->d_tmeta; w.pos = P->d_pmeta; w.coef = P->d_coef;
         w.sq = P->d_sq; w.ss = P->d_ss; w.si = P->d_si; w.sqch = P->d_sqch;
         w.exports = export_series; w.n_export = (int32_t)P->n_export;
         w.rec = P->d_ring; w.rec_chunks = Div32((uint32_t)S.rec_chunks);
@@ -577,7 +608,7 @@ int session_launch_tick(rr_plan *P, int64_t tau)
         UnitTickArgs ua{};
         ua.t = a; ua.hw_children = P->d_hwc; ua.qch = P->d_qch;
         ua.a2 = P->unit_general ? P->d_a2 : nullptr; ua.c1own = P->d_c1own;
-        if (P->unit_general) ua.t.c1row = nullptr;
+        if (P->unit_general) { ua.t.c1row = nullptr; ua.zc = P->d_z + (tau % 3) * n; ua.za = P->d_z + ((tau + 2) % 3) * n; }
         if (one) hipLaunchKernelGGL(k_tick_unit<true>, g, dim3(kBlock), 0, S.stream, ua);
         else hipLaunchKernelGGL(k_tick_unit<false>, g, dim3(kBlock), 0, S.stream, ua);
     } else if (S.mode == Mode::Rapid) {
@@ -605,11 +636,11 @@ int session_launch_tick(rr_plan *P, int64_t tau)
 typedef void (*tile_kernel_t)(const TileArgs);
 
 // Tile = one position per thread; 16 waves per CU whose two record buffers fill the register file, as 1, 2 or 4 workgroups.
-tile_kernel_t tile_kernel(int threads, bool unit, bool sub)
+tile_kernel_t tile_kernel(int threads, bool unit, bool sub, bool lean = false)
 {
 #define RR_TILE_PICK(T_) (unit ? (sub ? (tile_kernel_t)k_tile<T_, true, true> : (tile_kernel_t)k_tile<T_, true, false>)   \
-                               : (sub ? (tile_kernel_t)k_tile<T_, false, true> : (tile_kernel_t)k_tile<T_, false, false>))
-    return threads == 256 ? RR_TILE_PICK(256) : (threads == 512 ? RR_TILE_PICK(512) : RR_TILE_PICK(1024));
+                               : (sub ? (tile_kernel_t)k_tile<T_, false, true> : (lean ? (tile_kernel_t)k_tile<T_, false, false, true> : (tile_kernel_t)k_tile<T_, false, false>)))
+    return threads == 128 ? RR_TILE_PICK(128) : (threads == 256 ? RR_TILE_PICK(256) : (threads == 512 ? RR_TILE_PICK(512) : RR_TILE_PICK(1024)));
 #undef RR_TILE_PICK
 }
 
@@ -642,7 +673,15 @@ int session_launch_diag(rr_plan *P, int64_t d)
     // one workgroup per resident slot (16 waves per CU); each walks its share of the launch's tiles
     const dim3 g((unsigned)std::min<int64_t>(t_hi - t_lo, (int64_t)P->cu_count * (1024 / P->wave_threads)));
     const size_t lds_bytes = tile_lds_bytes(P->wave_threads);
-    hipLaunchKernelGGL(tile_kernel(P->wave_threads, S.mode == Mode::Unit, S.nsub > 1), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
+    // RapidMuskingum with one sub-step per row runs the short tick (k_tile<..., LEAN>), and beside it the general kernel for
+    // the tiles the short tick does not take (a reach with more than three upstream reaches); RR_TILE_LEAN=0: the general one
+    const bool lean = S.mode == Mode::Rapid && S.nsub == 1 && P->lean_enabled;
+    w.tile_filter = lean ? 1 : 0;
+    hipLaunchKernelGGL(tile_kernel(P->wave_threads, S.mode == Mode::Unit, S.nsub > 1, lean), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
+    if (lean && P->n_wide_tiles > 0) {
+        w.tile_filter = 2;
+        hipLaunchKernelGGL(tile_kernel(P->wave_threads, false, false, false), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
+    }
     if (sample) {
         HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));
         P->ev_reaches.push_back((int64_t)(TP.tile_ptr[t_hi] - TP.tile_ptr[t_lo]) * K);
@@ -663,7 +702,7 @@ void launch_ghost_permute(rr_plan *P, int64_t batch)
     ra.batch = batch; ra.nsub = Div32(1u); ra.colmeta = P->d_ghostmeta; ra.scale = nullptr;
     ra.rows = RowView{const_cast<double *>(S.ghost_series), P->n_ghost, 0, (uint32_t)S.total};
     ra.factor = Div32(1u);
-    hipLaunchKernelGGL(k_rec_in<false>, dim3((unsigned)((P->n_ghost + kRecCols - 1) / kRecCols)), dim3(kRecThreads), 0, rec_stream(P), ra);
+    hipLaunchKernelGGL(k_rec_in<false>, dim3((unsigned)std::min<int64_t>((P->n_ghost + kRecCols - 1) / kRecCols, (int64_t)P->cu_count * 4)), dim3(kRecThreads), 0, rec_stream(P), ra);
 }
 
 typedef void (*rec_in_uh_t)(const RecPermArgs, const UhArgs);
@@ -702,7 +741,11 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
         ra.swizzle = (knob >> (in ? 0 : 1)) & 1;
     }
     const dim3 g((unsigned)((n + kRecCols - 1) / kRecCols));
+    // the plain passes are persistent: as many workgroups as the CUs hold at once (38 KB of LDS each: four per CU), each walking
+    // its share of the column tiles with the next tile's loads in flight
+    static const int per_cu = getenv("RR_REC_WGS_PER_CU") ? std::max(1, atoi(getenv("RR_REC_WGS_PER_CU"))) : 4;      // measurements
     const bool sub = S.nsub > 1;
+    const dim3 gp((unsigned)std::min<int64_t>(g.x, (int64_t)P->cu_count * ((in && sub) ? std::min(per_cu, 3) : per_cu)));      // k_rec_in<true>: 129 registers, three per CU
     hipStream_t st = rec_stream(P);
     if (in && S.io.runoff) {
         const dim3 gr((unsigned)((n + kRunoffInThreads - 1) / kRunoffInThreads), (unsigned)kRecBatch);
@@ -715,14 +758,14 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
             hipLaunchKernelGGL(rec_in_uh_kernel(sub, S.io.uh_nks), g, dim3(kUhInThreads), rec_in_uh_lds_bytes(uh_padded_taps(S.io.uh_nks)), st, ra, ua);
         }
     } else if (in) {
-        if (sub) hipLaunchKernelGGL(k_rec_in<true>, g, dim3(kRecThreads), 0, st, ra);
-        else hipLaunchKernelGGL(k_rec_in<false>, g, dim3(kRecThreads), 0, st, ra);
+        if (sub) hipLaunchKernelGGL(k_rec_in<true>, gp, dim3(kRecThreads), 0, st, ra);
+        else hipLaunchKernelGGL(k_rec_in<false>, gp, dim3(kRecThreads), 0, st, ra);
     } else if (ra.rows32) {
-        if (sub) hipLaunchKernelGGL((k_rec_out<true, true>), g, dim3(kRecThreads), 0, st, ra);
-        else hipLaunchKernelGGL((k_rec_out<false, true>), g, dim3(kRecThreads), 0, st, ra);
+        if (sub) hipLaunchKernelGGL((k_rec_out<true, true>), gp, dim3(kRecThreads), 0, st, ra);
+        else hipLaunchKernelGGL((k_rec_out<false, true>), gp, dim3(kRecThreads), 0, st, ra);
     } else {
-        if (sub) hipLaunchKernelGGL((k_rec_out<true, false>), g, dim3(kRecThreads), 0, st, ra);
-        else hipLaunchKernelGGL((k_rec_out<false, false>), g, dim3(kRecThreads), 0, st, ra);
+        if (sub) hipLaunchKernelGGL((k_rec_out<true, false>), gp, dim3(kRecThreads), 0, st, ra);
+        else hipLaunchKernelGGL((k_rec_out<false, false>), gp, dim3(kRecThreads), 0, st, ra);
     }
 }
 
@@ -931,7 +974,7 @@ int launch_state_in(rr_plan *P, Mode mode, const double *d_q, hipStream_t stream
     if (use_wave(P, mode)) {
         const int64_t np = P->tp.np;
         hipLaunchKernelGGL(k_tile_state_in, grid1(np), dim3(kBlock), 0, stream, P->d_sq, P->d_ss, P->d_si, d_q, P->d_tperm,
-                           P->d_cfirst, P->d_ccnt, (int32_t)np);
+                           P->d_pmeta, (int32_t)np);
         return RR_OK;
     }
     hipLaunchKernelGGL(k_state_in, grid1(n), dim3(kBlock), 0, stream, P->d_x, P->d_x + n, P->d_x + 2 * n, d_q,
@@ -1152,7 +1195,7 @@ int unit_state_in(rr_plan *P, const double *d_qch, const double *d_qfull, hipStr
             hipLaunchKernelGGL(k_unit_scatter, grid1(ni), dim3(kBlock), 0, stream, P->d_full, P->d_chan, d_qfull, d_qch, P->d_inner_idx, (int32_t)ni);
         if (e0 == hipSuccess)
             hipLaunchKernelGGL(k_tile_unit_state_in, grid1(P->tp.np), dim3(kBlock), 0, stream, P->d_sq, P->d_ss, P->d_si, P->d_sqch,
-                               (const double *)P->d_full, (const double *)P->d_chan, P->d_tperm, P->d_cfirst, P->d_ccnt, (int32_t)P->tp.np);
+                               (const double *)P->d_full, (const double *)P->d_chan, P->d_tperm, P->d_pmeta, (int32_t)P->tp.np);
     } else {
         e0 = hipMemsetAsync(P->d_x, 0, 3 * n * sizeof(double), stream);
         if (e0 == hipSuccess && ni > 0)

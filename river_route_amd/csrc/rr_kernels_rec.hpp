@@ -45,32 +45,39 @@ constexpr int kRecTileLd = kRecCols + 1;
 
 // Second half of the in-pass: the LDS tile (row = runoff row - row_first, kRecTileLd doubles per row) becomes records.
 // BATCH records per column; a.batch counts launches of BATCH records (the fused convolution works in half batches).
-template <bool SUB, int THREADS = kRecThreads, int BATCH = kRecBatch>
-__device__ __forceinline__ void write_records(const RecPermArgs &a, const double *tile, int64_t col0, int64_t tick_first, int64_t row_first)
+// smeta / sscale: the tile's column metadata and scale in LDS (k_rec_in keeps them there: loaded with the rows, no registers
+// held across the stores), or NULL: read from the plan's arrays.
+template <bool SUB, int THREADS = kRecThreads, int BATCH = kRecBatch, bool LDSMETA = false>
+__device__ __forceinline__ void write_records(const RecPermArgs &a, const double *tile, int64_t col0, int64_t tick_first, int64_t row_first,
+                                              const int2 *smeta = nullptr, const double *sscale = nullptr)
 {
     constexpr int R = 16 * BATCH + 15;
     const int tid = threadIdx.x;
     static_assert(kRecCols * BATCH * 8 % THREADS == 0, "records of a tile must divide among the threads");
     constexpr int IT = kRecCols * BATCH * 8 / THREADS;
-    int2 meta[IT];
-    double f[IT];
+    int2 meta[LDSMETA ? 1 : IT];
+    double f[LDSMETA ? 1 : IT];
+    if constexpr (!LDSMETA) {
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {     // all metadata loads first: they are independent
-        const int64_t i = col0 + (it * THREADS + tid) / (8 * BATCH);
-        meta[it] = i < a.n ? a.colmeta[i] : make_int2(-1, 0);
+        for (int it = 0; it < IT; ++it) {     // all metadata loads first: they are independent
+            const int64_t i = col0 + (it * THREADS + tid) / (8 * BATCH);
+            meta[it] = i < a.n ? a.colmeta[i] : make_int2(-1, 0);
+        }
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int64_t i = col0 + (it * THREADS + tid) / (8 * BATCH);
+            f[it] = (a.scale && i < a.n) ? a.scale[i] : 1.0;
+        }
     }
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int64_t i = col0 + (it * THREADS + tid) / (8 * BATCH);
-        f[it] = (a.scale && i < a.n) ? a.scale[i] : 1.0;
-    }
-#pragma unroll
+#pragma unroll(LDSMETA ? (SUB ? 2 : 4) : IT)
     for (int it = 0; it < IT; ++it) {
         const int piece = it * THREADS + tid;       // (column, record, 16-byte part): 8 consecutive lanes = one record
         const int c = piece / (8 * BATCH), k = (piece >> 3) % BATCH, part = piece & 7;
-        const int32_t p = meta[it].x;
+        const int2 m = LDSMETA ? smeta[c] : meta[LDSMETA ? 0 : it];
+        const double scale = LDSMETA ? sscale[c] : f[LDSMETA ? 0 : it];
+        const int32_t p = m.x;
         if (p < 0) continue;
-        const int32_t lag = meta[it].y & kLagMask;
+        const int32_t lag = m.y & kLagMask;
         const int o = lag & 15;
         const uint32_t chunk = (uint32_t)BATCH * (uint32_t)a.batch + (uint32_t)(lag >> 4) + k;
         const int r = 15 - o + 16 * k + 2 * part;       // tick-row tick_first + r
@@ -80,9 +87,9 @@ __device__ __forceinline__ void write_records(const RecPermArgs &a, const double
             uint32_t s;
             const int r0 = t0 < 0 ? 0 : (int)((int64_t)a.nsub.div((uint32_t)t0, s) - row_first);
             const int r1 = t1 < 0 ? 0 : (int)((int64_t)a.nsub.div((uint32_t)t1, s) - row_first);
-            v0 = tile[min(r0, R - 1) * kRecTileLd + c] * f[it]; v1 = tile[min(r1, R - 1) * kRecTileLd + c] * f[it];
+            v0 = tile[min(r0, R - 1) * kRecTileLd + c] * scale; v1 = tile[min(r1, R - 1) * kRecTileLd + c] * scale;
         } else {
-            v0 = tile[r * kRecTileLd + c] * f[it]; v1 = tile[(r + 1) * kRecTileLd + c] * f[it];
+            v0 = tile[r * kRecTileLd + c] * scale; v1 = tile[(r + 1) * kRecTileLd + c] * scale;
         }
         double2 *dst = reinterpret_cast<double2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.np + p) * kRec) + part;
         typedef double d2 __attribute__((ext_vector_type(2)));
@@ -90,36 +97,62 @@ __device__ __forceinline__ void write_records(const RecPermArgs &a, const double
     }
 }
 
+// Persistent and software-pipelined: a workgroup walks the column tiles blockIdx.x, blockIdx.x + gridDim.x, ... and requests
+// the rows of its NEXT tile before it turns the current one into records, so row loads are in flight while the LDS tile is read
+// back and the records are stored.  One tile per workgroup (rounds 1 and 2) left each side of the pass waiting for the other:
+// 419 us per 128 rows at 1M reaches, when the rows alone read in 186 us (162 us non-temporal) and the records alone store in
+// 199 us (profiles/r03_rec_probe.txt, r03_alias_kernel_times.txt).
 template <bool SUB>
 __global__ __launch_bounds__(kRecThreads) void k_rec_in(const RecPermArgs a)
 {
     constexpr int R = kRecTileRows;
     __shared__ double tile[R * kRecTileLd];
+    __shared__ int2 smeta[kRecCols];
+    __shared__ double sscale[kRecCols];
     const int tid = threadIdx.x;
-    const int64_t col0 = (int64_t)(a.swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x) * kRecCols;
     const int64_t tick_first = kRecRows * a.batch - 15;                 // may be negative in the first batch
     uint32_t sub_unused;
     const int64_t row_first = SUB ? (int64_t)a.nsub.div((uint32_t)(tick_first < 0 ? 0 : tick_first), sub_unused) : tick_first;
-    {   // all row loads in flight first (branch-free: out-of-range rows/columns are clamped and zeroed afterwards)
-        constexpr int RPT = (R + kRecThreads / kRecCols - 1) / (kRecThreads / kRecCols);
-        const int c = tid % kRecCols, r0 = tid / kRecCols;
+    constexpr int RPT = (R + kRecThreads / kRecCols - 1) / (kRecThreads / kRecCols);
+    const int c = tid % kRecCols, r0 = tid / kRecCols;
+    const int need = SUB ? (int)((uint32_t)(R - 1) / a.nsub.d) + 2 : R;     // runoff rows behind the batch's tick-rows
+    const uint32_t n_tiles = (uint32_t)((a.n + kRecCols - 1) / kRecCols);
+    auto col_of = [&](uint32_t t) { return (int64_t)(a.swizzle ? xcd_swizzle(t, n_tiles) : t) * kRecCols; };
+    double v[RPT];
+    int2 cm = make_int2(-1, 0);
+    double cs = 1.0;
+    auto request = [&](int64_t col0) {      // branch-free: out-of-range rows / columns are clamped here and zeroed on the way into LDS
         const int64_t i = min(col0 + c, a.n - 1);
-        const int need = SUB ? (int)((uint32_t)(R - 1) / a.nsub.d) + 2 : R;     // runoff rows behind the batch's tick-rows
-        double v[RPT];
+        if (tid < kRecCols) {      // the tile's column metadata and scale travel with its rows
+            cm = col0 + c < a.n ? a.colmeta[i] : make_int2(-1, 0);
+            cs = a.scale ? a.scale[i] : 1.0;
+        }
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const int64_t t = row_first + min(r0 + q * (kRecThreads / kRecCols), need - 1);
             v[q] = ld_site<kNtInRows>(a.rows.row(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t)) + i);
         }
+    };
+    uint32_t t = blockIdx.x;
+    if (t >= n_tiles) return;
+    request(col_of(t));
+    for (;;) {
+        const int64_t col0 = col_of(t);
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const int r = r0 + q * (kRecThreads / kRecCols);
-            const int64_t t = row_first + r;
-            if (r < R) tile[r * kRecTileLd + c] = (t >= 0 && t < a.T && col0 + c < a.n) ? v[q] : 0.0;
+            const int64_t row = row_first + r;
+            if (r < R) tile[r * kRecTileLd + c] = (row >= 0 && row < a.T && col0 + c < a.n) ? v[q] : 0.0;
         }
+        if (tid < kRecCols) { smeta[c] = cm; sscale[c] = cs; }
+        __syncthreads();
+        const uint32_t next = t + gridDim.x;
+        if (next < n_tiles) request(col_of(next));      // in flight while this tile leaves as records
+        write_records<SUB, kRecThreads, kRecBatch, true>(a, tile, col0, tick_first, row_first, smeta, sscale);
+        if (next >= n_tiles) break;
+        __syncthreads();      // every record of this tile has been read out of LDS
+        t = next;
     }
-    __syncthreads();
-    write_records<SUB>(a, tile, col0, tick_first, row_first);
 }
 
 // The in-pass with the unit-hydrograph convolution fused in (UnitHydrograph.py:93-107, direct form): the tile is COMPUTED
@@ -206,72 +239,83 @@ __global__ __launch_bounds__(kUhInThreads) void k_rec_in_uh(const RecPermArgs a,
 
 // OUT32: the router's post-processing fused in (TransformMuskingum.py:128-142): mean over `factor` consecutive rows
 // (sequential sum, one division, as numpy reduces a strided axis) and the float32 cast; 128 % (factor * nsub) == 0.
+// Persistent and software-pipelined like k_rec_in: the records of the workgroup's next column tile are requested before the
+// rows of the current one are written.
 template <bool SUB, bool OUT32>
 __global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
 {
     constexpr int S = 16 * (kRecBatch + 1);
     __shared__ double recs[kRecCols][S + 1];
     const int tid = threadIdx.x;
-    const int64_t col0 = (int64_t)(a.swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x) * kRecCols;
     constexpr int IT = kRecCols * (kRecBatch + 1) * 8 / kRecThreads;
-    int2 meta[IT];
+    const uint32_t n_tiles = (uint32_t)((a.n + kRecCols - 1) / kRecCols);
+    auto col_of = [&](uint32_t t) { return (int64_t)(a.swizzle ? xcd_swizzle(t, n_tiles) : t) * kRecCols; };
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 v[IT];
+    auto request = [&](int64_t col0) {      // all record reads in flight; a column past the end reads position 0 and is not written
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int64_t i = col0 + (it * kRecThreads + tid) / ((kRecBatch + 1) * 8);
-        meta[it] = i < a.n ? a.colmeta[i] : make_int2(-1, 0);
-    }
-    double2 v[IT];
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {     // all record reads in flight before the first LDS write
-        const int piece = it * kRecThreads + tid;
-        const int k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
-        const int32_t p = meta[it].x < 0 ? 0 : meta[it].x;
-        const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)((meta[it].y & kLagMask) >> 4) + k;
-        typedef double d2 __attribute__((ext_vector_type(2)));
-        const d2 got = ld_site<kNtOutRec>(reinterpret_cast<const d2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.np + p) * kRec) + part);
-        v[it] = make_double2(got.x, got.y);
-    }
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int piece = it * kRecThreads + tid;
-        const int c = piece / ((kRecBatch + 1) * 8), k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
-        recs[c][16 * k + 2 * part] = v[it].x;
-        recs[c][16 * k + 2 * part + 1] = v[it].y;
-    }
-    __syncthreads();
-    const int c = tid % kRecCols;
-    const int64_t i = col0 + c;
-    if (i >= a.n) return;
-    const int32_t my = a.colmeta[i].y;
-    const int o = my & 15;
-    // single sub-step: the records hold the unclamped discharge (a ghost's record is a copy of its reach's); the reference's
-    // clip at zero (_numba_kernels.py:80) happens here.  UnitMuskingum leaves its headwaters' lateral inflow as it is (:122-123).
-    const bool clamp = !SUB && (a.clamp == 1 || (a.clamp == 2 && !(my & kColHeadwater)));
-    auto out = [&](double v) { return clamp && !(v > 0.0) ? 0.0 : v; };
+        for (int it = 0; it < IT; ++it) {
+            const int piece = it * kRecThreads + tid;
+            const int k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
+            const int64_t i = col0 + piece / ((kRecBatch + 1) * 8);
+            const int2 meta = i < a.n ? a.colmeta[i] : make_int2(0, 0);
+            const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)((meta.y & kLagMask) >> 4) + k;
+            v[it] = ld_site<kNtOutRec>(reinterpret_cast<const d2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.np + meta.x) * kRec) + part);
+        }
+    };
+    uint32_t t = blockIdx.x;
+    if (t >= n_tiles) return;
+    request(col_of(t));
     const int64_t tick0 = kRecRows * a.batch;
-    if (OUT32) {
-        // output row q averages runoff rows [q * factor, (q + 1) * factor), each the slot of its last sub-step
-        const int step = (int)(a.factor.d * (SUB ? a.nsub.d : 1u));          // tick-rows per output row, divides 128
-        const int64_t q0 = tick0 / step;
-        for (int q = tid / kRecCols; q < kRecRows / step; q += kRecThreads / kRecCols) {
-            if ((q0 + q + 1) * step > a.total) break;
-            const int nsub = SUB ? (int)a.nsub.d : 1;
-            double acc = out(recs[c][o + q * step + nsub - 1]);
-            for (int j = 1; j < (int)a.factor.d; ++j) acc += out(recs[c][o + q * step + j * nsub + nsub - 1]);
-            a.rows32[(q0 + q) * a.n + i] = (float)(a.factor.d > 1 ? acc / (double)a.factor.d : acc);
+    for (;;) {
+        const int64_t col0 = col_of(t);
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int piece = it * kRecThreads + tid;
+            const int c = piece / ((kRecBatch + 1) * 8), k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
+            recs[c][16 * k + 2 * part] = v[it].x;
+            recs[c][16 * k + 2 * part + 1] = v[it].y;
         }
-        return;
-    }
-    for (int r = tid / kRecCols; r < kRecRows; r += kRecThreads / kRecCols) {
-        const int64_t tick = tick0 + r;
-        if (tick >= a.total) break;
-        if (SUB) {
-            uint32_t s;
-            const uint32_t t = a.nsub.div((uint32_t)tick, s);
-            if (s + 1 == a.nsub.d) st_site<kNtOutRows>(a.rows.row(t) + i, recs[c][o + r]);
-        } else {
-            st_site<kNtOutRows>(a.rows.row(tick) + i, out(recs[c][o + r]));
+        __syncthreads();
+        const uint32_t next = t + gridDim.x;
+        if (next < n_tiles) request(col_of(next));      // in flight while this tile's rows are written
+        const int c = tid % kRecCols;
+        const int64_t i = col0 + c;
+        if (i < a.n) {
+            const int32_t my = a.colmeta[i].y;
+            const int o = my & 15;
+            // single sub-step: the records hold the unclamped discharge (a ghost's record is a copy of its reach's); the reference's
+            // clip at zero (_numba_kernels.py:80) happens here.  UnitMuskingum leaves its headwaters' lateral inflow as it is (:122-123).
+            const bool clamp = !SUB && (a.clamp == 1 || (a.clamp == 2 && !(my & kColHeadwater)));
+            auto out = [&](double x) { return clamp && !(x > 0.0) ? 0.0 : x; };
+            if (OUT32) {
+                // output row q averages runoff rows [q * factor, (q + 1) * factor), each the slot of its last sub-step
+                const int step = (int)(a.factor.d * (SUB ? a.nsub.d : 1u));          // tick-rows per output row, divides 128
+                const int64_t q0 = tick0 / step;
+                for (int q = tid / kRecCols; q < kRecRows / step; q += kRecThreads / kRecCols) {
+                    if ((q0 + q + 1) * step > a.total) break;
+                    const int nsub = SUB ? (int)a.nsub.d : 1;
+                    double acc = out(recs[c][o + q * step + nsub - 1]);
+                    for (int j = 1; j < (int)a.factor.d; ++j) acc += out(recs[c][o + q * step + j * nsub + nsub - 1]);
+                    a.rows32[(q0 + q) * a.n + i] = (float)(a.factor.d > 1 ? acc / (double)a.factor.d : acc);
+                }
+            } else {
+                for (int r = tid / kRecCols; r < kRecRows; r += kRecThreads / kRecCols) {
+                    const int64_t tick = tick0 + r;
+                    if (tick >= a.total) break;
+                    if (SUB) {
+                        uint32_t sub;
+                        const uint32_t row = a.nsub.div((uint32_t)tick, sub);
+                        if (sub + 1 == a.nsub.d) st_site<kNtOutRows>(a.rows.row(row) + i, recs[c][o + r]);
+                    } else {
+                        st_site<kNtOutRows>(a.rows.row(tick) + i, out(recs[c][o + r]));
+                    }
+                }
+            }
         }
+        if (next >= n_tiles) break;
+        __syncthreads();      // every row of this tile has been read out of LDS
+        t = next;
     }
 }
 

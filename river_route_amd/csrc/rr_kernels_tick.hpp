@@ -86,6 +86,8 @@ struct UnitTickArgs {
     // general edge data (rr_plan_set_unit_weights; never produced by the reference's callers, whose A is all ones and whose
     // lhs_off_data is -c1[row]): a2[u] = a_inner_data / a_hw_data of the edge leaving u, c1own[p] = c1 of the reach itself
     const double *a2, *c1own;
+    double *zc;                   // general edge data: this tick's q_ch+ of every inner reach ...
+    const double *za;             // ... and last tick's (the work rows hold a reach's discharge where its lateral inflow was: in place)
 };
 
 // One routing tick for UnitMuskingum (river_route/routers/_numba_kernels.py:113-171 in gather form).
@@ -128,12 +130,12 @@ __global__ __launch_bounds__(kBlock) void k_tick_unit(const UnitTickArgs ua)
         // - lhs_off q_ch+, with the upstream reach's own lateral (same row, its position) separating q_ch+ from what it published
         r = a.c3[p] * ua.qch[p];
         const double c1 = ua.c1own[p], c2 = a.c2[p];
-        const double *lrow = a.in + (int64_t)a.in_rows.mod(t) * a.in_ld;
         for (int32_t u = u0; u < uh; ++u) r += (c1 + c2) * (ua.a2[u] * a.xa[u]);
         for (int32_t u = uh; u < u1; ++u) {
-            const double lu = lrow[u];
-            r += c2 * a.xb[u] + c1 * (ua.a2[u] * lu) + a.w[u] * (a.xa[u] - lu);
+            const double qu = ua.za[u];      // q_ch+ of the upstream reach; what it published is q_ch+ + its lateral inflow
+            r += c2 * a.xb[u] + c1 * (ua.a2[u] * (a.xa[u] - qu)) + a.w[u] * qu;
         }
+        ua.zc[p] = r;
     } else {
         r = a.c3[p] * ua.qch[p];
         const double c2 = a.c2[p];

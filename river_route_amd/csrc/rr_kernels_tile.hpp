@@ -21,12 +21,21 @@ namespace {
 // (its unclamped discharge, 8 bytes per tick; a ghost has the lag of its reach, so the ticks line up), and the ghost
 // receives its record like any other position and republishes it: no load, wait or branch of its own.
 
+// Per-tile and per-position constants travel packed, one pointer each: a kernel argument costs two scalar registers for the
+// whole kernel, and with the record buffers in 64 of a wave's 128 vector registers every scalar spilled is a vector one lost.
+struct TileMeta {
+    int32_t b0, b1;          // positions [b0, b1)
+    int32_t level;           // launch d runs macro-chunk d - level
+    int32_t lag_lo, lag_hi;  // smallest / largest lag of the tile's positions
+    int32_t flags;           // kTileWide | kTileExports
+    int32_t pad0, pad1;
+};
+constexpr int32_t kTileWide = 1, kTileExports = 2, kTaskTested = 4;      // TileMeta::flags: a position with more than three upstream positions / a boundary export in the tile
 struct TileArgs {
-    const int32_t *tile_ptr, *tile_level, *tile_lag_lo, *tile_lag_hi;
-    const int32_t *lag, *cfirst;
-    const int32_t *xpos;                  // kTileExportBit: position of the ghost that mirrors this reach; kExportBit: its slot in the export series (never both)
-    const uint32_t *ccnt;
-    const double *c1row, *c2, *c3;        // c1row: the (uniform) weight of a reach's upstream terms
+    const TileMeta *tiles;
+    const int4 *pos;                      // per position {lag | flags, first upstream position, xpos, upstream count | headwaters among them << 16};
+                                          // xpos: kTileExportBit: position of the ghost that mirrors this reach; kExportBit: its slot in the export series (never both)
+    const double *coef;                   // per position {c1row, c2, c3}: c1row is the (uniform) weight of a reach's upstream terms
     double *sq, *ss, *si, *sqch;          // carried state: discharge, sum of upstream discharges one tick back, interval sum, channel discharge
     double *exports;                      // boundary series another GPU reads (multi-GPU)
     int32_t n_export;
@@ -36,6 +45,7 @@ struct TileArgs {
     long long *trace; int32_t trace_diag;   // development build: per-block timestamps of one launch (profiles/microbench/wave_dbg.py)
 #endif
     int32_t np, t_first, t_last, KC, diag, n_macro, total, has_lat;
+    int32_t tile_filter;                  // 0: every tile of the launch; 1: all but the kTileWide ones (the LEAN kernel); 2: only those (its companion launch of the general kernel)
     Div32 nsub;
     double inv_nsub;
 };
@@ -90,24 +100,32 @@ constexpr int kStageLanes = 32;    // positions transposed at a time: half a wav
 // Lanes of one wave exchange data through its staging area without a workgroup barrier: a wave's LDS instructions
 // execute in order.  The compiler still has to be told that other lanes wrote (it would reuse earlier reads).
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-// LDS in doubles: X[2][TH] | stage[waves][kStageLanes * kStageStride]: the tile's discharges of the last two ticks and the
-// per-wave transpose areas.
+// LDS in doubles: X[2][TH + 2] | stage[waves][kStageLanes * kStageStride]: the tile's discharges of the last two ticks, each
+// buffer followed by a slot that always holds 0.0 (the "upstream position" of a reach that has none: the short tick reads two
+// upstream values unconditionally), and the per-wave transpose areas.
+constexpr int kTilePad = 2;
 constexpr size_t tile_lds_bytes(int threads)
 {
-    return (size_t)(2 * (int64_t)threads + (threads / 64) * kStageLanes * kStageStride) * sizeof(double);
+    return (size_t)(2 * ((int64_t)threads + kTilePad) + (threads / 64) * kStageLanes * kStageStride) * sizeof(double);
 }
 
 // One task: KC record chunks of one tile, one position per thread.  R[16] is the record the ticks work on, in place
 // (lateral in, discharge out); N[16] receives the NEXT chunk's record while the 16 ticks of this one run, so inside a task
 // HBM traffic and tick arithmetic overlap and only the first chunk's load is exposed.  Whole 128-byte records are
 // requested at once (a half record would cost the fabric a full line: measured, FETCH_SIZE 1.8x).
-template <int TH, bool UNIT, bool SUB>
+// LEAN: RapidMuskingum with one sub-step per row, the headline's case: the short tick below instead of the general one (the
+// two do not fit one kernel: with the record buffers in 64 of 128 registers the allocator spills the records in flight).
+template <int TH, bool UNIT, bool SUB, bool LEAN = false>
 __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 waves per CU: 1,024 / TH workgroups of 128 VGPRs
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
     const int32_t total = a.total, K = a.KC * kRec;
-    double *stage = lds + 2 * TH + (size_t)(tid >> 6) * (kStageLanes * kStageStride);   // this wave's transpose area
+    constexpr int THP = TH + kTilePad;      // doubles per discharge buffer
+    // this wave's transpose area and the lane number, rebuilt from the thread index wherever they are used: kept in registers
+    // across a task the allocator spills them, and the reload waits for every record load in flight
+    auto stage_of = [&](int32_t t) { return lds + 2 * THP + (size_t)(t >> 6) * (kStageLanes * kStageStride); };
+    if (tid < 2) lds[tid * THP + TH] = 0.0;      // the zero slots; nothing else ever writes them (first barrier: before the first tick)
     auto ring = [&](int32_t chunk) { return make_rsrc(a.rec + (int64_t)a.rec_chunks.mod((uint32_t)chunk) * a.np * kRec, (uint32_t)a.np * 128u); };   // np < 2^25
 
     // A workgroup takes the tiles t_last - blockIdx.x - g * gridDim.x, g = 0, 1, ... of this launch (highest level first:
@@ -115,13 +133,18 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
     // requested while the current one still ticks.  A tile none of whose positions is active during its task has nothing
     // to do (pipeline fill and drain; a ghost has the lag of the reach it mirrors, so it is idle exactly when its owner
     // did not write its record) and is skipped.
-    struct Task { int32_t tile, m, b0, b1; };
+    struct Task { int32_t tile, m, b0, b1, plain; };
     auto select = [&](int32_t from, Task &t) {
         for (int32_t c = from; c >= a.t_first; c -= (int32_t)gridDim.x) {
-            const int32_t m = a.diag - a.tile_level[c];
+            const TileMeta tm = a.tiles[c];
+            if (a.tile_filter && ((tm.flags & kTileWide) != 0) != (a.tile_filter == 2)) continue;
+            const int32_t m = a.diag - tm.level;
             if (m < 0 || m >= a.n_macro) continue;
-            if (m * K >= a.tile_lag_hi[c] + total || (m + 1) * K <= a.tile_lag_lo[c]) continue;
-            t.tile = c; t.m = m; t.b0 = a.tile_ptr[c]; t.b1 = a.tile_ptr[c + 1];
+            if (m * K >= tm.lag_hi + total || (m + 1) * K <= tm.lag_lo) continue;
+            t.tile = c; t.m = m; t.b0 = tm.b0; t.b1 = tm.b1;
+            // LEAN: 1 = every position active on every tick of the task, nothing special in the tile: the tick without any test;
+            // else the tile's flags | kTaskTested
+            t.plain = (tm.flags == 0 && m * K >= tm.lag_hi && (m + 1) * K <= tm.lag_lo + total) ? 1 : (tm.flags | kTaskTested);
             return true;
         }
         return false;
@@ -151,6 +174,8 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                    N[8 * half + 2 * i], N[8 * half + 2 * i + 1]);
     };
     auto receive = [&]() {
+        const int32_t tl = fresh(tid), lane = tl & 63;
+        double *stage = stage_of(tl);
 #pragma unroll
         for (int half = 0; half < 2; ++half)
 #pragma unroll
@@ -177,14 +202,15 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
         s.c1 = s.c2 = s.c3 = s.s_prev = s.qch = s.isum = s.q = 0.0;
         const int32_t p = t.b0 + tid;
         if (p < t.b1) {
-            const uint32_t cc = a.ccnt[p];
-            const int32_t first_up = a.cfirst[p] - t.b0;
-            s.lg = a.lag[p]; s.up = first_up | (int32_t)((cc & 0xFFFFu) << 16);
-            s.xp = a.xpos[p];
+            const int4 pm = a.pos[p];
+            const uint32_t cc = (uint32_t)pm.w;
+            const int32_t first_up = pm.y - t.b0;
+            s.lg = pm.x; s.up = first_up | (int32_t)((cc & 0xFFFFu) << 16);
+            s.xp = pm.z;
             if (UNIT) { s.uh = first_up + (int32_t)(cc >> 16); s.qch = a.sqch[p]; }
             if (SUB) s.isum = a.si[p];
             s.s_prev = a.ss[p];
-            s.q = a.sq[p]; s.c1 = a.c1row[p]; s.c2 = a.c2[p]; s.c3 = a.c3[p];
+            s.q = a.sq[p]; s.c1 = a.coef[3 * (int64_t)p]; s.c2 = a.coef[3 * (int64_t)p + 1]; s.c3 = a.coef[3 * (int64_t)p + 2];
         }
     };
     // The first tile: state and coefficients are requested BEFORE the record: memory operations retire in order, so the
@@ -206,7 +232,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
         int32_t lg = st.lg, up = st.up, xp = st.xp, uh = st.uh, sub = 0;
         double c1 = st.c1, c2 = st.c2, c3 = st.c3, s_prev = st.s_prev, qch = st.qch, isum = st.isum;
         const int32_t b0 = cur.b0, tau_begin = cur.m * K;
-        lds[(size_t)((tau_begin + 1) & 1) * TH + tid] = st.q;       // tick tau_begin reads the buffer of tick tau_begin - 1
+        lds[(size_t)((tau_begin + 1) & 1) * THP + tid] = st.q;       // tick tau_begin reads the buffer of tick tau_begin - 1
         if (SUB && lg >= 0) {      // phase of the position's sub-step counter at the first tick of the task
             const int32_t ts0 = tau_begin - (lg & kLagMask);
             const uint32_t r = a.nsub.mod((uint32_t)(ts0 < 0 ? -ts0 : ts0));
@@ -218,6 +244,8 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
         // Eight slots of the record are final: write that 64-byte sector.  Half a wave at a time parks its sectors in
         // the wave's staging area, then all 64 lanes store them, four lanes per sector.
         auto store_half = [&](__amdgpu_buffer_rsrc_t dst, int half) {
+            const int32_t tl = fresh(tid), lane = tl & 63;
+            double *stage = stage_of(tl);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 if (lane / kStageLanes == h) {
@@ -254,8 +282,8 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                 // accepts only so many requests at a time, and a wave that waits to issue its loads cannot tick
                 if (half == 0) issue_load(rec_next, nb0, nb1, s8, more);
                 const int32_t tau = tau0 + s;
-                const double *rd = lds + (size_t)((tau + 1) & 1) * TH;
-                double *wr = lds + (size_t)(tau & 1) * TH;
+                const double *rd = lds + (size_t)((tau + 1) & 1) * THP;
+                double *wr = lds + (size_t)(tau & 1) * THP;
                 const int32_t t = fresh(tid), lgk = fresh(lg), upk = fresh(up);
                 const int32_t u0 = upk & 0xFFFF, u1 = u0 + (int32_t)((uint32_t)upk >> 16);
                 double qk = rd[t];       // own discharge one tick back
@@ -310,6 +338,59 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
             }
         };
 
+        // The short tick (LEAN).  A tick is: own value and three upstream values from LDS (a reach with fewer reads the zero slot
+        // instead), three fused multiply-adds, one LDS write, the barrier -- no flag test, no loop.  During pipeline fill and drain
+        // (a task in which some position is not yet, or no longer, active on some tick) an activity test and four selects keep an
+        // idle position's value and record slot as they are; every other task -- 99 % of a year's -- runs without.  1M reaches,
+        // K = 64: k_tile 241 -> us per launch (profiles/r03_tile_diet.txt).  The sum is the general tick's in the same order
+        // (first + second + third; the general tick's leading 0.0 + and the zero slot's + 0.0 can only change the sign of a zero).
+        // A ghost position needs nothing special: its coefficients are zero (rr_plan_set_coeffs) and it has no upstream position,
+        // so the three multiply-adds hand back its record slot, which is what it publishes.  A tile with a reach of more than three
+        // upstream reaches is left to a companion launch of the general kernel (TileArgs::tile_filter); boundary exports of a
+        // partitioned network are stored from the record registers when a half record is complete (store_exports).
+        const int32_t kind = LEAN ? cur.plain : 0;
+        int32_t own_b = 0, up0_b = 0, up1_b = 0, up2_b = 0, lagm = 0;      // LDS byte offsets inside a discharge buffer: own slot, the three upstream slots (or the zero slot)
+        auto lds_at = [&](int parity, int32_t byte) -> double & { return *reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + parity * (THP * 8) + byte); };
+        // record loads of the short path: one address register per chunk, the piece of load j is an immediate / scalar offset
+        auto issue_load_plain = [&](__amdgpu_buffer_rsrc_t src, int32_t voff, int j) {
+            const int i = j >> 1, half = j & 1;
+            const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(src, voff, ((i >> 1) * kStageLanes + 16 * (i & 1)) * 128 + half * 64, (RR_NT_MASK & kNtTileLoad) ? 2 : 0);
+            double2 v;
+            __builtin_memcpy(&v, &bits, sizeof v);
+            N[8 * half + 2 * i] = v.x; N[8 * half + 2 * i + 1] = v.y;
+        };
+        auto ticks_plain = [&](auto tested, int32_t tau0, int half, __amdgpu_buffer_rsrc_t rec_next, int32_t nvoff) {
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) {
+                const int s = 8 * half + s8;      // tau0 is a multiple of 16: the parity of the tick is the parity of s
+                if (half == 0) issue_load_plain(rec_next, nvoff, s8);
+                const double q_old = lds_at((s + 1) & 1, own_b);
+                const double s_cur = (lds_at((s + 1) & 1, up0_b) + lds_at((s + 1) & 1, up1_b)) + lds_at((s + 1) & 1, up2_b);
+                double qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev, __builtin_fma(c3, q_old, R[s])));
+                if (decltype(tested)::value) {
+                    const bool active = (uint32_t)(tau0 + s - lagm) < (uint32_t)total;
+                    R[s] = active ? qk : R[s];
+                    qk = active ? qk : q_old;
+                } else {
+                    R[s] = qk;      // unclamped: k_rec_out clamps
+                }
+                s_prev = s_cur;
+                lds_at(s & 1, own_b) = qk;
+                barrier_lds();
+            }
+        };
+        // boundary exports of a partitioned network: with one sub-step per row the record slot of a tick IS the discharge of that
+        // sub-step, so the export series is written from the half record that has just been completed
+        auto store_exports = [&](int32_t tau0, int half) {
+            const int32_t lgk = fresh(lg);
+            if (lgk >= 0 && (lgk & kExportBit)) {
+                const int32_t ts0 = tau0 + 8 * half - (lgk & kLagMask), slot = fresh(xp);      // xp: the export slot (see TileArgs::pos)
+#pragma unroll
+                for (int s8 = 0; s8 < 8; ++s8)
+                    if ((uint32_t)(ts0 + s8) < (uint32_t)total) a.exports[(int64_t)(ts0 + s8) * a.n_export + slot] = R[8 * half + s8];
+            }
+        };
+
         barrier_lds();      // the buffer of tick tau_begin - 1 is in place (and every wave has left the previous tile)
         for (int32_t cc = 0; cc < a.KC; ++cc) {
             const int32_t chunk = cur.m * a.KC + cc, tau0 = chunk * kRec;
@@ -317,14 +398,38 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
             // what arrives during this chunk: the tile's next chunk, or -- in its last one -- the first chunk of the next tile
             const __amdgpu_buffer_rsrc_t rec_next = ring(last ? nxt.m * a.KC : chunk + 1);
             const int32_t nb0 = last ? nxt.b0 : b0, nb1 = last ? nxt.b1 : cur.b1;
-            ticks(tau0, 0, rec_next, nb0, nb1, !last || has_next);
-            if (cc == 0) RR_TRACE(3);
-            store_half(rec_cur, 0);
-            ticks(tau0, 1, rec_next, nb0, nb1, false);
-            if (cc == 0) RR_TRACE(6);
+            if constexpr (LEAN) {
+                // a position past the end of the next tile reads whatever follows it in the ring (or zeros past its end): never used
+                const int32_t t = fresh(tid), ln = t & 63, upk = fresh(up);
+                const int32_t cnt = (int32_t)((uint32_t)upk >> 16), u0s = upk & 0xFFFF;
+                own_b = t * 8; up0_b = (cnt >= 1 ? u0s : TH) * 8; up1_b = (cnt >= 2 ? u0s + 1 : TH) * 8; up2_b = (cnt >= 3 ? u0s + 2 : TH) * 8;
+                const int32_t nvoff = (nb0 + (t - ln) + (ln >> 2)) * 128 + (ln & 3) * 16;
+                const __amdgpu_buffer_rsrc_t src = (!last || has_next) ? rec_next : make_rsrc(a.rec, 0u);
+                if (kind == 1) {
+                    ticks_plain(std::false_type(), tau0, 0, src, nvoff);
+                    store_half(rec_cur, 0);
+                    ticks_plain(std::false_type(), tau0, 1, src, nvoff);
+                } else {
+                    lagm = lg < 0 ? 0x40000000 : (fresh(lg) & kLagMask);      // a slot past the end of the tile is never active
+                    ticks_plain(std::true_type(), tau0, 0, src, nvoff);
+                    if (kind & kTileExports) store_exports(tau0, 0);
+                    store_half(rec_cur, 0);
+                    ticks_plain(std::true_type(), tau0, 1, src, nvoff);
+                    if (kind & kTileExports) store_exports(tau0, 1);
+                }
+            } else {
+                ticks(tau0, 0, rec_next, nb0, nb1, !last || has_next);
+                if (cc == 0) RR_TRACE(3);
+                store_half(rec_cur, 0);
+                ticks(tau0, 1, rec_next, nb0, nb1, false);
+                if (cc == 0) RR_TRACE(6);
+            }
             store_half(rec_cur, 1);
             if (cc == 0) RR_TRACE(7);
-            if (last && has_next) load_state(nxt, st);      // small, and only the wait for it is exposed between two tiles
+            // the next tile's state: small, and only the wait for it is exposed between two tiles.  LEAN asks for it after the
+            // chunk loop: requested inside, its thirteen registers are live across every chunk beside both record buffers, and
+            // what the allocator spills it reloads behind a wait for every load in flight
+            if (!LEAN && last && has_next) load_state(nxt, st);
             receive();      // the record that has had 16 ticks to arrive (zeros after the last chunk of the last tile)
             if (cc == 0) RR_TRACE(8);
             rec_cur = rec_next;
@@ -332,10 +437,11 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
         RR_TRACE(12);
         if (lg >= 0) {
             const int32_t p = b0 + tid;
-            a.sq[p] = lds[(size_t)((tau_begin + K - 1) & 1) * TH + tid]; a.ss[p] = s_prev;
+            a.sq[p] = lds[(size_t)((tau_begin + K - 1) & 1) * THP + tid]; a.ss[p] = s_prev;
             if (UNIT) a.sqch[p] = qch;
             if (SUB) a.si[p] = isum;
         }
+        if (LEAN && has_next) load_state(nxt, st);
         RR_TRACE(13);
 #ifdef RR_WAVE_TRACE
         trace = false;      // the first tile of the workgroup only
@@ -349,12 +455,13 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
 
 // sq = q0 at every position (a ghost starts from the state of the reach it mirrors), ss = sum of the upstream q0
 __global__ __launch_bounds__(kBlock) void k_tile_state_in(double *sq, double *ss, double *si, const double *q_t, const int32_t *perm,
-                                                          const int32_t *cfirst, const uint32_t *ccnt, int32_t np)
+                                                          const int4 *pos, int32_t np)
 {
     const int32_t p = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
     if (p >= np) return;
     double s = 0.0;
-    const int32_t u0 = cfirst[p], u1 = u0 + (int32_t)(ccnt[p] & 0xFFFFu);
+    const int4 pm = pos[p];
+    const int32_t u0 = pm.y, u1 = u0 + (int32_t)((uint32_t)pm.w & 0xFFFFu);
     for (int32_t u = u0; u < u1; ++u) s += q_t[perm[u]];
     sq[p] = q_t[perm[p]]; ss[p] = s; si[p] = 0.0;
 }
@@ -363,14 +470,14 @@ __global__ __launch_bounds__(kBlock) void k_tile_state_in(double *sq, double *ss
 // their first tick), ss = sum over the INNER tributaries only (the headwater ones come first), qch = channel discharge.
 // full[i] / chan[i]: q_full / q_ch scattered to params order, zeros on headwaters (k_unit_scatter).
 __global__ __launch_bounds__(kBlock) void k_tile_unit_state_in(double *sq, double *ss, double *si, double *sqch, const double *full,
-                                                               const double *chan, const int32_t *perm, const int32_t *cfirst,
-                                                               const uint32_t *ccnt, int32_t np)
+                                                               const double *chan, const int32_t *perm, const int4 *pos, int32_t np)
 {
     const int32_t p = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
     if (p >= np) return;
     double s = 0.0;
-    const uint32_t cc = ccnt[p];
-    const int32_t u0 = cfirst[p] + (int32_t)(cc >> 16), u1 = cfirst[p] + (int32_t)(cc & 0xFFFFu);
+    const int4 pm = pos[p];
+    const uint32_t cc = (uint32_t)pm.w;
+    const int32_t u0 = pm.y + (int32_t)(cc >> 16), u1 = pm.y + (int32_t)(cc & 0xFFFFu);
     for (int32_t u = u0; u < u1; ++u) s += full[perm[u]];
     sq[p] = full[perm[p]]; ss[p] = s; si[p] = 0.0; sqch[p] = chan[perm[p]];
 }

@@ -358,6 +358,10 @@ void build_tile_plan(const std::vector<int32_t> &down, const std::vector<int32_t
     }
     T.np = (int64_t)T.perm.size();
     T.tile_ptr[n_tiles] = (int32_t)T.np;
+    T.tile_flags.assign(n_tiles, 0);
+    for (int32_t t = 0; t < n_tiles; ++t)
+        for (int32_t p = T.tile_ptr[t]; p < T.tile_ptr[t + 1]; ++p)
+            if ((T.ccnt[p] & 0xFFFFu) > 3) { T.tile_flags[t] = 1; break; }      // kTileWide (rr_kernels_tile.hpp)
     T.n_ghost = (int64_t)ghost_positions.size();
     T.xpos.assign(T.np, -1);
     T.tile_of.assign(T.np, 0);

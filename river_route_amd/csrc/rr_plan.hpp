@@ -85,6 +85,7 @@ struct TilePlan {
     std::vector<int32_t> tile_ptr;     // [n_tiles + 1] first position of each tile
     std::vector<int32_t> tile_level;   // [n_tiles] non-decreasing
     std::vector<int32_t> tile_lag_lo, tile_lag_hi;   // [n_tiles] smallest / largest lag of the tile's positions
+    std::vector<int32_t> tile_flags;   // [n_tiles] 1: a position of the tile has more than three upstream positions (not for k_tile's short tick)
     std::vector<int32_t> level_start;  // [n_levels + 1] first tile of each level
     std::vector<int32_t> perm;         // [np] params index of the reach at (or mirrored by) a position
     std::vector<int32_t> inv;          // [n]  position of reach i

@@ -402,12 +402,18 @@ def bench_main(args, rank: int, local_rank: int, world: int) -> None:
     from .engine import partition_forest
 
     n, T, nsub, dt = args.reaches * world, args.runoff_steps, args.substeps, 900.0      # 1.25M per GPU by default: 10M on 8 GPUs (BASELINE config 5)
+    # Every rank builds the network and the partition itself: both are deterministic functions of (n, seed), 21 s of one host
+    # core at 10M reaches (17.6 s the synthetic network, 3.7 s the partition; profiles/r03_multi_setup.txt) against shipping
+    # 10M x 4 arrays from rank 0; `setup_s` in the line says what it cost on the box.
+    t_setup = time.perf_counter()
     net = synth.synth_network(n, order=args.order)
     has = net.down_index >= 0
     indptr = np.concatenate([[0], np.cumsum(has)]).astype(np.int32)
     indices = net.down_index[has].astype(np.int32)
+    t_net = time.perf_counter()
     part_of, sizes = partition_forest(indptr, indices, world)
     spec = split_network(net.down_index, part_of, rank, world)
+    t_part = time.perf_counter()
     r = dt / net.k
     den = r + 2.0 * (1.0 - net.x)
     c1, c2, c3 = (r - 2.0 * net.x) / den, (r + 2.0 * net.x) / den, (2.0 * (1.0 - net.x) - r) / den
@@ -416,6 +422,10 @@ def bench_main(args, rank: int, local_rank: int, world: int) -> None:
     eng = HipPartEngine(spec, c1, c2, c3, (c1 + c2) / (dt * nsub), np.zeros(n), lateral, T, nsub, local_rank,
                         out_rows=min(T, 128), sample_every=args.sample_every)      # sink of one out-pass batch: no row written twice by a launch
     chunk_rows = max(16, args.exchange_rows)
+    from .engine import MODE_RAPID
+    sched = eng.plan.reserve(MODE_RAPID, T, nsub)      # the record ring, before anything is timed
+    torch.cuda.synchronize()
+    t_ready = time.perf_counter()
 
     def one_pass():
         run_distributed(eng, spec, T, nsub, chunk_rows, dist)
@@ -435,8 +445,10 @@ def bench_main(args, rank: int, local_rank: int, world: int) -> None:
     elapsed = float(elapsed.item())
 
     prof = eng.plan.profile()
-    info = torch.tensor([float(spec.real_global.size), float(spec.n_ghost), float(eng.plan.depth)],
-                        dtype=torch.float64, device=cdev)
+    tiles = eng.plan.tile_info()
+    info = torch.tensor([float(spec.real_global.size), float(spec.n_ghost), float(eng.plan.depth), sched['ring_bytes'] / 1e9,
+                         float(sched['ticks_per_launch']), float(tiles['levels']), t_net - t_setup, t_part - t_net, t_ready - t_part,
+                         prof['region_ms']], dtype=torch.float64, device=cdev)
     gathered = [torch.zeros_like(info) for _ in range(world)]
     dist.all_gather(gathered, info)
     if rank == 0:
@@ -454,6 +466,12 @@ def bench_main(args, rank: int, local_rank: int, world: int) -> None:
                        'part_reaches': [int(g[0].item()) for g in gathered],
                        'part_ghosts': [int(g[1].item()) for g in gathered],
                        'part_depth': [int(g[2].item()) for g in gathered],
+                       'part_ring_gb': [round(g[3].item(), 1) for g in gathered],
+                       'part_ticks_per_launch': [int(g[4].item()) for g in gathered],
+                       'part_tile_levels': [int(g[5].item()) for g in gathered],
+                       'part_pass_ms': [round(g[9].item(), 1) for g in gathered],      # first to last routing launch of the last pass, per GPU
+                       'setup_s': {'network': [round(g[6].item(), 1) for g in gathered], 'partition': [round(g[7].item(), 1) for g in gathered],
+                                   'plan_forcing_ring': [round(g[8].item(), 1) for g in gathered]},
                        'exchange_rows': chunk_rows},
             'roofline': roofline, 'cpu_baseline': None,
         }

@@ -119,6 +119,46 @@ def synth_network(n: int, seed: int = NETWORK_SEED, params_seed: int = PARAMS_SE
         root = int(np.flatnonzero(parent < 0)[0])
         parent = np.append(parent, -1)
         parent[root] = n - 1
+    return _network_from_parents(parent, seed, params_seed, order)
+
+
+def synth_network_chain(n: int, seed: int = NETWORK_SEED, p_chain: float = 0.0, n_outlets: int = 1, p_third: float = 0.0,
+                        params_seed: int = PARAMS_SEED, order: str = 'random') -> SynthNetwork:
+    """
+    The generator SURVEY.md section 8(d) specifies, next to the Remy tree above: outlet-first growth.  Node 0 (and the other
+    n_outlets - 1 first nodes) is an outlet with two open upstream slots; node u = 1, 2, ... attaches with probability
+    p_chain to a slot of node u - 1 (it extends the current channel: this is the depth knob, long in-degree-1 runs as real
+    networks have them) and otherwise to a uniformly random open slot; every new node opens two slots (three with probability
+    p_third), so in-degree <= 2 (<= 3), about half the reaches of a p_chain = 0 network are headwaters, and several outlets
+    make a forest.  Reaches are then numbered upstream-before-downstream (`order` as in synth_network).
+    """
+    if n < 1 or not (0.0 <= p_chain < 1.0) or n_outlets < 1:
+        raise ValueError('need n >= 1, 0 <= p_chain < 1, n_outlets >= 1')
+    n_outlets = min(n_outlets, n)
+    idx = np.arange(n, dtype=np.int64)
+    chain = (u01(seed + 11, idx) < p_chain).tolist()
+    pick = u01(seed + 12, idx).tolist()
+    third = (u01(seed + 13, idx) < p_third).tolist()
+    parent = [-1] * n
+    slots: list = []                # open upstream slots, one entry (the node) per slot
+    for u in range(n):
+        if u >= n_outlets:
+            if chain[u] and u > n_outlets:      # the slots of node u - 1 are the last entries: nothing has touched them yet
+                parent[u] = slots.pop()
+            else:
+                j = int(pick[u] * len(slots))
+                parent[u] = slots[j]
+                slots[j] = slots[-1]
+                slots.pop()
+        slots.append(u)
+        slots.append(u)
+        if third[u]:
+            slots.append(u)
+    return _network_from_parents(np.asarray(parent, dtype=np.int64), seed, params_seed, order)
+
+
+def _network_from_parents(parent: np.ndarray, seed: int, params_seed: int, order: str) -> SynthNetwork:
+    n = parent.shape[0]
     levels = _levels_from_headwaters(parent)
 
     if order == 'random':
