@@ -320,7 +320,70 @@ def secondary_lines(args, device_index):
     line = bench_unit(a, device_index)
     line['config']['baseline_config'] = 4
     out.append(line)
+    out.append(bench_rapid_f32(args, device_index))
     return out
+
+
+def bench_rapid_f32(args, device_index, factor: int = 4):
+    """The headline's network and year the way the routers run a float32 qlateral file with hourly output: float32 lateral
+    rows in (rr_rapid_route_f32in_dev, exact in float64), float32 rows out, each the mean of `factor` routed rows
+    (TransformMuskingum.py:128-142 fused into the out-pass): 4 + 8 B through the in-pass and 8 + 4 / factor B through the
+    out-pass per reach-step instead of 8 + 8 and 8 + 8.  Gate: the first 96 rows against the oracle on the float64 copy of
+    the same float32 values, mean and cast as numpy does them."""
+    import torch
+    from river_route_amd import synth
+    from river_route_amd.engine import Plan
+    from river_route_amd.multi_gpu import roofline_from_profile
+    n, T, nsub, dt = args.reaches, args.runoff_steps, 1, 900.0
+    rows = min(args.forcing_rows, T)
+    dev = torch.device('cuda', device_index)
+    net = synth.synth_network(n, order=args.order)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = muskingum_coefficients(net.k, net.x, dt)
+    plan = Plan(indptr, indices, device=device_index)
+    plan.set_coeffs(-c1[indices], c2, c3, (c1 + c2) / dt)
+    plan.set_options(rows_per_chunk=args.chunk_rows, sample_every=args.sample_every)
+    ql32 = synth.synth_qlateral_torch(n, 0, rows, dev, dt=dt).to(torch.float32)
+    out32 = torch.zeros((T // factor, n), dtype=torch.float32, device=dev)
+    q_t = torch.zeros(n, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    gate = None
+    if not args.no_cpu_baseline:
+        from oracle import oracle
+        chk_T = 96
+        ql_h = ql32[:chk_T].cpu().numpy().astype(np.float64)
+        q_ref, d_ref = np.zeros(n), np.zeros((chk_T, n))
+        oracle.rapid_route(indptr, indices, -c1[indices], c2, c3, (c1 + c2) / dt, q_ref, ql_h, d_ref, 1)
+        want = d_ref.reshape(chk_T // factor, factor, n).mean(axis=1).astype(np.float32)
+        chk = torch.zeros((chk_T // factor, n), dtype=torch.float32, device=dev)
+        plan.rapid_route_f32in_dev(q_t, ql32, rows, chk_T, 1, discharge32=chk, factor=factor, stream=stream)
+        torch.cuda.synchronize()
+        got = chk.cpu().numpy()
+        if not np.allclose(got, want, rtol=1.2e-7, atol=1e-10 * float(np.abs(want).max())):
+            raise SystemExit('bench.py: float32 path differs from the oracle; refusing to report a number')
+        gate = f'{chk_T} rows x {n} reaches == oracle on the float64 copy, mean of {factor} rows and float32 cast as numpy, <= 1 ulp(f32)'
+
+    def one_pass():
+        q_t.zero_()
+        plan.rapid_route_f32in_dev(q_t, ql32, rows, T, 1, discharge32=out32, factor=factor, stream=stream)
+
+    for _ in range(args.warmup):
+        one_pass()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    roofline = roofline_from_profile(plan.profile(), 1, HBM_PEAK_GBS)
+    plan.close()
+    return {'metric': 'reach-steps/sec', 'value': float(n) * T * args.steps / elapsed, 'unit': 'reach-steps/s', 'n_gpus': 1, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': f'RapidMuskingum, {n}-reach synthetic network, {T} runoff steps @ 900 s, fp64 arithmetic, float32 lateral rows in '
+                                   f'({rows}-row cyclic array) and float32 discharge out as means of {factor} rows ({T // factor} rows, all kept), 1xMI355X',
+                       'reaches': n, 'runoff_steps': T, 'rows_per_output': factor, 'params_order': args.order, 'variant_of_baseline_config': 3},
+            'roofline': roofline, 'cpu_baseline': None if gate is None else {'parity_gate': gate}}
 
 
 def bench_rapid(args, local_rank, net, indptr, indices, c1, c2, c3, base):
@@ -415,15 +478,15 @@ def engine_sha16():
 def pmc_traffic(plan, n, nsub, kernel='k_tile', key='hbm_bytes_per_position_tick'):
     """(bytes per position-tick, source) of the routing kernel from the committed counter passes -- only for the
     configuration they were taken on and only while the kernel sources are the ones they were taken with."""
-    path = os.path.join(REPO, 'profiles', 'r02_pmc_traffic.json')
+    path = os.path.join(REPO, 'profiles', 'r03_pmc_traffic.json')
     if n != 1_000_000 or nsub != 1 or any(k.startswith(('RR_WAVE', 'RR_TILE')) for k in os.environ):
         return None, None
     try:
         with open(path) as f:
             rec = json.load(f)
         if rec.get('engine_sha16') != engine_sha16():
-            return None, f'profiles/r02_pmc_traffic.json is from other kernel sources ({rec.get("engine_sha16")}): not used'
-        return rec['kernels'][kernel][key], f'profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, engine {rec["engine_sha16"]})'
+            return None, f'profiles/r03_pmc_traffic.json is from other kernel sources ({rec.get("engine_sha16")}): not used'
+        return rec['kernels'][kernel][key], f'profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, engine {rec["engine_sha16"]})'
     except (OSError, KeyError, ValueError):
         return None, None
 

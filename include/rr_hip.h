@@ -181,6 +181,13 @@ int rr_uh_convolve_dev(int device, const double *kernel, double *state, const do
  * sub-steps does not divide 128: use the float64 form and rr_resample_cast_dev then. */
 int rr_rapid_route_f32_dev(rr_plan *plan, double *q_t, const double *qlateral, int64_t ql_rows, float *discharge32,
                            int64_t num_runoff_steps, int64_t num_substeps, int64_t factor, void *stream);
+/* rr_rapid_route_dev with float32 lateral rows, as qlateral files store them: 4 bytes read per value instead of 8, and the
+ * routers upload half the bytes; float32 -> float64 is exact, so the result equals rr_rapid_route_dev on the converted rows
+ * bit for bit.  Exactly one of discharge (float64 rows, out_rows >= 1 cyclic) and discharge32 (float32 rows, `factor` routed
+ * rows averaged, as rr_rapid_route_f32_dev).  Time-tiled kernel only (RR_E_UNSUPPORTED otherwise: convert and call
+ * rr_rapid_route_dev). */
+int rr_rapid_route_f32in_dev(rr_plan *plan, double *q_t, const float *qlateral32, int64_t ql_rows, double *discharge, int64_t out_rows,
+                             float *discharge32, int64_t factor, int64_t T, int64_t nsub, void *stream);
 int rr_muskingum_route_f32_dev(rr_plan *plan, double *q_t, float *discharge32, int64_t num_output_steps,
                                int64_t num_routing_per_output, void *stream);
 int rr_unit_route_f32_dev(rr_plan *plan, double *q_ch, double *q_full, const double *convolved_lateral, int64_t conv_rows,

@@ -1,8 +1,8 @@
 """Reduce two rocprofv3 counter passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE; separate runs of the same bench command) to HBM
-bytes per dispatch of the routing kernel and the two record passes -> profiles/r02_pmc_traffic.json.
+bytes per dispatch of the routing kernel and the two record passes -> profiles/r03_pmc_traffic.json.
 
     python profiles/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> --positions 1035935 --ticks 64 \
-        --reaches 1000000 > profiles/r02_pmc_traffic.json
+        --reaches 1000000 > profiles/r03_pmc_traffic.json
 
 gfx950 correction (/opt/skills/guides/MI355X_MICROARCH.md, HBM/rocprofv3 section): FETCH_SIZE counts half of a coalesced
 read stream -> doubled; WRITE_SIZE exact.  Raw counters are KiB.  FETCH_SIZE is the L2's fabric-side request count: reads

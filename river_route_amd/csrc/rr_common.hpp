@@ -69,7 +69,8 @@ struct RowView {
     Div32 rows;
     RowView() = default;
     RowView(double *base_, int64_t ld_, int64_t t0_, uint32_t rows_) : base(base_), ld(ld_), t0(t0_), rows(rows_) {}
-    __device__ __forceinline__ double *row(int64_t t) const { return base + (int64_t)rows.mod((uint32_t)(t - t0)) * ld; }
+    __device__ __forceinline__ int64_t offset(int64_t t) const { return (int64_t)rows.mod((uint32_t)(t - t0)) * ld; }      // in elements
+    __device__ __forceinline__ double *row(int64_t t) const { return base + offset(t); }
 };
 
 // Non-temporal hints of the kernels' global accesses, one bit per access site (measurements: profiles/r03_nt_sweep.txt).
@@ -77,6 +78,9 @@ struct RowView {
 // keeping them in a cache; whether the hint pays is a property of the memory system, hence measured per site.
 #ifndef RR_NT_MASK
 #define RR_NT_MASK 0
+#endif
+#ifndef RR_SC1_MASK
+#define RR_SC1_MASK 0      // the same sites, stores only: write-through (sc1) -- a plain flat store kernel: 6.9 -> 7.1 TB/s (profiles/r03_write_probe.txt)
 #endif
 constexpr int kNtInRows = 1, kNtInRec = 2, kNtOutRec = 4, kNtOutRows = 8, kNtTileLoad = 16, kNtTileStore = 32;
 template <int SITE, typename T> __device__ __forceinline__ T ld_site(const T *p)
@@ -86,7 +90,12 @@ template <int SITE, typename T> __device__ __forceinline__ T ld_site(const T *p)
 }
 template <int SITE, typename T> __device__ __forceinline__ void st_site(T *p, T v)
 {
-    if (RR_NT_MASK & SITE) __builtin_nontemporal_store(v, p); else *p = v;
+    if (RR_SC1_MASK & SITE) {
+        if constexpr (sizeof(T) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+        else if constexpr (sizeof(T) == 8) asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+        else *p = v;
+    } else if (RR_NT_MASK & SITE) __builtin_nontemporal_store(v, p);
+    else *p = v;
 }
 
 inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }

@@ -572,6 +572,23 @@ int rr_rapid_route_f32_dev(rr_plan *P, double *q_t, const double *qlateral, int6
     return rapid_like(P, Mode::Rapid, q_t, io, T, nsub, (hipStream_t)stream, false);
 }
 
+int rr_rapid_route_f32in_dev(rr_plan *P, double *q_t, const float *qlateral32, int64_t ql_rows, double *discharge, int64_t out_rows,
+                             float *discharge32, int64_t factor, int64_t T, int64_t nsub, void *stream)
+{
+    int rc = check_route_args(P, true, T, nsub);
+    if (rc) return rc;
+    const bool f32 = discharge32 != nullptr;
+    if (P->h.n > 0 && T > 0 && (!q_t || !qlateral32 || ql_rows < 1 || (!discharge && !discharge32) || (discharge && discharge32) || (discharge && out_rows < 1)))
+        return fail(RR_E_INVALID, "rr_rapid_route_f32in_dev: null array, empty row count, or both or neither output");
+    if (P->h.n == 0 || T == 0) return RR_OK;
+    if (f32) { rc = f32_output_applies(P, Mode::Rapid, T, nsub, factor); if (rc) return rc; }
+    else if (!choose_schedule(P, Mode::Rapid, T, nsub, false, false).tiled) return fail(RR_E_UNSUPPORTED, "rr_rapid_route_f32in_dev needs the time-tiled kernel, which this call does not get");
+    Rows io; io.dev_in32 = qlateral32; io.dev_in = P->d_c4_params; io.rows_in = ql_rows;      // (dev_in only has to be non-NULL for the executor)
+    if (f32) { io.dev_out32 = discharge32; io.out_factor = factor; io.rows_out = T / factor; }
+    else { io.dev_out = discharge; io.rows_out = out_rows; }
+    return rapid_like(P, Mode::Rapid, q_t, io, T, nsub, (hipStream_t)stream, false);
+}
+
 int rr_muskingum_route_f32_dev(rr_plan *P, double *q_t, float *discharge32, int64_t n_out, int64_t n_per_out, void *stream)
 {
     int rc = check_route_args(P, false, n_out, n_per_out);
@@ -864,7 +881,7 @@ int rr_copy_bandwidth(int device, int64_t bytes, int reps, double *gbps)
         hipError_t e = hipMemset(a, 0, (size_t)count * 16);
         if (e == hipSuccess) e = hipEventCreate(&e0);
         if (e == hipSuccess) e = hipEventCreate(&e1);
-        const dim3 g((unsigned)std::min<int64_t>((count + kBlock - 1) / kBlock, 256 * 16));
+        const dim3 g((unsigned)((count + kBlock - 1) / kBlock));      // one element per thread (count <= 2^31 x 256 elements)
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_copy16, g, dim3(kBlock), 0, nullptr, (const double2 *)a, b, count);      // warm-up
             e = hipEventRecord(e0, nullptr);

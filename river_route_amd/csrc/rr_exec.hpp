@@ -11,6 +11,7 @@ enum class Mode { Rapid, Muskingum, Unit };
 // Where the (time, reach) rows in params order come from / go to.
 struct Rows {
     const double *dev_in = nullptr;   // device array, rows_in rows
+    const float *dev_in32 = nullptr;  // instead of dev_in: float32 lateral rows (RapidMuskingum; exact in float64)
     const double *host_in = nullptr;  // host array, T rows
     int64_t rows_in = 0;
     double *dev_out = nullptr;
@@ -48,6 +49,7 @@ struct Session {
     int64_t out_limit = std::numeric_limits<int64_t>::max();   // rows the caller's output ring can take (host pipeline)
     int64_t diag = 0, n_diags = 0, n_macro = 0;
     int64_t ghost_batches = 0;    // batches of the boundary (ghost) series turned into records
+    int64_t batches_per_launch = 1;      // record-pass batches one launch may take (small networks)
     int64_t ghost_slack = 0, export_skew = 0;      // boundary reaches of a partitioned network in the time-tiled schedule (level skew included)
     TileArgs ta{};
     bool bracket_open = false;
@@ -120,7 +122,7 @@ struct rr_plan {
     bool wave_enabled = true, wave_forced = false, wave_now = false, weights_uniform = false;
     int wave_threads = 1024, wave_ppt = 2;
     int64_t wave_K = 0;          // ticks per task (multiple of 16); 0 = chosen per call
-    int64_t next_KC = 1, next_chunks = 0;   // prepare_call: task length and record ring of the call about to start
+    int64_t next_KC = 1, next_chunks = 0, next_batches = 1;   // prepare_call: task length, record ring and batches per record-pass launch of the call about to start
     int64_t kc_cap = int64_t{1} << 20;      // longest task (record chunks) the device had room for; 0: no record ring fits, the plan streams
     TileMeta *d_tmeta = nullptr;     // per tile (rr_kernels_tile.hpp)
     int4 *d_pmeta = nullptr;         // per position {lag | flags, first upstream position, xpos, upstream counts}
@@ -256,9 +258,9 @@ int upload_tiled_permutations(rr_plan *P)
 
 // Record chunks per task.  A longer task amortises the load of the tile's state and of its first half chunk, which
 // nothing overlaps; every tile level adds one task of skew to the pipeline and to the record ring.  Tasks of 128 and 256
-// ticks are for long calls on networks whose ring stays small (choose_schedule: an eighth of the card): they are worth
-// 11 % at 100k reaches, 7 % at 250k, 3 % at 500k (profiles/microbench/k_sweep_small.sh); at 1M reaches they would
-// make the ring 50 GB for 2.5 %, and 64 ticks stay.
+// ticks are for long calls on networks whose ring then stays under a fifth of the card (choose_schedule): they are worth
+// 11 % at 100k reaches, 7 % at 250k, 3 % at 500k (profiles/microbench/k_sweep_small.sh) and 2-3 % at 1M, where 128 ticks
+// make the ring 50 GB (366.5 / 367.3 ms per year against 374.3 / 382.3 at 64 ticks, profiles/r03_k_sweep.txt).
 int64_t pick_KC(const rr_plan *P, int64_t total_ticks)
 {
     if (P->wave_K > 0) return std::max<int64_t>(1, P->wave_K / kRec);
@@ -281,6 +283,7 @@ int64_t pick_KC(const rr_plan *P, int64_t total_ticks)
 struct Schedule {
     bool tiled = false;
     int64_t KC = 1, chunks = 0;       // time-tiled: record chunks per task, chunks of the record ring
+    int64_t batches_per_launch = 1;   // time-tiled: batches of 128 tick-rows one launch of a record pass may take
     int64_t ring = 0;                 // doubles of P->d_ring: record ring, or the work rows of the streaming kernel
     int64_t mrows = 0, stage = 0;     // streaming kernel: doubles of the permutation's intermediate rows / of the host staging rows
 };
@@ -295,14 +298,25 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
     if (ok) {
         const int64_t np = P->tp.np, levels = P->tp.n_levels;
         const int64_t all_chunks = kRecBatch * ((total + 14) / kRecRows + 2) + (dmax >> 4) + 2;
+        // room for the in-pass to run ahead of the routing: four batches of 128 tick-rows.  (More room and several batches per
+        // launch of a record pass on small networks -- 100k reaches: a batch is 0.1 GB -- were measured: 44.2 ms per year against
+        // 43.8, the passes run at the rate of the large networks' already.)
+        const int64_t slack = 4;
         ok = false;
-        for (int64_t KC = std::min(pick_KC(P, total + dmax), P->kc_cap); KC >= 1; KC /= 2) {
+        // a part of a cut network that feeds another GPU keeps to 64 ticks: every tile level delays its boundary series by one
+        // task, and the GPU downstream waits for it (10M reaches on 8 GPUs: whole job 7.2 against 7.1 x 10^11 reach-steps/s in the
+        // time-weighted simulation, profiles/r03_pipeline_sim_time.txt)
+        const int64_t kc_long = P->n_export > 0 && P->wave_K <= 0 ? 4 : (int64_t{1} << 20);
+        for (int64_t KC = std::min(std::min(pick_KC(P, total + dmax), P->kc_cap), kc_long); KC >= 1; KC /= 2) {
             static const int64_t extra = getenv("RR_RING_EXTRA") ? atoll(getenv("RR_RING_EXTRA")) : 0;      // measurements: a larger ring than needed
-            const int64_t chunks = std::min<int64_t>(all_chunks, (dmax + levels * KC * kRec) / kRec + 4 * kRecBatch + extra);
+            const int64_t chunks = std::min<int64_t>(all_chunks, (dmax + levels * KC * kRec) / kRec + slack * kRecBatch + extra);
             const int64_t bytes = chunks * kRec * np * (int64_t)sizeof(double);
-            if (P->dev_total_bytes > 0 && bytes > (int64_t)(P->dev_total_bytes / 8 * 5)) continue;
-            if (KC > 4 && P->wave_K <= 0 && P->dev_total_bytes > 0 && bytes > (int64_t)(P->dev_total_bytes / 8)) continue;      // long tasks only with a small ring
+            // five eighths of the card; the shortest tasks may take thirteen sixteenths: the streaming kernel, the only alternative,
+            // keeps depth x n work rows itself (1M reaches 24k deep: 204 GB of records at K = 16 against 192 GB of rows)
+            if (P->dev_total_bytes > 0 && bytes > (int64_t)(P->dev_total_bytes / 16 * (KC == 1 ? 13 : 10))) continue;
+            if (KC > 4 && P->wave_K <= 0 && P->dev_total_bytes > 0 && bytes > (int64_t)(P->dev_total_bytes / 5)) continue;      // long tasks only while the ring stays under a fifth of the card
             sch.tiled = true; sch.KC = KC; sch.chunks = chunks; sch.ring = chunks * kRec * np;
+            sch.batches_per_launch = 1;
             ok = true;
             break;
         }
@@ -368,7 +382,7 @@ int prepare_call(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_stre
                                         std::to_string((P->ring_cap + P->mrows_cap + P->stage_cap) * 8) + " reserved): call rr_plan_reserve(plan, mode, " +
                                         std::to_string(T) + ", " + std::to_string(nsub) + ", ...) first; the *_dev entry points only enqueue work");
     }
-    P->wave_now = sch.tiled; P->next_KC = sch.KC; P->next_chunks = sch.chunks;
+    P->wave_now = sch.tiled; P->next_KC = sch.KC; P->next_chunks = sch.chunks; P->next_batches = sch.batches_per_launch;
     return RR_OK;
 }
 
@@ -449,7 +463,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
     if (io.dev_out32 && !S.wave) { S.open = false; return fail(RR_E_UNSUPPORTED, "float32 output needs the time-tiled kernel"); }
 
     int rc = RR_OK;
-    if (S.wave) { S.KC = P->next_KC; S.rec_chunks = P->next_chunks; }     // ring sized by choose_schedule, allocated by rr_plan_reserve
+    if (S.wave) { S.KC = P->next_KC; S.rec_chunks = P->next_chunks; S.batches_per_launch = P->next_batches; }     // ring sized by choose_schedule, allocated by rr_plan_reserve
     S.two = S.wave && P->rec_stream_enabled && P->s_rec != nullptr && !P->pipe_active;
     P->ev_pool_next = 0;      // the previous call's events are all behind its closing join
     if (S.two) { rc = fork_join_caller(P); if (rc) { S.open = false; return rc; } }
@@ -702,7 +716,7 @@ void launch_ghost_permute(rr_plan *P, int64_t batch)
     ra.batch = batch; ra.nsub = Div32(1u); ra.colmeta = P->d_ghostmeta; ra.scale = nullptr;
     ra.rows = RowView{const_cast<double *>(S.ghost_series), P->n_ghost, 0, (uint32_t)S.total};
     ra.factor = Div32(1u);
-    hipLaunchKernelGGL(k_rec_in<false>, dim3((unsigned)std::min<int64_t>((P->n_ghost + kRecCols - 1) / kRecCols, (int64_t)P->cu_count * 4)), dim3(kRecThreads), 0, rec_stream(P), ra);
+    hipLaunchKernelGGL(k_rec_in<false>, dim3((unsigned)((P->n_ghost + kRecInCols - 1) / kRecInCols)), dim3(kRecInThreads), 0, rec_stream(P), ra);
 }
 
 typedef void (*rec_in_uh_t)(const RecPermArgs, const UhArgs);
@@ -716,7 +730,7 @@ rec_in_uh_t rec_in_uh_kernel(bool sub, int64_t n_ks)
 #undef RR_UHIN_PICK
 }
 
-void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
+void launch_rec_permute(rr_plan *P, bool in, int64_t batch, int64_t count = 1)      // batches [batch, batch + count) in one launch (plain passes only)
 {
     Session &S = P->ses;
     const int64_t n = P->h.n;
@@ -731,6 +745,7 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
     ra.rows = in ? RowView{const_cast<double *>(S.io.dev_in), n, 0, (uint32_t)S.io.rows_in}
                  : RowView{S.io.dev_out, n, 0, (uint32_t)std::max<int64_t>(1, S.io.rows_out)};
     ra.rows32 = in ? nullptr : S.io.dev_out32;
+    ra.rows_in32 = in ? S.io.dev_in32 : nullptr;
     ra.factor = Div32((uint32_t)std::max<int64_t>(1, S.io.out_factor));
     ra.clamp = S.nsub > 1 ? 0 : (S.mode == Mode::Unit ? 2 : 1);
     {   // The out-pass walks its column tiles in XCD-contiguous order (xcd_swizzle): where the row pitch is not a whole number
@@ -740,12 +755,15 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
         static const int knob = getenv("RR_REC_SWIZZLE") ? atoi(getenv("RR_REC_SWIZZLE")) : 2;      // measurements: bit 0 in-pass, bit 1 out-pass
         ra.swizzle = (knob >> (in ? 0 : 1)) & 1;
     }
-    const dim3 g((unsigned)((n + kRecCols - 1) / kRecCols));
-    // the plain passes are persistent: as many workgroups as the CUs hold at once (38 KB of LDS each: four per CU), each walking
-    // its share of the column tiles with the next tile's loads in flight
-    static const int per_cu = getenv("RR_REC_WGS_PER_CU") ? std::max(1, atoi(getenv("RR_REC_WGS_PER_CU"))) : 4;      // measurements
+    const dim3 g((unsigned)((n + (in ? kRecInCols : kRecOutCols) - 1) / (in ? kRecInCols : kRecOutCols)));
+    // The plain passes walk their column tiles in a loop with the next tile's loads in flight, so they can run as persistent
+    // workgroups (RR_REC_WGS_PER_CU per CU).  Measured, that is no faster than one tile per workgroup -- 427 / 469 us per 128 rows
+    // against 419 / 434-448 at 1M reaches, and a plain copy shows the same: 4.5-5.7 TB/s from a persistent grid, 6.3-6.7 TB/s
+    // with one 16-byte element per thread (profiles/r03_hbm_probe_*.txt): workgroups dispatched in order keep the chip's
+    // accesses inside a narrow window of addresses -- so one tile per workgroup is the default (0).
+    static const int per_cu = getenv("RR_REC_WGS_PER_CU") ? std::max(0, atoi(getenv("RR_REC_WGS_PER_CU"))) : 0;
     const bool sub = S.nsub > 1;
-    const dim3 gp((unsigned)std::min<int64_t>(g.x, (int64_t)P->cu_count * ((in && sub) ? std::min(per_cu, 3) : per_cu)));      // k_rec_in<true>: 129 registers, three per CU
+    const dim3 gp(per_cu > 0 ? (unsigned)std::min<int64_t>(g.x, (int64_t)P->cu_count * per_cu) : g.x, (unsigned)count);
     hipStream_t st = rec_stream(P);
     if (in && S.io.runoff) {
         const dim3 gr((unsigned)((n + kRunoffInThreads - 1) / kRunoffInThreads), (unsigned)kRecBatch);
@@ -755,17 +773,20 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
         UhArgs ua{S.io.uh_kernel, S.io.uh_state, (int32_t)S.io.uh_nks};
         for (int half = 0; half < kRecBatch / kUhBatch; ++half) {      // the fused convolution's windows fit registers for 8 records at a time
             ra.batch = batch * (kRecBatch / kUhBatch) + half;
-            hipLaunchKernelGGL(rec_in_uh_kernel(sub, S.io.uh_nks), g, dim3(kUhInThreads), rec_in_uh_lds_bytes(uh_padded_taps(S.io.uh_nks)), st, ra, ua);
+            hipLaunchKernelGGL(rec_in_uh_kernel(sub, S.io.uh_nks), dim3((unsigned)((n + kUhCols - 1) / kUhCols)), dim3(kUhInThreads), rec_in_uh_lds_bytes(uh_padded_taps(S.io.uh_nks)), st, ra, ua);
         }
+    } else if (in && ra.rows_in32) {
+        if (sub) hipLaunchKernelGGL((k_rec_in<true, true>), gp, dim3(kRecInThreads), 0, st, ra);
+        else hipLaunchKernelGGL((k_rec_in<false, true>), gp, dim3(kRecInThreads), 0, st, ra);
     } else if (in) {
-        if (sub) hipLaunchKernelGGL(k_rec_in<true>, gp, dim3(kRecThreads), 0, st, ra);
-        else hipLaunchKernelGGL(k_rec_in<false>, gp, dim3(kRecThreads), 0, st, ra);
+        if (sub) hipLaunchKernelGGL(k_rec_in<true>, gp, dim3(kRecInThreads), 0, st, ra);
+        else hipLaunchKernelGGL(k_rec_in<false>, gp, dim3(kRecInThreads), 0, st, ra);
     } else if (ra.rows32) {
-        if (sub) hipLaunchKernelGGL((k_rec_out<true, true>), gp, dim3(kRecThreads), 0, st, ra);
-        else hipLaunchKernelGGL((k_rec_out<false, true>), gp, dim3(kRecThreads), 0, st, ra);
+        if (sub) hipLaunchKernelGGL((k_rec_out<true, true>), gp, dim3(kRecOutThreads), 0, st, ra);
+        else hipLaunchKernelGGL((k_rec_out<false, true>), gp, dim3(kRecOutThreads), 0, st, ra);
     } else {
-        if (sub) hipLaunchKernelGGL((k_rec_out<true, false>), gp, dim3(kRecThreads), 0, st, ra);
-        else hipLaunchKernelGGL((k_rec_out<false, false>), gp, dim3(kRecThreads), 0, st, ra);
+        if (sub) hipLaunchKernelGGL((k_rec_out<true, false>), gp, dim3(kRecOutThreads), 0, st, ra);
+        else hipLaunchKernelGGL((k_rec_out<false, false>), gp, dim3(kRecOutThreads), 0, st, ra);
     }
 }
 
@@ -797,9 +818,15 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
             return must_have_left <= 0 || S.ticks_stored >= std::min(S.total, must_have_left);
         };
         if (S.has_in && S.in_batches < S.n_in_batches && ticks_ready >= std::min(kRecRows * (S.in_batches + 1), S.total) && slot_free(S.in_batches)) {
-            launch_rec_permute(P, true, S.in_batches);
-            if (S.two) { int rc = fork_record(P, S.ev_in); if (rc) return rc; }
-            ++S.in_batches;
+            // as many batches as are ready and have room, in one launch: on a small network a batch is a few dozen microseconds
+            // of work, and the ring is given room for several (choose_schedule)
+            int64_t count = 1;
+            const bool plain_pass = !S.io.runoff && !S.io.uh_kernel;
+            while (plain_pass && count < S.batches_per_launch && S.in_batches + count < S.n_in_batches &&
+                   ticks_ready >= std::min(kRecRows * (S.in_batches + count + 1), S.total) && slot_free(S.in_batches + count)) ++count;
+            launch_rec_permute(P, true, S.in_batches, count);
+            for (int64_t k = 0; k < count; ++k) if (S.two) { int rc = fork_record(P, S.ev_in); if (rc) return rc; }
+            S.in_batches += count;
             progressed = true;
         }
         if (P->n_ghost > 0 && S.ghost_batches < S.n_in_batches && (!S.has_in || S.ghost_batches < S.in_batches) &&      // after the lateral batch: that one writes zeros into the ghosts' records
@@ -841,12 +868,17 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
         if (S.diag >= S.n_diags) done = S.total;
         else if (m_done >= 0) done = std::max<int64_t>(0, (m_done + 1) * K - dmax);
         done = std::min(done, S.total);
-        while (S.out_batches < S.n_out_batches && done >= std::min(kRecRows * (S.out_batches + 1), S.total) &&
-               (std::min(kRecRows * (S.out_batches + 1), S.total) + S.nsub - 1) / S.nsub <= S.out_limit) {
+        auto out_ready = [&](int64_t j) {
+            return j < S.n_out_batches && done >= std::min(kRecRows * (j + 1), S.total) && (std::min(kRecRows * (j + 1), S.total) + S.nsub - 1) / S.nsub <= S.out_limit;
+        };
+        while (out_ready(S.out_batches)) {
             if (S.two && S.diags_marked < S.diag) { int rc = fork_join_caller(P); if (rc) return rc; S.diags_marked = S.diag; }      // the launches that finished these rows
-            launch_rec_permute(P, false, S.out_batches);
-            if (S.two) { int rc = fork_record(P, S.ev_out); if (rc) return rc; }
-            ++S.out_batches;
+            int64_t count = 1;
+            // a cyclic output array takes the batches of one launch only while they do not wrap onto each other
+            while (count < S.batches_per_launch && out_ready(S.out_batches + count) && (S.io.dev_out32 || kRecRows * (count + 1) <= S.io.rows_out * S.nsub)) ++count;
+            launch_rec_permute(P, false, S.out_batches, count);
+            for (int64_t k = 0; k < count; ++k) if (S.two) { int rc = fork_record(P, S.ev_out); if (rc) return rc; }
+            S.out_batches += count;
             S.ticks_stored = std::min(S.total, kRecRows * S.out_batches);
             progressed = true;
         }

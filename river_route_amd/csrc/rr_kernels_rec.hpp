@@ -22,7 +22,21 @@ namespace {
 #ifndef RR_REC_THREADS
 #define RR_REC_THREADS 256
 #endif
+#ifndef RR_REC_IN_THREADS
+#define RR_REC_IN_THREADS RR_REC_THREADS
+#endif
+#ifndef RR_REC_OUT_THREADS
+#define RR_REC_OUT_THREADS RR_REC_THREADS
+#endif
 constexpr int kRecCols = RR_REC_COLS, kRecBatch = RR_REC_BATCH, kRecThreads = RR_REC_THREADS;
+constexpr int kRecInThreads = RR_REC_IN_THREADS, kRecOutThreads = RR_REC_OUT_THREADS;      // workgroup sizes of k_rec_in / k_rec_out (measurements)
+#ifndef RR_REC_IN_COLS
+#define RR_REC_IN_COLS RR_REC_COLS
+#endif
+#ifndef RR_REC_OUT_COLS
+#define RR_REC_OUT_COLS RR_REC_COLS
+#endif
+constexpr int kRecInCols = RR_REC_IN_COLS, kRecOutCols = RR_REC_OUT_COLS;      // columns of a tile of k_rec_in / k_rec_out
 constexpr int kRecRows = 16 * kRecBatch;    // tick-rows of one batch
 
 struct RecPermArgs {
@@ -33,6 +47,7 @@ struct RecPermArgs {
     const int2 *colmeta;      // per params column: {position, lag}
     const double *scale;      // c4dt in PARAMS order (RapidMuskingum: the ring holds c4dt * lateral) or NULL
     RowView rows;             // params-order rows (source of k_rec_in, destination of k_rec_out)
+    const float *rows_in32;   // k_rec_in<..., IN32>: the source rows are float32 (a qlateral file stored that way: 4 B read instead of 8, exact in float64); same shape as `rows`
     float *rows32;            // k_rec_out: float32 destination with `factor` rows averaged (router post-processing), or NULL
     Div32 factor;
     int32_t swizzle;          // column tiles in XCD-contiguous order (rr_common.hpp: xcd_swizzle)
@@ -47,14 +62,14 @@ constexpr int kRecTileLd = kRecCols + 1;
 // BATCH records per column; a.batch counts launches of BATCH records (the fused convolution works in half batches).
 // smeta / sscale: the tile's column metadata and scale in LDS (k_rec_in keeps them there: loaded with the rows, no registers
 // held across the stores), or NULL: read from the plan's arrays.
-template <bool SUB, int THREADS = kRecThreads, int BATCH = kRecBatch, bool LDSMETA = false>
+template <bool SUB, int THREADS = kRecThreads, int BATCH = kRecBatch, bool LDSMETA = false, int COLS = kRecCols>
 __device__ __forceinline__ void write_records(const RecPermArgs &a, const double *tile, int64_t col0, int64_t tick_first, int64_t row_first,
                                               const int2 *smeta = nullptr, const double *sscale = nullptr)
 {
     constexpr int R = 16 * BATCH + 15;
     const int tid = threadIdx.x;
-    static_assert(kRecCols * BATCH * 8 % THREADS == 0, "records of a tile must divide among the threads");
-    constexpr int IT = kRecCols * BATCH * 8 / THREADS;
+    static_assert(COLS * BATCH * 8 % THREADS == 0, "records of a tile must divide among the threads");
+    constexpr int IT = COLS * BATCH * 8 / THREADS;
     int2 meta[LDSMETA ? 1 : IT];
     double f[LDSMETA ? 1 : IT];
     if constexpr (!LDSMETA) {
@@ -87,9 +102,9 @@ __device__ __forceinline__ void write_records(const RecPermArgs &a, const double
             uint32_t s;
             const int r0 = t0 < 0 ? 0 : (int)((int64_t)a.nsub.div((uint32_t)t0, s) - row_first);
             const int r1 = t1 < 0 ? 0 : (int)((int64_t)a.nsub.div((uint32_t)t1, s) - row_first);
-            v0 = tile[min(r0, R - 1) * kRecTileLd + c] * scale; v1 = tile[min(r1, R - 1) * kRecTileLd + c] * scale;
+            v0 = tile[min(r0, R - 1) * (COLS + 1) + c] * scale; v1 = tile[min(r1, R - 1) * (COLS + 1) + c] * scale;
         } else {
-            v0 = tile[r * kRecTileLd + c] * scale; v1 = tile[(r + 1) * kRecTileLd + c] * scale;
+            v0 = tile[r * (COLS + 1) + c] * scale; v1 = tile[(r + 1) * (COLS + 1) + c] * scale;
         }
         double2 *dst = reinterpret_cast<double2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.np + p) * kRec) + part;
         typedef double d2 __attribute__((ext_vector_type(2)));
@@ -97,40 +112,43 @@ __device__ __forceinline__ void write_records(const RecPermArgs &a, const double
     }
 }
 
-// Persistent and software-pipelined: a workgroup walks the column tiles blockIdx.x, blockIdx.x + gridDim.x, ... and requests
-// the rows of its NEXT tile before it turns the current one into records, so row loads are in flight while the LDS tile is read
-// back and the records are stored.  One tile per workgroup (rounds 1 and 2) left each side of the pass waiting for the other:
-// 419 us per 128 rows at 1M reaches, when the rows alone read in 186 us (162 us non-temporal) and the records alone store in
-// 199 us (profiles/r03_rec_probe.txt, r03_alias_kernel_times.txt).
-template <bool SUB>
-__global__ __launch_bounds__(kRecThreads) void k_rec_in(const RecPermArgs a)
+// A workgroup walks the column tiles blockIdx.x, blockIdx.x + gridDim.x, ... and requests the rows of its NEXT tile before it
+// turns the current one into records.  Launched with one tile per workgroup (the default) that loop runs once; launched as a
+// persistent grid the loads of the next tile are in flight while the records of this one are stored -- measured, no gain: the
+// rows alone read in 186 us per 128 rows at 1M reaches, the records alone store in 199 us, the pass takes 419 us either way,
+// within 7 % of the two one after the other (profiles/r03_rec_probe.txt, r03_alias_kernel_times.txt, rr_exec.hpp).
+template <bool SUB, bool IN32 = false>
+__global__ __launch_bounds__(kRecInThreads) void k_rec_in(const RecPermArgs a_first)
 {
+    RecPermArgs a = a_first;
+    a.batch += blockIdx.y;      // a launch may take several batches at once (small networks: rr_exec.hpp)
     constexpr int R = kRecTileRows;
-    __shared__ double tile[R * kRecTileLd];
-    __shared__ int2 smeta[kRecCols];
-    __shared__ double sscale[kRecCols];
+    __shared__ double tile[R * (kRecInCols + 1)];
+    __shared__ int2 smeta[kRecInCols];
+    __shared__ double sscale[kRecInCols];
     const int tid = threadIdx.x;
     const int64_t tick_first = kRecRows * a.batch - 15;                 // may be negative in the first batch
     uint32_t sub_unused;
     const int64_t row_first = SUB ? (int64_t)a.nsub.div((uint32_t)(tick_first < 0 ? 0 : tick_first), sub_unused) : tick_first;
-    constexpr int RPT = (R + kRecThreads / kRecCols - 1) / (kRecThreads / kRecCols);
-    const int c = tid % kRecCols, r0 = tid / kRecCols;
+    constexpr int RPT = (R + kRecInThreads / kRecInCols - 1) / (kRecInThreads / kRecInCols);
+    const int c = tid % kRecInCols, r0 = tid / kRecInCols;
     const int need = SUB ? (int)((uint32_t)(R - 1) / a.nsub.d) + 2 : R;     // runoff rows behind the batch's tick-rows
-    const uint32_t n_tiles = (uint32_t)((a.n + kRecCols - 1) / kRecCols);
-    auto col_of = [&](uint32_t t) { return (int64_t)(a.swizzle ? xcd_swizzle(t, n_tiles) : t) * kRecCols; };
+    const uint32_t n_tiles = (uint32_t)((a.n + kRecInCols - 1) / kRecInCols);
+    auto col_of = [&](uint32_t t) { return (int64_t)(a.swizzle ? xcd_swizzle(t, n_tiles) : t) * kRecInCols; };
     double v[RPT];
     int2 cm = make_int2(-1, 0);
     double cs = 1.0;
     auto request = [&](int64_t col0) {      // branch-free: out-of-range rows / columns are clamped here and zeroed on the way into LDS
         const int64_t i = min(col0 + c, a.n - 1);
-        if (tid < kRecCols) {      // the tile's column metadata and scale travel with its rows
+        if (tid < kRecInCols) {      // the tile's column metadata and scale travel with its rows
             cm = col0 + c < a.n ? a.colmeta[i] : make_int2(-1, 0);
             cs = a.scale ? a.scale[i] : 1.0;
         }
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-            const int64_t t = row_first + min(r0 + q * (kRecThreads / kRecCols), need - 1);
-            v[q] = ld_site<kNtInRows>(a.rows.row(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t)) + i);
+            const int64_t t = row_first + min(r0 + q * (kRecInThreads / kRecInCols), need - 1);
+            const int64_t off = a.rows.offset(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t)) + i;
+            v[q] = IN32 ? (double)ld_site<kNtInRows>(a.rows_in32 + off) : ld_site<kNtInRows>(a.rows.base + off);
         }
     };
     uint32_t t = blockIdx.x;
@@ -140,15 +158,15 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_in(const RecPermArgs a)
         const int64_t col0 = col_of(t);
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
-            const int r = r0 + q * (kRecThreads / kRecCols);
+            const int r = r0 + q * (kRecInThreads / kRecInCols);
             const int64_t row = row_first + r;
-            if (r < R) tile[r * kRecTileLd + c] = (row >= 0 && row < a.T && col0 + c < a.n) ? v[q] : 0.0;
+            if (r < R) tile[r * (kRecInCols + 1) + c] = (row >= 0 && row < a.T && col0 + c < a.n) ? v[q] : 0.0;
         }
-        if (tid < kRecCols) { smeta[c] = cm; sscale[c] = cs; }
+        if (tid < kRecInCols) { smeta[c] = cm; sscale[c] = cs; }
         __syncthreads();
         const uint32_t next = t + gridDim.x;
         if (next < n_tiles) request(col_of(next));      // in flight while this tile leaves as records
-        write_records<SUB, kRecThreads, kRecBatch, true>(a, tile, col0, tick_first, row_first, smeta, sscale);
+        write_records<SUB, kRecInThreads, kRecBatch, true, kRecInCols>(a, tile, col0, tick_first, row_first, smeta, sscale);
         if (next >= n_tiles) break;
         __syncthreads();      // every record of this tile has been read out of LDS
         t = next;
@@ -165,22 +183,29 @@ struct UhArgs {
     const double *kernel, *state;     // (n_ks, n) taps and carried-in state, params order
     int32_t n_ks;
 };
-constexpr int kUhInThreads = 256;       // 8 groups of rows x 32 columns: 18 outputs per thread, windows of 18 + NK - 1 depth values (512 threads x 9 rows: 20 % slower)
+#ifndef RR_UH_COLS
+#define RR_UH_COLS 16
+#endif
+// Columns of a tile of the fused convolution: 16 (128-byte row pieces, 32 KB of LDS and 140 registers: three workgroups per
+// CU) against the 32 of the plain passes (63 KB, 180 registers: two): 52.6 against 55.2 ms for BASELINE config 4
+// (profiles/r03_small_networks_and_uh16.txt).
+constexpr int kUhCols = RR_UH_COLS, kUhTileLd = kUhCols + 1;
+constexpr int kUhInThreads = 256;       // groups of rows x columns: 9 outputs per thread at 16 columns, windows of 9 + NK - 1 depth values
 constexpr int kUhBatch = 8;             // records per column and launch: two launches per batch of the plain passes (a.batch counts these half batches)
 static_assert(kRecBatch % kUhBatch == 0, "the fused convolution works in whole fractions of a record batch");
 constexpr int kUhTileRows = 16 * kUhBatch + 15;
-constexpr int kUhRowsPerThread = (kUhTileRows + kUhInThreads / kRecCols - 1) / (kUhInThreads / kRecCols);
-constexpr size_t rec_in_uh_lds_bytes(int nk) { return (size_t)((kUhTileRows + nk - 1) + nk) * kRecTileLd * sizeof(double); }
+constexpr int kUhRowsPerThread = (kUhTileRows + kUhInThreads / kUhCols - 1) / (kUhInThreads / kUhCols);
+constexpr size_t rec_in_uh_lds_bytes(int nk) { return (size_t)((kUhTileRows + nk - 1) + nk) * kUhTileLd * sizeof(double); }
 
 template <bool SUB, int NK>
 __global__ __launch_bounds__(kUhInThreads) void k_rec_in_uh(const RecPermArgs a, const UhArgs u)
 {
-    constexpr int R = kUhTileRows, G = kUhInThreads / kRecCols, RP = kUhRowsPerThread, W = RP + NK - 1;
+    constexpr int R = kUhTileRows, G = kUhInThreads / kUhCols, RP = kUhRowsPerThread, W = RP + NK - 1;
     extern __shared__ __attribute__((aligned(16))) double uh_lds[];
-    double *dt = uh_lds;                                   // [R + NK - 1][kRecTileLd] depth rows row_first - (NK - 1) ...
-    double *tp = uh_lds + (R + NK - 1) * kRecTileLd;       // [NK][kRecTileLd] taps
-    const int tid = threadIdx.x, c = tid % kRecCols, g = tid / kRecCols;
-    const int64_t col0 = (int64_t)(a.swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x) * kRecCols;
+    double *dt = uh_lds;                                   // [R + NK - 1][kUhTileLd] depth rows row_first - (NK - 1) ...
+    double *tp = uh_lds + (R + NK - 1) * kUhTileLd;       // [NK][kUhTileLd] taps
+    const int tid = threadIdx.x, c = tid % kUhCols, g = tid / kUhCols;
+    const int64_t col0 = (int64_t)(a.swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x) * kUhCols;
     const int64_t tick_first = 16 * kUhBatch * a.batch - 15;
     uint32_t sub_unused;
     const int64_t row_first = SUB ? (int64_t)a.nsub.div((uint32_t)(tick_first < 0 ? 0 : tick_first), sub_unused) : tick_first;
@@ -201,12 +226,12 @@ __global__ __launch_bounds__(kUhInThreads) void k_rec_in_uh(const RecPermArgs a,
         for (int q = 0; q < DPT; ++q) {
             const int r = g + q * G;
             const int64_t t = row_first - (NK - 1) + r;
-            if (r < R + NK - 1) dt[r * kRecTileLd + c] = (live && t >= 0 && t < a.T) ? dv[q] : 0.0;
+            if (r < R + NK - 1) dt[r * kUhTileLd + c] = (live && t >= 0 && t < a.T) ? dv[q] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < TPT; ++q) {
             const int k = g + q * G;
-            if (k < NK) tp[k * kRecTileLd + c] = (live && k < u.n_ks) ? tv[q] : 0.0;
+            if (k < NK) tp[k * kUhTileLd + c] = (live && k < u.n_ks) ? tv[q] : 0.0;
         }
     }
     __syncthreads();
@@ -215,7 +240,7 @@ __global__ __launch_bounds__(kUhInThreads) void k_rec_in_uh(const RecPermArgs a,
     if (rb < need) {
         double win[W];
 #pragma unroll
-        for (int q = 0; q < W; ++q) win[q] = dt[min(rb + q, R + NK - 2) * kRecTileLd + c];      // depth row (row_first + rb + q - (NK - 1))
+        for (int q = 0; q < W; ++q) win[q] = dt[min(rb + q, R + NK - 2) * kUhTileLd + c];      // depth row (row_first + rb + q - (NK - 1))
 #pragma unroll
         for (int j = 0; j < RP; ++j) {
             const int64_t t = row_first + rb + j;
@@ -223,7 +248,7 @@ __global__ __launch_bounds__(kUhInThreads) void k_rec_in_uh(const RecPermArgs a,
         }
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-            const double tap = tp[k * kRecTileLd + c];
+            const double tap = tp[k * kUhTileLd + c];
 #pragma unroll
             for (int j = 0; j < RP; ++j) acc[j] = __builtin_fma(tap, win[j + (NK - 1) - k], acc[j]);
         }
@@ -231,36 +256,43 @@ __global__ __launch_bounds__(kUhInThreads) void k_rec_in_uh(const RecPermArgs a,
     __syncthreads();      // every window is in registers: the depth tile's space now takes the outputs
     if (rb < need) {
 #pragma unroll
-        for (int j = 0; j < RP; ++j) if (rb + j < R) dt[(rb + j) * kRecTileLd + c] = acc[j];
+        for (int j = 0; j < RP; ++j) if (rb + j < R) dt[(rb + j) * kUhTileLd + c] = acc[j];
     }
     __syncthreads();
-    write_records<SUB, kUhInThreads, kUhBatch>(a, dt, col0, tick_first, row_first);
+    write_records<SUB, kUhInThreads, kUhBatch, false, kUhCols>(a, dt, col0, tick_first, row_first);
 }
 
 // OUT32: the router's post-processing fused in (TransformMuskingum.py:128-142): mean over `factor` consecutive rows
 // (sequential sum, one division, as numpy reduces a strided axis) and the float32 cast; 128 % (factor * nsub) == 0.
-// Persistent and software-pipelined like k_rec_in: the records of the workgroup's next column tile are requested before the
-// rows of the current one are written.
+// The same loop as k_rec_in: the records of the workgroup's next column tile (if the grid is persistent) are requested before
+// the rows of the current one are written.
 template <bool SUB, bool OUT32>
-__global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
+__global__ __launch_bounds__(kRecOutThreads) void k_rec_out(const RecPermArgs a_first)
 {
+    RecPermArgs a = a_first;
+    a.batch += blockIdx.y;
     constexpr int S = 16 * (kRecBatch + 1);
-    __shared__ double recs[kRecCols][S + 1];
+    __shared__ double recs[kRecOutCols][S + 1];
     const int tid = threadIdx.x;
-    constexpr int IT = kRecCols * (kRecBatch + 1) * 8 / kRecThreads;
-    const uint32_t n_tiles = (uint32_t)((a.n + kRecCols - 1) / kRecCols);
-    auto col_of = [&](uint32_t t) { return (int64_t)(a.swizzle ? xcd_swizzle(t, n_tiles) : t) * kRecCols; };
+    static_assert(kRecOutCols * (kRecBatch + 1) * 8 % kRecOutThreads == 0, "record pieces of a tile must divide among the threads");
+    constexpr int IT = kRecOutCols * (kRecBatch + 1) * 8 / kRecOutThreads;
+    const uint32_t n_tiles = (uint32_t)((a.n + kRecOutCols - 1) / kRecOutCols);
+    auto col_of = [&](uint32_t t) { return (int64_t)(a.swizzle ? xcd_swizzle(t, n_tiles) : t) * kRecOutCols; };
     typedef double d2 __attribute__((ext_vector_type(2)));
     d2 v[IT];
     auto request = [&](int64_t col0) {      // all record reads in flight; a column past the end reads position 0 and is not written
+        int2 meta[IT];
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {      // every metadata load first: the record loads depend on them, one wait for all
+            const int64_t i = col0 + (it * kRecOutThreads + tid) / ((kRecBatch + 1) * 8);
+            meta[it] = i < a.n ? a.colmeta[i] : make_int2(0, 0);
+        }
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int piece = it * kRecThreads + tid;
+            const int piece = it * kRecOutThreads + tid;
             const int k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
-            const int64_t i = col0 + piece / ((kRecBatch + 1) * 8);
-            const int2 meta = i < a.n ? a.colmeta[i] : make_int2(0, 0);
-            const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)((meta.y & kLagMask) >> 4) + k;
-            v[it] = ld_site<kNtOutRec>(reinterpret_cast<const d2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.np + meta.x) * kRec) + part);
+            const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)((meta[it].y & kLagMask) >> 4) + k;
+            v[it] = ld_site<kNtOutRec>(reinterpret_cast<const d2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.np + meta[it].x) * kRec) + part);
         }
     };
     uint32_t t = blockIdx.x;
@@ -271,7 +303,7 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
         const int64_t col0 = col_of(t);
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            const int piece = it * kRecThreads + tid;
+            const int piece = it * kRecOutThreads + tid;
             const int c = piece / ((kRecBatch + 1) * 8), k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
             recs[c][16 * k + 2 * part] = v[it].x;
             recs[c][16 * k + 2 * part + 1] = v[it].y;
@@ -279,7 +311,7 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
         __syncthreads();
         const uint32_t next = t + gridDim.x;
         if (next < n_tiles) request(col_of(next));      // in flight while this tile's rows are written
-        const int c = tid % kRecCols;
+        const int c = tid % kRecOutCols;
         const int64_t i = col0 + c;
         if (i < a.n) {
             const int32_t my = a.colmeta[i].y;
@@ -292,7 +324,7 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
                 // output row q averages runoff rows [q * factor, (q + 1) * factor), each the slot of its last sub-step
                 const int step = (int)(a.factor.d * (SUB ? a.nsub.d : 1u));          // tick-rows per output row, divides 128
                 const int64_t q0 = tick0 / step;
-                for (int q = tid / kRecCols; q < kRecRows / step; q += kRecThreads / kRecCols) {
+                for (int q = tid / kRecOutCols; q < kRecRows / step; q += kRecOutThreads / kRecOutCols) {
                     if ((q0 + q + 1) * step > a.total) break;
                     const int nsub = SUB ? (int)a.nsub.d : 1;
                     double acc = out(recs[c][o + q * step + nsub - 1]);
@@ -300,7 +332,7 @@ __global__ __launch_bounds__(kRecThreads) void k_rec_out(const RecPermArgs a)
                     a.rows32[(q0 + q) * a.n + i] = (float)(a.factor.d > 1 ? acc / (double)a.factor.d : acc);
                 }
             } else {
-                for (int r = tid / kRecCols; r < kRecRows; r += kRecThreads / kRecCols) {
+                for (int r = tid / kRecOutCols; r < kRecRows; r += kRecOutThreads / kRecOutCols) {
                     const int64_t tick = tick0 + r;
                     if (tick >= a.total) break;
                     if (SUB) {

@@ -143,16 +143,14 @@ __global__ __launch_bounds__(kRunoffInThreads) void k_rec_in_runoff(const RecPer
     }
 }
 
-// Device copy rate probe (bench.py reports it beside the nominal HBM peak): 16 bytes per lane, grid-stride.
+// Device copy rate probe (bench.py reports it beside the nominal HBM peak): one 16-byte element per thread, non-temporal --
+// the shape that copies fastest on this chip (6.3-6.7 TB/s; the grid-stride form of rounds 1-2 read 4.5-5.7 TB/s on the same
+// boxes, profiles/r03_hbm_probe_*.txt: workgroups dispatched in order keep the chip's accesses inside a narrow window).
 __global__ __launch_bounds__(kBlock) void k_copy16(const double2 *__restrict__ src, double2 *__restrict__ dst, int64_t count)
 {
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-    for (; i + 3 * stride < count; i += 4 * stride) {      // four loads in flight per lane
-        const double2 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-    }
-    for (; i < count; i += stride) dst[i] = src[i];
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < count) __builtin_nontemporal_store(__builtin_nontemporal_load(reinterpret_cast<const d2 *>(src) + i), reinterpret_cast<d2 *>(dst) + i);
 }
 
 }  // namespace

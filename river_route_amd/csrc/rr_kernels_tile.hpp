@@ -75,7 +75,7 @@ __device__ __forceinline__ void store_f64x2(__amdgpu_buffer_rsrc_t r, uint32_t b
 {
     u32x4 bits;
     __builtin_memcpy(&bits, &v, sizeof bits);
-    __builtin_amdgcn_raw_buffer_store_b128(bits, r, (int)byte_off, 0, (RR_NT_MASK & kNtTileStore) ? 2 : 0);      // aux bit 1: nt
+    __builtin_amdgcn_raw_buffer_store_b128(bits, r, (int)byte_off, 0, ((RR_NT_MASK & kNtTileStore) ? 2 : 0) | ((RR_SC1_MASK & kNtTileStore) ? 16 : 0));      // aux bit 1: nt, bit 4: sc1
 }
 __device__ __forceinline__ void load_f64x2(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, double &x, double &y)
 {

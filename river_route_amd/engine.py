@@ -197,6 +197,13 @@ class Plan:
         check(_lib.lib().rr_rapid_route_f32_dev(self._h, ptr(q_t), ptr(qlateral), int(ql_rows), ptr(discharge32), int(T),
                                                 int(num_substeps), int(factor), stream))
 
+    def rapid_route_f32in_dev(self, q_t, qlateral32, ql_rows, T, num_substeps, discharge=None, out_rows=0, discharge32=None, factor=1,
+                              stream=None) -> None:
+        """rr_rapid_route_f32in_dev: float32 lateral rows in (exact in float64); exactly one of discharge / discharge32."""
+        self.reserve(MODE_RAPID, T, num_substeps)
+        check(_lib.lib().rr_rapid_route_f32in_dev(self._h, ptr(q_t), ptr(qlateral32), int(ql_rows), ptr(discharge), int(out_rows),
+                                                  ptr(discharge32), int(factor), int(T), int(num_substeps), stream))
+
     def muskingum_route_f32_dev(self, q_t, discharge32, num_output_steps, num_routing_per_output, stream=None) -> None:
         self.reserve(MODE_MUSKINGUM, num_output_steps, num_routing_per_output)
         check(_lib.lib().rr_muskingum_route_f32_dev(self._h, ptr(q_t), ptr(discharge32), int(num_output_steps),

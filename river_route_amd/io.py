@@ -24,13 +24,19 @@ def _decode_cf_time(values: np.ndarray, units: str) -> np.ndarray:
     return origin + secs.astype('timedelta64[s]')
 
 
-def read_qlateral(path, var_t: str = 'time', var: str = 'qlateral'):
+def read_qlateral(path, var_t: str = 'time', var: str = 'qlateral', keep_float32: bool = False):
     """-> (dates datetime64[s][T], array float64[T, n]) as TransformMuskingum._qlateral_generator yields them
-    (river_route/routers/TransformMuskingum.py:33-36)."""
+    (river_route/routers/TransformMuskingum.py:33-36).  keep_float32: a variable the file stores as float32 is returned as it
+    is (the caller converts on the device: half the bytes to upload and to read, the same float64 values)."""
+    def cast(values):
+        values = np.asarray(values)
+        if keep_float32 and values.dtype == np.float32:
+            return np.ascontiguousarray(values)
+        return values.astype(np.float64, copy=False)
     try:
         import xarray as xr
         with xr.open_dataset(path) as ds:
-            return ds[var_t].values.astype('datetime64[s]'), ds[var].values.astype(np.float64, copy=False)
+            return ds[var_t].values.astype('datetime64[s]'), cast(ds[var].values)
     except ImportError:
         pass
     try:
@@ -38,7 +44,7 @@ def read_qlateral(path, var_t: str = 'time', var: str = 'qlateral'):
         with nc.Dataset(str(path)) as ds:
             tv = ds[var_t]
             dates = _decode_cf_time(np.asarray(tv[:]), tv.units)
-            return dates, np.asarray(ds[var][:], dtype=np.float64)
+            return dates, cast(np.asarray(ds[var][:]))
     except ImportError:
         pass
     from scipy.io import netcdf_file
@@ -46,7 +52,8 @@ def read_qlateral(path, var_t: str = 'time', var: str = 'qlateral'):
         tv = ds.variables[var_t]
         units = tv.units.decode() if isinstance(tv.units, bytes) else tv.units
         dates = _decode_cf_time(tv[:].copy(), units)
-        return dates, np.array(ds.variables[var][:], dtype=np.float64)
+        raw = ds.variables[var][:]
+        return dates, cast(np.array(raw, dtype=raw.dtype.newbyteorder('=')))
 
 
 def _cf_decode(raw: np.ndarray, attrs: dict) -> np.ndarray:

@@ -25,10 +25,32 @@ class RapidMuskingum(TransformMuskingum):
     _engine_router = _router
 
     def _router_device(self, qlateral: np.ndarray, rows_per_output: int) -> tuple[np.ndarray, np.ndarray]:
+        from .._lib import RR_E_UNSUPPORTED, RRError
         from ._device import Arena
-        ql = self._check_lateral(qlateral)
+        ql = self._check_lateral(qlateral, keep_float32=True)
+        if ql.dtype == np.float32:      # a float32 file: uploaded as it is, converted in the pass that fills the engine's records
+            try:
+                with Arena(self.cfg.device) as arena:
+                    return self._route_on_device_f32in(arena, arena.put(ql), ql.shape[0], rows_per_output)
+            except RRError as e:
+                if e.code != RR_E_UNSUPPORTED:
+                    raise
+            ql = ql.astype(np.float64)
         with Arena(self.cfg.device) as arena:
             return self._route_on_device(arena, arena.put(ql), ql.shape[0], rows_per_output)
+
+    def _route_on_device_f32in(self, arena, d_ql32, T: int, rows_per_output: int) -> tuple[np.ndarray, np.ndarray]:
+        """Lateral volumes on the device as (T, n) float32 rows -> (final state, float32 discharge rows): rr_rapid_route_f32in_dev,
+        bit for bit what the float64 rows give (float32 -> float64 is exact)."""
+        from ._device import float32_rows
+        n, nsub = self.A.shape[0], self.num_routing_steps_per_runoff
+        self._lateral_coefficient()
+        d_q = arena.put(np.array(self.channel_state, dtype=np.float64, order='C'))
+        q_array = float32_rows(
+            arena, T, n, rows_per_output,
+            fused=lambda d32: self._plan.rapid_route_f32in_dev(d_q, d_ql32, T, T, nsub, discharge32=d32, factor=rows_per_output),
+            plain=lambda d64: self._plan.rapid_route_f32in_dev(d_q, d_ql32, T, T, nsub, discharge=d64, out_rows=T))
+        return d_q.download(np.float64, (n,)), q_array
 
     def _route_on_device(self, arena, d_ql, T: int, rows_per_output: int) -> tuple[np.ndarray, np.ndarray]:
         """Lateral volumes already on the device, (T, n) float64 rows -> (final state, float32 discharge rows)."""

@@ -25,7 +25,10 @@ class TransformMuskingum(Muskingum, ABC):
             from ..io import read_qlateral
             for lateral_file, discharge_file in zip(self.cfg.qlateral_files, self.cfg.discharge_files):
                 self.logger.info('-' * 60)
-                dates, array = read_qlateral(lateral_file, self.cfg.var_t)
+                # a router that converts on the device takes a float32 file as float32 (RapidMuskingum: rr_rapid_route_f32in_dev)
+                keep32 = self._device_postprocess and hasattr(self, '_route_on_device_f32in') and \
+                    type(self)._router is getattr(type(self), '_engine_router', None)
+                dates, array = read_qlateral(lateral_file, self.cfg.var_t, keep_float32=keep32)
                 yield dates, array, lateral_file, discharge_file
         elif self.cfg.grid_runoff_files and self.cfg.grid_weights_file:
             # gridded runoff -> catchment inflow on the device (TransformMuskingum.py:38-51 -> runoff.runoff_to_qlateral).  A
@@ -181,8 +184,9 @@ class TransformMuskingum(Muskingum, ABC):
     def _router_device(self, qlateral: np.ndarray, rows_per_output: int) -> tuple[np.ndarray, np.ndarray]:
         """(final state float64[n], discharge float32[T / rows_per_output, n]) with the whole file on the device."""
 
-    def _check_lateral(self, qlateral: np.ndarray) -> np.ndarray:
-        ql = np.ascontiguousarray(qlateral, dtype=np.float64)
+    def _check_lateral(self, qlateral: np.ndarray, keep_float32: bool = False) -> np.ndarray:
+        qlateral = np.asarray(qlateral)
+        ql = np.ascontiguousarray(qlateral, dtype=np.float32 if keep_float32 and qlateral.dtype == np.float32 else np.float64)
         if ql.shape != (self.num_runoff_steps, self.A.shape[0]):
             raise ValueError(f'lateral inflow has shape {ql.shape}, expected '
                              f'({self.num_runoff_steps}, {self.A.shape[0]}) from the time options')

@@ -489,3 +489,65 @@ def test_export_reach_with_a_downstream_reach_in_the_plan(monkeypatch, wave):
         assert_close(d_exp.download(np.float64, (T * nsub, exports.size)), series_ref, 'export series')
         for b in (d_q, d_ql, d_out, d_exp):
             b.free()
+
+
+@pytest.mark.parametrize('p_chain,n_outlets,p_third', [(0.999, 3, 0.02), (0.97, 40, 0.3)])
+def test_chain_grown_forests_vs_oracle(monkeypatch, p_chain, n_outlets, p_third):
+    """SURVEY section 8(d)'s generator (synth_network_chain): long in-degree-1 runs, several outlets, in-degree 3 -- the shapes
+    real networks have and the Remy tree does not.  200k reaches more than 10k deep (and a shallow forest with many
+    three-way confluences) through the time-tiled kernel the engine picks by itself, against the oracle."""
+    set_env(monkeypatch, {})
+    n, T = 200_000, 96
+    net = synth.synth_network_chain(n, seed=77, p_chain=p_chain, n_outlets=n_outlets, p_third=p_third)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0)
+    lhs, c4_dt = -c1[indices], (c1 + c2) / 900.0
+    ql = synth.synth_qlateral(n, 0, T)
+    q0 = 2.0 * synth.u01(3, np.arange(n))
+    q_ref, d_ref = q0.copy(), np.zeros((T, n))
+    oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql, d_ref, 1)
+    with Plan(indptr, indices) as plan:
+        if p_chain > 0.99:
+            assert plan.depth > 10_000
+        assert plan.n_outlets == n_outlets
+        plan.set_coeffs(lhs, c2, c3, c4_dt)
+        d_q, d_ql, d_out = DeviceBuffer(n * 8).upload(q0), DeviceBuffer(ql.nbytes).upload(ql), DeviceBuffer(T * n * 8)
+        plan.rapid_route_dev(d_q, d_ql, T, d_out, T, T, 1)
+        prof = plan.profile()
+        assert prof['ticks_per_launch'] > 1, 'the time-tiled kernel was expected'
+        assert_close(d_out.download(np.float64, (T, n)), d_ref, 'discharge')
+        assert_close(d_q.download(np.float64, (n,)), q_ref, 'q_t')
+        for b in (d_q, d_ql, d_out):
+            b.free()
+
+
+@pytest.mark.parametrize('n,T,nsub,factor', [(100_000, 256, 1, 1), (100_000, 256, 1, 4), (50_001, 128, 2, 2)])
+def test_float32_lateral_rows_equal_their_float64_copy(monkeypatch, n, T, nsub, factor):
+    """rr_rapid_route_f32in_dev: float32 lateral rows converted inside the in-pass.  Both output forms, against
+    rr_rapid_route_dev / rr_rapid_route_f32_dev on the float64 copy of the same values: bit for bit."""
+    set_env(monkeypatch, {})
+    net = synth.synth_network(n, seed=41)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0 / nsub)
+    ql32 = synth.synth_qlateral(n, 0, T).astype(np.float32)
+    ql64 = ql32.astype(np.float64)
+    q0 = 2.0 * synth.u01(3, np.arange(n))
+    with Plan(indptr, indices) as plan:
+        plan.set_coeffs(-c1[indices], c2, c3, (c1 + c2) / 900.0)
+        d_ql32, d_ql64 = DeviceBuffer(ql32.nbytes).upload(ql32), DeviceBuffer(ql64.nbytes).upload(ql64)
+        d_q, d_a, d_b = DeviceBuffer(n * 8), DeviceBuffer(T * n * 8), DeviceBuffer(T * n * 8)
+        d_q.upload(q0); plan.rapid_route_dev(d_q, d_ql64, T, d_a, T, T, nsub)
+        qa = d_q.download(np.float64, (n,))
+        d_q.upload(q0); plan.rapid_route_f32in_dev(d_q, d_ql32, T, T, nsub, discharge=d_b, out_rows=T)
+        np.testing.assert_array_equal(d_b.download(np.float64, (T, n)), d_a.download(np.float64, (T, n)))
+        np.testing.assert_array_equal(d_q.download(np.float64, (n,)), qa)
+        d_q.upload(q0); plan.rapid_route_f32_dev(d_q, d_ql64, T, d_a, T, nsub, factor)
+        d_q.upload(q0); plan.rapid_route_f32in_dev(d_q, d_ql32, T, T, nsub, discharge32=d_b, factor=factor)
+        np.testing.assert_array_equal(d_b.download(np.float32, (T // factor, n)), d_a.download(np.float32, (T // factor, n)))
+        # and against the oracle on the float64 copy
+        q_ref, d_ref = q0.copy(), np.zeros((T, n))
+        oracle.rapid_route(indptr, indices, -c1[indices], c2, c3, (c1 + c2) / 900.0, q_ref, ql64, d_ref, nsub)
+        d_q.upload(q0); plan.rapid_route_f32in_dev(d_q, d_ql32, T, T, nsub, discharge=d_b, out_rows=T)
+        assert_close(d_b.download(np.float64, (T, n)), d_ref, 'discharge')
+        for b in (d_ql32, d_ql64, d_q, d_a, d_b):
+            b.free()

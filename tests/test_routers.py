@@ -236,6 +236,39 @@ def test_netcdf_files_end_to_end(backend, case):
     assert rr.RapidMuskingum(str(jcfg), dt_routing=900).cfg.dt_routing == 900   # kwargs override the file
 
 
+def test_float32_qlateral_file_routes_like_its_float64_copy(backend, case):
+    """A qlateral file that stores float32 (half the bytes) is uploaded as float32 and converted on its way into the engine's
+    records (rr_rapid_route_f32in_dev); the discharge equals that of the same values stored as float64, bit for bit."""
+    from scipy.io import netcdf_file
+    g, tmp = case['g'], case['tmp']
+    results = {}
+    for kind in ('f4', 'f8'):
+        files = []
+        for i in range(2):
+            path = str(tmp / f'{kind}_ql{i}.nc')
+            files.append(path)
+            with netcdf_file(path, 'w', version=2) as ds:
+                T, n = g[f'vol{i}'].shape
+                ds.createDimension('time', T)
+                ds.createDimension('river_id', n)
+                tv = ds.createVariable('time', 'f8', ('time',))
+                tv.units = 'seconds since 1970-01-01 00:00:00'
+                tv[:] = g[f'dates{i}'].astype(np.float64)
+                v = ds.createVariable('qlateral', kind, ('time', 'river_id'))
+                v[:] = g[f'vol{i}'].astype(np.float32)      # the same float32-representable values in both files
+        out = []
+        (tmp / kind).mkdir()
+        r = rr.RapidMuskingum(params_file=case['params'], qlateral_files=files, discharge_dir=str(tmp / kind), channel_state_init_file=case['init'],
+                              dt_routing=900, log=False)
+        r.set_write_discharges(lambda dates, q, q_file, routed_file='': out.append(np.array(q)))
+        r.route()
+        results[kind] = (out, r.channel_state.copy())
+    for a, b in zip(results['f4'][0], results['f8'][0]):
+        assert a.dtype == np.float32
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(results['f4'][1], results['f8'][1])
+
+
 # ---------------------------------------------------------------- config / validation behaviour (no compute)
 
 def test_configs_validation(tmp_path):
