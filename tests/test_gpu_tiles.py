@@ -10,7 +10,7 @@ from river_route_amd import synth
 from river_route_amd.engine import DeviceBuffer, Plan, partition_forest, uh_convolve
 
 pytestmark = pytest.mark.gpu
-KNOBS = ('RR_WAVE', 'RR_WAVE_K', 'RR_WAVE_THREADS', 'RR_TILE_BLOCK')
+KNOBS = ('RR_WAVE', 'RR_WAVE_K', 'RR_WAVE_THREADS', 'RR_TILE_BLOCK') + ('RR_REC_STREAM', 'RR_TILE_LEAN')
 
 
 def csc_from_down(down_index):
@@ -550,4 +550,46 @@ def test_float32_lateral_rows_equal_their_float64_copy(monkeypatch, n, T, nsub, 
         d_q.upload(q0); plan.rapid_route_f32in_dev(d_q, d_ql32, T, T, nsub, discharge=d_b, out_rows=T)
         assert_close(d_b.download(np.float64, (T, n)), d_ref, 'discharge')
         for b in (d_ql32, d_ql64, d_q, d_a, d_b):
+            b.free()
+
+
+def _wide_network(n, seed=5, fan=8):
+    """Reach i flows into one of the next `fan` reaches: in-degrees are Poisson-like, several per cent of the reaches have four
+    or more upstream reaches (no synthetic family above has more than three), the last one is the outlet."""
+    rng = np.random.default_rng(seed)
+    down = np.arange(n) + 1 + rng.integers(0, fan, n)
+    down[down >= n] = n - 1
+    down[n - 1] = -1
+    return down.astype(np.int64)
+
+
+@pytest.mark.parametrize('env', [{}, {'RR_REC_STREAM': '1'}, {'RR_TILE_LEAN': '0'}])
+def test_confluences_of_four_and_more_vs_oracle(monkeypatch, env):
+    """The short tick reads three upstream values; a tile that holds a reach with more goes to the companion launch of the
+    general kernel in the same step (TileArgs::tile_filter).  Also: the record passes on the second stream (RR_REC_STREAM=1)
+    and the general kernel alone (RR_TILE_LEAN=0) on the same network."""
+    set_env(monkeypatch, env)
+    n, T = 150_000, 130
+    down = _wide_network(n)
+    indeg = np.bincount(down[down >= 0], minlength=n)
+    assert indeg.max() >= 5 and (indeg >= 4).mean() > 0.005
+    indptr, indices = csc_from_down(down)
+    rng = np.random.default_rng(1)
+    k, x = rng.uniform(900.0, 7200.0, n), rng.uniform(0.05, 0.45, n)
+    c1, c2, c3 = oracle.muskingum_coefficients(k, x, 900.0)
+    lhs, c4_dt = -c1[indices], (c1 + c2) / 900.0
+    ql = synth.synth_qlateral(n, 0, T)
+    q0 = 2.0 * synth.u01(3, np.arange(n))
+    q_ref, d_ref = q0.copy(), np.zeros((T, n))
+    oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql, d_ref, 1)
+    with Plan(indptr, indices) as plan:
+        plan.set_coeffs(lhs, c2, c3, c4_dt)
+        d_q, d_ql, d_out = DeviceBuffer(n * 8).upload(q0), DeviceBuffer(ql.nbytes).upload(ql), DeviceBuffer(T * n * 8)
+        for rep in range(2):      # the second call continues from the first one's state
+            plan.rapid_route_dev(d_q, d_ql, T, d_out, T, T, 1)
+            assert plan.profile()['ticks_per_launch'] > 1
+            assert_close(d_out.download(np.float64, (T, n)), d_ref, f'discharge, call {rep}')
+            assert_close(d_q.download(np.float64, (n,)), q_ref, f'q_t, call {rep}')
+            oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql, d_ref, 1)
+        for b in (d_q, d_ql, d_out):
             b.free()
