@@ -133,6 +133,38 @@ __global__ __launch_bounds__(512) void tile_rw(double *__restrict__ rec, int64_t
     }
 }
 
+// The in-pass without its transpose: a workgroup reads its 143 x 32 tile of rows (18 loads per thread), then writes 8 records
+// per column (8 stores per thread) whose values depend on what it read -- no LDS, no barrier.  SYNC: one __syncthreads between
+// the two halves, as the real kernel has.  What the mix of the two access streams in one workgroup costs by itself.
+template <int SYNC, int NTL>
+__global__ __launch_bounds__(256) void tile_read_rec_write(const double *__restrict__ rows, double *__restrict__ rec, const int32_t *__restrict__ pos,
+                                                           int64_t n, int64_t np, int R)
+{
+    __shared__ double dummy[256];
+    const int tid = threadIdx.x, c = tid % 32, r0 = tid / 32;
+    const int64_t col0 = (int64_t)blockIdx.x * 32;
+    const int64_t i = col0 + c < n ? col0 + c : n - 1;
+    double v[18];
+#pragma unroll
+    for (int q = 0; q < 18; ++q) {
+        const int r = r0 + q * 8 < R ? r0 + q * 8 : R - 1;
+        v[q] = NTL ? __builtin_nontemporal_load(rows + (int64_t)r * n + i) : rows[(int64_t)r * n + i];
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int q = 0; q < 18; ++q) acc += v[q];
+    if (SYNC) { dummy[tid] = acc; __syncthreads(); acc = dummy[tid ^ 1]; }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int piece = it * 256 + tid;
+        const int cc = piece / 64, k = (piece >> 3) % 8, part = piece & 7;
+        const int64_t col = col0 + cc;
+        if (col >= n) continue;
+        const int32_t p = pos[col];
+        *(reinterpret_cast<v2 *>(rec + ((int64_t)k * np + p) * 16) + part) = v2{acc, acc};
+    }
+}
+
 struct Timer {
     hipEvent_t e0, e1;
     Timer() { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); }
@@ -200,6 +232,11 @@ int main(int argc, char **argv)
     ROW("read 128 B records, positions in column order (no scatter)", cb, (rec_read<128, 0><<<(unsigned)((n + 31) / 32), 256>>>(rec, pos_id, n, np, (int)planes, 32, sink)));
     ROW("read 256 B records x 4 per column, random positions", cb, (rec_read<256, 0><<<(unsigned)((n + 31) / 32), 256>>>(rec, pos_rand, n, np, 4, 32, sink)));
     ROW("read 512 B records x 2 per column, random positions", cb, (rec_read<512, 0><<<(unsigned)((n + 31) / 32), 256>>>(rec, pos_rand, n, np, 2, 32, sink)));
+    printf("the in-pass without its transpose: 143 x 32 rows read, 8 records per column written by the same workgroup (2.2 GB per launch):\n");
+    ROW("read then write, no barrier", rb + cb, (tile_read_rec_write<0, 0><<<(unsigned)((n + 31) / 32), 256>>>(rows, rec, pos_rand, n, np, (int)R)));
+    ROW("read then write, one barrier between", rb + cb, (tile_read_rec_write<1, 0><<<(unsigned)((n + 31) / 32), 256>>>(rows, rec, pos_rand, n, np, (int)R)));
+    ROW("non-temporal reads, one barrier", rb + cb, (tile_read_rec_write<1, 1><<<(unsigned)((n + 31) / 32), 256>>>(rows, rec, pos_rand, n, np, (int)R)));
+    ROW("read then write, positions in column order", rb + cb, (tile_read_rec_write<1, 0><<<(unsigned)((n + 31) / 32), 256>>>(rows, rec, pos_id, n, np, (int)R)));
     {
         const int64_t blocks = 32 * np * 128 / 65536;      // the whole record buffer: 4.2 GB at n = 1M
         const double tb = 2.0 * blocks * 65536;
