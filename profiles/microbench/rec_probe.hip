@@ -110,11 +110,12 @@ __global__ __launch_bounds__(256) void tile_write(double *__restrict__ rows, int
 // 64-byte sector, an instruction touches 16 half lines, the next one their other halves.  SHAPE 1: eight lanes per 128-byte
 // record, an instruction touches 8 whole lines.  SHAPE 2: lane-linear (an instruction = 1 KiB contiguous).
 template <int SHAPE, int NT>
-__global__ __launch_bounds__(512) void tile_rw(double *__restrict__ rec, int64_t n_blocks)
+__global__ __launch_bounds__(512) void tile_rw(double *__restrict__ rec, int64_t n_blocks, int64_t out_shift = 0)      // out_shift: write block b + out_shift (not in place)
 {
     const int tid = threadIdx.x, ln = tid & 63, wb = tid - ln;      // wb: first position of the wave inside the tile
     for (int64_t b = blockIdx.x; b < n_blocks; b += gridDim.x) {
         char *base = reinterpret_cast<char *>(rec) + b * 65536;
+        char *obase = reinterpret_cast<char *>(rec) + (b + out_shift) * 65536;
         v2 v[8];
         int off[8];
 #pragma unroll
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(512) void tile_rw(double *__restrict__ rec, int64_t
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             v[j] += 1.0;
-            if (NT) __builtin_nontemporal_store(v[j], reinterpret_cast<v2 *>(base + off[j])); else *reinterpret_cast<v2 *>(base + off[j]) = v[j];
+            if (NT) __builtin_nontemporal_store(v[j], reinterpret_cast<v2 *>(obase + off[j])); else *reinterpret_cast<v2 *>(obase + off[j]) = v[j];
         }
     }
 }
@@ -247,6 +248,10 @@ int main(int argc, char **argv)
         ROW("eight lanes per record, non-temporal", tb, (tile_rw<1, 1><<<512, 512>>>(rec, blocks)));
         ROW("eight lanes per record, 1024 workgroups", tb, (tile_rw<1, 0><<<1024, 512>>>(rec, blocks)));
         ROW("four lanes per sector, 1024 workgroups", tb, (tile_rw<0, 0><<<1024, 512>>>(rec, blocks)));
+        ROW("eight lanes per record, written to the other half of the buffer", tb / 2, (tile_rw<1, 0><<<512, 512>>>(rec, blocks / 2, blocks / 2)));
+        ROW("lane-linear, written to the other half of the buffer", tb / 2, (tile_rw<2, 0><<<512, 512>>>(rec, blocks / 2, blocks / 2)));
+        ROW("lane-linear, one workgroup per 64 KB (not persistent), in place", tb, (tile_rw<2, 0><<<(unsigned)blocks, 512>>>(rec, blocks)));
+        ROW("lane-linear, one workgroup per 64 KB, other half", tb / 2, (tile_rw<2, 0><<<(unsigned)(blocks / 2), 512>>>(rec, blocks / 2, blocks / 2)));
     }
     CK(hipDeviceSynchronize());
     CK(hipGetLastError());
