@@ -49,7 +49,6 @@ struct Session {
     int64_t out_limit = std::numeric_limits<int64_t>::max();   // rows the caller's output ring can take (host pipeline)
     int64_t diag = 0, n_diags = 0, n_macro = 0;
     int64_t ghost_batches = 0;    // batches of the boundary (ghost) series turned into records
-    int64_t batches_per_launch = 1;      // record-pass batches one launch may take (small networks)
     int64_t ghost_slack = 0, export_skew = 0;      // boundary reaches of a partitioned network in the time-tiled schedule (level skew included)
     TileArgs ta{};
     bool bracket_open = false;
@@ -122,7 +121,7 @@ struct rr_plan {
     bool wave_enabled = true, wave_forced = false, wave_now = false, weights_uniform = false;
     int wave_threads = 1024, wave_ppt = 2;
     int64_t wave_K = 0;          // ticks per task (multiple of 16); 0 = chosen per call
-    int64_t next_KC = 1, next_chunks = 0, next_batches = 1;   // prepare_call: task length, record ring and batches per record-pass launch of the call about to start
+    int64_t next_KC = 1, next_chunks = 0;   // prepare_call: task length and record ring of the call about to start
     int64_t kc_cap = int64_t{1} << 20;      // longest task (record chunks) the device had room for; 0: no record ring fits, the plan streams
     TileMeta *d_tmeta = nullptr;     // per tile (rr_kernels_tile.hpp)
     int4 *d_pmeta = nullptr;         // per position {lag | flags, first upstream position, xpos, upstream counts}
@@ -283,7 +282,6 @@ int64_t pick_KC(const rr_plan *P, int64_t total_ticks)
 struct Schedule {
     bool tiled = false;
     int64_t KC = 1, chunks = 0;       // time-tiled: record chunks per task, chunks of the record ring
-    int64_t batches_per_launch = 1;   // time-tiled: batches of 128 tick-rows one launch of a record pass may take
     int64_t ring = 0;                 // doubles of P->d_ring: record ring, or the work rows of the streaming kernel
     int64_t mrows = 0, stage = 0;     // streaming kernel: doubles of the permutation's intermediate rows / of the host staging rows
 };
@@ -298,10 +296,7 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
     if (ok) {
         const int64_t np = P->tp.np, levels = P->tp.n_levels;
         const int64_t all_chunks = kRecBatch * ((total + 14) / kRecRows + 2) + (dmax >> 4) + 2;
-        // room for the in-pass to run ahead of the routing: four batches of 128 tick-rows.  (More room and several batches per
-        // launch of a record pass on small networks -- 100k reaches: a batch is 0.1 GB -- were measured: 44.2 ms per year against
-        // 43.8, the passes run at the rate of the large networks' already.)
-        const int64_t slack = 4;
+        const int64_t slack = 4;      // room for the in-pass to run ahead of the routing: four batches of 128 tick-rows
         ok = false;
         // a part of a cut network that feeds another GPU keeps to 64 ticks: every tile level delays its boundary series by one
         // task, and the GPU downstream waits for it (10M reaches on 8 GPUs: whole job 7.2 against 7.1 x 10^11 reach-steps/s in the
@@ -316,7 +311,6 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
             if (P->dev_total_bytes > 0 && bytes > (int64_t)(P->dev_total_bytes / 16 * (KC == 1 ? 13 : 10))) continue;
             if (KC > 4 && P->wave_K <= 0 && P->dev_total_bytes > 0 && bytes > (int64_t)(P->dev_total_bytes / 5)) continue;      // long tasks only while the ring stays under a fifth of the card
             sch.tiled = true; sch.KC = KC; sch.chunks = chunks; sch.ring = chunks * kRec * np;
-            sch.batches_per_launch = 1;
             ok = true;
             break;
         }
@@ -382,7 +376,7 @@ int prepare_call(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_stre
                                         std::to_string((P->ring_cap + P->mrows_cap + P->stage_cap) * 8) + " reserved): call rr_plan_reserve(plan, mode, " +
                                         std::to_string(T) + ", " + std::to_string(nsub) + ", ...) first; the *_dev entry points only enqueue work");
     }
-    P->wave_now = sch.tiled; P->next_KC = sch.KC; P->next_chunks = sch.chunks; P->next_batches = sch.batches_per_launch;
+    P->wave_now = sch.tiled; P->next_KC = sch.KC; P->next_chunks = sch.chunks;
     return RR_OK;
 }
 
@@ -463,7 +457,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
     if (io.dev_out32 && !S.wave) { S.open = false; return fail(RR_E_UNSUPPORTED, "float32 output needs the time-tiled kernel"); }
 
     int rc = RR_OK;
-    if (S.wave) { S.KC = P->next_KC; S.rec_chunks = P->next_chunks; S.batches_per_launch = P->next_batches; }     // ring sized by choose_schedule, allocated by rr_plan_reserve
+    if (S.wave) { S.KC = P->next_KC; S.rec_chunks = P->next_chunks; }     // ring sized by choose_schedule, allocated by rr_plan_reserve
     S.two = S.wave && P->rec_stream_enabled && P->s_rec != nullptr && !P->pipe_active;
     P->ev_pool_next = 0;      // the previous call's events are all behind its closing join
     if (S.two) { rc = fork_join_caller(P); if (rc) { S.open = false; return rc; } }
@@ -730,7 +724,7 @@ rec_in_uh_t rec_in_uh_kernel(bool sub, int64_t n_ks)
 #undef RR_UHIN_PICK
 }
 
-void launch_rec_permute(rr_plan *P, bool in, int64_t batch, int64_t count = 1)      // batches [batch, batch + count) in one launch (plain passes only)
+void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
 {
     Session &S = P->ses;
     const int64_t n = P->h.n;
@@ -763,7 +757,7 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch, int64_t count = 1)  
     // accesses inside a narrow window of addresses -- so one tile per workgroup is the default (0).
     static const int per_cu = getenv("RR_REC_WGS_PER_CU") ? std::max(0, atoi(getenv("RR_REC_WGS_PER_CU"))) : 0;
     const bool sub = S.nsub > 1;
-    const dim3 gp(per_cu > 0 ? (unsigned)std::min<int64_t>(g.x, (int64_t)P->cu_count * per_cu) : g.x, (unsigned)count);
+    const dim3 gp(per_cu > 0 ? (unsigned)std::min<int64_t>(g.x, (int64_t)P->cu_count * per_cu) : g.x);
     hipStream_t st = rec_stream(P);
     if (in && S.io.runoff) {
         const dim3 gr((unsigned)((n + kRunoffInThreads - 1) / kRunoffInThreads), (unsigned)kRecBatch);
@@ -818,15 +812,9 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
             return must_have_left <= 0 || S.ticks_stored >= std::min(S.total, must_have_left);
         };
         if (S.has_in && S.in_batches < S.n_in_batches && ticks_ready >= std::min(kRecRows * (S.in_batches + 1), S.total) && slot_free(S.in_batches)) {
-            // as many batches as are ready and have room, in one launch: on a small network a batch is a few dozen microseconds
-            // of work, and the ring is given room for several (choose_schedule)
-            int64_t count = 1;
-            const bool plain_pass = !S.io.runoff && !S.io.uh_kernel;
-            while (plain_pass && count < S.batches_per_launch && S.in_batches + count < S.n_in_batches &&
-                   ticks_ready >= std::min(kRecRows * (S.in_batches + count + 1), S.total) && slot_free(S.in_batches + count)) ++count;
-            launch_rec_permute(P, true, S.in_batches, count);
-            for (int64_t k = 0; k < count; ++k) if (S.two) { int rc = fork_record(P, S.ev_in); if (rc) return rc; }
-            S.in_batches += count;
+            launch_rec_permute(P, true, S.in_batches);
+            if (S.two) { int rc = fork_record(P, S.ev_in); if (rc) return rc; }
+            ++S.in_batches;
             progressed = true;
         }
         if (P->n_ghost > 0 && S.ghost_batches < S.n_in_batches && (!S.has_in || S.ghost_batches < S.in_batches) &&      // after the lateral batch: that one writes zeros into the ghosts' records
@@ -868,17 +856,12 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
         if (S.diag >= S.n_diags) done = S.total;
         else if (m_done >= 0) done = std::max<int64_t>(0, (m_done + 1) * K - dmax);
         done = std::min(done, S.total);
-        auto out_ready = [&](int64_t j) {
-            return j < S.n_out_batches && done >= std::min(kRecRows * (j + 1), S.total) && (std::min(kRecRows * (j + 1), S.total) + S.nsub - 1) / S.nsub <= S.out_limit;
-        };
-        while (out_ready(S.out_batches)) {
+        while (S.out_batches < S.n_out_batches && done >= std::min(kRecRows * (S.out_batches + 1), S.total) &&
+               (std::min(kRecRows * (S.out_batches + 1), S.total) + S.nsub - 1) / S.nsub <= S.out_limit) {
             if (S.two && S.diags_marked < S.diag) { int rc = fork_join_caller(P); if (rc) return rc; S.diags_marked = S.diag; }      // the launches that finished these rows
-            int64_t count = 1;
-            // a cyclic output array takes the batches of one launch only while they do not wrap onto each other
-            while (count < S.batches_per_launch && out_ready(S.out_batches + count) && (S.io.dev_out32 || kRecRows * (count + 1) <= S.io.rows_out * S.nsub)) ++count;
-            launch_rec_permute(P, false, S.out_batches, count);
-            for (int64_t k = 0; k < count; ++k) if (S.two) { int rc = fork_record(P, S.ev_out); if (rc) return rc; }
-            S.out_batches += count;
+            launch_rec_permute(P, false, S.out_batches);
+            if (S.two) { int rc = fork_record(P, S.ev_out); if (rc) return rc; }
+            ++S.out_batches;
             S.ticks_stored = std::min(S.total, kRecRows * S.out_batches);
             progressed = true;
         }

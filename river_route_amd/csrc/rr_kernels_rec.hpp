@@ -118,10 +118,8 @@ __device__ __forceinline__ void write_records(const RecPermArgs &a, const double
 // rows alone read in 186 us per 128 rows at 1M reaches, the records alone store in 199 us, the pass takes 419 us either way,
 // within 7 % of the two one after the other (profiles/r03_rec_probe.txt, r03_alias_kernel_times.txt, rr_exec.hpp).
 template <bool SUB, bool IN32 = false>
-__global__ __launch_bounds__(kRecInThreads) void k_rec_in(const RecPermArgs a_first)
+__global__ __launch_bounds__(kRecInThreads) void k_rec_in(const RecPermArgs a)
 {
-    RecPermArgs a = a_first;
-    a.batch += blockIdx.y;      // a launch may take several batches at once (small networks: rr_exec.hpp)
     constexpr int R = kRecTileRows;
     __shared__ double tile[R * (kRecInCols + 1)];
     __shared__ int2 smeta[kRecInCols];
@@ -267,10 +265,8 @@ __global__ __launch_bounds__(kUhInThreads) void k_rec_in_uh(const RecPermArgs a,
 // The same loop as k_rec_in: the records of the workgroup's next column tile (if the grid is persistent) are requested before
 // the rows of the current one are written.
 template <bool SUB, bool OUT32>
-__global__ __launch_bounds__(kRecOutThreads) void k_rec_out(const RecPermArgs a_first)
+__global__ __launch_bounds__(kRecOutThreads) void k_rec_out(const RecPermArgs a)
 {
-    RecPermArgs a = a_first;
-    a.batch += blockIdx.y;
     constexpr int S = 16 * (kRecBatch + 1);
     __shared__ double recs[kRecOutCols][S + 1];
     const int tid = threadIdx.x;
