@@ -593,3 +593,36 @@ def test_confluences_of_four_and_more_vs_oracle(monkeypatch, env):
             oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql, d_ref, 1)
         for b in (d_q, d_ql, d_out):
             b.free()
+
+
+def test_record_ring_goes_round_three_times_vs_oracle(monkeypatch):
+    """6,048 rows over a 200k-reach network: the record ring (depth + levels x K tick-rows, ~2k) is reused three times, the
+    forcing is a 96-row cyclic array and the discharge goes to a 128-row cyclic sink (one out-pass batch, as in bench.py) --
+    against the oracle carried through the same 63 passes over the forcing: the rows left in the sink are the oracle's last
+    128, the state its final state.  (At 1M reaches x 35,040 rows the same wrap-around is compared with the streaming kernel
+    bit for bit, test_full_year_at_1m_time_tiled_equals_streaming; this is the oracle's word on it at a size it finishes in seconds.)"""
+    set_env(monkeypatch, {})
+    n, rows, passes, sink = 200_000, 96, 63, 128
+    T = rows * passes
+    net = synth.synth_network(n, seed=9)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0)
+    lhs, c4_dt = -c1[indices], (c1 + c2) / 900.0
+    ql = synth.synth_qlateral(n, 0, rows)
+    q_ref, d_now, d_before = np.zeros(n), np.zeros((rows, n)), np.zeros((rows, n))
+    for _ in range(passes):
+        d_before, d_now = d_now, d_before
+        oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql, d_now, 1)
+    last = np.concatenate([d_before, d_now])[-sink:]                      # rows T - 128 ... T - 1
+    with Plan(indptr, indices) as plan:
+        plan.set_coeffs(lhs, c2, c3, c4_dt)
+        from river_route_amd.engine import MODE_RAPID
+        sch = plan.reserve(MODE_RAPID, T, 1)
+        assert sch['tiled'] and sch['ring_chunks'] * 16 * 3 < T, sch      # three revolutions
+        d_q, d_ql, d_out = DeviceBuffer(n * 8).upload(np.zeros(n)), DeviceBuffer(ql.nbytes).upload(ql), DeviceBuffer(sink * n * 8)
+        plan.rapid_route_dev(d_q, d_ql, rows, d_out, sink, T, 1)
+        got = d_out.download(np.float64, (sink, n))[(np.arange(T - sink, T) % sink)]      # row t sits at t % 128
+        assert_close(got, last, 'last 128 rows')
+        assert_close(d_q.download(np.float64, (n,)), q_ref, 'final state')
+        for b in (d_q, d_ql, d_out):
+            b.free()
