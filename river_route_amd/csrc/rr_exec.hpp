@@ -151,7 +151,7 @@ struct rr_plan {
     std::vector<hipEvent_t> ev_pool;
     size_t ev_pool_next = 0;
     bool lean_enabled = true;
-    bool rec_stream_enabled = false, pipe_active = false;      // measured: no gain (profiles/r03_rec_stream.txt); RR_REC_STREAM=1 switches it on
+    bool rec_stream_enabled = false, pipe_active = false;      // measured: no gain (395 against 388 ms per year, profiles/r03_nt_and_rec_stream_ab.txt); RR_REC_STREAM=1 switches it on
 
     // profile of the last route call
     std::vector<hipEvent_t> ev;
@@ -384,12 +384,14 @@ bool use_wave(const rr_plan *P, Mode) { return P->wave_now; }
 
 // ---- second stream -------------------------------------------------------------------------------
 // A routing launch (k_tile) ends with a tail in which half of its persistent workgroups have left, and the record passes
-// of the neighbouring batches depend on launches several steps away, not on the one running.  In device-array calls they
-// therefore run on the plan's own stream beside the caller's: the in-pass of a batch as soon as its rows are there and its
+// of the neighbouring batches depend on launches several steps away, not on the one running.  With RR_REC_STREAM=1 (off by
+// default: the passes then slow the routing launch down by what they gain, 395 against 388 ms per year) they run, in
+// device-array calls, on the plan's own stream beside the caller's: the in-pass of a batch as soon as its rows are there and its
 // ring slots are free (up to four batches ahead of the routing), the out-pass once the launch that finishes its rows is
 // done.  Every dependence that stream order used to give is an event:
-//   in-pass / boundary batch j   -> the routing launch that first reads its records waits for it (fork_wait_inputs)
-//   out-pass batch j             -> waits for the last routing launch enqueued before it (fork_mark_routing); a routing
+//   in-pass / boundary batch j   -> the routing launch that first reads its records waits for it (wait_for in
+//                                   session_advance_tile, on the event fork_record left behind the batch)
+//   out-pass batch j             -> waits for the last routing launch enqueued before it (fork_join_caller); a routing
 //                                   launch that rewrites ring slots one revolution on waits for the out-pass that emptied them
 //   in-pass after out-pass       -> same stream
 //   caller's stream              -> the second stream waits for it when a call opens and whenever rows or boundary values

@@ -596,13 +596,13 @@ def test_confluences_of_four_and_more_vs_oracle(monkeypatch, env):
 
 
 def test_record_ring_goes_round_three_times_vs_oracle(monkeypatch):
-    """6,048 rows over a 200k-reach network: the record ring (depth + levels x K tick-rows, ~2k) is reused three times, the
+    """6,720 rows over a 200k-reach network: the record ring (depth + levels x K tick-rows, 2,048 here) is reused three times, the
     forcing is a 96-row cyclic array and the discharge goes to a 128-row cyclic sink (one out-pass batch, as in bench.py) --
-    against the oracle carried through the same 63 passes over the forcing: the rows left in the sink are the oracle's last
+    against the oracle carried through the same 70 passes over the forcing: the rows left in the sink are the oracle's last
     128, the state its final state.  (At 1M reaches x 35,040 rows the same wrap-around is compared with the streaming kernel
     bit for bit, test_full_year_at_1m_time_tiled_equals_streaming; this is the oracle's word on it at a size it finishes in seconds.)"""
     set_env(monkeypatch, {})
-    n, rows, passes, sink = 200_000, 96, 63, 128
+    n, rows, passes, sink = 200_000, 96, 70, 128
     T = rows * passes
     net = synth.synth_network(n, seed=9)
     indptr, indices = csc_from_down(net.down_index)
@@ -626,3 +626,109 @@ def test_record_ring_goes_round_three_times_vs_oracle(monkeypatch):
         assert_close(d_q.download(np.float64, (n,)), q_ref, 'final state')
         for b in (d_q, d_ql, d_out):
             b.free()
+
+
+def _sub_basins(down, lo, hi, want):
+    """`want` disjoint sub-basins (a reach and everything upstream of it) of lo..hi reaches, spread over the index range:
+    (columns ascending, down index within them)."""
+    n = down.size
+    dl, size = down.tolist(), [1] * n
+    for i in range(n):                           # upstream reaches come first (tools.py:103-104)
+        if dl[i] >= 0:
+            size[dl[i]] += size[i]
+    size = np.asarray(size)
+    below = np.where(down >= 0, size[np.maximum(down, 0)], hi + 1)
+    roots = np.flatnonzero((size >= lo) & (size <= hi) & (below > hi))      # the largest such basins: none inside another
+    assert roots.size >= want
+    roots = roots[np.linspace(0, roots.size - 1, want).astype(np.int64)]
+    is_root = np.zeros(n, dtype=bool)
+    is_root[roots] = True
+    jump = np.where(is_root | (down < 0), np.arange(n), down)
+    while True:                                  # pointer doubling: every reach ends at the first chosen root below it, or at its outlet
+        nxt = jump[jump]
+        if np.array_equal(nxt, jump):
+            break
+        jump = nxt
+    cols = np.flatnonzero(is_root[jump])
+    assert cols.size == size[roots].sum()
+    sub_down = np.where(is_root[cols], -1, np.searchsorted(cols, down[cols]))
+    return cols, sub_down
+
+
+def test_full_year_at_1m_sub_basins_vs_oracle(monkeypatch):
+    """BASELINE config 3 at full length against the ORACLE: discharge of a reach depends on its sub-basin only, so the oracle
+    routes four sub-basins (3k-6k reaches each) of the 1M-reach network on their own through all 35,040 steps, and the engine's
+    rows for those columns -- from two calls of 17,520 rows over the whole network (140 GB of discharge rows each, the record
+    ring of 6,000 tick-rows gone round almost three times per call, state carried over, the schedule of the headline: 128 ticks per task) -- must be theirs row
+    by row.  Complements test_full_year_at_1m_time_tiled_equals_streaming, which covers every column but against k_tick."""
+    import torch
+    set_env(monkeypatch, {})
+    n, T, rows, calls = 1_000_000, 35_040, 120, 2      # 146 passes over the forcing per call
+    net = synth.synth_network(n)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0)
+    lhs, c4_dt = -c1[indices], (c1 + c2) / 900.0
+    cols, sub_down = _sub_basins(net.down_index, 3_000, 6_000, 4)
+    s_indptr, s_indices = csc_from_down(sub_down)
+    dev = torch.device('cuda:0')
+    ql = synth.synth_qlateral_torch(n, 0, rows, dev)
+    cols_t = torch.from_numpy(cols).to(dev)
+    ql_sub = ql[:, cols_t].cpu().numpy()
+    s_c1, s_c2, s_c3, s_c4 = c1[cols], np.ascontiguousarray(c2[cols]), np.ascontiguousarray(c3[cols]), np.ascontiguousarray(c4_dt[cols])
+    s_lhs = -s_c1[s_indices]
+    q_ref, d_ref = np.zeros(cols.size), np.zeros((rows, cols.size))
+    Tc = T // calls
+    assert Tc % rows == 0
+    worst = 0.0
+    with Plan(indptr, indices) as plan:
+        plan.set_coeffs(lhs, c2, c3, c4_dt)
+        from river_route_amd.engine import MODE_RAPID
+        sch = plan.reserve(MODE_RAPID, Tc, 1)
+        q = torch.zeros(n, dtype=torch.float64, device=dev)
+        out = torch.empty((Tc, n), dtype=torch.float64, device=dev)
+        for call in range(calls):
+            out.fill_(-1.0)
+            plan.rapid_route_dev(q, ql, rows, out, Tc, Tc, 1, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert plan.profile()['ticks_per_launch'] == 128 and sch['ring_chunks'] * 16 * 2 < Tc, sch
+            kept = out[:, cols_t]                                                 # (17,520, ~18k)
+            for r0 in range(0, Tc, rows):
+                oracle.rapid_route(s_indptr, s_indices, s_lhs, s_c2, s_c3, s_c4, q_ref, ql_sub, d_ref, 1)
+                got = kept[r0:r0 + rows].cpu().numpy()
+                scale = np.abs(d_ref).max()
+                err = np.abs(got - d_ref).max() / scale
+                worst = max(worst, err)
+                assert err <= 1e-10, f'call {call}, rows {r0}..{r0 + rows}: {err:.3e} of the largest discharge'
+            del kept
+        assert_close(q[cols_t].cpu().numpy(), q_ref, 'final state of the sub-basins')
+    print(f'sub-basins: {cols.size} reaches x {T} steps against the oracle, worst difference {worst:.2e} of the largest discharge')
+
+
+def test_constant_forcing_settles_at_the_basin_sums(monkeypatch):
+    """A size-independent property at full size, no oracle involved: under a forcing that does not change, the update
+    q+ = c3 q + c4 ql/dt + c2 A q + c1 A q+ (_numba_kernels.py:68-78) has the fixed point q = A q + ql/dt because
+    1 - c3 = c1 + c2 = c4 (Muskingum.py:174-179): every reach ends at the lateral inflow accumulated over its basin.  One year
+    over 1M reaches (one forcing row read 35,040 times, the ring reused eight times) must have arrived there at EVERY reach,
+    outlet included."""
+    import torch
+    set_env(monkeypatch, {})
+    n, T, sink = 1_000_000, 35_040, 128
+    net = synth.synth_network(n)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0)
+    row = synth.synth_qlateral(n, 0, 1)
+    acc, dl = (row[0] / 900.0).tolist(), net.down_index.tolist()
+    for i in range(n):
+        if dl[i] >= 0:
+            acc[dl[i]] += acc[i]
+    want = np.asarray(acc)
+    dev = torch.device('cuda:0')
+    with Plan(indptr, indices) as plan:
+        plan.set_coeffs(-c1[indices], c2, c3, (c1 + c2) / 900.0)
+        q = torch.zeros(n, dtype=torch.float64, device=dev)
+        out = torch.zeros((sink, n), dtype=torch.float64, device=dev)
+        plan.rapid_route_dev(q, torch.from_numpy(row).to(dev), 1, out, sink, T, 1, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert plan.profile()['ticks_per_launch'] >= 64
+        np.testing.assert_allclose(q.cpu().numpy(), want, rtol=1e-9, err_msg='final state')
+        np.testing.assert_allclose(out.cpu().numpy(), np.broadcast_to(want, (sink, n)), rtol=1e-9, err_msg='last 128 rows')
