@@ -118,8 +118,9 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
                 (void)hipGetLastError();
                 P->wave_enabled = false;
             }
-        for (int v = 0; v < 2; ++v)
-            (void)hipFuncSetAttribute((const void *)rec_in_uh_kernel(v != 0, 64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rec_in_uh_lds_bytes(64));
+        if (const char *e2 = getenv("RR_UH_PAIRS")) P->uh_pairs = atoi(e2) != 0;
+        for (int v = 0; v < 4; ++v)
+            (void)hipFuncSetAttribute((const void *)rec_in_uh_kernel((v & 1) != 0, 64, 1 + (v >> 1)), hipFuncAttributeMaxDynamicSharedMemorySize, (int)rec_in_uh_lds_bytes(64, 1 + (v >> 1)));
         (void)hipGetLastError();
         const rr::HostPlan &H = P->h;
         const int64_t ni = (int64_t)H.inner_pos.size();

@@ -151,6 +151,7 @@ struct rr_plan {
     std::vector<hipEvent_t> ev_pool;
     size_t ev_pool_next = 0;
     bool lean_enabled = true;
+    bool uh_pairs = true;               // the fused convolution takes two record batches per launch where it can (RR_UH_PAIRS=0: measurements / tests)
     bool rec_stream_enabled = false, pipe_active = false;      // measured: no gain (395 against 388 ms per year, profiles/r03_nt_and_rec_stream_ab.txt); RR_REC_STREAM=1 switches it on
 
     // profile of the last route call
@@ -718,15 +719,18 @@ void launch_ghost_permute(rr_plan *P, int64_t batch)
 typedef void (*rec_in_uh_t)(const RecPermArgs, const UhArgs);
 constexpr int kUhFusedMaxTaps = 64;
 int uh_padded_taps(int64_t n_ks) { return n_ks <= 16 ? 16 : (n_ks <= 48 ? 48 : 64); }
-rec_in_uh_t rec_in_uh_kernel(bool sub, int64_t n_ks)
+rec_in_uh_t rec_in_uh_kernel(bool sub, int64_t n_ks, int batches)
 {
     const int nk = uh_padded_taps(n_ks);
-#define RR_UHIN_PICK(NK_) (sub ? (rec_in_uh_t)k_rec_in_uh<true, NK_> : (rec_in_uh_t)k_rec_in_uh<false, NK_>)
+#define RR_UHIN_SUB(NK_, B_) (sub ? (rec_in_uh_t)k_rec_in_uh<true, NK_, B_> : (rec_in_uh_t)k_rec_in_uh<false, NK_, B_>)
+#define RR_UHIN_PICK(NK_) (batches == 2 ? RR_UHIN_SUB(NK_, 2) : RR_UHIN_SUB(NK_, 1))
     return nk == 16 ? RR_UHIN_PICK(16) : (nk == 48 ? RR_UHIN_PICK(48) : RR_UHIN_PICK(64));
 #undef RR_UHIN_PICK
+#undef RR_UHIN_SUB
 }
 
-void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
+// `count` batches from `batch` on: 1, or 2 for the fused convolution when its rows are there (session_advance_tile)
+void launch_rec_permute(rr_plan *P, bool in, int64_t batch, int count = 1)
 {
     Session &S = P->ses;
     const int64_t n = P->h.n;
@@ -767,10 +771,8 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch)
         else hipLaunchKernelGGL(k_rec_in_runoff<double>, gr, dim3(kRunoffInThreads), 0, st, ra, *S.io.runoff);
     } else if (in && S.io.uh_kernel) {
         UhArgs ua{S.io.uh_kernel, S.io.uh_state, (int32_t)S.io.uh_nks};
-        for (int half = 0; half < kRecBatch / kUhBatch; ++half) {      // the fused convolution's windows fit registers for 8 records at a time
-            ra.batch = batch * (kRecBatch / kUhBatch) + half;
-            hipLaunchKernelGGL(rec_in_uh_kernel(sub, S.io.uh_nks), dim3((unsigned)((n + kUhCols - 1) / kUhCols)), dim3(kUhInThreads), rec_in_uh_lds_bytes(uh_padded_taps(S.io.uh_nks)), st, ra, ua);
-        }
+        hipLaunchKernelGGL(rec_in_uh_kernel(sub, S.io.uh_nks, count), dim3((unsigned)((n + kUhCols - 1) / kUhCols)), dim3(uh_threads(count)),
+                           rec_in_uh_lds_bytes(uh_padded_taps(S.io.uh_nks), count), st, ra, ua);
     } else if (in && ra.rows_in32) {
         if (sub) hipLaunchKernelGGL((k_rec_in<true, true>), gp, dim3(kRecInThreads), 0, st, ra);
         else hipLaunchKernelGGL((k_rec_in<false, true>), gp, dim3(kRecInThreads), 0, st, ra);
@@ -814,9 +816,13 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
             return must_have_left <= 0 || S.ticks_stored >= std::min(S.total, must_have_left);
         };
         if (S.has_in && S.in_batches < S.n_in_batches && ticks_ready >= std::min(kRecRows * (S.in_batches + 1), S.total) && slot_free(S.in_batches)) {
-            launch_rec_permute(P, true, S.in_batches);
-            if (S.two) { int rc = fork_record(P, S.ev_in); if (rc) return rc; }
-            ++S.in_batches;
+            // the fused convolution takes the next batch along when that one's rows and ring slots are there too (less to read per value)
+            const int count = (S.io.uh_kernel && !S.io.runoff && P->uh_pairs && S.in_batches + 2 <= S.n_in_batches &&
+                               ticks_ready >= std::min(kRecRows * (S.in_batches + 2), S.total) && slot_free(S.in_batches + 1)) ? 2 : 1;
+            launch_rec_permute(P, true, S.in_batches, count);
+            for (int k = 0; k < count; ++k)
+                if (S.two) { int rc = fork_record(P, S.ev_in); if (rc) return rc; }
+            S.in_batches += count;
             progressed = true;
         }
         if (P->n_ghost > 0 && S.ghost_batches < S.n_in_batches && (!S.has_in || S.ghost_batches < S.in_batches) &&      // after the lateral batch: that one writes zeros into the ghosts' records

@@ -58,8 +58,21 @@ constexpr int32_t kColHeadwater = 1 << 30;      // colmeta[].y: lag | this flag
 constexpr int kRecTileRows = 16 * kRecBatch + 15;      // tick-rows behind one batch of records
 constexpr int kRecTileLd = kRecCols + 1;
 
+// Ring chunk `first + ahead`, first < chunks and ahead = lag / 16 + a record of the batch: the ring is longer than the deepest
+// lag plus two batches (rr_exec.hpp: choose_schedule), so one subtraction wraps it -- the division costs 12 VALU instructions,
+// and the fused convolution is bound by those (profiles/r03_uh_diet.txt).
+__device__ __forceinline__ uint32_t ring_chunk(const Div32 &chunks, uint32_t first, uint32_t ahead)
+{
+#ifdef RR_DEBUG_ALIAS
+    return chunks.mod(first + ahead);      // measurement builds alias the ring to one chunk
+#else
+    const uint32_t c = first + ahead;
+    return c >= chunks.d ? c - chunks.d : c;
+#endif
+}
+
 // Second half of the in-pass: the LDS tile (row = runoff row - row_first, kRecTileLd doubles per row) becomes records.
-// BATCH records per column; a.batch counts launches of BATCH records (the fused convolution works in half batches).
+// BATCH records per column from tick-row kRecRows * a.batch - 15 on (the fused convolution takes two batches at a time).
 // smeta / sscale: the tile's column metadata and scale in LDS (k_rec_in keeps them there: loaded with the rows, no registers
 // held across the stores), or NULL: read from the plan's arrays.
 template <bool SUB, int THREADS = kRecThreads, int BATCH = kRecBatch, bool LDSMETA = false, int COLS = kRecCols>
@@ -84,6 +97,7 @@ __device__ __forceinline__ void write_records(const RecPermArgs &a, const double
             f[it] = (a.scale && i < a.n) ? a.scale[i] : 1.0;
         }
     }
+    const uint32_t chunk_first = a.rec_chunks.mod((uint32_t)kRecBatch * (uint32_t)a.batch);
 #pragma unroll(LDSMETA ? (SUB ? 2 : 4) : IT)
     for (int it = 0; it < IT; ++it) {
         const int piece = it * THREADS + tid;       // (column, record, 16-byte part): 8 consecutive lanes = one record
@@ -94,7 +108,7 @@ __device__ __forceinline__ void write_records(const RecPermArgs &a, const double
         if (p < 0) continue;
         const int32_t lag = m.y & kLagMask;
         const int o = lag & 15;
-        const uint32_t chunk = (uint32_t)BATCH * (uint32_t)a.batch + (uint32_t)(lag >> 4) + k;
+        const uint32_t chunk = ring_chunk(a.rec_chunks, chunk_first, (uint32_t)(lag >> 4) + k);
         const int r = 15 - o + 16 * k + 2 * part;       // tick-row tick_first + r
         double v0, v1;
         if (SUB) {
@@ -106,7 +120,7 @@ __device__ __forceinline__ void write_records(const RecPermArgs &a, const double
         } else {
             v0 = tile[r * (COLS + 1) + c] * scale; v1 = tile[(r + 1) * (COLS + 1) + c] * scale;
         }
-        double2 *dst = reinterpret_cast<double2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.np + p) * kRec) + part;
+        double2 *dst = reinterpret_cast<double2 *>(a.rec + ((int64_t)chunk * a.np + p) * kRec) + part;
         typedef double d2 __attribute__((ext_vector_type(2)));
         st_site<kNtInRec>(reinterpret_cast<d2 *>(dst), d2{v0, v1});
     }
@@ -184,47 +198,74 @@ struct UhArgs {
 #ifndef RR_UH_COLS
 #define RR_UH_COLS 16
 #endif
-// Columns of a tile of the fused convolution: 16 (128-byte row pieces, 32 KB of LDS and 140 registers: three workgroups per
-// CU) against the 32 of the plain passes (63 KB, 180 registers: two): 52.6 against 55.2 ms for BASELINE config 4
-// (profiles/r03_small_networks_and_uh16.txt).
+// Columns of a tile of the fused convolution: 16 (128-byte row pieces) against the 32 of the plain passes: 52.6 against 55.2 ms
+// for BASELINE config 4 (profiles/r03_small_networks_and_uh16.txt).
+// BATCH = batches of kRecBatch records (128 tick-rows) per launch, 1 or 2: the n_ks - 1 depth rows before a tile and the taps
+// are read once per tile, so the pair moves 19.4 B per value where the single batch moves 22.9 (n_ks = 48); a workgroup has
+// 32 threads per record: 16 columns x (2 x records) groups of 9 rows.
 constexpr int kUhCols = RR_UH_COLS, kUhTileLd = kUhCols + 1;
-constexpr int kUhInThreads = 256;       // groups of rows x columns: 9 outputs per thread at 16 columns, windows of 9 + NK - 1 depth values
-constexpr int kUhBatch = 8;             // records per column and launch: two launches per batch of the plain passes (a.batch counts these half batches)
-static_assert(kRecBatch % kUhBatch == 0, "the fused convolution works in whole fractions of a record batch");
-constexpr int kUhTileRows = 16 * kUhBatch + 15;
-constexpr int kUhRowsPerThread = (kUhTileRows + kUhInThreads / kUhCols - 1) / (kUhInThreads / kUhCols);
-constexpr size_t rec_in_uh_lds_bytes(int nk) { return (size_t)((kUhTileRows + nk - 1) + nk) * kUhTileLd * sizeof(double); }
+constexpr int kUhMaxBatches = 2;
+constexpr int uh_threads(int batches) { return 32 * kRecBatch * batches; }
+constexpr int uh_tile_rows(int batches) { return 16 * kRecBatch * batches + 15; }
+constexpr int uh_groups(int batches) { return uh_threads(batches) / kUhCols; }
+constexpr int uh_rows_per_thread(int batches) { return (uh_tile_rows(batches) + uh_groups(batches) - 1) / uh_groups(batches); }
+constexpr int uh_win_rows(int batches) { return uh_groups(batches) * uh_rows_per_thread(batches); }      // rows the windows start in: one more than the tile has
+// depth rows [win_rows + nk - 1] (the last ones are padding: the windows of the threads past the tile's end reach them) | taps [nk]
+constexpr size_t rec_in_uh_lds_bytes(int nk, int batches) { return (size_t)((uh_win_rows(batches) + nk - 1) + nk) * kUhTileLd * sizeof(double); }
 
-template <bool SUB, int NK>
-__global__ __launch_bounds__(kUhInThreads) void k_rec_in_uh(const RecPermArgs a, const UhArgs u)
+// The kernel issues 432 multiply-adds per thread at NK = 48 and used to issue 670 other vector instructions around them: a
+// division per cyclic row and record, clamps and 64-bit compares per LDS access (SQ_INSTS_VALU, profiles/r03_b_sq_counters_*);
+// at 16 lanes per cycle that was 450 of its 770 us.  Now: LDS accesses at compile-time offsets from one address per thread
+// (the tile is padded instead of the indices clamped), the cyclic rows stepped from one division, 32-bit range tests, the
+// carried-in state behind a branch the whole launch takes the same way.
+template <bool SUB, int NK, int BATCHES>
+__global__ __launch_bounds__(uh_threads(BATCHES)) void k_rec_in_uh(const RecPermArgs a, const UhArgs u)
 {
-    constexpr int R = kUhTileRows, G = kUhInThreads / kUhCols, RP = kUhRowsPerThread, W = RP + NK - 1;
+    constexpr int R = uh_tile_rows(BATCHES), G = uh_groups(BATCHES), RP = uh_rows_per_thread(BATCHES);
+    constexpr int ROWS = uh_win_rows(BATCHES) + NK - 1, DATA = R + NK - 1;      // depth rows in LDS / those that hold data
     extern __shared__ __attribute__((aligned(16))) double uh_lds[];
-    double *dt = uh_lds;                                   // [R + NK - 1][kUhTileLd] depth rows row_first - (NK - 1) ...
-    double *tp = uh_lds + (R + NK - 1) * kUhTileLd;       // [NK][kUhTileLd] taps
+    double *dt = uh_lds;                          // [ROWS][kUhTileLd] depth rows row_first - (NK - 1) ...
+    double *tp = uh_lds + ROWS * kUhTileLd;      // [NK][kUhTileLd] taps
     const int tid = threadIdx.x, c = tid % kUhCols, g = tid / kUhCols;
     const int64_t col0 = (int64_t)(a.swizzle ? xcd_swizzle(blockIdx.x, gridDim.x) : blockIdx.x) * kUhCols;
-    const int64_t tick_first = 16 * kUhBatch * a.batch - 15;
+    const int64_t tick_first = kRecRows * a.batch - 15;
     uint32_t sub_unused;
     const int64_t row_first = SUB ? (int64_t)a.nsub.div((uint32_t)(tick_first < 0 ? 0 : tick_first), sub_unused) : tick_first;
     const int need = SUB ? (int)((uint32_t)(R - 1) / a.nsub.d) + 2 : R;
     const int64_t i = min(col0 + c, a.n - 1);
     const bool live = col0 + c < a.n;
-    {   // all loads in flight first (branch-free: out-of-range rows/columns are clamped and zeroed afterwards)
-        constexpr int DPT = (R + NK - 1 + G - 1) / G, TPT = (NK + G - 1) / G;
+    const int32_t tb = (int32_t)row_first - (NK - 1) + g;      // depth row of this thread's first load (negative in a call's first launch); T < 2^31
+    {   // all loads in flight first (branch-free: rows outside the call and columns past the end load something valid and are zeroed afterwards)
+        constexpr int DPT = (ROWS + G - 1) / G, TPT = (NK + G - 1) / G;
         double dv[DPT], tv[TPT];
+        if constexpr (SUB) {
 #pragma unroll
-        for (int q = 0; q < DPT; ++q) {
-            const int64_t t = row_first - (NK - 1) + min(g + q * G, need + NK - 2);
-            dv[q] = ld_site<kNtInRows>(a.rows.row(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t)) + i);
+            for (int q = 0; q < DPT; ++q) {
+                const int64_t t = row_first - (NK - 1) + min(g + q * G, need + NK - 2);
+                dv[q] = ld_site<kNtInRows>(a.rows.row(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t)) + i);
+            }
+        } else {
+            // load q reads the cyclic row (tb + G q - t0) mod rows: one division, for the first q whose row cannot be negative,
+            // and steps of G mod rows either way from there (a row before the call's first steps to some row of the array: loaded, not used)
+            constexpr int QM = (NK - 1 + 15 + G - 1) / G;
+            static_assert(QM < DPT, "the tile is longer than the rows before it");
+            const uint32_t d = a.rows.rows.d, step = a.rows.rows.mod((uint32_t)G);
+            uint32_t m[DPT];
+            m[QM] = a.rows.rows.mod((uint32_t)(tb + G * QM - (int32_t)a.rows.t0));
+#pragma unroll
+            for (int q = QM + 1; q < DPT; ++q) { const uint32_t x = m[q - 1] + step; m[q] = x >= d ? x - d : x; }
+#pragma unroll
+            for (int q = QM - 1; q >= 0; --q) m[q] = m[q + 1] >= step ? m[q + 1] - step : m[q + 1] + d - step;
+#pragma unroll
+            for (int q = 0; q < DPT; ++q) dv[q] = ld_site<kNtInRows>(a.rows.base + ((int64_t)m[q] * a.rows.ld + i));
         }
 #pragma unroll
         for (int q = 0; q < TPT; ++q) tv[q] = u.kernel[(int64_t)min(g + q * G, u.n_ks - 1) * a.n + i];
 #pragma unroll
         for (int q = 0; q < DPT; ++q) {
             const int r = g + q * G;
-            const int64_t t = row_first - (NK - 1) + r;
-            if (r < R + NK - 1) dt[r * kUhTileLd + c] = (live && t >= 0 && t < a.T) ? dv[q] : 0.0;
+            const bool inside = (uint32_t)(tb + q * G) < (uint32_t)a.T;      // 0 <= row < T in one test
+            if (r < ROWS) dt[r * kUhTileLd + c] = (live && inside && r < DATA) ? dv[q] : 0.0;
         }
 #pragma unroll
         for (int q = 0; q < TPT; ++q) {
@@ -234,30 +275,50 @@ __global__ __launch_bounds__(kUhInThreads) void k_rec_in_uh(const RecPermArgs a,
     }
     __syncthreads();
     const int rb = g * RP;      // first output row of this thread
+    const bool mine = !SUB || rb < need;
     double acc[RP];
-    if (rb < need) {
-        double win[W];
+    if (mine) {
+        const double *wp = dt + rb * kUhTileLd + c;       // depth row (row_first + rb + q - (NK - 1)) at wp[q * kUhTileLd]: rb + W - 1 < ROWS
+        if (row_first < (int64_t)u.n_ks) {      // the carried-in state reaches the first n_ks rows of a call: a few launches, all of whose workgroups come here
 #pragma unroll
-        for (int q = 0; q < W; ++q) win[q] = dt[min(rb + q, R + NK - 2) * kUhTileLd + c];      // depth row (row_first + rb + q - (NK - 1))
+            for (int j = 0; j < RP; ++j) {
+                const int64_t t = row_first + rb + j;
+                acc[j] = (live && t >= 0 && t < u.n_ks && t < a.T) ? u.state[t * a.n + i] : 0.0;
+            }
+        } else {
 #pragma unroll
-        for (int j = 0; j < RP; ++j) {
-            const int64_t t = row_first + rb + j;
-            acc[j] = (live && t >= 0 && t < u.n_ks && t < a.T) ? u.state[t * a.n + i] : 0.0;
+            for (int j = 0; j < RP; ++j) acc[j] = 0.0;
         }
+        // Half of the taps in registers at a time and the window streamed past them (each depth value meets the taps it is
+        // multiplied with while it is in one register): 24 taps + 9 sums instead of a 56-value window, 90 registers instead of
+        // 142, five workgroups per CU instead of three.  Every sum still adds its products in the order k = 0, 1, ...
+        const double *kp = tp + c;
+        constexpr int KH = NK / 2;
+        static_assert(NK % 2 == 0, "taps are padded to an even count");
 #pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const double tap = tp[k * kUhTileLd + c];
+        for (int h = 0; h < 2; ++h) {
+            double tap[KH];
 #pragma unroll
-            for (int j = 0; j < RP; ++j) acc[j] = __builtin_fma(tap, win[j + (NK - 1) - k], acc[j]);
+            for (int k = 0; k < KH; ++k) tap[k] = kp[(h * KH + k) * kUhTileLd];
+#pragma unroll
+            for (int w = RP - 1 + NK - 1 - h * KH; w >= NK - 1 - h * KH - (KH - 1); --w) {      // window index j + NK - 1 - k, k ascending for each j
+                const double x = wp[w * kUhTileLd];
+#pragma unroll
+                for (int j = 0; j < RP; ++j) {
+                    const int k = j + NK - 1 - w - h * KH;
+                    if (k >= 0 && k < KH) acc[j] = __builtin_fma(tap[k], x, acc[j]);
+                }
+            }
         }
     }
     __syncthreads();      // every window is in registers: the depth tile's space now takes the outputs
-    if (rb < need) {
+    if (mine) {
+        double *op = dt + rb * kUhTileLd + c;
 #pragma unroll
-        for (int j = 0; j < RP; ++j) if (rb + j < R) dt[(rb + j) * kUhTileLd + c] = acc[j];
+        for (int j = 0; j < RP; ++j) op[j * kUhTileLd] = acc[j];      // rb + j < win_rows: the rows past the tile's end are written and never read
     }
     __syncthreads();
-    write_records<SUB, kUhInThreads, kUhBatch, false, kUhCols>(a, dt, col0, tick_first, row_first);
+    write_records<SUB, uh_threads(BATCHES), kRecBatch * BATCHES, false, kUhCols>(a, dt, col0, tick_first, row_first);
 }
 
 // OUT32: the router's post-processing fused in (TransformMuskingum.py:128-142): mean over `factor` consecutive rows
@@ -276,6 +337,7 @@ __global__ __launch_bounds__(kRecOutThreads) void k_rec_out(const RecPermArgs a)
     auto col_of = [&](uint32_t t) { return (int64_t)(a.swizzle ? xcd_swizzle(t, n_tiles) : t) * kRecOutCols; };
     typedef double d2 __attribute__((ext_vector_type(2)));
     d2 v[IT];
+    const uint32_t chunk_first = a.rec_chunks.mod((uint32_t)kRecBatch * (uint32_t)a.batch);
     auto request = [&](int64_t col0) {      // all record reads in flight; a column past the end reads position 0 and is not written
         int2 meta[IT];
 #pragma unroll
@@ -287,8 +349,8 @@ __global__ __launch_bounds__(kRecOutThreads) void k_rec_out(const RecPermArgs a)
         for (int it = 0; it < IT; ++it) {
             const int piece = it * kRecOutThreads + tid;
             const int k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
-            const uint32_t chunk = (uint32_t)kRecBatch * (uint32_t)a.batch + (uint32_t)((meta[it].y & kLagMask) >> 4) + k;
-            v[it] = ld_site<kNtOutRec>(reinterpret_cast<const d2 *>(a.rec + ((int64_t)a.rec_chunks.mod(chunk) * a.np + meta[it].x) * kRec) + part);
+            const uint32_t chunk = ring_chunk(a.rec_chunks, chunk_first, (uint32_t)((meta[it].y & kLagMask) >> 4) + k);
+            v[it] = ld_site<kNtOutRec>(reinterpret_cast<const d2 *>(a.rec + ((int64_t)chunk * a.np + meta[it].x) * kRec) + part);
         }
     };
     uint32_t t = blockIdx.x;

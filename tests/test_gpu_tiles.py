@@ -10,7 +10,7 @@ from river_route_amd import synth
 from river_route_amd.engine import DeviceBuffer, Plan, partition_forest, uh_convolve
 
 pytestmark = pytest.mark.gpu
-KNOBS = ('RR_WAVE', 'RR_WAVE_K', 'RR_WAVE_THREADS', 'RR_TILE_BLOCK') + ('RR_REC_STREAM', 'RR_TILE_LEAN')
+KNOBS = ('RR_WAVE', 'RR_WAVE_K', 'RR_WAVE_THREADS', 'RR_TILE_BLOCK') + ('RR_REC_STREAM', 'RR_TILE_LEAN', 'RR_UH_PAIRS')
 
 
 def csc_from_down(down_index):
@@ -320,14 +320,16 @@ def test_float32_output_fused_into_the_record_pass(monkeypatch, n, T, nsub, fact
             b.free()
 
 
-@pytest.mark.parametrize('n,T,nsub,n_ks', [(60_000, 200, 1, 48), (300_000, 150, 1, 48), (60_000, 70, 3, 12), (60_000, 40, 1, 60),
-                                           (60_000, 33, 1, 1),
-                                           (1_000_000, 80, 1, 48)])      # BASELINE config 4's shape: the kernel bench.py times, k_rec_in_uh<false, 48>
-def test_unit_route_with_fused_convolution_vs_oracle(monkeypatch, n, T, nsub, n_ks):
+@pytest.mark.parametrize('n,T,nsub,n_ks,env', [(60_000, 200, 1, 48, {}), (300_000, 150, 1, 48, {}), (60_000, 70, 3, 12, {}), (60_000, 40, 1, 60, {}),
+                                               (60_000, 33, 1, 1, {}),
+                                               (60_000, 400, 1, 48, {}), (60_000, 330, 1, 16, {}), (60_000, 130, 2, 60, {}),      # two pairs of record batches; a pair and a single one; sub-steps
+                                               (60_000, 400, 1, 48, {'RR_UH_PAIRS': '0'}), (60_000, 130, 2, 60, {'RR_UH_PAIRS': '0'}),      # one batch per launch
+                                               (1_000_000, 200, 1, 48, {})])      # BASELINE config 4's shape: the kernel bench.py times, k_rec_in_uh<false, 48, 2>
+def test_unit_route_with_fused_convolution_vs_oracle(monkeypatch, n, T, nsub, n_ks, env):
     """rr_unit_route_uh_dev: UnitHydrograph.convolve + unit_route + the router's state bookkeeping
     (river_route/routers/UnitMuskingum.py:72-98) in one call, the convolved lateral never written as rows; two files, so
     the UH carry-over state (including T < n_ks leftovers) and the channel state both cross a file boundary."""
-    set_env(monkeypatch, {})
+    set_env(monkeypatch, env)
     net = synth.synth_network(n, seed=23)
     indptr, indices = csc_from_down(net.down_index)
     hw_idx, inner_idx, A_in, A_hw = unit_split(indptr, indices, n)
