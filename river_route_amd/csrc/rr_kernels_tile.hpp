@@ -109,6 +109,14 @@ constexpr size_t tile_lds_bytes(int threads)
     return (size_t)(2 * ((int64_t)threads + kTilePad) + (threads / 64) * kStageLanes * kStageStride) * sizeof(double);
 }
 
+// A record leaves in two 64-byte sectors (store_half).  Stored as soon as its eight ticks are done, the first sector's line is
+// often written back before the second arrives and the memory system moves more than the record: WRITE_SIZE 649 MB per launch
+// against 620 with both sectors stored after the sixteenth tick, k_tile 428.6 -> 414.9 us (profiles/r03_tile_store_whole.txt).
+#ifndef RR_TILE_HALF_STORES
+#define RR_TILE_HALF_STORES 0      // 1: the first sector after eight ticks (rounds 1-3; measurements)
+#endif
+constexpr bool kHalfStores = RR_TILE_HALF_STORES != 0;
+
 // One task: KC record chunks of one tile, one position per thread.  R[16] is the record the ticks work on, in place
 // (lateral in, discharge out); N[16] receives the NEXT chunk's record while the 16 ticks of this one run, so inside a task
 // HBM traffic and tick arithmetic overlap and only the first chunk's load is exposed.  Whole 128-byte records are
@@ -407,23 +415,24 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                 const __amdgpu_buffer_rsrc_t src = (!last || has_next) ? rec_next : make_rsrc(a.rec, 0u);
                 if (kind == 1) {
                     ticks_plain(std::false_type(), tau0, 0, src, nvoff);
-                    store_half(rec_cur, 0);
+                    if (kHalfStores) store_half(rec_cur, 0);
                     ticks_plain(std::false_type(), tau0, 1, src, nvoff);
                 } else {
                     lagm = lg < 0 ? 0x40000000 : (fresh(lg) & kLagMask);      // a slot past the end of the tile is never active
                     ticks_plain(std::true_type(), tau0, 0, src, nvoff);
                     if (kind & kTileExports) store_exports(tau0, 0);
-                    store_half(rec_cur, 0);
+                    if (kHalfStores) store_half(rec_cur, 0);
                     ticks_plain(std::true_type(), tau0, 1, src, nvoff);
                     if (kind & kTileExports) store_exports(tau0, 1);
                 }
             } else {
                 ticks(tau0, 0, rec_next, nb0, nb1, !last || has_next);
                 if (cc == 0) RR_TRACE(3);
-                store_half(rec_cur, 0);
+                if (kHalfStores) store_half(rec_cur, 0);
                 ticks(tau0, 1, rec_next, nb0, nb1, false);
                 if (cc == 0) RR_TRACE(6);
             }
+            if (!kHalfStores) store_half(rec_cur, 0);
             store_half(rec_cur, 1);
             if (cc == 0) RR_TRACE(7);
             // the next tile's state: small, and only the wait for it is exposed between two tiles.  LEAN asks for it after the
