@@ -324,6 +324,7 @@ def test_float32_output_fused_into_the_record_pass(monkeypatch, n, T, nsub, fact
                                                (60_000, 33, 1, 1, {}),
                                                (60_000, 400, 1, 48, {}), (60_000, 330, 1, 16, {}), (60_000, 130, 2, 60, {}),      # two pairs of record batches; a pair and a single one; sub-steps
                                                (60_000, 400, 1, 48, {'RR_UH_PAIRS': '0'}), (60_000, 130, 2, 60, {'RR_UH_PAIRS': '0'}),      # one batch per launch
+                                               (60_007, 300, 1, 33, {}), (40_003, 100, 1, 5, {}),      # a last column tile of 7 and of 3 columns
                                                (1_000_000, 200, 1, 48, {})])      # BASELINE config 4's shape: the kernel bench.py times, k_rec_in_uh<false, 48, 2>
 def test_unit_route_with_fused_convolution_vs_oracle(monkeypatch, n, T, nsub, n_ks, env):
     """rr_unit_route_uh_dev: UnitHydrograph.convolve + unit_route + the router's state bookkeeping
