@@ -97,6 +97,11 @@ constexpr int kRec = 16;
 // record: a quarter of the requests.
 constexpr int kStageStride = 10;   // doubles per position in the staging area: 64 bytes + 16 of padding (bank spread, skip flag)
 constexpr int kStageLanes = 32;    // positions transposed at a time: half a wave (2.5 KiB of staging per wave)
+#ifndef RR_TILE_LINE_STORES
+#define RR_TILE_LINE_STORES 1      // 1: a record leaves as one 128-byte line per eight lanes (store_record); 0: as two 64-byte sectors (store_half)
+#endif
+constexpr bool kLineStores = RR_TILE_LINE_STORES != 0;
+constexpr int kStageStrideOut = kLineStores ? 18 : kStageStride;   // store_record parks whole records: 128 bytes + 16 of padding and flags
 // Lanes of one wave exchange data through its staging area without a workgroup barrier: a wave's LDS instructions
 // execute in order.  The compiler still has to be told that other lanes wrote (it would reuse earlier reads).
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -106,7 +111,7 @@ __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmc
 constexpr int kTilePad = 2;
 constexpr size_t tile_lds_bytes(int threads)
 {
-    return (size_t)(2 * ((int64_t)threads + kTilePad) + (threads / 64) * kStageLanes * kStageStride) * sizeof(double);
+    return (size_t)(2 * ((int64_t)threads + kTilePad) + (threads / 64) * kStageLanes * kStageStrideOut) * sizeof(double);
 }
 
 // A record leaves in two 64-byte sectors (store_half).  Stored as soon as its eight ticks are done, the first sector's line is
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
     constexpr int THP = TH + kTilePad;      // doubles per discharge buffer
     // this wave's transpose area and the lane number, rebuilt from the thread index wherever they are used: kept in registers
     // across a task the allocator spills them, and the reload waits for every record load in flight
-    auto stage_of = [&](int32_t t) { return lds + 2 * THP + (size_t)(t >> 6) * (kStageLanes * kStageStride); };
+    auto stage_of = [&](int32_t t) { return lds + 2 * THP + (size_t)(t >> 6) * (kStageLanes * kStageStrideOut); };
     if (tid < 2) lds[tid * THP + TH] = 0.0;      // the zero slots; nothing else ever writes them (first barrier: before the first tick)
     auto ring = [&](int32_t chunk) { return make_rsrc(a.rec + (int64_t)a.rec_chunks.mod((uint32_t)chunk) * a.np * kRec, (uint32_t)a.np * 128u); };   // np < 2^25
 
@@ -277,6 +282,39 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                     if (!SUB) {     // the same sector into the record of the ghost that mirrors the reach (always issued, see store_f64)
                         const int32_t gx = reinterpret_cast<const int32_t *>(theirs + 4)[1];
                         store_f64x2(dst, gx < 0 ? kDropAccess : (uint32_t)gx * 128u + (uint32_t)half * 64u + (uint32_t)piece * 16u, v);
+                    }
+                }
+                wave_lds_fence();
+            }
+        };
+        // The whole record at once: half a wave parks its 32 records, then all 64 lanes store them, eight lanes per 128-byte
+        // line -- both sectors of a line in one instruction, so no line is ever written back half filled.
+        auto store_record = [&](__amdgpu_buffer_rsrc_t dst) {
+            const int32_t tl = fresh(tid), lane = tl & 63;
+            double *stage = stage_of(tl);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (lane / kStageLanes == h) {
+                    double2 *mine = reinterpret_cast<double2 *>(stage + (lane % kStageLanes) * kStageStrideOut);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) mine[j] = make_double2(R[2 * j], R[2 * j + 1]);
+                    int32_t *word = reinterpret_cast<int32_t *>(mine + 8);
+                    word[0] = (lg < 0 || (lg & (kGhostBit | kTileGhostBit))) ? 1 : 0;   // not this tile's to write
+                    if (!SUB) word[1] = (lg >= 0 && (lg & kTileExportBit)) ? fresh(xp) : -1;      // position of the ghost that mirrors this reach
+                }
+                wave_lds_fence();
+                const int32_t t = fresh(tid), ln = t & 63;
+                const uint32_t first = (uint32_t)(b0 + (t - ln) + h * kStageLanes) * 128u;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {       // lanes 8i .. 8i+7: the eight 16-byte pieces of position 8 g + i
+                    const int pm = 8 * g + (ln >> 3), piece = ln & 7;
+                    const double2 *theirs = reinterpret_cast<const double2 *>(stage + pm * kStageStrideOut);
+                    const double2 v = theirs[piece];
+                    const bool skip = reinterpret_cast<const int32_t *>(theirs + 8)[0] != 0;
+                    store_f64x2(dst, skip ? kDropAccess : first + (uint32_t)pm * 128u + (uint32_t)piece * 16u, v);
+                    if (!SUB) {     // the same line into the record of the ghost that mirrors the reach (always issued, see store_f64)
+                        const int32_t gx = reinterpret_cast<const int32_t *>(theirs + 8)[1];
+                        store_f64x2(dst, gx < 0 ? kDropAccess : (uint32_t)gx * 128u + (uint32_t)piece * 16u, v);
                     }
                 }
                 wave_lds_fence();
@@ -432,8 +470,9 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                 ticks(tau0, 1, rec_next, nb0, nb1, false);
                 if (cc == 0) RR_TRACE(6);
             }
-            if (!kHalfStores) store_half(rec_cur, 0);
-            store_half(rec_cur, 1);
+            if (!kHalfStores && !kLineStores) store_half(rec_cur, 0);
+            if (!kHalfStores && kLineStores) store_record(rec_cur);
+            else store_half(rec_cur, 1);
             if (cc == 0) RR_TRACE(7);
             // the next tile's state: small, and only the wait for it is exposed between two tiles.  LEAN asks for it after the
             // chunk loop: requested inside, its thirteen registers are live across every chunk beside both record buffers, and
