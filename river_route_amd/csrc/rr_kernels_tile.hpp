@@ -101,7 +101,11 @@ constexpr int kStageLanes = 32;    // positions transposed at a time: half a wav
 #define RR_TILE_LINE_STORES 1      // 1: a record leaves as one 128-byte line per eight lanes (store_record); 0: as two 64-byte sectors (store_half)
 #endif
 constexpr bool kLineStores = RR_TILE_LINE_STORES != 0;
-constexpr int kStageStrideOut = kLineStores ? 18 : kStageStride;   // store_record parks whole records: 128 bytes + 16 of padding and flags
+#ifndef RR_TILE_LINE_LOADS
+#define RR_TILE_LINE_LOADS 1       // 1: a record arrives as one 128-byte line per eight lanes; 0: as two 64-byte sectors per four lanes, requested one tick apart
+#endif
+constexpr bool kLineLoads = RR_TILE_LINE_LOADS != 0;
+constexpr int kStageStrideOut = (kLineStores || kLineLoads) ? 18 : kStageStride;   // whole records parked: 128 bytes + 16 of padding and flags
 // Lanes of one wave exchange data through its staging area without a workgroup barrier: a wave's LDS instructions
 // execute in order.  The compiler still has to be told that other lanes wrote (it would reuse earlier reads).
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -181,6 +185,11 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
     // sectors of a 128-byte line are requested by consecutive loads
     auto issue_load = [&](__amdgpu_buffer_rsrc_t src, int32_t b0, int32_t b1, int j, bool real) {
         const int32_t t = fresh(tid), ln = t & 63;      // addresses are rebuilt at every use, not kept in registers across the task
+        if (kLineLoads) {      // load j: positions 8 j ... 8 j + 7 of the wave, eight lanes per 128-byte record
+            const int32_t pos = min(b0 + (t - ln) + 8 * j + (ln >> 3), b1 - 1);
+            load_f64x2(src, real ? (uint32_t)pos * 128u + (uint32_t)((ln & 7) * 16) : kDropAccess, N[2 * j], N[2 * j + 1]);
+            return;
+        }
         const int i = j >> 1, half = j & 1;
         const int32_t pos = min(b0 + (t - ln) + (i >> 1) * kStageLanes + 16 * (i & 1) + (ln >> 2), b1 - 1);
         load_f64x2(src, real ? (uint32_t)pos * 128u + (uint32_t)(half * 64 + (ln & 3) * 16) : kDropAccess,
@@ -189,6 +198,23 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
     auto receive = [&]() {
         const int32_t tl = fresh(tid), lane = tl & 63;
         double *stage = stage_of(tl);
+        if (kLineLoads) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {      // the records of half a wave at a time: loads 4 h ... 4 h + 3
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    reinterpret_cast<double2 *>(stage + (8 * g + (lane >> 3)) * kStageStrideOut)[lane & 7] =
+                        make_double2(N[2 * (4 * h + g)], N[2 * (4 * h + g) + 1]);
+                wave_lds_fence();
+                if (lane / kStageLanes == h) {
+                    const double2 *src = reinterpret_cast<const double2 *>(stage + (lane % kStageLanes) * kStageStrideOut);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const double2 v = src[j]; R[2 * j] = v.x; R[2 * j + 1] = v.y; }
+                }
+                wave_lds_fence();
+            }
+            return;
+        }
 #pragma unroll
         for (int half = 0; half < 2; ++half)
 #pragma unroll
@@ -400,10 +426,11 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
         // record loads of the short path: one address register per chunk, the piece of load j is an immediate / scalar offset
         auto issue_load_plain = [&](__amdgpu_buffer_rsrc_t src, int32_t voff, int j) {
             const int i = j >> 1, half = j & 1;
-            const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(src, voff, ((i >> 1) * kStageLanes + 16 * (i & 1)) * 128 + half * 64, (RR_NT_MASK & kNtTileLoad) ? 2 : 0);
+            const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(src, voff, kLineLoads ? j * 1024 : ((i >> 1) * kStageLanes + 16 * (i & 1)) * 128 + half * 64, (RR_NT_MASK & kNtTileLoad) ? 2 : 0);
             double2 v;
             __builtin_memcpy(&v, &bits, sizeof v);
-            N[8 * half + 2 * i] = v.x; N[8 * half + 2 * i + 1] = v.y;
+            if (kLineLoads) { N[2 * j] = v.x; N[2 * j + 1] = v.y; }
+            else { N[8 * half + 2 * i] = v.x; N[8 * half + 2 * i + 1] = v.y; }
         };
         auto ticks_plain = [&](auto tested, int32_t tau0, int half, __amdgpu_buffer_rsrc_t rec_next, int32_t nvoff) {
 #pragma unroll
@@ -449,7 +476,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                 const int32_t t = fresh(tid), ln = t & 63, upk = fresh(up);
                 const int32_t cnt = (int32_t)((uint32_t)upk >> 16), u0s = upk & 0xFFFF;
                 own_b = t * 8; up0_b = (cnt >= 1 ? u0s : TH) * 8; up1_b = (cnt >= 2 ? u0s + 1 : TH) * 8; up2_b = (cnt >= 3 ? u0s + 2 : TH) * 8;
-                const int32_t nvoff = (nb0 + (t - ln) + (ln >> 2)) * 128 + (ln & 3) * 16;
+                const int32_t nvoff = kLineLoads ? (nb0 + (t - ln) + (ln >> 3)) * 128 + (ln & 7) * 16 : (nb0 + (t - ln) + (ln >> 2)) * 128 + (ln & 3) * 16;
                 const __amdgpu_buffer_rsrc_t src = (!last || has_next) ? rec_next : make_rsrc(a.rec, 0u);
                 if (kind == 1) {
                     ticks_plain(std::false_type(), tau0, 0, src, nvoff);
