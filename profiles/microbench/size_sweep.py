@@ -4,7 +4,7 @@ import json, subprocess, sys, time
 import numpy as np
 sys.path.insert(0, '.')
 for n, T in ((100_000, 35040), (250_000, 35040), (500_000, 35040), (1_000_000, 35040), (2_000_000, 17520), (4_000_000, 8760)):
-    out = subprocess.run([sys.executable, 'bench.py', '--reaches', str(n), '--runoff-steps', str(T), '--steps', '2', '--warmup', '1', '--no-cpu-baseline'],
+    out = subprocess.run([sys.executable, 'bench.py', '--reaches', str(n), '--runoff-steps', str(T), '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-secondary'],
                          capture_output=True, text=True, env={**__import__('os').environ, 'RR_VERBOSE': '1'})
     line = [l for l in out.stdout.splitlines() if l.startswith('{')]
     rr = [l for l in out.stderr.splitlines() if l.startswith('rr:')]
