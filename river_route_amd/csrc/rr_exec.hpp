@@ -677,8 +677,8 @@ int session_launch_diag(rr_plan *P, int64_t d)
     TileArgs &w = S.ta;
     w.diag = (int32_t)d; w.t_first = (int32_t)t_lo; w.t_last = (int32_t)t_hi - 1;
     // every fourth launch is bracketed by HIP events, full or not (fill and drain launches run fewer tiles), so the
-    // sampled average is the average rocprofv3 reports for the kernel; the reach-ticks of a sample are those of the
-    // tiles it launched
+    // sampled average is the average rocprofv3 reports for the kernel; the position-ticks of a sample are those of the
+    // tiles that run a task in it
     const bool sample = S.max_samples > 0 && (P->prof_launches % 4) == 0 && (size_t)P->prof_brackets < S.max_samples;
     if (sample) HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets], S.stream));
     // one workgroup per resident slot (16 waves per CU); each walks its share of the launch's tiles
@@ -695,7 +695,15 @@ int session_launch_diag(rr_plan *P, int64_t d)
     }
     if (sample) {
         HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));
-        P->ev_reaches.push_back((int64_t)(TP.tile_ptr[t_hi] - TP.tile_ptr[t_lo]) * K);
+        // position-ticks of the sample: the tiles that run a task in this launch (k_tile's select(): the macro-chunk exists and
+        // some position is active in it); a tile that returns at once moves nothing -- in a short call most of a launch's tiles
+        int64_t moved = 0;
+        for (int64_t c = t_lo; c < t_hi; ++c) {
+            const int64_t m = d - TP.tile_level[c];
+            if (m < 0 || m >= S.n_macro || m * K >= TP.tile_lag_hi[c] + S.total || (m + 1) * K <= TP.tile_lag_lo[c]) continue;
+            moved += TP.tile_ptr[c + 1] - TP.tile_ptr[c];
+        }
+        P->ev_reaches.push_back(moved * K);
         P->prof_samples += K;
         ++P->prof_brackets;
     }

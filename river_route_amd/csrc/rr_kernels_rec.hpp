@@ -36,6 +36,16 @@ constexpr int kRecInThreads = RR_REC_IN_THREADS, kRecOutThreads = RR_REC_OUT_THR
 #ifndef RR_REC_OUT_COLS
 #define RR_REC_OUT_COLS RR_REC_COLS
 #endif
+#ifndef RR_REC_PERSISTENT
+#define RR_REC_PERSISTENT 1      // 1: k_rec_in / k_rec_out loop over column tiles (RR_REC_WGS_PER_CU > 0 then launches a persistent grid); 0: one tile per workgroup only
+#endif
+constexpr bool kRecPersistent = RR_REC_PERSISTENT != 0;
+#ifndef RR_REC_IN_MIN_WGS
+#define RR_REC_IN_MIN_WGS 1      // workgroups per CU the register allocation of k_rec_in / k_rec_out leaves room for (measurements)
+#endif
+#ifndef RR_REC_OUT_MIN_WGS
+#define RR_REC_OUT_MIN_WGS 1
+#endif
 constexpr int kRecInCols = RR_REC_IN_COLS, kRecOutCols = RR_REC_OUT_COLS;      // columns of a tile of k_rec_in / k_rec_out
 constexpr int kRecRows = 16 * kRecBatch;    // tick-rows of one batch
 
@@ -132,7 +142,7 @@ __device__ __forceinline__ void write_records(const RecPermArgs &a, const double
 // rows alone read in 186 us per 128 rows at 1M reaches, the records alone store in 199 us, the pass takes 419 us either way,
 // within 7 % of the two one after the other (profiles/r03_rec_probe.txt, r03_alias_kernel_times.txt, rr_exec.hpp).
 template <bool SUB, bool IN32 = false>
-__global__ __launch_bounds__(kRecInThreads) void k_rec_in(const RecPermArgs a)
+__global__ __launch_bounds__(kRecInThreads, RR_REC_IN_MIN_WGS) void k_rec_in(const RecPermArgs a)
 {
     constexpr int R = kRecTileRows;
     __shared__ double tile[R * (kRecInCols + 1)];
@@ -166,6 +176,19 @@ __global__ __launch_bounds__(kRecInThreads) void k_rec_in(const RecPermArgs a)
     uint32_t t = blockIdx.x;
     if (t >= n_tiles) return;
     request(col_of(t));
+    if constexpr (!kRecPersistent) {      // one tile per workgroup: the loads' registers are free before the records are written
+        const int64_t col0 = col_of(t);
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int r = r0 + q * (kRecInThreads / kRecInCols);
+            const int64_t row = row_first + r;
+            if (r < R) tile[r * (kRecInCols + 1) + c] = (row >= 0 && row < a.T && col0 + c < a.n) ? v[q] : 0.0;
+        }
+        if (tid < kRecInCols) { smeta[c] = cm; sscale[c] = cs; }
+        __syncthreads();
+        write_records<SUB, kRecInThreads, kRecBatch, true, kRecInCols>(a, tile, col0, tick_first, row_first, smeta, sscale);
+        return;
+    }
     for (;;) {
         const int64_t col0 = col_of(t);
 #pragma unroll
@@ -326,7 +349,7 @@ __global__ __launch_bounds__(uh_threads(BATCHES)) void k_rec_in_uh(const RecPerm
 // The same loop as k_rec_in: the records of the workgroup's next column tile (if the grid is persistent) are requested before
 // the rows of the current one are written.
 template <bool SUB, bool OUT32>
-__global__ __launch_bounds__(kRecOutThreads) void k_rec_out(const RecPermArgs a)
+__global__ __launch_bounds__(kRecOutThreads, RR_REC_OUT_MIN_WGS) void k_rec_out(const RecPermArgs a)
 {
     constexpr int S = 16 * (kRecBatch + 1);
     __shared__ double recs[kRecOutCols][S + 1];
@@ -367,7 +390,7 @@ __global__ __launch_bounds__(kRecOutThreads) void k_rec_out(const RecPermArgs a)
             recs[c][16 * k + 2 * part + 1] = v[it].y;
         }
         __syncthreads();
-        const uint32_t next = t + gridDim.x;
+        const uint32_t next = kRecPersistent ? t + gridDim.x : n_tiles;      // one tile per workgroup: the loop below ends after it
         if (next < n_tiles) request(col_of(next));      // in flight while this tile's rows are written
         const int c = tid % kRecOutCols;
         const int64_t i = col0 + c;
