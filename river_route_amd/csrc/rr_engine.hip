@@ -45,7 +45,7 @@ void rr_plan_destroy(rr_plan *P)
     if (!P) return;
     if (P->device >= 0 && hipSetDevice(P->device) == hipSuccess) {
         void *ptrs[] = {P->d_child_ptr, P->d_lag, P->d_perm, P->d_inv, P->d_inner_pos, P->d_bidx, P->d_hwc, P->d_w, P->d_c1row_h, P->d_c2,
-                        P->d_coef, P->d_sq, P->d_ss, P->d_si, P->d_sqch, P->d_full, P->d_chan,
+                        P->d_coef, P->d_coef_unit, P->d_sq, P->d_ss, P->d_si, P->d_sqch, P->d_full, P->d_chan,
                         P->d_tmeta, P->d_pmeta,
                         P->d_tperm, P->d_tinv, P->d_inner_idx, P->d_colmeta, P->d_ghostmeta, P->d_c4_params,
                         P->d_c3, P->d_c4, P->d_x, P->d_isum, P->d_qch, P->d_a2, P->d_c1own, P->d_z, P->d_ring, P->d_stage, P->d_mrows,
@@ -112,8 +112,8 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         if (const char *e2 = getenv("RR_REC_STREAM")) P->rec_stream_enabled = atoi(e2) != 0;      // measurements: record passes on a second stream
         if (P->rec_stream_enabled && hipStreamCreateWithFlags(&P->s_rec, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); P->s_rec = nullptr; }
         if (const char *e2 = getenv("RR_TILE_LEAN")) P->lean_enabled = atoi(e2) != 0;      // measurements / tests: the general tick for every call
-        for (int v = 0; v < 5; ++v)    // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
-            if (hipFuncSetAttribute((const void *)tile_kernel(P->wave_threads, (v & 1) != 0, (v & 2) != 0, v == 4), hipFuncAttributeMaxDynamicSharedMemorySize,
+        for (int v = 0; v < 6; ++v)    // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel (v = 4, 5: the short ticks of Rapid and Unit)
+            if (hipFuncSetAttribute((const void *)tile_kernel(P->wave_threads, v < 4 ? (v & 1) != 0 : v == 5, v < 4 && (v & 2) != 0, v >= 4), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)tile_lds_bytes(P->wave_threads)) != hipSuccess) {
                 (void)hipGetLastError();
                 P->wave_enabled = false;
@@ -152,6 +152,7 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
             if (!rc) rc = dev_alloc(&P->d_tinv, n);
             if (!rc) rc = dev_upload(P->d_tinv, TP.inv);
             if (!rc) rc = dev_alloc(&P->d_coef, 3 * np);
+            if (!rc) rc = dev_alloc(&P->d_coef_unit, 3 * np);
             if (!rc) rc = dev_alloc(&P->d_sq, np);
             if (!rc) rc = dev_alloc(&P->d_ss, np);
             if (!rc) rc = dev_alloc(&P->d_si, np);

@@ -129,6 +129,7 @@ struct rr_plan {
     int32_t *d_inner_idx = nullptr;
     bool export_inside = false;      // an export reach that another tile mirrors (it has a downstream reach in this plan): streaming kernel only
     double *d_coef = nullptr;        // per position {c1row, c2, c3}
+    double *d_coef_unit = nullptr;   // the same with zeros at the positions without upstream positions (UnitMuskingum's short tick)
     std::vector<double> h_coef;      // the same on the host: boundary ghosts of a partitioned network get zeros (upload_tile_coef)
     int32_t n_wide_tiles = 0;        // tiles with a reach of more than three upstream reaches: general kernel beside the LEAN one
     double *d_sq = nullptr, *d_ss = nullptr, *d_si = nullptr, *d_sqch = nullptr;
@@ -230,7 +231,12 @@ int upload_tile_coef(rr_plan *P)
     if (P->h_coef.empty()) return RR_OK;
     std::vector<double> coef(P->h_coef);
     for (int32_t i : P->ghost_reach) { const int64_t p = P->tp.inv[i]; coef[3 * p] = coef[3 * p + 1] = coef[3 * p + 2] = 0.0; }
-    return dev_upload(P->d_coef, coef);
+    int rc = dev_upload(P->d_coef, coef);
+    if (rc) return rc;
+    // UnitMuskingum's short tick: a headwater publishes its lateral inflow (_numba_kernels.py:122-123), which zero coefficients do too
+    for (int64_t p = 0; p < P->tp.np; ++p)
+        if ((P->tp.ccnt[p] & 0xFFFFu) == 0) coef[3 * p] = coef[3 * p + 1] = coef[3 * p + 2] = 0.0;
+    return dev_upload(P->d_coef_unit, coef);
 }
 
 // The two-phase tiled permutation params order <-> lag order of the streaming kernel (k_perm_a / k_perm_b).  Built when a
@@ -649,7 +655,7 @@ typedef void (*tile_kernel_t)(const TileArgs);
 // Tile = one position per thread; 16 waves per CU whose two record buffers fill the register file, as 1, 2 or 4 workgroups.
 tile_kernel_t tile_kernel(int threads, bool unit, bool sub, bool lean = false)
 {
-#define RR_TILE_PICK(T_) (unit ? (sub ? (tile_kernel_t)k_tile<T_, true, true> : (tile_kernel_t)k_tile<T_, true, false>)   \
+#define RR_TILE_PICK(T_) (unit ? (sub ? (tile_kernel_t)k_tile<T_, true, true> : (lean ? (tile_kernel_t)k_tile<T_, true, false, true> : (tile_kernel_t)k_tile<T_, true, false>))   \
                                : (sub ? (tile_kernel_t)k_tile<T_, false, true> : (lean ? (tile_kernel_t)k_tile<T_, false, false, true> : (tile_kernel_t)k_tile<T_, false, false>)))
     return threads == 128 ? RR_TILE_PICK(128) : (threads == 256 ? RR_TILE_PICK(256) : (threads == 512 ? RR_TILE_PICK(512) : RR_TILE_PICK(1024)));
 #undef RR_TILE_PICK
@@ -686,12 +692,14 @@ int session_launch_diag(rr_plan *P, int64_t d)
     const size_t lds_bytes = tile_lds_bytes(P->wave_threads);
     // RapidMuskingum with one sub-step per row runs the short tick (k_tile<..., LEAN>), and beside it the general kernel for
     // the tiles the short tick does not take (a reach with more than three upstream reaches); RR_TILE_LEAN=0: the general one
-    const bool lean = S.mode == Mode::Rapid && S.nsub == 1 && P->lean_enabled;
+    const bool unit = S.mode == Mode::Unit;
+    const bool lean = (S.mode == Mode::Rapid || unit) && S.nsub == 1 && P->lean_enabled;
     w.tile_filter = lean ? 1 : 0;
-    hipLaunchKernelGGL(tile_kernel(P->wave_threads, S.mode == Mode::Unit, S.nsub > 1, lean), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
+    w.coef = (lean && unit) ? P->d_coef_unit : P->d_coef;
+    hipLaunchKernelGGL(tile_kernel(P->wave_threads, unit, S.nsub > 1, lean), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
     if (lean && P->n_wide_tiles > 0) {
-        w.tile_filter = 2;
-        hipLaunchKernelGGL(tile_kernel(P->wave_threads, false, false, false), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
+        w.tile_filter = 2; w.coef = P->d_coef;
+        hipLaunchKernelGGL(tile_kernel(P->wave_threads, unit, false, false), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
     }
     if (sample) {
         HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));

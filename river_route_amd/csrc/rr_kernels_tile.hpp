@@ -113,9 +113,16 @@ __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmc
 // buffer followed by a slot that always holds 0.0 (the "upstream position" of a reach that has none: the short tick reads two
 // upstream values unconditionally), and the per-wave transpose areas.
 constexpr int kTilePad = 2;
+// ... | aux[5][TH]: UnitMuskingum's short tick keeps c1, c2, c3, the channel discharge and the previous tick's upstream sum of every
+// position here instead of in registers (ten of them: the record buffers leave none to spare, and a spill reload waits for every
+// record load in flight); they are read with the upstream values at the top of a tick, so the tick's dependent chain is no longer
+constexpr int kTileAux = 5;
+#ifndef RR_UNIT_COEF_LDS
+#define RR_UNIT_COEF_LDS 0      // 1: c1, c2, c3 in LDS too (more loads in flight per tick, more spills: measured slower)
+#endif
 constexpr size_t tile_lds_bytes(int threads)
 {
-    return (size_t)(2 * ((int64_t)threads + kTilePad) + (threads / 64) * kStageLanes * kStageStrideOut) * sizeof(double);
+    return (size_t)(2 * ((int64_t)threads + kTilePad) + (threads / 64) * kStageLanes * kStageStrideOut + kTileAux * threads) * sizeof(double);
 }
 
 // A record leaves in two 64-byte sectors (store_half).  Stored as soon as its eight ticks are done, the first sector's line is
@@ -272,6 +279,10 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
         double c1 = st.c1, c2 = st.c2, c3 = st.c3, s_prev = st.s_prev, qch = st.qch, isum = st.isum;
         const int32_t b0 = cur.b0, tau_begin = cur.m * K;
         lds[(size_t)((tau_begin + 1) & 1) * THP + tid] = st.q;       // tick tau_begin reads the buffer of tick tau_begin - 1
+        if (LEAN && UNIT) {      // only this thread reads and writes these slots: no barrier
+            double *aux = lds + 2 * THP + (TH / 64) * (kStageLanes * kStageStrideOut);
+            aux[tid] = st.c1; aux[TH + tid] = st.c2; aux[2 * TH + tid] = st.c3; aux[3 * TH + tid] = st.qch; aux[4 * TH + tid] = st.s_prev;
+        }
         if (SUB && lg >= 0) {      // phase of the position's sub-step counter at the first tick of the task
             const int32_t ts0 = tau_begin - (lg & kLagMask);
             const uint32_t r = a.nsub.mod((uint32_t)(ts0 < 0 ? -ts0 : ts0));
@@ -422,6 +433,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
         // partitioned network are stored from the record registers when a half record is complete (store_exports).
         const int32_t kind = LEAN ? cur.plain : 0;
         int32_t own_b = 0, up0_b = 0, up1_b = 0, up2_b = 0, lagm = 0;      // LDS byte offsets inside a discharge buffer: own slot, the three upstream slots (or the zero slot)
+        int32_t hw0_b = 0, hw1_b = 0, hw2_b = 0;      // UnitMuskingum: the headwater tributaries' slots (they come first in the upstream range); up*_b then hold the inner ones
         auto lds_at = [&](int parity, int32_t byte) -> double & { return *reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + parity * (THP * 8) + byte); };
         // record loads of the short path: one address register per chunk, the piece of load j is an immediate / scalar offset
         auto issue_load_plain = [&](__amdgpu_buffer_rsrc_t src, int32_t voff, int j) {
@@ -439,15 +451,39 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                 if (half == 0) issue_load_plain(rec_next, nvoff, s8);
                 const double q_old = lds_at((s + 1) & 1, own_b);
                 const double s_cur = (lds_at((s + 1) & 1, up0_b) + lds_at((s + 1) & 1, up1_b)) + lds_at((s + 1) & 1, up2_b);
-                double qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev, __builtin_fma(c3, q_old, R[s])));
-                if (decltype(tested)::value) {
-                    const bool active = (uint32_t)(tau0 + s - lagm) < (uint32_t)total;
-                    R[s] = active ? qk : R[s];
-                    qk = active ? qk : q_old;
+                double qk;
+                if (UNIT) {      // _numba_kernels.py:142-167 in gather form; a headwater and a ghost have zero coefficients: r = 0, the slot is republished
+                    constexpr int kAux = (2 * THP + (TH / 64) * (kStageLanes * kStageStrideOut)) * 8;      // byte offset of aux[0][0]
+                    auto aux_at = [&](int k) -> double & { return *reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + kAux + k * (TH * 8) + own_b); };
+                    const double s_hw = (lds_at((s + 1) & 1, hw0_b) + lds_at((s + 1) & 1, hw1_b)) + lds_at((s + 1) & 1, hw2_b);
+                    const double qc = aux_at(3);
+#if RR_UNIT_COEF_LDS
+                    const double r = __builtin_fma(aux_at(0), s_hw + s_cur, __builtin_fma(aux_at(1), s_hw + aux_at(4), aux_at(2) * qc));
+#else
+                    const double r = __builtin_fma(c1, s_hw + s_cur, __builtin_fma(c2, s_hw + aux_at(4), c3 * qc));
+#endif
+                    qk = r + R[s];
+                    if (decltype(tested)::value) {
+                        const bool active = (uint32_t)(tau0 + s - lagm) < (uint32_t)total;
+                        R[s] = active ? qk : R[s];
+                        aux_at(3) = active ? r : qc;
+                        qk = active ? qk : q_old;
+                    } else {
+                        R[s] = qk;
+                        aux_at(3) = r;
+                    }
+                    aux_at(4) = s_cur;
                 } else {
-                    R[s] = qk;      // unclamped: k_rec_out clamps
+                    qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev, __builtin_fma(c3, q_old, R[s])));
+                    if (decltype(tested)::value) {
+                        const bool active = (uint32_t)(tau0 + s - lagm) < (uint32_t)total;
+                        R[s] = active ? qk : R[s];
+                        qk = active ? qk : q_old;
+                    } else {
+                        R[s] = qk;      // unclamped: k_rec_out clamps
+                    }
+                    s_prev = s_cur;
                 }
-                s_prev = s_cur;
                 lds_at(s & 1, own_b) = qk;
                 barrier_lds();
             }
@@ -475,7 +511,14 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                 // a position past the end of the next tile reads whatever follows it in the ring (or zeros past its end): never used
                 const int32_t t = fresh(tid), ln = t & 63, upk = fresh(up);
                 const int32_t cnt = (int32_t)((uint32_t)upk >> 16), u0s = upk & 0xFFFF;
-                own_b = t * 8; up0_b = (cnt >= 1 ? u0s : TH) * 8; up1_b = (cnt >= 2 ? u0s + 1 : TH) * 8; up2_b = (cnt >= 3 ? u0s + 2 : TH) * 8;
+                own_b = t * 8;
+                if (UNIT) {
+                    const int32_t nh = fresh(uh) - u0s, ni = cnt - nh, i0 = u0s + nh;      // headwater tributaries [u0s, uh), inner ones [uh, u0s + cnt)
+                    hw0_b = (nh >= 1 ? u0s : TH) * 8; hw1_b = (nh >= 2 ? u0s + 1 : TH) * 8; hw2_b = (nh >= 3 ? u0s + 2 : TH) * 8;
+                    up0_b = (ni >= 1 ? i0 : TH) * 8; up1_b = (ni >= 2 ? i0 + 1 : TH) * 8; up2_b = (ni >= 3 ? i0 + 2 : TH) * 8;
+                } else {
+                    up0_b = (cnt >= 1 ? u0s : TH) * 8; up1_b = (cnt >= 2 ? u0s + 1 : TH) * 8; up2_b = (cnt >= 3 ? u0s + 2 : TH) * 8;
+                }
                 const int32_t nvoff = kLineLoads ? (nb0 + (t - ln) + (ln >> 3)) * 128 + (ln & 7) * 16 : (nb0 + (t - ln) + (ln >> 2)) * 128 + (ln & 3) * 16;
                 const __amdgpu_buffer_rsrc_t src = (!last || has_next) ? rec_next : make_rsrc(a.rec, 0u);
                 if (kind == 1) {
@@ -512,8 +555,9 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
         RR_TRACE(12);
         if (lg >= 0) {
             const int32_t p = b0 + tid;
-            a.sq[p] = lds[(size_t)((tau_begin + K - 1) & 1) * THP + tid]; a.ss[p] = s_prev;
-            if (UNIT) a.sqch[p] = qch;
+            const double *aux = lds + 2 * THP + (TH / 64) * (kStageLanes * kStageStrideOut);
+            a.sq[p] = lds[(size_t)((tau_begin + K - 1) & 1) * THP + tid]; a.ss[p] = (LEAN && UNIT) ? aux[4 * TH + tid] : s_prev;
+            if (UNIT) a.sqch[p] = (LEAN && UNIT) ? aux[3 * TH + tid] : qch;
             if (SUB) a.si[p] = isum;
         }
         if (LEAN && has_next) load_state(nxt, st);

@@ -26,15 +26,18 @@ def set_env(monkeypatch, env):
         monkeypatch.setenv(k, v)
 
 
-@pytest.mark.parametrize('n,T,env', [(300_000, 80, {'RR_WAVE': '1'}), (1_000_000, 80, {'RR_WAVE': '1'}),
-                                      (300_000, 70, {'RR_WAVE': '1', 'RR_WAVE_THREADS': '1024', 'RR_WAVE_K': '32'}),
-                                      (60_000, 50, {'RR_WAVE': '1', 'RR_TILE_BLOCK': '64', 'RR_WAVE_THREADS': '256', 'RR_WAVE_K': '16'})])
-def test_unit_route_dev_time_tiled_vs_oracle(monkeypatch, n, T, env):
-    """BASELINE config 4's timed kernel (k_tile, UNIT) over many tiles and tile levels, device arrays, two consecutive
-    files with the state hand-off of UnitMuskingum._router (river_route/routers/UnitMuskingum.py:72-98)."""
+@pytest.mark.parametrize('n,T,env,wide', [(300_000, 80, {'RR_WAVE': '1'}, False), (1_000_000, 80, {'RR_WAVE': '1'}, False),
+                                           (300_000, 70, {'RR_WAVE': '1', 'RR_WAVE_THREADS': '1024', 'RR_WAVE_K': '32'}, False),
+                                           (60_000, 50, {'RR_WAVE': '1', 'RR_TILE_BLOCK': '64', 'RR_WAVE_THREADS': '256', 'RR_WAVE_K': '16'}, False),
+                                           (120_000, 70, {'RR_WAVE': '1', 'RR_TILE_LEAN': '0'}, False),      # the general tick for every tile
+                                           (120_000, 70, {'RR_WAVE': '1'}, True)])      # confluences of four to eight reaches: their tiles go to the general kernel beside the short tick
+def test_unit_route_dev_time_tiled_vs_oracle(monkeypatch, n, T, env, wide):
+    """BASELINE config 4's timed kernel (k_tile, UNIT; the short tick unless RR_TILE_LEAN=0) over many tiles and tile levels,
+    device arrays, two consecutive files with the state hand-off of UnitMuskingum._router (river_route/routers/UnitMuskingum.py:72-98)."""
     set_env(monkeypatch, env)
     net = synth.synth_network(n, seed=31)
-    indptr, indices = csc_from_down(net.down_index)
+    down = _wide_network(n) if wide else net.down_index
+    indptr, indices = csc_from_down(down)
     hw_idx, inner_idx, A_in, A_hw = unit_split(indptr, indices, n)
     c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0)
     c1i, c2i, c3i = c1[inner_idx], c2[inner_idx], c3[inner_idx]
