@@ -72,6 +72,8 @@ struct Session {
 // session the partitioned path uses (rows become ready chunk by chunk).
 struct HostPipe {
     static constexpr int kPinned = 3, kCopyThreads = 8;
+    int copy_threads = kCopyThreads;      // per direction (RR_COPY_THREADS: measurements)
+    int64_t chunk_mib = 512;              // staging chunk (RR_COPY_CHUNK_MIB: measurements)
     int64_t chunk_rows = 64, ring_chunks = 8;
     double *pin_in[kPinned] = {nullptr, nullptr, nullptr}, *pin_out[kPinned] = {nullptr, nullptr, nullptr};
     double *dev_in = nullptr, *dev_out = nullptr;
@@ -1048,7 +1050,9 @@ int host_pipe_prepare(rr_plan *P)
     HostPipe &H = P->pipe;
     const int64_t n = P->h.n;
     // chunks of about half a gigabyte: long enough for the DMA engines to reach their rate, short enough to pipeline
-    H.chunk_rows = std::max<int64_t>(16, std::min<int64_t>(4096, ((int64_t{1} << 29) / (n * 8) + 15) / 16 * 16));
+    if (const char *e = getenv("RR_COPY_THREADS")) H.copy_threads = std::max(1, std::min(64, atoi(e)));
+    if (const char *e = getenv("RR_COPY_CHUNK_MIB")) H.chunk_mib = std::max(16, std::min(4096, atoi(e)));
+    H.chunk_rows = std::max<int64_t>(16, std::min<int64_t>(4096, ((H.chunk_mib << 20) / (n * 8) + 15) / 16 * 16));
     if (n * 8 * 64 <= (int64_t{1} << 30)) H.chunk_rows = std::max<int64_t>(H.chunk_rows, 64);
     H.ring_chunks = std::max<int64_t>(8, (2 * kRecRows + 15) / H.chunk_rows + 6);      // a batch of rows + its 15-row overlap stays readable
     const int64_t pin_need = H.chunk_rows * n, dev_need = H.ring_chunks * H.chunk_rows * n;
@@ -1106,13 +1110,15 @@ int route_host_pipelined(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const d
 #define RR_PIPE(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return bail(RR_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)); } while (0)
     // One iteration: the copy threads fill the next pinned input chunk and empty the oldest downloaded output chunk while
     // this thread enqueues the upload of the chunk filled last time, the routing it enables and the downloads it completes.
+    double t_join = 0.0, t_wait = 0.0;      // RR_VERBOSE: seconds this thread waited for the copy threads / for events
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     while (copied_out < nchunks) {
         pool.clear();
         bool progressed = false;
         const bool fill = host_in && filled < nchunks && filled < h2d_issued + kPinned;
         if (fill) {
-            if (filled >= kPinned) RR_PIPE(hipEventSynchronize(H.ev_h2d[filled - kPinned]));      // the buffer's previous chunk has left
-            parallel_copy(H.pin_in[filled % kPinned], host_in + filled * C * n, (size_t)(rows_of(filled) * n), HostPipe::kCopyThreads, pool);
+            if (filled >= kPinned) { const double t0 = now(); RR_PIPE(hipEventSynchronize(H.ev_h2d[filled - kPinned])); t_wait += now() - t0; }      // the buffer's previous chunk has left
+            parallel_copy(H.pin_in[filled % kPinned], host_in + filled * C * n, (size_t)(rows_of(filled) * n), H.copy_threads, pool);
         }
         bool empty = false;
         if (copied_out < d2h_issued) {      // only a download that HAS arrived: waiting for one here would stall the uploads behind it
@@ -1121,7 +1127,7 @@ int route_host_pipelined(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const d
             else if (q != hipErrorNotReady) return bail(RR_E_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
         }
         if (empty) {
-            parallel_copy(host_out + copied_out * C * n, H.pin_out[copied_out % kPinned], (size_t)(rows_of(copied_out) * n), HostPipe::kCopyThreads, pool);
+            parallel_copy(host_out + copied_out * C * n, H.pin_out[copied_out % kPinned], (size_t)(rows_of(copied_out) * n), H.copy_threads, pool);
         }
         // upload of a chunk filled earlier, into the ring slot whose previous occupant has become records
         if (host_in && h2d_issued < filled) {
@@ -1169,15 +1175,18 @@ int route_host_pipelined(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const d
             ++d2h_issued;
             progressed = true;
         }
-        for (auto &t : pool) t.join();
+        { const double t0 = now(); for (auto &t : pool) t.join(); t_join += now() - t0; }
         if (fill) ++filled;
         if (empty) ++copied_out;
         if (!progressed && !fill && !empty) {
-            if (copied_out < d2h_issued) RR_PIPE(hipEventSynchronize(H.ev_d2h[copied_out]));      // nothing else to do but wait for it
+            if (copied_out < d2h_issued) { const double t0 = now(); RR_PIPE(hipEventSynchronize(H.ev_d2h[copied_out])); t_wait += now() - t0; }      // nothing else to do but wait for it
             else return bail(RR_E_STATE, "host pipeline: no stage can make progress");
         }
     }
 #undef RR_PIPE
+    if (getenv("RR_VERBOSE"))
+        fprintf(stderr, "rr: host pipeline: %lld chunks of %lld rows, %d copy threads per direction; waited %.1f ms for the copy threads, %.1f ms for transfers\n",
+                (long long)nchunks, (long long)C, H.copy_threads, t_join * 1e3, t_wait * 1e3);
     S.out_limit = std::numeric_limits<int64_t>::max();
     return session_end(P);
 }
