@@ -692,7 +692,7 @@ int session_launch_diag(rr_plan *P, int64_t d)
     // one workgroup per resident slot (16 waves per CU); each walks its share of the launch's tiles
     const dim3 g((unsigned)std::min<int64_t>(t_hi - t_lo, (int64_t)P->cu_count * (1024 / P->wave_threads)));
     const size_t lds_bytes = tile_lds_bytes(P->wave_threads);
-    // RapidMuskingum with one sub-step per row runs the short tick (k_tile<..., LEAN>), and beside it the general kernel for
+    // RapidMuskingum and UnitMuskingum with one sub-step per row run the short tick (k_tile<..., LEAN>), and beside it the general kernel for
     // the tiles the short tick does not take (a reach with more than three upstream reaches); RR_TILE_LEAN=0: the general one
     const bool unit = S.mode == Mode::Unit;
     const bool lean = (S.mode == Mode::Rapid || unit) && S.nsub == 1 && P->lean_enabled;

@@ -93,10 +93,11 @@ __device__ __forceinline__ int32_t fresh(int32_t v) { asm volatile("" : "+v"(v))
 constexpr int kRec = 16;
 // Records move between HBM and their owning lanes through a per-wave LDS transpose: a lane owns a position (its record
 // lives in registers), but a memory instruction in which every lane touches 16 bytes of a different record costs L2 one
-// request per lane.  Through the transpose four neighbouring lanes load or store the 64 contiguous bytes of one half
-// record: a quarter of the requests.
-constexpr int kStageStride = 10;   // doubles per position in the staging area: 64 bytes + 16 of padding (bank spread, skip flag)
-constexpr int kStageLanes = 32;    // positions transposed at a time: half a wave (2.5 KiB of staging per wave)
+// request per lane.  Through the transpose EIGHT neighbouring lanes load or store the 128 contiguous bytes of one record: a
+// memory instruction moves eight whole lines.  (Rounds 1-3 moved 64-byte sectors, four lanes each; a line that reaches the L2
+// in two parts is often written back half filled, and the launch then took 428 us instead of 360: DESIGN.md section 3c.)
+constexpr int kStageStride = 10;   // sector form: doubles per position in the staging area, 64 bytes + 16 of padding (bank spread, skip flag)
+constexpr int kStageLanes = 32;    // positions transposed at a time: half a wave (4.5 KiB of staging per wave with whole records)
 #ifndef RR_TILE_LINE_STORES
 #define RR_TILE_LINE_STORES 1      // 1: a record leaves as one 128-byte line per eight lanes (store_record); 0: as two 64-byte sectors (store_half)
 #endif
@@ -109,13 +110,13 @@ constexpr int kStageStrideOut = (kLineStores || kLineLoads) ? 18 : kStageStride;
 // Lanes of one wave exchange data through its staging area without a workgroup barrier: a wave's LDS instructions
 // execute in order.  The compiler still has to be told that other lanes wrote (it would reuse earlier reads).
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-// LDS in doubles: X[2][TH + 2] | stage[waves][kStageLanes * kStageStride]: the tile's discharges of the last two ticks, each
-// buffer followed by a slot that always holds 0.0 (the "upstream position" of a reach that has none: the short tick reads two
-// upstream values unconditionally), and the per-wave transpose areas.
+// LDS in doubles: X[2][TH + 2] | stage[waves][kStageLanes * kStageStrideOut] | aux[5][TH].  X: the tile's discharges of the
+// last two ticks, each buffer followed by slots that always hold 0.0 (the "upstream position" of a reach that has none: the
+// short tick reads three upstream values unconditionally); stage: the per-wave transpose areas; aux: UnitMuskingum's short tick
+// keeps the channel discharge (aux[3]) and the previous tick's upstream sum (aux[4]) of every position here instead of in
+// registers -- the record buffers leave none to spare, and a spill reload waits for every record load in flight -- and reads
+// them with the upstream values at the top of a tick (aux[0..2]: the coefficients, with -DRR_UNIT_COEF_LDS=1: slower).
 constexpr int kTilePad = 2;
-// ... | aux[5][TH]: UnitMuskingum's short tick keeps c1, c2, c3, the channel discharge and the previous tick's upstream sum of every
-// position here instead of in registers (ten of them: the record buffers leave none to spare, and a spill reload waits for every
-// record load in flight); they are read with the upstream values at the top of a tick, so the tick's dependent chain is no longer
 constexpr int kTileAux = 5;
 #ifndef RR_UNIT_COEF_LDS
 #define RR_UNIT_COEF_LDS 0      // 1: c1, c2, c3 in LDS too (more loads in flight per tick, more spills: measured slower)
@@ -125,9 +126,10 @@ constexpr size_t tile_lds_bytes(int threads)
     return (size_t)(2 * ((int64_t)threads + kTilePad) + (threads / 64) * kStageLanes * kStageStrideOut + kTileAux * threads) * sizeof(double);
 }
 
-// A record leaves in two 64-byte sectors (store_half).  Stored as soon as its eight ticks are done, the first sector's line is
+// The sector form (store_half, -DRR_TILE_LINE_STORES=0): stored as soon as its eight ticks are done, the first sector's line is
 // often written back before the second arrives and the memory system moves more than the record: WRITE_SIZE 649 MB per launch
-// against 620 with both sectors stored after the sixteenth tick, k_tile 428.6 -> 414.9 us (profiles/r03_tile_store_whole.txt).
+// against 620 with both sectors stored after the sixteenth tick, k_tile 428.6 -> 414.9 us (profiles/r03_tile_store_whole.txt);
+// whole lines (store_record, the default): 545.6 MB, 360.7 us (profiles/r03_tile_store_line.txt).
 #ifndef RR_TILE_HALF_STORES
 #define RR_TILE_HALF_STORES 0      // 1: the first sector after eight ticks (rounds 1-3; measurements)
 #endif
@@ -137,8 +139,8 @@ constexpr bool kHalfStores = RR_TILE_HALF_STORES != 0;
 // (lateral in, discharge out); N[16] receives the NEXT chunk's record while the 16 ticks of this one run, so inside a task
 // HBM traffic and tick arithmetic overlap and only the first chunk's load is exposed.  Whole 128-byte records are
 // requested at once (a half record would cost the fabric a full line: measured, FETCH_SIZE 1.8x).
-// LEAN: RapidMuskingum with one sub-step per row, the headline's case: the short tick below instead of the general one (the
-// two do not fit one kernel: with the record buffers in 64 of 128 registers the allocator spills the records in flight).
+// LEAN: one sub-step per row, RapidMuskingum (the headline's case) or UnitMuskingum: the short tick below instead of the general
+// one (the two do not fit one kernel: with the record buffers in 64 of 128 registers the allocator spills the records in flight).
 template <int TH, bool UNIT, bool SUB, bool LEAN = false>
 __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 waves per CU: 1,024 / TH workgroups of 128 VGPRs
 {
@@ -185,10 +187,10 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
 #endif
     RR_TRACE(0);
 
-    // Four lanes fetch (store) the four 16-byte pieces of one 64-byte sector: in flight a lane's N[] holds OTHER
-    // positions' pieces; receive() hands them to their owners through the wave's staging area.
+    // Eight lanes fetch (store) the eight 16-byte pieces of one record (four lanes one 64-byte sector in the sector form): in
+    // flight a lane's N[] holds OTHER positions' pieces; receive() hands them to their owners through the wave's staging area.
     double R[kRec], N[kRec];
-    // load j of a record: (i = j / 2: half wave and group of 16 positions, half = j % 2: which 64-byte sector), so the two
+    // load j of a record, sector form: (i = j / 2: half wave and group of 16 positions, half = j % 2: which 64-byte sector), so the two
     // sectors of a 128-byte line are requested by consecutive loads
     auto issue_load = [&](__amdgpu_buffer_rsrc_t src, int32_t b0, int32_t b1, int j, bool real) {
         const int32_t t = fresh(tid), ln = t & 63;      // addresses are rebuilt at every use, not kept in registers across the task
