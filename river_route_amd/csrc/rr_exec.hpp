@@ -299,7 +299,7 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
 {
     Schedule sch;
     const int64_t total = T * nsub, dmax = P->h.depth - 1, n = P->h.n;
-    bool ok = P->wave_enabled && P->tp.ok && P->weights_uniform && n > 0 && !force_streaming && P->tp.np < (int64_t{1} << 25) &&
+    bool ok = P->wave_enabled && P->tp.ok && P->weights_uniform && n > 0 && !force_streaming && P->tp.np < (int64_t{1} << (kRecPairs ? 24 : 25)) &&
               !P->export_inside && P->kc_cap >= 1 && !(mode == Mode::Unit && P->unit_general);
     if (ok && !P->wave_forced) ok = total >= 32;
     if (ok) {
@@ -313,7 +313,8 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
         const int64_t kc_long = P->n_export > 0 && P->wave_K <= 0 ? 4 : (int64_t{1} << 20);
         for (int64_t KC = std::min(std::min(pick_KC(P, total + dmax), P->kc_cap), kc_long); KC >= 1; KC /= 2) {
             static const int64_t extra = getenv("RR_RING_EXTRA") ? atoll(getenv("RR_RING_EXTRA")) : 0;      // measurements: a larger ring than needed
-            const int64_t chunks = std::min<int64_t>(all_chunks, (dmax + levels * KC * kRec) / kRec + slack * kRecBatch + extra);
+            int64_t chunks = std::min<int64_t>(all_chunks, (dmax + levels * KC * kRec) / kRec + slack * kRecBatch + extra);
+            if (kRecPairs) chunks += chunks & 1;      // the ring holds whole pairs of chunks
             const int64_t bytes = chunks * kRec * np * (int64_t)sizeof(double);
             // five eighths of the card; the shortest tasks may take thirteen sixteenths: the streaming kernel, the only alternative,
             // keeps depth x n work rows itself (1M reaches 24k deep: 204 GB of records at K = 16 against 192 GB of rows)

@@ -130,7 +130,7 @@ __device__ __forceinline__ void write_records(const RecPermArgs &a, const double
         } else {
             v0 = tile[r * (COLS + 1) + c] * scale; v1 = tile[(r + 1) * (COLS + 1) + c] * scale;
         }
-        double2 *dst = reinterpret_cast<double2 *>(a.rec + ((int64_t)chunk * a.np + p) * kRec) + part;
+        double2 *dst = reinterpret_cast<double2 *>(a.rec + rec_elem(chunk, a.np, p)) + part;
         typedef double d2 __attribute__((ext_vector_type(2)));
         st_site<kNtInRec>(reinterpret_cast<d2 *>(dst), d2{v0, v1});
     }
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(kRecOutThreads, RR_REC_OUT_MIN_WGS) void k_rec_out(
             const int piece = it * kRecOutThreads + tid;
             const int k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
             const uint32_t chunk = ring_chunk(a.rec_chunks, chunk_first, (uint32_t)((meta[it].y & kLagMask) >> 4) + k);
-            v[it] = ld_site<kNtOutRec>(reinterpret_cast<const d2 *>(a.rec + ((int64_t)chunk * a.np + meta[it].x) * kRec) + part);
+            v[it] = ld_site<kNtOutRec>(reinterpret_cast<const d2 *>(a.rec + rec_elem(chunk, a.np, meta[it].x)) + part);
         }
     };
     uint32_t t = blockIdx.x;

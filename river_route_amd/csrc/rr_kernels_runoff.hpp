@@ -79,7 +79,7 @@ template <typename RT>
 __global__ __launch_bounds__(kRunoffInThreads) void k_rec_in_runoff(const RecPermArgs a, const RunoffArgs g)
 {
     __shared__ double stage[kRunoffInThreads][kRec + 1];
-    __shared__ int64_t slot[kRunoffInThreads];      // record index (chunk % chunks) * np + position, -1: no record
+    __shared__ int64_t slot[kRunoffInThreads];      // offset of the record in the ring (rec_elem), -1: no record
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * kRunoffInThreads + tid;
     const int k = blockIdx.y;
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(kRunoffInThreads) void k_rec_in_runoff(const RecPer
             if (g.area) v = v * area;
             stage[tid][j - 1] = (t >= 0 && t < a.T) ? v * f : 0.0;
         }
-        slot[tid] = (int64_t)a.rec_chunks.mod(chunk) * a.np + meta.x;
+        slot[tid] = rec_elem(a.rec_chunks.mod(chunk), a.np, meta.x);
     }
     __syncthreads();
 #pragma unroll
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kRunoffInThreads) void k_rec_in_runoff(const RecPer
         const int piece = it * kRunoffInThreads + tid, r = piece >> 3, part = piece & 7;      // 8 consecutive lanes = one record
         const int64_t sl = slot[r];
         if (sl < 0) continue;
-        reinterpret_cast<double2 *>(a.rec + sl * kRec)[part] = make_double2(stage[r][2 * part], stage[r][2 * part + 1]);
+        reinterpret_cast<double2 *>(a.rec + sl)[part] = make_double2(stage[r][2 * part], stage[r][2 * part + 1]);
     }
 }
 

@@ -91,6 +91,20 @@ __device__ __forceinline__ void load_f64x2(__amdgpu_buffer_rsrc_t r, uint32_t by
 __device__ __forceinline__ int32_t fresh(int32_t v) { asm volatile("" : "+v"(v)); return v; }
 
 constexpr int kRec = 16;
+// Ring layout.  0: rec[chunk][position][16] -- a chunk is a plane, a tile's records of one chunk are contiguous.  1: the two
+// chunks of a pair side by side, rec[chunk / 2][position][chunk % 2][16]: what a record pass writes or reads for one column
+// -- consecutive chunks of one position -- then comes in 256-byte pieces instead of 128-byte ones (half the DRAM pages opened),
+// while a tile's records of one chunk are every other line of a block twice as long.
+#ifndef RR_REC_PAIRS
+#define RR_REC_PAIRS 0
+#endif
+constexpr bool kRecPairs = RR_REC_PAIRS != 0;
+constexpr uint32_t kPosBytes = kRecPairs ? 256u : 128u;      // from one position's record to the next position's in the same chunk
+__device__ __forceinline__ int64_t rec_elem(uint32_t ring_chunk, int64_t np, int64_t position)      // offset in doubles of a record
+{
+    return kRecPairs ? ((int64_t)(ring_chunk >> 1) * np + position) * (2 * kRec) + (ring_chunk & 1u) * kRec
+                     : ((int64_t)ring_chunk * np + position) * kRec;
+}
 // Records move between HBM and their owning lanes through a per-wave LDS transpose: a lane owns a position (its record
 // lives in registers), but a memory instruction in which every lane touches 16 bytes of a different record costs L2 one
 // request per lane.  Through the transpose EIGHT neighbouring lanes load or store the 128 contiguous bytes of one record: a
@@ -152,7 +166,10 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
     // across a task the allocator spills them, and the reload waits for every record load in flight
     auto stage_of = [&](int32_t t) { return lds + 2 * THP + (size_t)(t >> 6) * (kStageLanes * kStageStrideOut); };
     if (tid < 2) lds[tid * THP + TH] = 0.0;      // the zero slots; nothing else ever writes them (first barrier: before the first tick)
-    auto ring = [&](int32_t chunk) { return make_rsrc(a.rec + (int64_t)a.rec_chunks.mod((uint32_t)chunk) * a.np * kRec, (uint32_t)a.np * 128u); };   // np < 2^25
+    auto ring = [&](int32_t chunk) {      // the records of one chunk as a buffer: position p at byte p * kPosBytes (np * kPosBytes < 2^32: choose_schedule)
+        const uint32_t c = a.rec_chunks.mod((uint32_t)chunk);
+        return make_rsrc(a.rec + rec_elem(c, a.np, 0), (uint32_t)a.np * kPosBytes - (kRecPairs ? (c & 1u) * 128u : 0u));
+    };
 
     // A workgroup takes the tiles t_last - blockIdx.x - g * gridDim.x, g = 0, 1, ... of this launch (highest level first:
     // the few tiles with ghosts start in the first round), so that the first record and the state of its NEXT tile are
@@ -196,12 +213,12 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
         const int32_t t = fresh(tid), ln = t & 63;      // addresses are rebuilt at every use, not kept in registers across the task
         if (kLineLoads) {      // load j: positions 8 j ... 8 j + 7 of the wave, eight lanes per 128-byte record
             const int32_t pos = min(b0 + (t - ln) + 8 * j + (ln >> 3), b1 - 1);
-            load_f64x2(src, real ? (uint32_t)pos * 128u + (uint32_t)((ln & 7) * 16) : kDropAccess, N[2 * j], N[2 * j + 1]);
+            load_f64x2(src, real ? (uint32_t)pos * kPosBytes + (uint32_t)((ln & 7) * 16) : kDropAccess, N[2 * j], N[2 * j + 1]);
             return;
         }
         const int i = j >> 1, half = j & 1;
         const int32_t pos = min(b0 + (t - ln) + (i >> 1) * kStageLanes + 16 * (i & 1) + (ln >> 2), b1 - 1);
-        load_f64x2(src, real ? (uint32_t)pos * 128u + (uint32_t)(half * 64 + (ln & 3) * 16) : kDropAccess,
+        load_f64x2(src, real ? (uint32_t)pos * kPosBytes + (uint32_t)(half * 64 + (ln & 3) * 16) : kDropAccess,
                    N[8 * half + 2 * i], N[8 * half + 2 * i + 1]);
     };
     auto receive = [&]() {
@@ -310,17 +327,17 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                 }
                 wave_lds_fence();
                 const int32_t t = fresh(tid), ln = t & 63;
-                const uint32_t first = (uint32_t)(b0 + (t - ln) + h * kStageLanes) * 128u + (uint32_t)half * 64u;
+                const uint32_t first = (uint32_t)(b0 + (t - ln) + h * kStageLanes) * kPosBytes + (uint32_t)half * 64u;
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {       // lanes 4i .. 4i+3: the four 16-byte pieces of position 16 g + i
                     const int pm = 16 * g + (ln >> 2), piece = ln & 3;
                     const double2 *theirs = reinterpret_cast<const double2 *>(stage + pm * kStageStride);
                     const double2 v = theirs[piece];
                     const bool skip = reinterpret_cast<const int32_t *>(theirs + 4)[0] != 0;
-                    store_f64x2(dst, skip ? kDropAccess : first + (uint32_t)pm * 128u + (uint32_t)piece * 16u, v);
+                    store_f64x2(dst, skip ? kDropAccess : first + (uint32_t)pm * kPosBytes + (uint32_t)piece * 16u, v);
                     if (!SUB) {     // the same sector into the record of the ghost that mirrors the reach (always issued, see store_f64)
                         const int32_t gx = reinterpret_cast<const int32_t *>(theirs + 4)[1];
-                        store_f64x2(dst, gx < 0 ? kDropAccess : (uint32_t)gx * 128u + (uint32_t)half * 64u + (uint32_t)piece * 16u, v);
+                        store_f64x2(dst, gx < 0 ? kDropAccess : (uint32_t)gx * kPosBytes + (uint32_t)half * 64u + (uint32_t)piece * 16u, v);
                     }
                 }
                 wave_lds_fence();
@@ -343,17 +360,17 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                 }
                 wave_lds_fence();
                 const int32_t t = fresh(tid), ln = t & 63;
-                const uint32_t first = (uint32_t)(b0 + (t - ln) + h * kStageLanes) * 128u;
+                const uint32_t first = (uint32_t)(b0 + (t - ln) + h * kStageLanes) * kPosBytes;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {       // lanes 8i .. 8i+7: the eight 16-byte pieces of position 8 g + i
                     const int pm = 8 * g + (ln >> 3), piece = ln & 7;
                     const double2 *theirs = reinterpret_cast<const double2 *>(stage + pm * kStageStrideOut);
                     const double2 v = theirs[piece];
                     const bool skip = reinterpret_cast<const int32_t *>(theirs + 8)[0] != 0;
-                    store_f64x2(dst, skip ? kDropAccess : first + (uint32_t)pm * 128u + (uint32_t)piece * 16u, v);
+                    store_f64x2(dst, skip ? kDropAccess : first + (uint32_t)pm * kPosBytes + (uint32_t)piece * 16u, v);
                     if (!SUB) {     // the same line into the record of the ghost that mirrors the reach (always issued, see store_f64)
                         const int32_t gx = reinterpret_cast<const int32_t *>(theirs + 8)[1];
-                        store_f64x2(dst, gx < 0 ? kDropAccess : (uint32_t)gx * 128u + (uint32_t)piece * 16u, v);
+                        store_f64x2(dst, gx < 0 ? kDropAccess : (uint32_t)gx * kPosBytes + (uint32_t)piece * 16u, v);
                     }
                 }
                 wave_lds_fence();
@@ -418,7 +435,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                 // With sub-steps a record slot holds a row mean, not the tick's discharge: a reach mirrored by a ghost of another
                 // tile sends 8 bytes per tick into the ghost's record, always issued (see store_f64).  Without, the ghost gets a
                 // copy of the whole record in store_half.
-                if (SUB) store_f64(rec_cur, (lgk >= 0 && (lgk & kTileExportBit)) ? (uint32_t)fresh(xp) * 128u + (uint32_t)s * 8u : kDropAccess, qk);
+                if (SUB) store_f64(rec_cur, (lgk >= 0 && (lgk & kTileExportBit)) ? (uint32_t)fresh(xp) * kPosBytes + (uint32_t)s * 8u : kDropAccess, qk);
                 barrier_lds();
             }
         };
@@ -440,7 +457,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
         // record loads of the short path: one address register per chunk, the piece of load j is an immediate / scalar offset
         auto issue_load_plain = [&](__amdgpu_buffer_rsrc_t src, int32_t voff, int j) {
             const int i = j >> 1, half = j & 1;
-            const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(src, voff, kLineLoads ? j * 1024 : ((i >> 1) * kStageLanes + 16 * (i & 1)) * 128 + half * 64, (RR_NT_MASK & kNtTileLoad) ? 2 : 0);
+            const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(src, voff, kLineLoads ? j * 8 * (int)kPosBytes : ((i >> 1) * kStageLanes + 16 * (i & 1)) * (int)kPosBytes + half * 64, (RR_NT_MASK & kNtTileLoad) ? 2 : 0);
             double2 v;
             __builtin_memcpy(&v, &bits, sizeof v);
             if (kLineLoads) { N[2 * j] = v.x; N[2 * j + 1] = v.y; }
@@ -521,7 +538,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                 } else {
                     up0_b = (cnt >= 1 ? u0s : TH) * 8; up1_b = (cnt >= 2 ? u0s + 1 : TH) * 8; up2_b = (cnt >= 3 ? u0s + 2 : TH) * 8;
                 }
-                const int32_t nvoff = kLineLoads ? (nb0 + (t - ln) + (ln >> 3)) * 128 + (ln & 7) * 16 : (nb0 + (t - ln) + (ln >> 2)) * 128 + (ln & 3) * 16;
+                const int32_t nvoff = kLineLoads ? (nb0 + (t - ln) + (ln >> 3)) * (int32_t)kPosBytes + (ln & 7) * 16 : (nb0 + (t - ln) + (ln >> 2)) * (int32_t)kPosBytes + (ln & 3) * 16;
                 const __amdgpu_buffer_rsrc_t src = (!last || has_next) ? rec_next : make_rsrc(a.rec, 0u);
                 if (kind == 1) {
                     ticks_plain(std::false_type(), tau0, 0, src, nvoff);
