@@ -272,7 +272,8 @@ def run_distributed(engine, spec: PartSpec, T: int, nsub: int, chunk_rows: int, 
     """Serve one part's driver with torch.distributed point-to-point ops (nccl = RCCL on the GPU box, gloo on CPU).
     Rank == part.  The receives of a chunk are posted as ONE batch (one grouped RCCL call for all upstream parts) when the
     driver announces them -- a chunk before the values are used -- so the part that collects seven boundary series never
-    stands in a queue of blocking receives; sends are asynchronous, their buffers kept alive until the call ends."""
+    stands in a queue of blocking receives; sends are asynchronous (batches of one, so that both ends of a message use the same
+    communicator), their buffers kept alive until the call ends."""
     pending = []
     posted = {}                                 # (src, r0, r1) -> (work, staging buffer)
     via_host = dist.get_backend() != 'nccl'     # gloo moves host memory: stage device tensors through the CPU
@@ -295,7 +296,9 @@ def run_distributed(engine, spec: PartSpec, T: int, nsub: int, chunk_rows: int, 
         else:
             _, peer, view, r0, r1 = req
             buf = view.cpu().contiguous() if via_host else view.contiguous()
-            pending.append((dist.isend(buf, dst=peer), buf))
+            # a batch of one, not dist.isend: ProcessGroupNCCL sends a batched operation over the group's communicator and a single
+            # one over a two-rank communicator of its own, and a receive posted in a batch (above) only ever meets the former
+            pending.append((dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, peer)])[-1], buf))
     assert not posted
     for work, _ in pending:
         work.wait()
@@ -425,6 +428,7 @@ def bench_main(args, rank: int, local_rank: int, world: int) -> None:
     from .engine import MODE_RAPID
     sched = eng.plan.reserve(MODE_RAPID, T, nsub)      # the record ring, before anything is timed
     torch.cuda.synchronize()
+    dist.barrier()      # every rank is through its setup, and the group's communicator exists before the first batched send / receive uses it
     t_ready = time.perf_counter()
 
     def one_pass():

@@ -117,6 +117,7 @@ def hip_worker(rank, world, port, n, T, chunk_rows, out_dir, backend):
     spec = split_network(net.down_index, part_of, rank, world)
     ql = synth.synth_qlateral(n, 0, T)
     eng = HipPartEngine(spec, c1, c2, c3, (c1 + c2) / 900.0, q0, ql[:, spec.real_global], T, 1, device, out_rows=T)
+    dist.barrier()              # as bench.py: the group's communicator exists before the first batched send / receive
     for _ in range(2):          # bench.py reuses the engines pass after pass
         run_distributed(eng, spec, T, 1, chunk_rows, dist)
     torch.cuda.synchronize()
