@@ -33,6 +33,8 @@ import time
 
 import numpy as np
 
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # before the HIP runtime starts: RCCL's device-memory sharing needs dmabuf IPC on these hosts
+
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
@@ -277,7 +279,6 @@ def main():
     if not torch.cuda.is_available() or _lib.device_count() < 1:
         raise SystemExit('bench.py needs a GPU: the HIP engine has no CPU fallback')
     # one rank per GPU; RR_DIST_BACKEND=gloo lets several ranks share one card for a rehearsal on a 1-GPU box
-    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # RCCL's device-memory sharing needs dmabuf IPC on these hosts
     backend = os.environ.get('RR_DIST_BACKEND', 'nccl')
     device_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(device_index)
