@@ -212,6 +212,11 @@ int rr_rapid_route_runoff_dev(rr_plan *plan, double *q_t, int64_t n_points, cons
 int rr_unit_route_uh_dev(rr_plan *plan, double *q_ch, double *q_full, double *q_final, const double *uh_kernel, double *uh_state,
                          int64_t n_ks, const double *depth, double *discharge, float *discharge32, int64_t factor,
                          int64_t num_runoff_steps, int64_t num_substeps, void *stream);
+/* The same with float32 runoff depths, as runoff files usually store them (4 bytes read and uploaded per value instead of 8;
+ * float32 -> float64 is exact, so the results are those of the float64 copy, bit for bit). */
+int rr_unit_route_uh_f32in_dev(rr_plan *plan, double *q_ch, double *q_full, double *q_final, const double *uh_kernel, double *uh_state,
+                               int64_t n_ks, const float *depth32, double *discharge, float *discharge32, int64_t factor,
+                               int64_t num_runoff_steps, int64_t num_substeps, void *stream);
 
 /* ---- partitioned networks (multi-GPU): boundary reaches and streaming calls ----
  *

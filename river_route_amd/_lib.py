@@ -92,6 +92,7 @@ _SIGNATURES = {
     'rr_uh_convolve_dev': (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     'rr_rapid_route_runoff_dev': (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, C.c_int, _i64, _i64, _vp, C.c_int, _vp, _vp, _i64, _i64, _vp]),
     'rr_unit_route_uh_dev': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
+    'rr_unit_route_uh_f32in_dev': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _vp]),
     'rr_rapid_route_f32_dev': (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
     'rr_rapid_route_f32in_dev': (C.c_int, [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _vp]),
     'rr_muskingum_route_f32_dev': (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp]),

@@ -660,6 +660,27 @@ int rr_unit_route_uh_dev(rr_plan *P, double *q_ch, double *q_full, double *q_fin
     return unit_like(P, q_ch, q_full, io, T, nsub, (hipStream_t)stream, false, q_final, uh_state);
 }
 
+int rr_unit_route_uh_f32in_dev(rr_plan *P, double *q_ch, double *q_full, double *q_final, const double *uh_kernel, double *uh_state,
+                               int64_t n_ks, const float *depth32, double *discharge, float *discharge32, int64_t factor, int64_t T,
+                               int64_t nsub, void *stream)
+{
+    int rc = check_route_args(P, false, T, nsub);
+    if (rc) return rc;
+    const bool f32 = discharge32 != nullptr;
+    if (P->h.n > 0 && T > 0 && (!depth32 || !uh_kernel || !uh_state || (!discharge && !discharge32) || (discharge && discharge32) || n_ks < 1 ||
+                                (!P->h.inner_pos.empty() && (!q_ch || !q_full))))
+        return fail(RR_E_INVALID, "rr_unit_route_uh_f32in_dev: null array, both or neither output, or n_ks < 1");
+    if (P->h.n == 0 || T == 0) return RR_OK;
+    if (n_ks > kUhFusedMaxTaps) return fail(RR_E_UNSUPPORTED, "rr_unit_route_uh_f32in_dev: more than 64 kernel steps: convert the rows, convolve with rr_uh_convolve_dev, then rr_unit_route_dev");
+    if (f32) { rc = f32_output_applies(P, Mode::Unit, T, nsub, factor); if (rc) return rc; }
+    else if (!choose_schedule(P, Mode::Unit, T, nsub, false, false).tiled) return fail(RR_E_UNSUPPORTED, "rr_unit_route_uh_f32in_dev needs the time-tiled kernel, which this call does not get");
+    Rows io; io.dev_in32 = depth32; io.dev_in = uh_kernel; io.rows_in = T;      // (dev_in only has to be non-NULL for the executor)
+    if (f32) { io.dev_out32 = discharge32; io.out_factor = factor; io.rows_out = T / factor; }
+    else { io.dev_out = discharge; io.rows_out = T; }
+    io.uh_kernel = uh_kernel; io.uh_state = uh_state; io.uh_nks = n_ks;
+    return unit_like(P, q_ch, q_full, io, T, nsub, (hipStream_t)stream, false, q_final, uh_state);
+}
+
 int rr_uh_convolve_dev(int device, const double *kernel, double *state, const double *lateral, double *out,
                        int64_t T, int64_t n_ks, int64_t n, void *stream)
 {

@@ -738,14 +738,16 @@ void launch_ghost_permute(rr_plan *P, int64_t batch)
 typedef void (*rec_in_uh_t)(const RecPermArgs, const UhArgs);
 constexpr int kUhFusedMaxTaps = 64;
 int uh_padded_taps(int64_t n_ks) { return n_ks <= 16 ? 16 : (n_ks <= 48 ? 48 : 64); }
-rec_in_uh_t rec_in_uh_kernel(bool sub, int64_t n_ks, int batches)
+rec_in_uh_t rec_in_uh_kernel(bool sub, int64_t n_ks, int batches, bool in32 = false)
 {
     const int nk = uh_padded_taps(n_ks);
-#define RR_UHIN_SUB(NK_, B_) (sub ? (rec_in_uh_t)k_rec_in_uh<true, NK_, B_> : (rec_in_uh_t)k_rec_in_uh<false, NK_, B_>)
+#define RR_UHIN_IN(NK_, B_, S_) (in32 ? (rec_in_uh_t)k_rec_in_uh<S_, NK_, B_, true> : (rec_in_uh_t)k_rec_in_uh<S_, NK_, B_, false>)
+#define RR_UHIN_SUB(NK_, B_) (sub ? RR_UHIN_IN(NK_, B_, true) : RR_UHIN_IN(NK_, B_, false))
 #define RR_UHIN_PICK(NK_) (batches == 2 ? RR_UHIN_SUB(NK_, 2) : RR_UHIN_SUB(NK_, 1))
     return nk == 16 ? RR_UHIN_PICK(16) : (nk == 48 ? RR_UHIN_PICK(48) : RR_UHIN_PICK(64));
 #undef RR_UHIN_PICK
 #undef RR_UHIN_SUB
+#undef RR_UHIN_IN
 }
 
 // `count` batches from `batch` on: 1, or 2 for the fused convolution when its rows are there (session_advance_tile)
@@ -790,7 +792,7 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch, int count = 1)
         else hipLaunchKernelGGL(k_rec_in_runoff<double>, gr, dim3(kRunoffInThreads), 0, st, ra, *S.io.runoff);
     } else if (in && S.io.uh_kernel) {
         UhArgs ua{S.io.uh_kernel, S.io.uh_state, (int32_t)S.io.uh_nks};
-        hipLaunchKernelGGL(rec_in_uh_kernel(sub, S.io.uh_nks, count), dim3((unsigned)((n + kUhCols - 1) / kUhCols)), dim3(uh_threads(count)),
+        hipLaunchKernelGGL(rec_in_uh_kernel(sub, S.io.uh_nks, count, ra.rows_in32 != nullptr), dim3((unsigned)((n + kUhCols - 1) / kUhCols)), dim3(uh_threads(count)),
                            rec_in_uh_lds_bytes(uh_padded_taps(S.io.uh_nks), count), st, ra, ua);
     } else if (in && ra.rows_in32) {
         if (sub) hipLaunchKernelGGL((k_rec_in<true, true>), gp, dim3(kRecInThreads), 0, st, ra);
@@ -1298,7 +1300,12 @@ int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io_in, int64
     if (rc == RR_OK && io.uh_kernel && uh_state_inout) {      // carry-over state of the fused convolution, in place, after every batch has read the old one
         const dim3 gt((unsigned)((n + kUhTailThreads - 1) / kUhTailThreads));
         const int32_t nks = (int32_t)io.uh_nks;
-        if (nks <= 16) hipLaunchKernelGGL(k_uh_tail<16>, gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in, T, nks, n);
+        if (io.dev_in32) {      // float32 depth rows
+            if (nks <= 16) hipLaunchKernelGGL((k_uh_tail<16, float>), gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in32, T, nks, n);
+            else if (nks <= 48) hipLaunchKernelGGL((k_uh_tail<48, float>), gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in32, T, nks, n);
+            else hipLaunchKernelGGL((k_uh_tail<0, float>), gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in32, T, nks, n);
+        }
+        else if (nks <= 16) hipLaunchKernelGGL(k_uh_tail<16>, gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in, T, nks, n);
         else if (nks <= 48) hipLaunchKernelGGL(k_uh_tail<48>, gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in, T, nks, n);
         else hipLaunchKernelGGL(k_uh_tail<0>, gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in, T, nks, n);
     }

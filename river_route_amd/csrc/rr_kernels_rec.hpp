@@ -241,7 +241,7 @@ constexpr size_t rec_in_uh_lds_bytes(int nk, int batches) { return (size_t)((uh_
 // at 16 lanes per cycle that was 450 of its 770 us.  Now: LDS accesses at compile-time offsets from one address per thread
 // (the tile is padded instead of the indices clamped), the cyclic rows stepped from one division, 32-bit range tests, the
 // carried-in state behind a branch the whole launch takes the same way.
-template <bool SUB, int NK, int BATCHES>
+template <bool SUB, int NK, int BATCHES, bool IN32 = false>      // IN32: the depth rows are float32 (a.rows_in32, the shape of a.rows)
 __global__ __launch_bounds__(uh_threads(BATCHES)) void k_rec_in_uh(const RecPermArgs a, const UhArgs u)
 {
     constexpr int R = uh_tile_rows(BATCHES), G = uh_groups(BATCHES), RP = uh_rows_per_thread(BATCHES);
@@ -265,7 +265,8 @@ __global__ __launch_bounds__(uh_threads(BATCHES)) void k_rec_in_uh(const RecPerm
 #pragma unroll
             for (int q = 0; q < DPT; ++q) {
                 const int64_t t = row_first - (NK - 1) + min(g + q * G, need + NK - 2);
-                dv[q] = ld_site<kNtInRows>(a.rows.row(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t)) + i);
+                const int64_t off = a.rows.offset(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t)) + i;
+                dv[q] = IN32 ? (double)ld_site<kNtInRows>(a.rows_in32 + off) : ld_site<kNtInRows>(a.rows.base + off);
             }
         } else {
             // load q reads the cyclic row (tb + G q - t0) mod rows: one division, for the first q whose row cannot be negative,
@@ -280,7 +281,10 @@ __global__ __launch_bounds__(uh_threads(BATCHES)) void k_rec_in_uh(const RecPerm
 #pragma unroll
             for (int q = QM - 1; q >= 0; --q) m[q] = m[q + 1] >= step ? m[q + 1] - step : m[q + 1] + d - step;
 #pragma unroll
-            for (int q = 0; q < DPT; ++q) dv[q] = ld_site<kNtInRows>(a.rows.base + ((int64_t)m[q] * a.rows.ld + i));
+            for (int q = 0; q < DPT; ++q) {
+                const int64_t off = (int64_t)m[q] * a.rows.ld + i;
+                dv[q] = IN32 ? (double)ld_site<kNtInRows>(a.rows_in32 + off) : ld_site<kNtInRows>(a.rows.base + off);
+            }
         }
 #pragma unroll
         for (int q = 0; q < TPT; ++q) tv[q] = u.kernel[(int64_t)min(g + q * G, u.n_ks - 1) * a.n + i];

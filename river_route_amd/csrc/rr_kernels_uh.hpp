@@ -187,9 +187,9 @@ __global__ __launch_bounds__(kUhThreads) void k_uh_convolve_ring(const double *_
 // upwards: row s is written after row T + s > s has been read, so no second buffer (and no allocation, copy or
 // synchronisation inside an enqueue-only call) is needed.  NK > 0: taps and the last n_ks - 1 lateral rows sit in
 // registers (static indices, n_ks <= NK); NK == 0: any n_ks, straight from memory.
-template <int NK>
+template <int NK, typename TIn = double>      // TIn: the rows' type (float: runoff depths as the file stores them, exact in float64)
 __global__ __launch_bounds__(kUhTailThreads) void k_uh_tail(const double *__restrict__ kernel, double *__restrict__ state,
-                                                            const double *__restrict__ lateral, int64_t T, int32_t n_ks, int64_t n)
+                                                            const TIn *__restrict__ lateral, int64_t T, int32_t n_ks, int64_t n)
 {
     const int64_t i = (int64_t)blockIdx.x * kUhTailThreads + threadIdx.x;
     if (i >= n) return;
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kUhTailThreads) void k_uh_tail(const double *__rest
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             kv[k] = k < n_ks ? kernel[(int64_t)k * n + i] : 0.0;
-            lat[k] = (k < n_ks - 1 && k < T) ? lateral[(T - 1 - k) * n + i] : 0.0;
+            lat[k] = (k < n_ks - 1 && k < T) ? (double)lateral[(T - 1 - k) * n + i] : 0.0;
         }
 #pragma unroll
         for (int s = 0; s < NK; ++s) {
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(kUhTailThreads) void k_uh_tail(const double *__rest
             for (int32_t k = s + 1; k < n_ks; ++k) {
                 const int64_t tt = m - k;
                 if (tt < 0) break;
-                acc += kernel[(int64_t)k * n + i] * lateral[tt * n + i];
+                acc += kernel[(int64_t)k * n + i] * (double)lateral[tt * n + i];
             }
             state[(int64_t)s * n + i] = s == n_ks - 1 ? 0.0 : acc;
         }

@@ -230,6 +230,14 @@ class Plan:
                                               int(n_ks), ptr(depth), ptr(discharge), ptr(discharge32), int(factor), int(T),
                                               int(num_substeps), stream))
 
+    def unit_route_uh_f32in_dev(self, q_ch, q_full, q_final, uh_kernel, uh_state, n_ks, depth32, T, num_substeps, discharge=None,
+                                discharge32=None, factor=1, stream=None) -> None:
+        """rr_unit_route_uh_f32in_dev: the same from float32 runoff depths (as runoff files store them)."""
+        self.reserve(MODE_UNIT, T, num_substeps)
+        check(_lib.lib().rr_unit_route_uh_f32in_dev(self._h, ptr(q_ch), ptr(q_full), ptr(q_final), ptr(uh_kernel), ptr(uh_state),
+                                                    int(n_ks), ptr(depth32), ptr(discharge), ptr(discharge32), int(factor), int(T),
+                                                    int(num_substeps), stream))
+
     # -- partitioned networks: boundary reaches + streaming calls (include/rr_hip.h) --
     def set_boundary(self, ghost_reaches, export_reaches) -> None:
         g = np.ascontiguousarray(ghost_reaches, dtype=np.int64)

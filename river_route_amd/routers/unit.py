@@ -60,11 +60,40 @@ class UnitMuskingum(TransformMuskingum):
     _engine_router = _router
 
     def _router_device(self, qlateral: np.ndarray, rows_per_output: int) -> tuple[np.ndarray, np.ndarray]:
+        from .._lib import RR_E_UNSUPPORTED, RRError
         from ._device import Arena
         self._check_kernel()
-        depth = self._check_lateral(qlateral)
+        depth = self._check_lateral(qlateral, keep_float32=True)
+        if depth.dtype == np.float32:      # a float32 file: uploaded as it is, converted in the pass that convolves it into the engine's records
+            try:
+                with Arena(self.cfg.device) as arena:
+                    return self._route_on_device_f32in(arena, arena.put(depth), depth.shape[0], rows_per_output)
+            except RRError as e:
+                if e.code != RR_E_UNSUPPORTED:
+                    raise
+            depth = depth.astype(np.float64)
         with Arena(self.cfg.device) as arena:
             return self._route_on_device(arena, arena.put(depth), depth.shape[0], rows_per_output)
+
+    def _route_on_device_f32in(self, arena, d_depth32, T: int, rows_per_output: int) -> tuple[np.ndarray, np.ndarray]:
+        """Runoff depths on the device as (T, n) float32 rows -> (router state, float32 discharge rows): rr_unit_route_uh_f32in_dev,
+        bit for bit what the float64 rows give (float32 -> float64 is exact).  RR_E_UNSUPPORTED (a call the time-tiled kernel does not
+        take, more than 64 kernel steps) leaves the UH state as it was: the caller converts the rows and takes the float64 path."""
+        self._check_kernel()
+        n = self.A.shape[0]
+        n_ks, nsub = self._uh.kernel.shape[0], self.num_routing_steps_per_runoff
+        self._upload_coefficients(None, ('unit',))
+        seed = self._seed()
+        d_kern = arena.put(self._uh.kernel)
+        d_state = arena.put(np.ascontiguousarray(self._uh.state, dtype=np.float64))
+        d_qch, d_qfull, d_final = arena.put(seed), arena.put(seed), arena.empty(n * 8)
+        d_f32 = arena.empty((T // rows_per_output) * n * 4)
+        self._plan.unit_route_uh_f32in_dev(d_qch, d_qfull, d_final, d_kern, d_state, n_ks, d_depth32, T, nsub,
+                                           discharge32=d_f32, factor=rows_per_output)
+        q_array = d_f32.download(np.float32, (T // rows_per_output, n))
+        state = d_final.download(np.float64, (n,))
+        self._uh.state = d_state.download(np.float64, self._uh.kernel.shape)
+        return state, q_array
 
     def _route_on_device(self, arena, d_depth, T: int, rows_per_output: int) -> tuple[np.ndarray, np.ndarray]:
         """Runoff depths already on the device, (T, n) float64 rows -> (router state, float32 discharge rows).  Where the

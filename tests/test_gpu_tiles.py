@@ -738,3 +738,59 @@ def test_constant_forcing_settles_at_the_basin_sums(monkeypatch):
         assert plan.profile()['ticks_per_launch'] >= 64
         np.testing.assert_allclose(q.cpu().numpy(), want, rtol=1e-9, err_msg='final state')
         np.testing.assert_allclose(out.cpu().numpy(), np.broadcast_to(want, (sink, n)), rtol=1e-9, err_msg='last 128 rows')
+
+
+@pytest.mark.parametrize('n,T,nsub,n_ks,factor', [(60_007, 300, 1, 48, 1), (60_000, 130, 2, 12, 0), (100_000, 384, 1, 33, 4)])
+def test_float32_depth_rows_equal_their_float64_copy(monkeypatch, n, T, nsub, n_ks, factor):
+    """rr_unit_route_uh_f32in_dev: runoff depths as float32 rows (4 bytes read per value) give, bit for bit, what the same values
+    give as float64 rows through rr_unit_route_uh_dev -- discharge (float64 rows, or float32 rows averaged by `factor`), the
+    router's state, q_ch and the UH carry-over state -- over two files, the second shorter than the kernel."""
+    set_env(monkeypatch, {})
+    net = synth.synth_network(n, seed=29)
+    indptr, indices = csc_from_down(net.down_index)
+    hw_idx, inner_idx, A_in, A_hw = unit_split(indptr, indices, n)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0 / nsub)
+    kern = synth.synth_uh_kernel(n, n_ks)
+    ni = inner_idx.size
+    seed = 3.0 * synth.u01(7, np.arange(n))
+    results = {}
+    for kind in ('f4', 'f8'):
+        with Plan(indptr, indices) as plan:
+            plan.set_coeffs(-c1[indices], c2, c3, None)
+            d_kern, d_state = DeviceBuffer(kern.nbytes).upload(kern), DeviceBuffer(kern.nbytes).upload(np.zeros_like(kern))
+            d_fin, d_qc, d_qf = DeviceBuffer(n * 8), DeviceBuffer(ni * 8), DeviceBuffer(ni * 8)
+            state, got = seed.copy(), []
+            for f, Tf in enumerate((T, max(2, n_ks // 2))):
+                if factor and Tf % factor:
+                    Tf -= Tf % factor
+                depth32 = synth.synth_runoff_depth(n, f * T, f * T + Tf).astype(np.float32)
+                d_qc.upload(state[inner_idx].copy()); d_qf.upload(state[inner_idx].copy())
+                rows_out = Tf // factor if factor else Tf
+                d_out = DeviceBuffer(rows_out * n * (4 if factor else 8))
+                out = dict(discharge32=d_out, factor=factor) if factor else dict(discharge=d_out)
+                try:
+                    if kind == 'f4':
+                        d_depth = DeviceBuffer(depth32.nbytes).upload(depth32)
+                        plan.unit_route_uh_f32in_dev(d_qc, d_qf, d_fin, d_kern, d_state, n_ks, d_depth, Tf, nsub, **out)
+                    else:
+                        depth64 = depth32.astype(np.float64)
+                        d_depth = DeviceBuffer(depth64.nbytes).upload(depth64)
+                        plan.unit_route_uh_dev(d_qc, d_qf, d_fin, d_kern, d_state, n_ks, d_depth, Tf, nsub, **out)
+                except Exception as e:      # a call too short for the time-tiled kernel is refused by both forms alike
+                    from river_route_amd._lib import RR_E_UNSUPPORTED
+                    assert getattr(e, 'code', None) == RR_E_UNSUPPORTED
+                    got.append(None)
+                    break
+                state = d_fin.download(np.float64, (n,))
+                got.append((d_out.download(np.float32 if factor else np.float64, (rows_out, n)), state.copy(),
+                            d_qc.download(np.float64, (ni,)), d_state.download(np.float64, kern.shape)))
+                d_depth.free(); d_out.free()
+            for b in (d_kern, d_state, d_fin, d_qc, d_qf):
+                b.free()
+        results[kind] = got
+    assert len(results['f4']) == len(results['f8']) and results['f4'][0] is not None
+    for a, b in zip(results['f4'], results['f8']):
+        assert (a is None) == (b is None)
+        if a is not None:
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x, y)

@@ -269,6 +269,25 @@ def test_float32_qlateral_file_routes_like_its_float64_copy(backend, case):
     np.testing.assert_array_equal(results['f4'][1], results['f8'][1])
 
 
+def test_float32_runoff_depths_route_like_their_float64_copy(backend, case):
+    """UnitMuskingum fed float32 runoff depths (what a float32 file yields) takes them to the device as float32
+    (rr_unit_route_uh_f32in_dev where the engine offers it, its float64 path otherwise): discharge, router state and UH state are
+    those of the same values as float64, bit for bit."""
+    g = case['g']
+    kp, us = _unit_files(case)
+    d32 = [g['depth0'].astype(np.float32), g['depth1'].astype(np.float32)]
+    runs = []
+    for series in (d32, [d.astype(np.float64) for d in d32]):
+        r, got = drive(rr.UnitMuskingum, case, series, channel_state_init_file=case['init'], dt_routing=1200, uh_kernel_file=kp,
+                       uh_state_init_file=us)
+        runs.append((r, got))
+    for (_, q32, _, _), (_, q64, _, _) in zip(runs[0][1], runs[1][1]):
+        assert q32.dtype == np.float32
+        np.testing.assert_array_equal(q32, q64)
+    np.testing.assert_array_equal(runs[0][0].channel_state, runs[1][0].channel_state)
+    np.testing.assert_array_equal(runs[0][0]._uh.state, runs[1][0]._uh.state)
+
+
 # ---------------------------------------------------------------- config / validation behaviour (no compute)
 
 def test_configs_validation(tmp_path):
