@@ -112,8 +112,8 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         if (const char *e2 = getenv("RR_REC_STREAM")) P->rec_stream_enabled = atoi(e2) != 0;      // measurements: record passes on a second stream
         if (P->rec_stream_enabled && hipStreamCreateWithFlags(&P->s_rec, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); P->s_rec = nullptr; }
         if (const char *e2 = getenv("RR_TILE_LEAN")) P->lean_enabled = atoi(e2) != 0;      // measurements / tests: the general tick for every call
-        for (int v = 0; v < 6; ++v)    // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel (v = 4, 5: the short ticks of Rapid and Unit)
-            if (hipFuncSetAttribute((const void *)tile_kernel(P->wave_threads, v < 4 ? (v & 1) != 0 : v == 5, v < 4 && (v & 2) != 0, v >= 4), hipFuncAttributeMaxDynamicSharedMemorySize,
+        for (int v = 0; v < 7; ++v)    // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel (v = 4, 5, 6: the short ticks of Rapid, Unit, channel-only)
+            if (hipFuncSetAttribute((const void *)tile_kernel(P->wave_threads, v < 4 ? (v & 1) != 0 : v == 5, v < 4 && (v & 2) != 0, v >= 4, v == 6), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)tile_lds_bytes(P->wave_threads)) != hipSuccess) {
                 (void)hipGetLastError();
                 P->wave_enabled = false;

@@ -656,8 +656,11 @@ int session_launch_tick(rr_plan *P, int64_t tau)
 typedef void (*tile_kernel_t)(const TileArgs);
 
 // Tile = one position per thread; 16 waves per CU whose two record buffers fill the register file, as 1, 2 or 4 workgroups.
-tile_kernel_t tile_kernel(int threads, bool unit, bool sub, bool lean = false)
+tile_kernel_t tile_kernel(int threads, bool unit, bool sub, bool lean = false, bool nolat = false)
 {
+    if (lean && nolat && !unit && !sub)      // channel-only routing, one sub-step per row: the short tick without a lateral term
+        return threads == 128 ? (tile_kernel_t)k_tile<128, false, false, true, true> : (threads == 256 ? (tile_kernel_t)k_tile<256, false, false, true, true>
+             : (threads == 512 ? (tile_kernel_t)k_tile<512, false, false, true, true> : (tile_kernel_t)k_tile<1024, false, false, true, true>));
 #define RR_TILE_PICK(T_) (unit ? (sub ? (tile_kernel_t)k_tile<T_, true, true> : (lean ? (tile_kernel_t)k_tile<T_, true, false, true> : (tile_kernel_t)k_tile<T_, true, false>))   \
                                : (sub ? (tile_kernel_t)k_tile<T_, false, true> : (lean ? (tile_kernel_t)k_tile<T_, false, false, true> : (tile_kernel_t)k_tile<T_, false, false>)))
     return threads == 128 ? RR_TILE_PICK(128) : (threads == 256 ? RR_TILE_PICK(256) : (threads == 512 ? RR_TILE_PICK(512) : RR_TILE_PICK(1024)));
@@ -693,13 +696,13 @@ int session_launch_diag(rr_plan *P, int64_t d)
     // one workgroup per resident slot (16 waves per CU); each walks its share of the launch's tiles
     const dim3 g((unsigned)std::min<int64_t>(t_hi - t_lo, (int64_t)P->cu_count * (1024 / P->wave_threads)));
     const size_t lds_bytes = tile_lds_bytes(P->wave_threads);
-    // RapidMuskingum and UnitMuskingum with one sub-step per row run the short tick (k_tile<..., LEAN>), and beside it the general kernel for
+    // With one sub-step per row every mode runs the short tick (k_tile<..., LEAN>), and beside it the general kernel for
     // the tiles the short tick does not take (a reach with more than three upstream reaches); RR_TILE_LEAN=0: the general one
     const bool unit = S.mode == Mode::Unit;
-    const bool lean = (S.mode == Mode::Rapid || unit) && S.nsub == 1 && P->lean_enabled;
+    const bool lean = S.nsub == 1 && P->lean_enabled;      // every router's default (dt_routing = dt_runoff); sub-steps keep the general tick
     w.tile_filter = lean ? 1 : 0;
     w.coef = (lean && unit) ? P->d_coef_unit : P->d_coef;
-    hipLaunchKernelGGL(tile_kernel(P->wave_threads, unit, S.nsub > 1, lean), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
+    hipLaunchKernelGGL(tile_kernel(P->wave_threads, unit, S.nsub > 1, lean, S.mode == Mode::Muskingum), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
     if (lean && P->n_wide_tiles > 0) {
         w.tile_filter = 2; w.coef = P->d_coef;
         hipLaunchKernelGGL(tile_kernel(P->wave_threads, unit, false, false), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);

@@ -155,7 +155,9 @@ constexpr bool kHalfStores = RR_TILE_HALF_STORES != 0;
 // requested at once (a half record would cost the fabric a full line: measured, FETCH_SIZE 1.8x).
 // LEAN: one sub-step per row, RapidMuskingum (the headline's case) or UnitMuskingum: the short tick below instead of the general
 // one (the two do not fit one kernel: with the record buffers in 64 of 128 registers the allocator spills the records in flight).
-template <int TH, bool UNIT, bool SUB, bool LEAN = false>
+// NOLAT (short tick only): channel-only routing (Muskingum.py:262-290) -- no lateral rows were turned into records, so a record slot
+// holds whatever the ring held; only a ghost's slot means something (what its reach published).
+template <int TH, bool UNIT, bool SUB, bool LEAN = false, bool NOLAT = false>
 __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 waves per CU: 1,024 / TH workgroups of 128 VGPRs
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -453,6 +455,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
         const int32_t kind = LEAN ? cur.plain : 0;
         int32_t own_b = 0, up0_b = 0, up1_b = 0, up2_b = 0, lagm = 0;      // LDS byte offsets inside a discharge buffer: own slot, the three upstream slots (or the zero slot)
         int32_t hw0_b = 0, hw1_b = 0, hw2_b = 0;      // UnitMuskingum: the headwater tributaries' slots (they come first in the upstream range); up*_b then hold the inner ones
+        bool ghostm = false;                          // NOLAT: this position is a ghost (its record slot is its forcing)
         auto lds_at = [&](int parity, int32_t byte) -> double & { return *reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + parity * (THP * 8) + byte); };
         // record loads of the short path: one address register per chunk, the piece of load j is an immediate / scalar offset
         auto issue_load_plain = [&](__amdgpu_buffer_rsrc_t src, int32_t voff, int j) {
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                     }
                     aux_at(4) = s_cur;
                 } else {
-                    qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev, __builtin_fma(c3, q_old, R[s])));
+                    qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev, __builtin_fma(c3, q_old, (NOLAT && !ghostm) ? 0.0 : R[s])));
                     if (decltype(tested)::value) {
                         const bool active = (uint32_t)(tau0 + s - lagm) < (uint32_t)total;
                         R[s] = active ? qk : R[s];
@@ -531,6 +534,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                 const int32_t t = fresh(tid), ln = t & 63, upk = fresh(up);
                 const int32_t cnt = (int32_t)((uint32_t)upk >> 16), u0s = upk & 0xFFFF;
                 own_b = t * 8;
+                if (NOLAT) { const int32_t lgs = fresh(lg); ghostm = lgs >= 0 && (lgs & (kGhostBit | kTileGhostBit)) != 0; }
                 if (UNIT) {
                     const int32_t nh = fresh(uh) - u0s, ni = cnt - nh, i0 = u0s + nh;      // headwater tributaries [u0s, uh), inner ones [uh, u0s + cnt)
                     hw0_b = (nh >= 1 ? u0s : TH) * 8; hw1_b = (nh >= 2 ? u0s + 1 : TH) * 8; hw2_b = (nh >= 3 ? u0s + 2 : TH) * 8;
