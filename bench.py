@@ -249,14 +249,69 @@ def bench_unit(args, device_index):
     return line
 
 
+def launch_ranks(n_ranks: int) -> int:
+    """`python bench.py --gpus N` without torch.distributed.run: this process -- which never touches a GPU -- starts one
+    fresh child per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what torchrun would set), relays rank 0's
+    JSON line and returns non-zero if any rank fails.  RR_DIST_BACKEND=gloo lets the ranks share one card (rehearsal)."""
+    import socket
+    import subprocess
+    if os.environ.get('RR_DIST_BACKEND', 'nccl') == 'nccl':
+        import torch      # device_count() does not initialise the GPU
+        have = torch.cuda.device_count()
+        if have < n_ranks:
+            print(f'bench.py --gpus {n_ranks}: {have} GPU(s) visible; RCCL needs one per rank '
+                  f'(RR_DIST_BACKEND=gloo rehearses the same run with the ranks sharing a card)', file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    deadline = time.monotonic() + float(os.environ.get('RR_BENCH_TIMEOUT', '3000'))
+    failed = None
+    while failed is None and any(p.poll() is None for p in procs):
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0):
+                failed = f'rank {r} exited with code {p.returncode}'
+        if failed is None and time.monotonic() > deadline:
+            failed = 'deadline (RR_BENCH_TIMEOUT) passed'
+        if failed is None:
+            time.sleep(0.2)
+    if failed is None:
+        for r, p in enumerate(procs):
+            if p.returncode != 0:
+                failed = f'rank {r} exited with code {p.returncode}'
+    if failed is not None:
+        for p in procs:      # exactly the children started above
+            if p.poll() is None:
+                p.kill()
+    out = procs[0].stdout.read().decode('utf-8', 'replace') if procs[0].stdout else ''
+    for p in procs:
+        p.wait()
+    if failed is not None:
+        sys.stderr.write(out)
+        print(f'bench.py --gpus {n_ranks}: {failed}', file=sys.stderr)
+        return 1
+    lines = [ln for ln in out.splitlines() if ln.startswith('{')]
+    if not lines:
+        print(f'bench.py --gpus {n_ranks}: rank 0 printed no JSON line', file=sys.stderr)
+        return 1
+    print(lines[-1])
+    return 0
+
+
 def main():
     args = parse_args()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:      # stand-alone: be the launcher, before anything touches a GPU
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
         args.gpus = world
 
     from river_route_amd import synth
@@ -284,12 +339,16 @@ def main():
     torch.cuda.set_device(device_index)
     dev = torch.device('cuda', device_index)
     if world > 1:
+        import datetime
+        # a rank that never gets its message is reported by the exchange's own deadline (multi_gpu.run_distributed); this one
+        # bounds the collectives around it
+        limit = datetime.timedelta(seconds=float(os.environ.get('RR_DIST_TIMEOUT', '600')))
         if backend == 'nccl':
-            dist.init_process_group('nccl', device_id=dev)
+            dist.init_process_group('nccl', device_id=dev, timeout=limit)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=limit)
         from river_route_amd import multi_gpu
-        multi_gpu.bench_main(args, rank, device_index, world)
+        multi_gpu.bench_main(args, rank, device_index, world, gate=None if (args.no_cpu_baseline or args.substeps != 1) else part_parity_gate)
         return
     local_rank = device_index
 
@@ -300,6 +359,46 @@ def main():
     if not args.no_secondary and n == 1_000_000 and T == 35_040 and nsub == 1:
         line['secondary'] = secondary_lines(args, device_index)
     print(json.dumps(line))
+
+
+def part_parity_gate(eng, spec, coef, run, rows=96):
+    """N > 1: this rank's part against the oracle before anything is timed.  The first `rows` forcing rows go through the
+    distributed driver (`run`: the same exchange, engine and kernels as the timed passes) from a zero state into a plain
+    array; the oracle routes the part's own reaches on the host, the discharge arriving over the cut -- the boundary series
+    this rank RECEIVED, themselves rows the upstream ranks check against their own oracle runs -- folded into the lateral
+    volume of the reach it enters (c2 Q[t-1] + c1 Q[t], _numba_kernels.py:70-78 for an upstream reach that is not in the
+    local system).  One sub-step per row only.  Raises AssertionError on a mismatch."""
+    import torch
+    from oracle import oracle
+    c1, c2, c3, c4_dt = coef
+    ng, real = spec.n_ghost, spec.real_global
+    Tg = int(min(rows, eng.T, eng.lat_rows))
+    chk = torch.zeros((Tg, spec.n_local), dtype=torch.float64, device=eng.dev)
+    eng.reshape_call(Tg, chk, Tg)
+    run(Tg)
+    torch.cuda.synchronize()
+    got = chk.cpu().numpy()[:, ng:]
+    G = eng.ghost_series[:Tg].cpu().numpy()
+    E = eng.export_series[:Tg].cpu().numpy()
+    c1r, c2r, c3r, c4r = c1[real], c2[real], c3[real], c4_dt[real]
+    down = np.where(spec.down_local[ng:] >= 0, spec.down_local[ng:] - ng, -1)
+    has = down >= 0
+    indptr = np.concatenate([[0], np.cumsum(has)]).astype(np.int32)
+    indices = down[has].astype(np.int32)
+    ql = eng.lateral[:Tg, ng:].cpu().numpy().copy()
+    for g in range(ng):      # the engine's q0 is zero here, so a ghost's value before the first row is zero too
+        d = int(spec.down_local[g] - ng)
+        old = np.concatenate([[0.0], G[:-1, g]])
+        ql[:, d] += (c2r[d] * old + c1r[d] * G[:, g]) / c4r[d]
+    q, want = np.zeros(real.size), np.zeros((Tg, real.size))
+    oracle.rapid_route(indptr, indices, -c1r[indices], c2r, c3r, c4r, q, ql, want, 1)
+    scale = float(np.abs(want).max())
+    assert np.allclose(got, want, rtol=1e-10, atol=1e-10 * scale), f'part {spec.part}: max |diff| {float(np.abs(got - want).max()):.3e} of {scale:.3e}'
+    ex = np.searchsorted(real, spec.export_global)
+    if ex.size:
+        assert np.allclose(np.maximum(E[:, :ex.size], 0.0), want[:, ex], rtol=1e-10, atol=1e-10 * scale), f'part {spec.part}: export series differs'
+    return (f'first {Tg} rows of its part through the timed exchange and kernels == oracle on the part with the received boundary '
+            f'series folded in, rtol 1e-10')
 
 
 def secondary_lines(args, device_index):

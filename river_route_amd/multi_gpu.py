@@ -20,9 +20,15 @@ exactly as the reach it mirrors does in the uncut network, while a ghost that mi
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 
 import numpy as np
+
+# RCCL shares device memory between the ranks of a node through dmabuf IPC on these hosts; the legacy mode fails with
+# `hipIpcGetMemHandle: invalid argument`.  Has to be in the environment before the HIP runtime starts, so any program that
+# drives run_distributed over RCCL should import this module (or set the variable) before it touches the GPU.
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 __all__ = ['PartSpec', 'split_network', 'HipPartEngine', 'HipUnitPartEngine', 'part_driver', 'run_distributed', 'run_in_process',
            'bench_main']
@@ -145,6 +151,16 @@ class HipPartEngine:
         self.plan.stream_begin(self.q_t, self.lateral, self.lat_rows, self.discharge, self.out_rows, self.T,
                                self.nsub, self.ghost_series, self.export_series, stream)
 
+    def reshape_call(self, T: int, discharge=None, out_rows=None) -> None:
+        """The next calls route T runoff steps (at most the T the engine was built for: the boundary series are that long)
+        into `discharge` (a (out_rows, n_local) device tensor written cyclically) -- bench.py's parity gate routes the first rows
+        into a plain array with the engine it then times."""
+        if T * self.nsub > self.ghost_series.shape[0]:
+            raise ValueError('reshape_call: more steps than the boundary series hold')
+        self.T = int(T)
+        if discharge is not None:
+            self.discharge, self.out_rows = discharge, int(out_rows or discharge.shape[0])
+
     def advance(self, rows_ready: int, ghost_ready: int) -> int:
         return self.plan.stream_advance(rows_ready, ghost_ready)
 
@@ -255,13 +271,17 @@ def part_driver(engine, spec: PartSpec, T: int, nsub: int, chunk_rows: int):
     for k in range(n_chunks):
         rows1 = min(T, (k + 1) * chunk_rows)
         s1 = rows1 * nsub
-        if spec.upstream_parts and k + 1 < n_chunks:
-            yield ('post', k + 1, wanted(k + 1))      # the next chunk's boundary values travel while this one is routed
         for req in wanted(k):
             yield ('recv',) + req
         ready = engine.advance(rows1, s1 if spec.n_ghost else S)
         if spec.downstream_parts:
             yield from flush(ready, False)
+        # The next chunk's receives are posted after this chunk's sends: on RCCL both queue on the communicator's stream, and a
+        # receive posted first would hold this part's exports back until ITS upstream parts have produced the next chunk (one
+        # chunk of latency per level of the part graph).  The host never blocks on RCCL work, so they are still posted long before
+        # the values are used.
+        if spec.upstream_parts and k + 1 < n_chunks:
+            yield ('post', k + 1, wanted(k + 1))
     ready = engine.advance(T, S)
     if spec.downstream_parts:
         yield from flush(ready, True)
@@ -273,10 +293,51 @@ def run_distributed(engine, spec: PartSpec, T: int, nsub: int, chunk_rows: int, 
     Rank == part.  The receives of a chunk are posted as ONE batch (one grouped RCCL call for all upstream parts) when the
     driver announces them -- a chunk before the values are used -- so the part that collects seven boundary series never
     stands in a queue of blocking receives; sends are asynchronous (batches of one, so that both ends of a message use the same
-    communicator), their buffers kept alive until the call ends."""
-    pending = []
-    posted = {}                                 # (src, r0, r1) -> (work, staging buffer)
+    communicator), their buffers kept alive until the call ends.
+
+    Nothing here waits without a deadline (RR_EXCHANGE_TIMEOUT seconds, default 300): a message that does not arrive -- a
+    mismatched pair, a rank that died -- is reported with its peer and rows and the process exits with status 1, so the
+    launcher (bench.py / torchrun) takes the other ranks down instead of every rank hanging until its lease ends."""
+    import os
+    import sys
+    import time
+    limit = float(os.environ.get('RR_EXCHANGE_TIMEOUT', '300'))
+    rank = dist.get_rank()
+    pending = []                                # sends: (work, what, posted at, buffer kept alive)
+    posted = {}                                 # (src, r0, r1) -> (work, staging buffer, posted at)
+    watch = []                                  # RCCL receives the stream waits for: (work, what, posted at)
     via_host = dist.get_backend() != 'nccl'     # gloo moves host memory: stage device tensors through the CPU
+
+    def give_up(what, since):
+        print(f'rr: rank {rank}: {what} not complete after {time.monotonic() - since:.0f} s (RR_EXCHANGE_TIMEOUT={limit:g}); '
+              f'still open: {len(posted)} receive batch(es), {len(pending)} send(s) -- exiting', file=sys.stderr, flush=True)
+        os._exit(1)       # not sys.exit: interpreter teardown would wait for the communicator the stuck operation holds
+
+    def complete(work, what, since, block):
+        """True once `work` is done; with `block`, waits until then or until the deadline."""
+        if via_host:      # gloo's point-to-point work knows no is_completed(); its wait takes a timeout and raises when that passes
+            if not block:
+                return False
+            import datetime
+            try:
+                work.wait(datetime.timedelta(seconds=max(0.05, limit - (time.monotonic() - since))))
+            except RuntimeError:
+                give_up(what, since)
+            return True
+        while not work.is_completed():      # RCCL: a query of the event behind the operation
+            if time.monotonic() - since > limit:
+                give_up(what, since)
+            if not block:
+                return False
+            time.sleep(0.0005)
+        return True
+
+    def sweep(block=False):
+        while watch and complete(*watch[0], block):
+            watch.pop(0)
+        while pending and complete(*pending[0][:3], block):
+            pending.pop(0)
+
     for req in part_driver(engine, spec, T, nsub, chunk_rows):
         kind = req[0]
         if kind == 'post':
@@ -286,22 +347,29 @@ def run_distributed(engine, spec: PartSpec, T: int, nsub: int, chunk_rows: int, 
                 ops.append(dist.P2POp(dist.irecv, buf, src))
                 keys.append(((src, r0, r1), buf))
             works = dist.batch_isend_irecv(ops)
+            now = time.monotonic()
             for i, (key, buf) in enumerate(keys):
-                posted[key] = (works[i] if len(works) == len(keys) else works[-1], buf)      # RCCL returns one work for the group
+                posted[key] = (works[i] if len(works) == len(keys) else works[-1], buf, now)      # RCCL returns one work for the group
         elif kind == 'recv':
             _, peer, view, r0, r1 = req
-            work, buf = posted.pop((peer, r0, r1))
-            work.wait()                          # RCCL: the current stream waits, the host does not
+            work, buf, since = posted.pop((peer, r0, r1))
+            what = f'receive of boundary sub-steps [{r0}, {r1}) from part {peer}'
+            if via_host:
+                complete(work, what, since, True)      # the copy below reads host memory
+            else:
+                work.wait()                            # RCCL: the current stream waits, the host does not ...
+                watch.append((work, what, since))      # ... so the host looks again later
             view.copy_(buf)
         else:
             _, peer, view, r0, r1 = req
             buf = view.cpu().contiguous() if via_host else view.contiguous()
             # a batch of one, not dist.isend: ProcessGroupNCCL sends a batched operation over the group's communicator and a single
             # one over a two-rank communicator of its own, and a receive posted in a batch (above) only ever meets the former
-            pending.append((dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, peer)])[-1], buf))
+            work = dist.batch_isend_irecv([dist.P2POp(dist.isend, buf, peer)])[-1]
+            pending.append((work, f'send of boundary sub-steps [{r0}, {r1}) to part {peer}', time.monotonic(), buf))
+        sweep()
     assert not posted
-    for work, _ in pending:
-        work.wait()
+    sweep(block=True)
 
 
 def run_in_process(engines, specs, T: int, nsub: int, chunk_rows: int) -> None:
@@ -394,9 +462,13 @@ def roofline_from_profile(prof: dict, nsub: int, peak_gbs: float = 8000.0, traff
 
 # ------------------------------------------------------------------------------------------------ bench.py --gpus N
 
-def bench_main(args, rank: int, local_rank: int, world: int) -> None:
+def bench_main(args, rank: int, local_rank: int, world: int, gate=None) -> None:
     """N > 1 leg of bench.py: ONE network of args.reaches * N reaches, graph-partitioned over the N GPUs
-    (weak scaling: reaches per GPU fixed), boundary discharge exchanged over RCCL."""
+    (weak scaling: reaches per GPU fixed), boundary discharge exchanged over RCCL.
+
+    `gate(eng, spec, coefficients, run)` -> str: bench.py's parity gate (it owns the oracle: nothing in this package imports
+    it).  It routes the first rows through `run` -- the distributed driver that is then timed -- and compares this part's rows
+    with the oracle; every rank must pass before anything is timed."""
     import json
     import time
     import torch
@@ -430,6 +502,24 @@ def bench_main(args, rank: int, local_rank: int, world: int) -> None:
     torch.cuda.synchronize()
     dist.barrier()      # every rank is through its setup, and the group's communicator exists before the first batched send / receive uses it
     t_ready = time.perf_counter()
+    cdev = eng.dev if dist.get_backend() == 'nccl' else torch.device('cpu')
+
+    gate_note = None
+    if gate is not None:
+        sink, sink_rows = eng.discharge, eng.out_rows
+        ok, note = 1.0, ''
+        try:
+            note = gate(eng, spec, (c1, c2, c3, (c1 + c2) / (dt * nsub)), lambda Tg: run_distributed(eng, spec, Tg, nsub, min(chunk_rows, 32), dist))
+        except AssertionError as e:
+            ok, note = 0.0, str(e)
+        eng.reshape_call(T, sink, sink_rows)
+        flag = torch.tensor([ok], dtype=torch.float64, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if ok == 0.0:
+            print(f'bench.py: rank {rank}: partitioned result differs from the oracle: {note}', file=__import__('sys').stderr, flush=True)
+        if float(flag.item()) == 0.0:
+            raise SystemExit('bench.py: a part of the partitioned run does not reproduce the oracle; refusing to report a number')
+        gate_note = note
 
     def one_pass():
         run_distributed(eng, spec, T, nsub, chunk_rows, dist)
@@ -443,7 +533,6 @@ def bench_main(args, rank: int, local_rank: int, world: int) -> None:
         one_pass()
     torch.cuda.synchronize()
     dist.barrier()
-    cdev = eng.dev if dist.get_backend() == 'nccl' else torch.device('cpu')
     elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
     dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     elapsed = float(elapsed.item())
@@ -477,7 +566,7 @@ def bench_main(args, rank: int, local_rank: int, world: int) -> None:
                        'setup_s': {'network': [round(g[6].item(), 1) for g in gathered], 'partition': [round(g[7].item(), 1) for g in gathered],
                                    'plan_forcing_ring': [round(g[8].item(), 1) for g in gathered]},
                        'exchange_rows': chunk_rows},
-            'roofline': roofline, 'cpu_baseline': None,
+            'roofline': roofline, 'cpu_baseline': None if gate_note is None else {'parity_gate': f'every rank: {gate_note}'},
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     dist.destroy_process_group()

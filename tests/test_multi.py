@@ -4,6 +4,7 @@ boundary exchange.  CPU: world_size-2 gloo run with an oracle-backed engine inje
 against the single-domain oracle.  GPU: the real engine, all parts on one card through the in-process runner
 (the same driver and the same C-ABI streaming calls the RCCL run uses), against the single-plan result.
 """
+import os
 import socket
 
 import numpy as np
@@ -199,6 +200,81 @@ def test_two_ranks_rccl_vs_oracle(tmp_path):
     if torch.cuda.device_count() < 2:
         pytest.skip('needs 2 GPUs (RCCL refuses two ranks on one device)')
     _ranks_vs_oracle(tmp_path, 2, 'nccl')
+
+
+@pytest.mark.gpu
+def test_rccl_call_sequence_on_one_rank():
+    """Every RCCL call of bench.py's N > 1 leg on the one GPU this box has (a world of one rank, in a child process):
+    init with device and timeout, barrier, all_reduce, all_gather, batched irecv / isend of float64 rows, Work.is_completed."""
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(free_port()), RANK='0', WORLD_SIZE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), 'rccl_one_rank.py')], env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'rccl ok nccl' in r.stdout
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks_gloo_rehearsal():
+    """`python bench.py --gpus 4` with no launcher around it (how the driver starts the bench): the parent starts four ranks before
+    it touches the GPU, they share the card over gloo, every rank's part reproduces the oracle on its first 96 rows (the line's
+    parity gate) and rank 0's line comes back through the parent."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(RR_DIST_BACKEND='gloo', RR_EXCHANGE_TIMEOUT='240', RR_BENCH_TIMEOUT='900')
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py')
+    r = subprocess.run([sys.executable, bench, '--gpus', '4', '--reaches', '100000', '--runoff-steps', '2000', '--steps', '1', '--warmup', '1'],
+                       env=env, capture_output=True, text=True, timeout=1000)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    assert line['n_gpus'] == 4 and line['config']['reaches'] == 400_000 and line['value'] > 0 and line['scaling'] == 'weak'
+    assert sum(line['config']['part_reaches']) == 400_000 and len(line['config']['part_reaches']) == 4
+    assert 'oracle' in line['cpu_baseline']['parity_gate']
+
+
+def test_bench_launcher_reports_a_failed_rank():
+    """The launcher returns non-zero and says which rank failed (here: every rank, there is no GPU / bad argument) instead of hanging."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env.update(RR_DIST_BACKEND='gloo', RR_BENCH_TIMEOUT='300')
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py')
+    r = subprocess.run([sys.executable, bench, '--gpus', '2', '--reaches', '-5'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and 'exited with code' in r.stderr
+
+
+def test_exchange_deadline_names_the_missing_message(tmp_path):
+    """A receive nobody answers ends the rank with status 1 and a line naming peer and rows, not with a hang."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}); sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})\n"
+        "from river_route_amd.multi_gpu import run_distributed, split_network\n"
+        "from river_route_amd.engine import partition_forest\n"
+        "from multi_helpers import OraclePartEngine, setup_case\n"
+        "from river_route_amd import synth\n"
+        "dist.init_process_group('gloo')\n"
+        "rank = dist.get_rank()\n"
+        "net, indptr, indices, c1, c2, c3, q0 = setup_case(700)\n"
+        "part_of, _ = partition_forest(indptr, indices, 2)\n"
+        "spec = split_network(net.down_index, part_of, rank, 2)\n"
+        "ql = synth.synth_qlateral(700, 0, 16)\n"
+        "eng = OraclePartEngine(spec, c1, c2, c3, (c1 + c2) / 900.0, q0, ql[:, spec.real_global], 16, 1)\n"
+        "if rank == 0:\n"
+        "    import time; time.sleep(20); os._exit(0)      # the upstream part never sends\n"
+        "run_distributed(eng, spec, 16, 1, 8, dist)\n")
+    port = free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RR_EXCHANGE_TIMEOUT='3')
+        procs.append(subprocess.Popen([sys.executable, '-c', code], env=env, stderr=subprocess.PIPE, text=True))
+    err = procs[1].communicate(timeout=120)[1]
+    procs[0].wait(timeout=120)
+    assert procs[1].returncode == 1, err
+    assert 'receive of boundary sub-steps [0, 8) from part 0 not complete' in err
 
 
 def test_unit_split_gives_inner_ghosts_a_dummy_headwater():
