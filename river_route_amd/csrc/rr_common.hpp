@@ -73,31 +73,6 @@ struct RowView {
     __device__ __forceinline__ double *row(int64_t t) const { return base + offset(t); }
 };
 
-// Non-temporal hints of the kernels' global accesses, one bit per access site (measurements: profiles/r03_nt_sweep.txt).
-// Rows and records are each touched once per pass and the next use is gigabytes of traffic away, so nothing is lost by not
-// keeping them in a cache; whether the hint pays is a property of the memory system, hence measured per site.
-#ifndef RR_NT_MASK
-#define RR_NT_MASK 0
-#endif
-#ifndef RR_SC1_MASK
-#define RR_SC1_MASK 0      // the same sites, stores only: write-through (sc1) -- a plain flat store kernel: 6.9 -> 7.1 TB/s (profiles/r03_write_probe.txt)
-#endif
-constexpr int kNtInRows = 1, kNtInRec = 2, kNtOutRec = 4, kNtOutRows = 8, kNtTileLoad = 16, kNtTileStore = 32;
-template <int SITE, typename T> __device__ __forceinline__ T ld_site(const T *p)
-{
-    if (RR_NT_MASK & SITE) return __builtin_nontemporal_load(p);
-    return *p;
-}
-template <int SITE, typename T> __device__ __forceinline__ void st_site(T *p, T v)
-{
-    if (RR_SC1_MASK & SITE) {
-        if constexpr (sizeof(T) == 16) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
-        else if constexpr (sizeof(T) == 8) asm volatile("global_store_dwordx2 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
-        else *p = v;
-    } else if (RR_NT_MASK & SITE) __builtin_nontemporal_store(v, p);
-    else *p = v;
-}
-
 inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
 // Workgroups are handed to the eight XCDs in turn (blockIdx % 8 labels the workgroups that share an XCD and its L2, cdna

@@ -52,8 +52,6 @@ void rr_plan_destroy(rr_plan *P)
                         P->d_slot_a[0], P->d_slot_a[1], P->d_slot_b[0], P->d_slot_b[1], P->d_m_index[0], P->d_m_index[1]};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         P->pipe.destroy();
-        if (P->s_rec) (void)hipStreamDestroy(P->s_rec);
-        for (hipEvent_t e : P->ev_pool) (void)hipEventDestroy(e);
         for (hipEvent_t e : P->ev) (void)hipEventDestroy(e);
         if (P->ev_first) (void)hipEventDestroy(P->ev_first);
         if (P->ev_last) (void)hipEventDestroy(P->ev_last);
@@ -67,8 +65,9 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
     *out = nullptr;
     rr_plan *P = new (std::nothrow) rr_plan();
     if (!P) return fail(RR_E_ALLOC, "rr_plan_create: out of memory");
-    if (const char *e = getenv("RR_CHUNK_ROWS")) P->chunk_rows = std::max(1, atoi(e));        // tuning knobs
-    if (const char *e = getenv("RR_PERM_ROWS_PER_BLOCK")) P->perm_rows_per_block = std::max(1, atoi(e));
+    // Run-time switches, all for tests (each is exercised by tests/test_gpu_*.py): RR_WAVE=0 the streaming kernel for every call,
+    // =1 the time-tiled one wherever it applies; RR_WAVE_K ticks per task; RR_TILE_BLOCK tile capacity (many small tiles);
+    // RR_TILE_LEAN=0 the general tick; RR_UH_PAIRS=0 one record batch per fused-convolution launch; RR_VERBOSE=1 logs the schedule.
     if (const char *e = getenv("RR_WAVE")) { P->wave_enabled = atoi(e) != 0; P->wave_forced = atoi(e) == 1; }
     if (const char *e = getenv("RR_WAVE_K")) P->wave_K = std::max(kRec, atoi(e) / kRec * kRec);
     std::string err;
@@ -78,17 +77,8 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         int count = rr_device_count(), cus = 0;
         if (device >= 0 && device < count && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) P->cu_count = cus;
     }
-    if (const char *e2 = getenv("RR_TILE_SLOTS")) P->cu_count = std::max(1, atoi(e2));      // tests: few workgroups, many tiles each
-    {   // Time-tiled schedule: one position per thread, 16 waves per CU, tiles of 512 positions (two workgroups per CU: while
-        // the waves of one wait to issue their record loads the other one ticks; 368 ms per year at 1M reaches against 391
-        // with one 1,024-thread workgroup and 382 with four 256-thread ones).  Smaller tiles for smaller networks -- so that
-        // every CU has a tile: 100k reaches make 206 tiles of 512 -- were measured and do not pay: 7.5 / 7.6 / 7.4 x 10^10
-        // reach-steps/s at 100k with tiles of 128 / 256 / 512, 8.2 / 8.1 / 8.6 at 250k, 8.6 / 8.8 / 9.1 at 500k
-        // (profiles/r03_tile_size_sweep.txt): more tiles mean more ghosts and levels, and at that size the record passes, not
-        // the routing kernel, are most of the time.  RR_WAVE_THREADS picks another size.
-        P->wave_threads = 512;
-        if (const char *e = getenv("RR_WAVE_THREADS")) { const int v = atoi(e); if (v == 128 || v == 256 || v == 512 || v == 1024) P->wave_threads = v; }
-        P->wave_ppt = 1;
+    {   // Time-tiled schedule: one position per thread, tiles of at most kTileThreads positions (rr_exec.hpp: tile_kernel)
+        P->wave_threads = kTileThreads;
         int32_t block = P->wave_threads;
         if (const char *e = getenv("RR_TILE_BLOCK")) block = std::max(8, std::min(block, atoi(e)));     // tests: many small tiles
         std::vector<int32_t> lag_of((size_t)n);
@@ -109,11 +99,9 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) P->dev_total_bytes = total_b;
         }
-        if (const char *e2 = getenv("RR_REC_STREAM")) P->rec_stream_enabled = atoi(e2) != 0;      // measurements: record passes on a second stream
-        if (P->rec_stream_enabled && hipStreamCreateWithFlags(&P->s_rec, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); P->s_rec = nullptr; }
-        if (const char *e2 = getenv("RR_TILE_LEAN")) P->lean_enabled = atoi(e2) != 0;      // measurements / tests: the general tick for every call
+        if (const char *e2 = getenv("RR_TILE_LEAN")) P->lean_enabled = atoi(e2) != 0;
         for (int v = 0; v < 7; ++v)    // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel (v = 4, 5, 6: the short ticks of Rapid, Unit, channel-only)
-            if (hipFuncSetAttribute((const void *)tile_kernel(P->wave_threads, v < 4 ? (v & 1) != 0 : v == 5, v < 4 && (v & 2) != 0, v >= 4, v == 6), hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute((const void *)tile_kernel(v < 4 ? (v & 1) != 0 : v == 5, v < 4 && (v & 2) != 0, v >= 4, v == 6), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)tile_lds_bytes(P->wave_threads)) != hipSuccess) {
                 (void)hipGetLastError();
                 P->wave_enabled = false;

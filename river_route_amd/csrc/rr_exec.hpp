@@ -54,11 +54,6 @@ struct Session {
     bool bracket_open = false;
     int64_t bracket_reaches = 0;
     size_t max_samples = 0;
-    // record passes on the plan's second stream (rr_plan::s_rec), ordered against the routing launches by events: see fork_*
-    bool two = false;
-    std::vector<hipEvent_t> ev_in, ev_ghost, ev_out;      // one per batch launched on the second stream
-    int64_t in_waited = 0, ghost_waited = 0, out_waited = 0;      // batches the routing stream already waits for
-    int64_t diags_marked = 0;     // routing launches covered by the last event the second stream waits for
 };
 
 // ---- host-pointer calls: PCIe pipeline around the time-tiled kernel ----
@@ -72,8 +67,8 @@ struct Session {
 // session the partitioned path uses (rows become ready chunk by chunk).
 struct HostPipe {
     static constexpr int kPinned = 3, kCopyThreads = 8;
-    int copy_threads = kCopyThreads;      // per direction (RR_COPY_THREADS: measurements)
-    int64_t chunk_mib = 512;              // staging chunk (RR_COPY_CHUNK_MIB: measurements)
+    int copy_threads = kCopyThreads;      // per direction: PCIe carries 26 GB/s each way whatever the count (profiles/r03_host_path_threads.txt)
+    int64_t chunk_mib = 512;              // staging chunk: long enough for the DMA engines to reach their rate, short enough to pipeline
     int64_t chunk_rows = 64, ring_chunks = 8;
     double *pin_in[kPinned] = {nullptr, nullptr, nullptr}, *pin_out[kPinned] = {nullptr, nullptr, nullptr};
     double *dev_in = nullptr, *dev_out = nullptr;
@@ -121,7 +116,7 @@ struct rr_plan {
     // time-tiled routing (k_tile): subtree tiles of rr::TilePlan
     rr::TilePlan tp;
     bool wave_enabled = true, wave_forced = false, wave_now = false, weights_uniform = false;
-    int wave_threads = 1024, wave_ppt = 2;
+    int wave_threads = 512;
     int64_t wave_K = 0;          // ticks per task (multiple of 16); 0 = chosen per call
     int64_t next_KC = 1, next_chunks = 0;   // prepare_call: task length and record ring of the call about to start
     int64_t kc_cap = int64_t{1} << 20;      // longest task (record chunks) the device had room for; 0: no record ring fits, the plan streams
@@ -149,13 +144,9 @@ struct rr_plan {
 
     Session ses;
     HostPipe pipe;      // staging of the host-pointer entry points (allocated at first use)
-    // second stream for the record passes of device-array calls + a pool of untimed events (created at plan creation / first use)
-    hipStream_t s_rec = nullptr;
-    std::vector<hipEvent_t> ev_pool;
-    size_t ev_pool_next = 0;
-    bool lean_enabled = true;
-    bool uh_pairs = true;               // the fused convolution takes two record batches per launch where it can (RR_UH_PAIRS=0: measurements / tests)
-    bool rec_stream_enabled = false, pipe_active = false;      // measured: no gain (395 against 388 ms per year, profiles/r03_nt_and_rec_stream_ab.txt); RR_REC_STREAM=1 switches it on
+    bool lean_enabled = true;           // RR_TILE_LEAN=0 (tests): the general tick for every call
+    bool uh_pairs = true;               // the fused convolution takes two record batches per launch where it can (RR_UH_PAIRS=0: tests)
+    bool perm_ready = false;            // the streaming kernel's tiled permutations are on the device
 
     // profile of the last route call
     std::vector<hipEvent_t> ev;
@@ -259,7 +250,17 @@ int upload_tiled_permutations(rr_plan *P)
         if (!rc) rc = dev_upload(P->d_slot_b[w], tp.slot_b);
         if (!rc) rc = dev_upload(P->d_m_index[w], tp.m_index);
     }
-    return rc;
+    if (rc) {      // all or nothing: a later call must not find half of the tables
+        for (int w = 0; w < 2; ++w) {
+            if (P->d_slot_a[w]) (void)hipFree(P->d_slot_a[w]);
+            if (P->d_slot_b[w]) (void)hipFree(P->d_slot_b[w]);
+            if (P->d_m_index[w]) (void)hipFree(P->d_m_index[w]);
+            P->d_slot_a[w] = P->d_slot_b[w] = nullptr; P->d_m_index[w] = nullptr;
+        }
+        return rc;
+    }
+    P->perm_ready = true;
+    return RR_OK;
 }
 
 // ---- session -------------------------------------------------------------------------------------
@@ -299,7 +300,7 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
 {
     Schedule sch;
     const int64_t total = T * nsub, dmax = P->h.depth - 1, n = P->h.n;
-    bool ok = P->wave_enabled && P->tp.ok && P->weights_uniform && n > 0 && !force_streaming && P->tp.np < (int64_t{1} << (kRecPairs ? 24 : 25)) &&
+    bool ok = P->wave_enabled && P->tp.ok && P->weights_uniform && n > 0 && !force_streaming && P->tp.np < (int64_t{1} << 25) &&
               !P->export_inside && P->kc_cap >= 1 && !(mode == Mode::Unit && P->unit_general);
     if (ok && !P->wave_forced) ok = total >= 32;
     if (ok) {
@@ -312,9 +313,7 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
         // time-weighted simulation, profiles/r03_pipeline_sim_time.txt)
         const int64_t kc_long = P->n_export > 0 && P->wave_K <= 0 ? 4 : (int64_t{1} << 20);
         for (int64_t KC = std::min(std::min(pick_KC(P, total + dmax), P->kc_cap), kc_long); KC >= 1; KC /= 2) {
-            static const int64_t extra = getenv("RR_RING_EXTRA") ? atoll(getenv("RR_RING_EXTRA")) : 0;      // measurements: a larger ring than needed
-            int64_t chunks = std::min<int64_t>(all_chunks, (dmax + levels * KC * kRec) / kRec + slack * kRecBatch + extra);
-            if (kRecPairs) chunks += chunks & 1;      // the ring holds whole pairs of chunks
+            const int64_t chunks = std::min<int64_t>(all_chunks, (dmax + levels * KC * kRec) / kRec + slack * kRecBatch);
             const int64_t bytes = chunks * kRec * np * (int64_t)sizeof(double);
             // five eighths of the card; the shortest tasks may take thirteen sixteenths: the streaming kernel, the only alternative,
             // keeps depth x n work rows itself (1M reaches 24k deep: 204 GB of records at K = 16 against 192 GB of rows)
@@ -352,7 +351,7 @@ int reserve_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_stre
     }
     int rc = ensure_cap(&P->d_mrows, &P->mrows_cap, sch.mrows);
     if (!rc) rc = ensure_cap(&P->d_stage, &P->stage_cap, sch.stage);
-    if (!rc && !sch.tiled && !P->d_slot_a[0]) rc = upload_tiled_permutations(P);
+    if (!rc && !sch.tiled && !P->perm_ready) rc = upload_tiled_permutations(P);
     if (!rc && sch.tiled && host_io) rc = host_pipe_prepare(P);
     if (rc) return rc;
     // events: first / last of a call, the sampled launches (rr_plan_set_options), the second stream's
@@ -361,10 +360,6 @@ int reserve_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_stre
     size_t samples = P->sample_every >= kSampleGroup ? (size_t)std::min<int64_t>(4096, total_ticks / P->sample_every + 1) : 0;
     if (sch.tiled && samples > 0) samples = (size_t)std::min<int64_t>(4096, ((total_ticks + K - 1) / K + P->tp.n_levels) / 4 + 1);
     while (P->ev.size() < 2 * samples) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); P->ev.push_back(e); }
-    if (sch.tiled && P->s_rec) {
-        const size_t want = (size_t)(4 * ((T * nsub + 14) / kRecRows + 2) + 16);      // in, boundary, out batches + the joins of a one-call session
-        while (P->ev_pool.size() < want) { hipEvent_t e; HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); P->ev_pool.push_back(e); }
-    }
     if (out) *out = sch;
     return RR_OK;
 }
@@ -381,7 +376,7 @@ int prepare_call(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_stre
         sch = choose_schedule(P, mode, T, nsub, force_streaming, host_io);
         const size_t samples = P->sample_every >= kSampleGroup ? 1 : 0;
         if (P->h.n > 0 && T > 0 && (sch.ring > P->ring_cap || sch.mrows > P->mrows_cap || sch.stage > P->stage_cap || !P->ev_first || P->ev.size() < 2 * samples ||
-                                    (!sch.tiled && !P->d_slot_a[0] && sch.mrows > 0)))
+                                    (!sch.tiled && !P->perm_ready && sch.mrows > 0)))
             return fail(RR_E_STATE, "this call needs " + std::to_string((sch.ring + sch.mrows + sch.stage) * 8) + " bytes of work memory on the device (" +
                                         std::to_string((P->ring_cap + P->mrows_cap + P->stage_cap) * 8) + " reserved): call rr_plan_reserve(plan, mode, " +
                                         std::to_string(T) + ", " + std::to_string(nsub) + ", ...) first; the *_dev entry points only enqueue work");
@@ -392,50 +387,10 @@ int prepare_call(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_stre
 
 bool use_wave(const rr_plan *P, Mode) { return P->wave_now; }
 
-// ---- second stream -------------------------------------------------------------------------------
-// A routing launch (k_tile) ends with a tail in which half of its persistent workgroups have left, and the record passes
-// of the neighbouring batches depend on launches several steps away, not on the one running.  With RR_REC_STREAM=1 (off by
-// default: the passes then slow the routing launch down by what they gain, 395 against 388 ms per year) they run, in
-// device-array calls, on the plan's own stream beside the caller's: the in-pass of a batch as soon as its rows are there and its
-// ring slots are free (up to four batches ahead of the routing), the out-pass once the launch that finishes its rows is
-// done.  Every dependence that stream order used to give is an event:
-//   in-pass / boundary batch j   -> the routing launch that first reads its records waits for it (wait_for in
-//                                   session_advance_tile, on the event fork_record left behind the batch)
-//   out-pass batch j             -> waits for the last routing launch enqueued before it (fork_join_caller); a routing
-//                                   launch that rewrites ring slots one revolution on waits for the out-pass that emptied them
-//   in-pass after out-pass       -> same stream
-//   caller's stream              -> the second stream waits for it when a call opens and whenever rows or boundary values
-//                                   are announced (rr_stream_advance); it waits for the second stream when the call closes.
-// Nothing here synchronises with the host.
-hipEvent_t pool_event(rr_plan *P)
-{
-    if (P->ev_pool_next == P->ev_pool.size()) {
-        hipEvent_t e = nullptr;
-        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-        P->ev_pool.push_back(e);
-    }
-    return P->ev_pool[P->ev_pool_next++];
-}
-
-int fork_record(rr_plan *P, std::vector<hipEvent_t> &list)      // after a launch on the second stream
-{
-    hipEvent_t e = pool_event(P);
-    if (!e) return fail(RR_E_HIP, "event creation failed");
-    HIPCHK(hipEventRecord(e, P->s_rec));
-    list.push_back(e);
-    return RR_OK;
-}
-
-int fork_join_caller(rr_plan *P)      // the second stream sees everything the caller's stream has been given so far
-{
-    hipEvent_t e = pool_event(P);
-    if (!e) return fail(RR_E_HIP, "event creation failed");
-    HIPCHK(hipEventRecord(e, P->ses.stream));
-    HIPCHK(hipStreamWaitEvent(P->s_rec, e, 0));
-    return RR_OK;
-}
-
-hipStream_t rec_stream(const rr_plan *P) { return P->ses.two ? P->s_rec : P->ses.stream; }
+// The record passes run on the caller's stream between the routing launches.  (On a second stream beside them they slow the
+// routing launch down by what they gain: 395 against 388 ms per year, slower on small networks too --
+// profiles/r03_nt_and_rec_stream_ab.txt, r03_rec_stream_small_networks.txt.)
+hipStream_t rec_stream(const rr_plan *P) { return P->ses.stream; }
 
 int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io, hipStream_t stream,
                   const double *ghost_series, double *export_series)
@@ -468,11 +423,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
     if (P->n_export > 0 && !export_series) { S.open = false; return fail(RR_E_INVALID, "plan has export reaches but no export series was given"); }
     if (io.dev_out32 && !S.wave) { S.open = false; return fail(RR_E_UNSUPPORTED, "float32 output needs the time-tiled kernel"); }
 
-    int rc = RR_OK;
     if (S.wave) { S.KC = P->next_KC; S.rec_chunks = P->next_chunks; }     // ring sized by choose_schedule, allocated by rr_plan_reserve
-    S.two = S.wave && P->rec_stream_enabled && P->s_rec != nullptr && !P->pipe_active;
-    P->ev_pool_next = 0;      // the previous call's events are all behind its closing join
-    if (S.two) { rc = fork_join_caller(P); if (rc) { S.open = false; return rc; } }
     if (S.wave) {
         const rr::TilePlan &TP = P->tp;
         const int64_t K = S.KC * kRec;
@@ -495,18 +446,6 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         w.sq = P->d_sq; w.ss = P->d_ss; w.si = P->d_si; w.sqch = P->d_sqch;
         w.exports = export_series; w.n_export = (int32_t)P->n_export;
         w.rec = P->d_ring; w.rec_chunks = Div32((uint32_t)S.rec_chunks);
-#ifdef RR_WAVE_TRACE
-        w.trace = nullptr; w.trace_diag = -1;
-        if (getenv("RR_WAVE_TRACE_DIAG")) {
-            static long long *tbuf = nullptr;
-            if (!tbuf) (void)hipMalloc(&tbuf, 8 * 16 * 4096);
-            (void)hipMemset(tbuf, 0, 8 * 16 * 4096);
-            w.trace = tbuf; w.trace_diag = atoi(getenv("RR_WAVE_TRACE_DIAG"));
-        }
-#endif
-#ifdef RR_DEBUG_ALIAS      // measurement builds only (wrong results): every chunk of the ring is chunk 0, so the records stay in the caches
-        if (getenv("RR_ALIAS") && (atoi(getenv("RR_ALIAS")) & 1)) w.rec_chunks = Div32(1u);
-#endif
         w.np = (int32_t)TP.np; w.KC = (int32_t)S.KC; w.n_macro = (int32_t)S.n_macro; w.total = (int32_t)S.total;
         w.has_lat = S.has_in ? 1 : 0; w.nsub = Div32((uint32_t)nsub); w.inv_nsub = 1.0 / (double)nsub;
     }
@@ -655,16 +594,17 @@ int session_launch_tick(rr_plan *P, int64_t tau)
 
 typedef void (*tile_kernel_t)(const TileArgs);
 
-// Tile = one position per thread; 16 waves per CU whose two record buffers fill the register file, as 1, 2 or 4 workgroups.
-tile_kernel_t tile_kernel(int threads, bool unit, bool sub, bool lean = false, bool nolat = false)
+// Tile = one position per thread, 512 threads, two workgroups per CU: 16 waves per CU whose two record buffers fill the register
+// file, and while the waves of one workgroup wait to issue their record loads the other one ticks (368 ms per year at 1M reaches
+// against 391 with one 1,024-thread workgroup and 382 with four 256-thread ones; smaller tiles for smaller networks do not pay
+// either: profiles/r03_tile_size_sweep.txt).
+constexpr int kTileThreads = 512;
+tile_kernel_t tile_kernel(bool unit, bool sub, bool lean = false, bool nolat = false)
 {
-    if (lean && nolat && !unit && !sub)      // channel-only routing, one sub-step per row: the short tick without a lateral term
-        return threads == 128 ? (tile_kernel_t)k_tile<128, false, false, true, true> : (threads == 256 ? (tile_kernel_t)k_tile<256, false, false, true, true>
-             : (threads == 512 ? (tile_kernel_t)k_tile<512, false, false, true, true> : (tile_kernel_t)k_tile<1024, false, false, true, true>));
-#define RR_TILE_PICK(T_) (unit ? (sub ? (tile_kernel_t)k_tile<T_, true, true> : (lean ? (tile_kernel_t)k_tile<T_, true, false, true> : (tile_kernel_t)k_tile<T_, true, false>))   \
-                               : (sub ? (tile_kernel_t)k_tile<T_, false, true> : (lean ? (tile_kernel_t)k_tile<T_, false, false, true> : (tile_kernel_t)k_tile<T_, false, false>)))
-    return threads == 128 ? RR_TILE_PICK(128) : (threads == 256 ? RR_TILE_PICK(256) : (threads == 512 ? RR_TILE_PICK(512) : RR_TILE_PICK(1024)));
-#undef RR_TILE_PICK
+    constexpr int T = kTileThreads;
+    if (lean && nolat && !unit && !sub) return (tile_kernel_t)k_tile<T, false, false, true, true>;      // channel-only routing, one sub-step per row: the short tick without a lateral term
+    return unit ? (sub ? (tile_kernel_t)k_tile<T, true, true> : (lean ? (tile_kernel_t)k_tile<T, true, false, true> : (tile_kernel_t)k_tile<T, true, false>))
+                : (sub ? (tile_kernel_t)k_tile<T, false, true> : (lean ? (tile_kernel_t)k_tile<T, false, false, true> : (tile_kernel_t)k_tile<T, false, false>));
 }
 
 // Launch d of the time-tiled schedule: the tasks (tile, macro-chunk d - level) of every tile whose macro-chunk exists.
@@ -702,10 +642,10 @@ int session_launch_diag(rr_plan *P, int64_t d)
     const bool lean = S.nsub == 1 && P->lean_enabled;      // every router's default (dt_routing = dt_runoff); sub-steps keep the general tick
     w.tile_filter = lean ? 1 : 0;
     w.coef = (lean && unit) ? P->d_coef_unit : P->d_coef;
-    hipLaunchKernelGGL(tile_kernel(P->wave_threads, unit, S.nsub > 1, lean, S.mode == Mode::Muskingum), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
+    hipLaunchKernelGGL(tile_kernel(unit, S.nsub > 1, lean, S.mode == Mode::Muskingum), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
     if (lean && P->n_wide_tiles > 0) {
         w.tile_filter = 2; w.coef = P->d_coef;
-        hipLaunchKernelGGL(tile_kernel(P->wave_threads, unit, false, false), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
+        hipLaunchKernelGGL(tile_kernel(unit, false, false), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
     }
     if (sample) {
         HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));
@@ -760,9 +700,6 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch, int count = 1)
     const int64_t n = P->h.n;
     RecPermArgs ra{};
     ra.rec = P->d_ring; ra.rec_chunks = Div32((uint32_t)S.rec_chunks); ra.n = n; ra.np = P->tp.np; ra.T = S.T; ra.total = S.total; ra.batch = batch;
-#ifdef RR_DEBUG_ALIAS
-    if (getenv("RR_ALIAS") && (atoi(getenv("RR_ALIAS")) & (in ? 2 : 4))) ra.rec_chunks = Div32(1u);
-#endif
     ra.nsub = Div32((uint32_t)S.nsub);
     ra.colmeta = P->d_colmeta;
     ra.scale = (in && S.mode == Mode::Rapid) ? P->d_c4_params : nullptr;
@@ -772,22 +709,15 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch, int count = 1)
     ra.rows_in32 = in ? S.io.dev_in32 : nullptr;
     ra.factor = Div32((uint32_t)std::max<int64_t>(1, S.io.out_factor));
     ra.clamp = S.nsub > 1 ? 0 : (S.mode == Mode::Unit ? 2 : 1);
-    {   // The out-pass walks its column tiles in XCD-contiguous order (xcd_swizzle): where the row pitch is not a whole number
-        // of 128-byte lines neighbouring tiles write parts of the same lines, and on one XCD those meet in its L2 (1.25M-reach
-        // part with an odd column count: 522 -> 473 ms per year; 1% - 2% with an aligned pitch too).  The in-pass gains
-        // nothing from it (its shared lines are reads) and the two together were slower: profiles/r02_rec_swizzle.txt.
-        static const int knob = getenv("RR_REC_SWIZZLE") ? atoi(getenv("RR_REC_SWIZZLE")) : 2;      // measurements: bit 0 in-pass, bit 1 out-pass
-        ra.swizzle = (knob >> (in ? 0 : 1)) & 1;
-    }
-    const dim3 g((unsigned)((n + (in ? kRecInCols : kRecOutCols) - 1) / (in ? kRecInCols : kRecOutCols)));
-    // The plain passes walk their column tiles in a loop with the next tile's loads in flight, so they can run as persistent
-    // workgroups (RR_REC_WGS_PER_CU per CU).  Measured, that is no faster than one tile per workgroup -- 427 / 469 us per 128 rows
-    // against 419 / 434-448 at 1M reaches, and a plain copy shows the same: 4.5-5.7 TB/s from a persistent grid, 6.3-6.7 TB/s
-    // with one 16-byte element per thread (profiles/r03_hbm_probe_*.txt): workgroups dispatched in order keep the chip's
-    // accesses inside a narrow window of addresses -- so one tile per workgroup is the default (0).
-    static const int per_cu = getenv("RR_REC_WGS_PER_CU") ? std::max(0, atoi(getenv("RR_REC_WGS_PER_CU"))) : 0;
+    // The out-pass walks its column tiles in XCD-contiguous order (xcd_swizzle): where the row pitch is not a whole number
+    // of 128-byte lines neighbouring tiles write parts of the same lines, and on one XCD those meet in its L2 (1.25M-reach
+    // part with an odd column count: 522 -> 473 ms per year; 1% - 2% with an aligned pitch too).  The in-pass gains
+    // nothing from it (its shared lines are reads) and the two together were slower: profiles/r02_rec_swizzle.txt.
+    ra.swizzle = in ? 0 : 1;
+    // one column tile per workgroup, dispatched in address order: a persistent grid with the next tile's loads in flight was no
+    // faster (427 / 469 us per 128 rows against 419 / 434-448 at 1M reaches; a plain copy shows the same, profiles/r03_hbm_probe_*.txt)
+    const dim3 gp((unsigned)((n + (in ? kRecInCols : kRecOutCols) - 1) / (in ? kRecInCols : kRecOutCols)));
     const bool sub = S.nsub > 1;
-    const dim3 gp(per_cu > 0 ? (unsigned)std::min<int64_t>(g.x, (int64_t)P->cu_count * per_cu) : g.x);
     hipStream_t st = rec_stream(P);
     if (in && S.io.runoff) {
         const dim3 gr((unsigned)((n + kRunoffInThreads - 1) / kRunoffInThreads), (unsigned)kRecBatch);
@@ -819,14 +749,6 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
     Session &S = P->ses;
     const int64_t dmax = P->h.depth - 1, levels = P->tp.n_levels, K = S.KC * kRec;
     const int64_t ticks_ready = std::min(rows_ready, S.T) * S.nsub;
-    if (S.two) { int rc = fork_join_caller(P); if (rc) return rc; }      // rows and boundary values announced by this call are in place
-    // batches whose records cover the tick-rows below `ticks` (loaded_ticks below, inverted)
-    auto batches_for = [&](int64_t ticks) { return ticks <= 0 ? int64_t{0} : (ticks >= S.total ? S.n_in_batches : std::min(S.n_in_batches, (ticks + 15 + kRecRows - 1) / kRecRows)); };
-    auto wait_for = [&](std::vector<hipEvent_t> &list, int64_t &waited, int64_t upto) -> int {      // the routing stream waits for batches [0, upto)
-        upto = std::min<int64_t>(upto, (int64_t)list.size());
-        if (upto > waited) { HIPCHK(hipStreamWaitEvent(S.stream, list[(size_t)upto - 1], 0)); waited = upto; }
-        return RR_OK;
-    };
     for (;;) {
         bool progressed = false;
         // one batch of tick-rows -> records; a record slot is recycled only after every tick-row it can hold has left.
@@ -844,15 +766,12 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
             const int count = (S.io.uh_kernel && !S.io.runoff && P->uh_pairs && S.in_batches + 2 <= S.n_in_batches &&
                                ticks_ready >= std::min(kRecRows * (S.in_batches + 2), S.total) && slot_free(S.in_batches + 1)) ? 2 : 1;
             launch_rec_permute(P, true, S.in_batches, count);
-            for (int k = 0; k < count; ++k)
-                if (S.two) { int rc = fork_record(P, S.ev_in); if (rc) return rc; }
             S.in_batches += count;
             progressed = true;
         }
         if (P->n_ghost > 0 && S.ghost_batches < S.n_in_batches && (!S.has_in || S.ghost_batches < S.in_batches) &&      // after the lateral batch: that one writes zeros into the ghosts' records
             ghost_ready >= std::min(kRecRows * (S.ghost_batches + 1), S.total) && slot_free(S.ghost_batches)) {
             launch_ghost_permute(P, S.ghost_batches);
-            if (S.two) { int rc = fork_record(P, S.ev_ghost); if (rc) return rc; }
             ++S.ghost_batches;
             progressed = true;
         }
@@ -871,12 +790,6 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
             // one ring revolution earlier (their chunks are at most (d + 1) KC - 1)
             const int64_t top = std::min(S.diag + 1, S.n_macro) * S.KC - 1;
             if (top >= S.rec_chunks && S.ticks_stored < std::min(S.total, kRec * (top - S.rec_chunks + 1))) break;
-            if (S.two) {      // the events behind the three conditions above
-                int rc = S.has_in ? wait_for(S.ev_in, S.in_waited, batches_for(need_ticks)) : RR_OK;
-                if (!rc && P->n_ghost > 0) rc = wait_for(S.ev_ghost, S.ghost_waited, batches_for(std::min(std::max<int64_t>(0, (S.diag + 1) * K - S.ghost_slack), S.total)));
-                if (!rc && top >= S.rec_chunks) rc = wait_for(S.ev_out, S.out_waited, (std::min(S.total, kRec * (top - S.rec_chunks + 1)) + kRecRows - 1) / kRecRows);
-                if (rc) return rc;
-            }
             int rc = session_launch_diag(P, S.diag);
             if (rc) return rc;
             ++S.diag; ++launched;
@@ -890,9 +803,7 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
         done = std::min(done, S.total);
         while (S.out_batches < S.n_out_batches && done >= std::min(kRecRows * (S.out_batches + 1), S.total) &&
                (std::min(kRecRows * (S.out_batches + 1), S.total) + S.nsub - 1) / S.nsub <= S.out_limit) {
-            if (S.two && S.diags_marked < S.diag) { int rc = fork_join_caller(P); if (rc) return rc; S.diags_marked = S.diag; }      // the launches that finished these rows
             launch_rec_permute(P, false, S.out_batches);
-            if (S.two) { int rc = fork_record(P, S.ev_out); if (rc) return rc; }
             ++S.out_batches;
             S.ticks_stored = std::min(S.total, kRecRows * S.out_batches);
             progressed = true;
@@ -969,26 +880,8 @@ int session_end(rr_plan *P)
     if (!complete) return fail(RR_E_STATE, "routing call closed before all of its time steps were routed");
     if (P->h.n == 0 || S.total == 0) return RR_OK;
     if (S.bracket_open) P->prof_samples -= P->prof_samples % kSampleGroup;   // incomplete bracket: not counted
-    if (S.two) {      // the caller's stream continues after the last record pass
-        hipEvent_t e = pool_event(P);
-        if (!e) return fail(RR_E_HIP, "event creation failed");
-        HIPCHK(hipEventRecord(e, P->s_rec));
-        HIPCHK(hipStreamWaitEvent(S.stream, e, 0));
-    }
     HIPCHK(hipEventRecord(P->ev_last, S.stream));
     HIPCHK(hipGetLastError());
-#ifdef RR_WAVE_TRACE
-    if (S.wave && S.ta.trace) {
-        std::vector<long long> hbuf(16 * 4096);
-        (void)hipStreamSynchronize(S.stream);
-        (void)hipMemcpy(hbuf.data(), S.ta.trace, hbuf.size() * 8, hipMemcpyDeviceToHost);
-        if (FILE *f = fopen(getenv("RR_WAVE_TRACE_FILE") ? getenv("RR_WAVE_TRACE_FILE") : "/tmp/wave_trace.txt", "w")) {
-            for (int b = 0; b < 4096; ++b)
-                if (hbuf[16 * b]) { fprintf(f, "%d", b); for (int k = 0; k < 15; ++k) fprintf(f, " %lld", hbuf[16 * b + k]); fprintf(f, "\n"); }
-            fclose(f);
-        }
-    }
-#endif
     return RR_OK;
 }
 
@@ -1056,8 +949,6 @@ int host_pipe_prepare(rr_plan *P)
     HostPipe &H = P->pipe;
     const int64_t n = P->h.n;
     // chunks of about half a gigabyte: long enough for the DMA engines to reach their rate, short enough to pipeline
-    if (const char *e = getenv("RR_COPY_THREADS")) H.copy_threads = std::max(1, std::min(64, atoi(e)));
-    if (const char *e = getenv("RR_COPY_CHUNK_MIB")) H.chunk_mib = std::max(16, std::min(4096, atoi(e)));
     H.chunk_rows = std::max<int64_t>(16, std::min<int64_t>(4096, ((H.chunk_mib << 20) / (n * 8) + 15) / 16 * 16));
     if (n * 8 * 64 <= (int64_t{1} << 30)) H.chunk_rows = std::max<int64_t>(H.chunk_rows, 64);
     H.ring_chunks = std::max<int64_t>(8, (2 * kRecRows + 15) / H.chunk_rows + 6);      // a batch of rows + its 15-row overlap stays readable
@@ -1098,9 +989,7 @@ int route_host_pipelined(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const d
         return fail(RR_E_HIP, "host pipeline: event creation failed");
     Rows io;
     io.dev_in = host_in ? H.dev_in : nullptr; io.rows_in = NR * C; io.dev_out = H.dev_out; io.rows_out = NR * C;
-    P->pipe_active = true;      // its staging rings are recycled by events on `stream`: record passes stay on it
     rc = session_begin(P, mode, T, nsub, io, stream, nullptr, nullptr);
-    P->pipe_active = false;
     if (rc) return rc;
     Session &S = P->ses;
     auto rows_of = [&](int64_t c) { return std::min(C, T - c * C); };
@@ -1346,15 +1235,13 @@ int uh_convolve_core(const double *d_kernel, double *d_state, const double *d_la
             hipLaunchKernelGGL((k_uh_convolve_ring<NK_, NT_, R_, D_>), g, dim3(kUhThreads), lds, stream, d_kernel, (const double *)d_state,     \
                                d_lateral, d_out, T, (int32_t)n_ks, n, seg_rows);                                   \
         } while (0)
-#define RR_UH_LAUNCH_X(...) RR_UH_LAUNCH(__VA_ARGS__)
         if (n_ks <= 5) RR_UH_LAUNCH(8, 5, 4, 2);            // NK >= NT + R - 1 window slots
         else if (n_ks <= 13) RR_UH_LAUNCH(16, 13, 4, 2);
         else if (n_ks <= 24) RR_UH_LAUNCH(32, 24, 8, 2);
         else if (n_ks <= 29) RR_UH_LAUNCH(32, 29, 4, 2);
-        else if (n_ks <= 48) RR_UH_LAUNCH_X(RR_UH48);
+        else if (n_ks <= 48) RR_UH_LAUNCH(64, 48, 8, 2);
         else RR_UH_LAUNCH(64, 57, 8, 2);
 #undef RR_UH_LAUNCH
-#undef RR_UH_LAUNCH_X
     } else {
         dim3 g((unsigned)((n + kBlock - 1) / kBlock), (unsigned)((T + TB - 1) / TB));
         hipLaunchKernelGGL(k_uh_convolve<TB>, g, dim3(kBlock), 0, stream, d_kernel, (const double *)d_state, d_lateral,

@@ -15,38 +15,12 @@ namespace {
 // the share of rows / records read twice at a batch's edge but needs 72 KB of LDS per workgroup: 1 % slower when every row
 // comes from HBM (380 vs 384 ms per year), faster only while a short cyclic forcing array is found in a cache
 // (profiles/r02_rec_batch.txt).
-#ifndef RR_REC_BATCH
-#define RR_REC_BATCH 8
-#define RR_REC_COLS 32
-#endif
-#ifndef RR_REC_THREADS
-#define RR_REC_THREADS 256
-#endif
-#ifndef RR_REC_IN_THREADS
-#define RR_REC_IN_THREADS RR_REC_THREADS
-#endif
-#ifndef RR_REC_OUT_THREADS
-#define RR_REC_OUT_THREADS RR_REC_THREADS
-#endif
-constexpr int kRecCols = RR_REC_COLS, kRecBatch = RR_REC_BATCH, kRecThreads = RR_REC_THREADS;
-constexpr int kRecInThreads = RR_REC_IN_THREADS, kRecOutThreads = RR_REC_OUT_THREADS;      // workgroup sizes of k_rec_in / k_rec_out (measurements)
-#ifndef RR_REC_IN_COLS
-#define RR_REC_IN_COLS RR_REC_COLS
-#endif
-#ifndef RR_REC_OUT_COLS
-#define RR_REC_OUT_COLS RR_REC_COLS
-#endif
-#ifndef RR_REC_PERSISTENT
-#define RR_REC_PERSISTENT 1      // 1: k_rec_in / k_rec_out loop over column tiles (RR_REC_WGS_PER_CU > 0 then launches a persistent grid); 0: one tile per workgroup only
-#endif
-constexpr bool kRecPersistent = RR_REC_PERSISTENT != 0;
-#ifndef RR_REC_IN_MIN_WGS
-#define RR_REC_IN_MIN_WGS 1      // workgroups per CU the register allocation of k_rec_in / k_rec_out leaves room for (measurements)
-#endif
-#ifndef RR_REC_OUT_MIN_WGS
-#define RR_REC_OUT_MIN_WGS 1
-#endif
-constexpr int kRecInCols = RR_REC_IN_COLS, kRecOutCols = RR_REC_OUT_COLS;      // columns of a tile of k_rec_in / k_rec_out
+// Tile shapes, each the winner of an A/B on the GPU box: 256 threads (128 to 1,024: within 0.5 %, profiles/r03_rec_threads_ab.txt),
+// 32 columns (16 to 64: the same, r03_rec_tile_width_ab.txt), one tile per workgroup (persistent workgroups with the next tile's
+// loads in flight: 427 / 469 us per 128 rows against 419 / 434, r03_rec_persistent_ab.txt), 8 records per batch (r02_rec_batch.txt).
+constexpr int kRecCols = 32, kRecBatch = 8, kRecThreads = 256;
+constexpr int kRecInThreads = kRecThreads, kRecOutThreads = kRecThreads;      // workgroup sizes of k_rec_in / k_rec_out
+constexpr int kRecInCols = kRecCols, kRecOutCols = kRecCols;                  // columns of a tile of k_rec_in / k_rec_out
 constexpr int kRecRows = 16 * kRecBatch;    // tick-rows of one batch
 
 struct RecPermArgs {
@@ -73,12 +47,8 @@ constexpr int kRecTileLd = kRecCols + 1;
 // and the fused convolution is bound by those (profiles/r03_uh_diet.txt).
 __device__ __forceinline__ uint32_t ring_chunk(const Div32 &chunks, uint32_t first, uint32_t ahead)
 {
-#ifdef RR_DEBUG_ALIAS
-    return chunks.mod(first + ahead);      // measurement builds alias the ring to one chunk
-#else
     const uint32_t c = first + ahead;
     return c >= chunks.d ? c - chunks.d : c;
-#endif
 }
 
 // Second half of the in-pass: the LDS tile (row = runoff row - row_first, kRecTileLd doubles per row) becomes records.
@@ -132,17 +102,16 @@ __device__ __forceinline__ void write_records(const RecPermArgs &a, const double
         }
         double2 *dst = reinterpret_cast<double2 *>(a.rec + rec_elem(chunk, a.np, p)) + part;
         typedef double d2 __attribute__((ext_vector_type(2)));
-        st_site<kNtInRec>(reinterpret_cast<d2 *>(dst), d2{v0, v1});
+        *reinterpret_cast<d2 *>(dst) = d2{v0, v1};
     }
 }
 
-// A workgroup walks the column tiles blockIdx.x, blockIdx.x + gridDim.x, ... and requests the rows of its NEXT tile before it
-// turns the current one into records.  Launched with one tile per workgroup (the default) that loop runs once; launched as a
-// persistent grid the loads of the next tile are in flight while the records of this one are stored -- measured, no gain: the
-// rows alone read in 186 us per 128 rows at 1M reaches, the records alone store in 199 us, the pass takes 419 us either way,
-// within 7 % of the two one after the other (profiles/r03_rec_probe.txt, r03_alias_kernel_times.txt, rr_exec.hpp).
+// One column tile per workgroup: all of its row loads in flight before the first LDS write, the tile's column metadata and
+// scale travelling with the rows into LDS (no registers held across the stores).  The rows alone read in 186 us per 128 rows at 1M
+// reaches, the records alone store in 199 us, the pass takes 415: within 7 % of the two one after the other
+// (profiles/r03_rec_probe.txt, r03_alias_kernel_times.txt).
 template <bool SUB, bool IN32 = false>
-__global__ __launch_bounds__(kRecInThreads, RR_REC_IN_MIN_WGS) void k_rec_in(const RecPermArgs a)
+__global__ __launch_bounds__(kRecInThreads) void k_rec_in(const RecPermArgs a)
 {
     constexpr int R = kRecTileRows;
     __shared__ double tile[R * (kRecInCols + 1)];
@@ -156,13 +125,14 @@ __global__ __launch_bounds__(kRecInThreads, RR_REC_IN_MIN_WGS) void k_rec_in(con
     const int c = tid % kRecInCols, r0 = tid / kRecInCols;
     const int need = SUB ? (int)((uint32_t)(R - 1) / a.nsub.d) + 2 : R;     // runoff rows behind the batch's tick-rows
     const uint32_t n_tiles = (uint32_t)((a.n + kRecInCols - 1) / kRecInCols);
-    auto col_of = [&](uint32_t t) { return (int64_t)(a.swizzle ? xcd_swizzle(t, n_tiles) : t) * kRecInCols; };
+    if (blockIdx.x >= n_tiles) return;
+    const int64_t col0 = (int64_t)(a.swizzle ? xcd_swizzle(blockIdx.x, n_tiles) : blockIdx.x) * kRecInCols;
     double v[RPT];
     int2 cm = make_int2(-1, 0);
     double cs = 1.0;
-    auto request = [&](int64_t col0) {      // branch-free: out-of-range rows / columns are clamped here and zeroed on the way into LDS
+    {   // branch-free: out-of-range rows / columns are clamped here and zeroed on the way into LDS
         const int64_t i = min(col0 + c, a.n - 1);
-        if (tid < kRecInCols) {      // the tile's column metadata and scale travel with its rows
+        if (tid < kRecInCols) {
             cm = col0 + c < a.n ? a.colmeta[i] : make_int2(-1, 0);
             cs = a.scale ? a.scale[i] : 1.0;
         }
@@ -170,42 +140,18 @@ __global__ __launch_bounds__(kRecInThreads, RR_REC_IN_MIN_WGS) void k_rec_in(con
         for (int q = 0; q < RPT; ++q) {
             const int64_t t = row_first + min(r0 + q * (kRecInThreads / kRecInCols), need - 1);
             const int64_t off = a.rows.offset(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t)) + i;
-            v[q] = IN32 ? (double)ld_site<kNtInRows>(a.rows_in32 + off) : ld_site<kNtInRows>(a.rows.base + off);
+            v[q] = IN32 ? (double)a.rows_in32[off] : a.rows.base[off];
         }
-    };
-    uint32_t t = blockIdx.x;
-    if (t >= n_tiles) return;
-    request(col_of(t));
-    if constexpr (!kRecPersistent) {      // one tile per workgroup: the loads' registers are free before the records are written
-        const int64_t col0 = col_of(t);
-#pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-            const int r = r0 + q * (kRecInThreads / kRecInCols);
-            const int64_t row = row_first + r;
-            if (r < R) tile[r * (kRecInCols + 1) + c] = (row >= 0 && row < a.T && col0 + c < a.n) ? v[q] : 0.0;
-        }
-        if (tid < kRecInCols) { smeta[c] = cm; sscale[c] = cs; }
-        __syncthreads();
-        write_records<SUB, kRecInThreads, kRecBatch, true, kRecInCols>(a, tile, col0, tick_first, row_first, smeta, sscale);
-        return;
     }
-    for (;;) {
-        const int64_t col0 = col_of(t);
 #pragma unroll
-        for (int q = 0; q < RPT; ++q) {
-            const int r = r0 + q * (kRecInThreads / kRecInCols);
-            const int64_t row = row_first + r;
-            if (r < R) tile[r * (kRecInCols + 1) + c] = (row >= 0 && row < a.T && col0 + c < a.n) ? v[q] : 0.0;
-        }
-        if (tid < kRecInCols) { smeta[c] = cm; sscale[c] = cs; }
-        __syncthreads();
-        const uint32_t next = t + gridDim.x;
-        if (next < n_tiles) request(col_of(next));      // in flight while this tile leaves as records
-        write_records<SUB, kRecInThreads, kRecBatch, true, kRecInCols>(a, tile, col0, tick_first, row_first, smeta, sscale);
-        if (next >= n_tiles) break;
-        __syncthreads();      // every record of this tile has been read out of LDS
-        t = next;
+    for (int q = 0; q < RPT; ++q) {
+        const int r = r0 + q * (kRecInThreads / kRecInCols);
+        const int64_t row = row_first + r;
+        if (r < R) tile[r * (kRecInCols + 1) + c] = (row >= 0 && row < a.T && col0 + c < a.n) ? v[q] : 0.0;
     }
+    if (tid < kRecInCols) { smeta[c] = cm; sscale[c] = cs; }
+    __syncthreads();
+    write_records<SUB, kRecInThreads, kRecBatch, true, kRecInCols>(a, tile, col0, tick_first, row_first, smeta, sscale);
 }
 
 // The in-pass with the unit-hydrograph convolution fused in (UnitHydrograph.py:93-107, direct form): the tile is COMPUTED
@@ -218,15 +164,12 @@ struct UhArgs {
     const double *kernel, *state;     // (n_ks, n) taps and carried-in state, params order
     int32_t n_ks;
 };
-#ifndef RR_UH_COLS
-#define RR_UH_COLS 16
-#endif
 // Columns of a tile of the fused convolution: 16 (128-byte row pieces) against the 32 of the plain passes: 52.6 against 55.2 ms
 // for BASELINE config 4 (profiles/r03_small_networks_and_uh16.txt).
 // BATCH = batches of kRecBatch records (128 tick-rows) per launch, 1 or 2: the n_ks - 1 depth rows before a tile and the taps
 // are read once per tile, so the pair moves 19.4 B per value where the single batch moves 22.9 (n_ks = 48); a workgroup has
 // 32 threads per record: 16 columns x (2 x records) groups of 9 rows.
-constexpr int kUhCols = RR_UH_COLS, kUhTileLd = kUhCols + 1;
+constexpr int kUhCols = 16, kUhTileLd = kUhCols + 1;
 constexpr int kUhMaxBatches = 2;
 constexpr int uh_threads(int batches) { return 32 * kRecBatch * batches; }
 constexpr int uh_tile_rows(int batches) { return 16 * kRecBatch * batches + 15; }
@@ -266,7 +209,7 @@ __global__ __launch_bounds__(uh_threads(BATCHES)) void k_rec_in_uh(const RecPerm
             for (int q = 0; q < DPT; ++q) {
                 const int64_t t = row_first - (NK - 1) + min(g + q * G, need + NK - 2);
                 const int64_t off = a.rows.offset(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t)) + i;
-                dv[q] = IN32 ? (double)ld_site<kNtInRows>(a.rows_in32 + off) : ld_site<kNtInRows>(a.rows.base + off);
+                dv[q] = IN32 ? (double)a.rows_in32[off] : a.rows.base[off];
             }
         } else {
             // load q reads the cyclic row (tb + G q - t0) mod rows: one division, for the first q whose row cannot be negative,
@@ -283,7 +226,7 @@ __global__ __launch_bounds__(uh_threads(BATCHES)) void k_rec_in_uh(const RecPerm
 #pragma unroll
             for (int q = 0; q < DPT; ++q) {
                 const int64_t off = (int64_t)m[q] * a.rows.ld + i;
-                dv[q] = IN32 ? (double)ld_site<kNtInRows>(a.rows_in32 + off) : ld_site<kNtInRows>(a.rows.base + off);
+                dv[q] = IN32 ? (double)a.rows_in32[off] : a.rows.base[off];
             }
         }
 #pragma unroll
@@ -350,10 +293,9 @@ __global__ __launch_bounds__(uh_threads(BATCHES)) void k_rec_in_uh(const RecPerm
 
 // OUT32: the router's post-processing fused in (TransformMuskingum.py:128-142): mean over `factor` consecutive rows
 // (sequential sum, one division, as numpy reduces a strided axis) and the float32 cast; 128 % (factor * nsub) == 0.
-// The same loop as k_rec_in: the records of the workgroup's next column tile (if the grid is persistent) are requested before
-// the rows of the current one are written.
+// One column tile per workgroup, every record read of it in flight at once.
 template <bool SUB, bool OUT32>
-__global__ __launch_bounds__(kRecOutThreads, RR_REC_OUT_MIN_WGS) void k_rec_out(const RecPermArgs a)
+__global__ __launch_bounds__(kRecOutThreads) void k_rec_out(const RecPermArgs a)
 {
     constexpr int S = 16 * (kRecBatch + 1);
     __shared__ double recs[kRecOutCols][S + 1];
@@ -361,11 +303,12 @@ __global__ __launch_bounds__(kRecOutThreads, RR_REC_OUT_MIN_WGS) void k_rec_out(
     static_assert(kRecOutCols * (kRecBatch + 1) * 8 % kRecOutThreads == 0, "record pieces of a tile must divide among the threads");
     constexpr int IT = kRecOutCols * (kRecBatch + 1) * 8 / kRecOutThreads;
     const uint32_t n_tiles = (uint32_t)((a.n + kRecOutCols - 1) / kRecOutCols);
-    auto col_of = [&](uint32_t t) { return (int64_t)(a.swizzle ? xcd_swizzle(t, n_tiles) : t) * kRecOutCols; };
+    if (blockIdx.x >= n_tiles) return;
+    const int64_t col0 = (int64_t)(a.swizzle ? xcd_swizzle(blockIdx.x, n_tiles) : blockIdx.x) * kRecOutCols;
     typedef double d2 __attribute__((ext_vector_type(2)));
     d2 v[IT];
     const uint32_t chunk_first = a.rec_chunks.mod((uint32_t)kRecBatch * (uint32_t)a.batch);
-    auto request = [&](int64_t col0) {      // all record reads in flight; a column past the end reads position 0 and is not written
+    {   // a column past the end reads position 0 and is not written
         int2 meta[IT];
 #pragma unroll
         for (int it = 0; it < IT; ++it) {      // every metadata load first: the record loads depend on them, one wait for all
@@ -377,62 +320,50 @@ __global__ __launch_bounds__(kRecOutThreads, RR_REC_OUT_MIN_WGS) void k_rec_out(
             const int piece = it * kRecOutThreads + tid;
             const int k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
             const uint32_t chunk = ring_chunk(a.rec_chunks, chunk_first, (uint32_t)((meta[it].y & kLagMask) >> 4) + k);
-            v[it] = ld_site<kNtOutRec>(reinterpret_cast<const d2 *>(a.rec + rec_elem(chunk, a.np, meta[it].x)) + part);
+            v[it] = reinterpret_cast<const d2 *>(a.rec + rec_elem(chunk, a.np, meta[it].x))[part];
         }
-    };
-    uint32_t t = blockIdx.x;
-    if (t >= n_tiles) return;
-    request(col_of(t));
+    }
     const int64_t tick0 = kRecRows * a.batch;
-    for (;;) {
-        const int64_t col0 = col_of(t);
 #pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int piece = it * kRecOutThreads + tid;
-            const int c = piece / ((kRecBatch + 1) * 8), k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
-            recs[c][16 * k + 2 * part] = v[it].x;
-            recs[c][16 * k + 2 * part + 1] = v[it].y;
+    for (int it = 0; it < IT; ++it) {
+        const int piece = it * kRecOutThreads + tid;
+        const int c = piece / ((kRecBatch + 1) * 8), k = (piece >> 3) % (kRecBatch + 1), part = piece & 7;
+        recs[c][16 * k + 2 * part] = v[it].x;
+        recs[c][16 * k + 2 * part + 1] = v[it].y;
+    }
+    __syncthreads();
+    const int c = tid % kRecOutCols;
+    const int64_t i = col0 + c;
+    if (i >= a.n) return;
+    const int32_t my = a.colmeta[i].y;
+    const int o = my & 15;
+    // single sub-step: the records hold the unclamped discharge (a ghost's record is a copy of its reach's); the reference's
+    // clip at zero (_numba_kernels.py:80) happens here.  UnitMuskingum leaves its headwaters' lateral inflow as it is (:122-123).
+    const bool clamp = !SUB && (a.clamp == 1 || (a.clamp == 2 && !(my & kColHeadwater)));
+    auto out = [&](double x) { return clamp && !(x > 0.0) ? 0.0 : x; };
+    if (OUT32) {
+        // output row q averages runoff rows [q * factor, (q + 1) * factor), each the slot of its last sub-step
+        const int step = (int)(a.factor.d * (SUB ? a.nsub.d : 1u));          // tick-rows per output row, divides 128
+        const int64_t q0 = tick0 / step;
+        for (int q = tid / kRecOutCols; q < kRecRows / step; q += kRecOutThreads / kRecOutCols) {
+            if ((q0 + q + 1) * step > a.total) break;
+            const int nsub = SUB ? (int)a.nsub.d : 1;
+            double acc = out(recs[c][o + q * step + nsub - 1]);
+            for (int j = 1; j < (int)a.factor.d; ++j) acc += out(recs[c][o + q * step + j * nsub + nsub - 1]);
+            a.rows32[(q0 + q) * a.n + i] = (float)(a.factor.d > 1 ? acc / (double)a.factor.d : acc);
         }
-        __syncthreads();
-        const uint32_t next = kRecPersistent ? t + gridDim.x : n_tiles;      // one tile per workgroup: the loop below ends after it
-        if (next < n_tiles) request(col_of(next));      // in flight while this tile's rows are written
-        const int c = tid % kRecOutCols;
-        const int64_t i = col0 + c;
-        if (i < a.n) {
-            const int32_t my = a.colmeta[i].y;
-            const int o = my & 15;
-            // single sub-step: the records hold the unclamped discharge (a ghost's record is a copy of its reach's); the reference's
-            // clip at zero (_numba_kernels.py:80) happens here.  UnitMuskingum leaves its headwaters' lateral inflow as it is (:122-123).
-            const bool clamp = !SUB && (a.clamp == 1 || (a.clamp == 2 && !(my & kColHeadwater)));
-            auto out = [&](double x) { return clamp && !(x > 0.0) ? 0.0 : x; };
-            if (OUT32) {
-                // output row q averages runoff rows [q * factor, (q + 1) * factor), each the slot of its last sub-step
-                const int step = (int)(a.factor.d * (SUB ? a.nsub.d : 1u));          // tick-rows per output row, divides 128
-                const int64_t q0 = tick0 / step;
-                for (int q = tid / kRecOutCols; q < kRecRows / step; q += kRecOutThreads / kRecOutCols) {
-                    if ((q0 + q + 1) * step > a.total) break;
-                    const int nsub = SUB ? (int)a.nsub.d : 1;
-                    double acc = out(recs[c][o + q * step + nsub - 1]);
-                    for (int j = 1; j < (int)a.factor.d; ++j) acc += out(recs[c][o + q * step + j * nsub + nsub - 1]);
-                    a.rows32[(q0 + q) * a.n + i] = (float)(a.factor.d > 1 ? acc / (double)a.factor.d : acc);
-                }
+    } else {
+        for (int r = tid / kRecOutCols; r < kRecRows; r += kRecOutThreads / kRecOutCols) {
+            const int64_t tick = tick0 + r;
+            if (tick >= a.total) break;
+            if (SUB) {
+                uint32_t sub;
+                const uint32_t row = a.nsub.div((uint32_t)tick, sub);
+                if (sub + 1 == a.nsub.d) a.rows.row(row)[i] = recs[c][o + r];
             } else {
-                for (int r = tid / kRecOutCols; r < kRecRows; r += kRecOutThreads / kRecOutCols) {
-                    const int64_t tick = tick0 + r;
-                    if (tick >= a.total) break;
-                    if (SUB) {
-                        uint32_t sub;
-                        const uint32_t row = a.nsub.div((uint32_t)tick, sub);
-                        if (sub + 1 == a.nsub.d) st_site<kNtOutRows>(a.rows.row(row) + i, recs[c][o + r]);
-                    } else {
-                        st_site<kNtOutRows>(a.rows.row(tick) + i, out(recs[c][o + r]));
-                    }
-                }
+                a.rows.row(tick)[i] = out(recs[c][o + r]);
             }
         }
-        if (next >= n_tiles) break;
-        __syncthreads();      // every row of this tile has been read out of LDS
-        t = next;
     }
 }
 

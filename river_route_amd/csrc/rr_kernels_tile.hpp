@@ -41,9 +41,6 @@ struct TileArgs {
     int32_t n_export;
     double *rec;                          // record ring [rec_chunks][np][16]
     Div32 rec_chunks;
-#ifdef RR_WAVE_TRACE
-    long long *trace; int32_t trace_diag;   // development build: per-block timestamps of one launch (profiles/microbench/wave_dbg.py)
-#endif
     int32_t np, t_first, t_last, KC, diag, n_macro, total, has_lat;
     int32_t tile_filter;                  // 0: every tile of the launch; 1: all but the kTileWide ones (the LEAN kernel); 2: only those (its companion launch of the general kernel)
     Div32 nsub;
@@ -75,11 +72,11 @@ __device__ __forceinline__ void store_f64x2(__amdgpu_buffer_rsrc_t r, uint32_t b
 {
     u32x4 bits;
     __builtin_memcpy(&bits, &v, sizeof bits);
-    __builtin_amdgcn_raw_buffer_store_b128(bits, r, (int)byte_off, 0, ((RR_NT_MASK & kNtTileStore) ? 2 : 0) | ((RR_SC1_MASK & kNtTileStore) ? 16 : 0));      // aux bit 1: nt, bit 4: sc1
+    __builtin_amdgcn_raw_buffer_store_b128(bits, r, (int)byte_off, 0, 0);
 }
 __device__ __forceinline__ void load_f64x2(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, double &x, double &y)
 {
-    const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, (RR_NT_MASK & kNtTileLoad) ? 2 : 0);   // one 16-byte request per lane
+    const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);   // one 16-byte request per lane
     double2 v;
     __builtin_memcpy(&v, &bits, sizeof v);
     x = v.x; y = v.y;
@@ -91,36 +88,21 @@ __device__ __forceinline__ void load_f64x2(__amdgpu_buffer_rsrc_t r, uint32_t by
 __device__ __forceinline__ int32_t fresh(int32_t v) { asm volatile("" : "+v"(v)); return v; }
 
 constexpr int kRec = 16;
-// Ring layout.  0: rec[chunk][position][16] -- a chunk is a plane, a tile's records of one chunk are contiguous.  1: the two
-// chunks of a pair side by side, rec[chunk / 2][position][chunk % 2][16]: what a record pass writes or reads for one column
-// -- consecutive chunks of one position -- then comes in 256-byte pieces instead of 128-byte ones (half the DRAM pages opened),
-// while a tile's records of one chunk are every other line of a block twice as long.
-#ifndef RR_REC_PAIRS
-#define RR_REC_PAIRS 0
-#endif
-constexpr bool kRecPairs = RR_REC_PAIRS != 0;
-constexpr uint32_t kPosBytes = kRecPairs ? 256u : 128u;      // from one position's record to the next position's in the same chunk
+// Ring layout: rec[chunk][position][16] -- a chunk is a plane, a tile's records of one chunk are contiguous.  (Pairs of chunks side
+// by side, so that a record pass moves 256-byte pieces, changed nothing: profiles/r03_rec_pairs_ab.txt.)
+constexpr uint32_t kPosBytes = 128u;      // from one position's record to the next position's in the same chunk
 __device__ __forceinline__ int64_t rec_elem(uint32_t ring_chunk, int64_t np, int64_t position)      // offset in doubles of a record
 {
-    return kRecPairs ? ((int64_t)(ring_chunk >> 1) * np + position) * (2 * kRec) + (ring_chunk & 1u) * kRec
-                     : ((int64_t)ring_chunk * np + position) * kRec;
+    return ((int64_t)ring_chunk * np + position) * kRec;
 }
 // Records move between HBM and their owning lanes through a per-wave LDS transpose: a lane owns a position (its record
 // lives in registers), but a memory instruction in which every lane touches 16 bytes of a different record costs L2 one
 // request per lane.  Through the transpose EIGHT neighbouring lanes load or store the 128 contiguous bytes of one record: a
-// memory instruction moves eight whole lines.  (Rounds 1-3 moved 64-byte sectors, four lanes each; a line that reaches the L2
-// in two parts is often written back half filled, and the launch then took 428 us instead of 360: DESIGN.md section 3c.)
-constexpr int kStageStride = 10;   // sector form: doubles per position in the staging area, 64 bytes + 16 of padding (bank spread, skip flag)
-constexpr int kStageLanes = 32;    // positions transposed at a time: half a wave (4.5 KiB of staging per wave with whole records)
-#ifndef RR_TILE_LINE_STORES
-#define RR_TILE_LINE_STORES 1      // 1: a record leaves as one 128-byte line per eight lanes (store_record); 0: as two 64-byte sectors (store_half)
-#endif
-constexpr bool kLineStores = RR_TILE_LINE_STORES != 0;
-#ifndef RR_TILE_LINE_LOADS
-#define RR_TILE_LINE_LOADS 1       // 1: a record arrives as one 128-byte line per eight lanes; 0: as two 64-byte sectors per four lanes, requested one tick apart
-#endif
-constexpr bool kLineLoads = RR_TILE_LINE_LOADS != 0;
-constexpr int kStageStrideOut = (kLineStores || kLineLoads) ? 18 : kStageStride;   // whole records parked: 128 bytes + 16 of padding and flags
+// memory instruction moves eight whole lines.  (Rounds 1-3 moved 64-byte sectors, four lanes each, the first as soon as its
+// eight ticks were done; a line that reaches the L2 in two parts is often written back half filled, and the launch then took
+// 428 us instead of 360: DESIGN.md section 3c, profiles/r03_tile_store_whole.txt, r03_tile_store_line.txt, r03_tile_load_line.txt.)
+constexpr int kStageLanes = 32;    // positions transposed at a time: half a wave (4.5 KiB of staging per wave)
+constexpr int kStageStrideOut = 18;   // doubles per parked record: 128 bytes + 16 of padding and flags
 // Lanes of one wave exchange data through its staging area without a workgroup barrier: a wave's LDS instructions
 // execute in order.  The compiler still has to be told that other lanes wrote (it would reuse earlier reads).
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -129,25 +111,13 @@ __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmc
 // short tick reads three upstream values unconditionally); stage: the per-wave transpose areas; aux: UnitMuskingum's short tick
 // keeps the channel discharge (aux[3]) and the previous tick's upstream sum (aux[4]) of every position here instead of in
 // registers -- the record buffers leave none to spare, and a spill reload waits for every record load in flight -- and reads
-// them with the upstream values at the top of a tick (aux[0..2]: the coefficients, with -DRR_UNIT_COEF_LDS=1: slower).
+// them with the upstream values at the top of a tick (the coefficients there too was slower: profiles/r03_unit_lean.txt).
 constexpr int kTilePad = 2;
 constexpr int kTileAux = 5;
-#ifndef RR_UNIT_COEF_LDS
-#define RR_UNIT_COEF_LDS 0      // 1: c1, c2, c3 in LDS too (more loads in flight per tick, more spills: measured slower)
-#endif
 constexpr size_t tile_lds_bytes(int threads)
 {
     return (size_t)(2 * ((int64_t)threads + kTilePad) + (threads / 64) * kStageLanes * kStageStrideOut + kTileAux * threads) * sizeof(double);
 }
-
-// The sector form (store_half, -DRR_TILE_LINE_STORES=0): stored as soon as its eight ticks are done, the first sector's line is
-// often written back before the second arrives and the memory system moves more than the record: WRITE_SIZE 649 MB per launch
-// against 620 with both sectors stored after the sixteenth tick, k_tile 428.6 -> 414.9 us (profiles/r03_tile_store_whole.txt);
-// whole lines (store_record, the default): 545.6 MB, 360.7 us (profiles/r03_tile_store_line.txt).
-#ifndef RR_TILE_HALF_STORES
-#define RR_TILE_HALF_STORES 0      // 1: the first sector after eight ticks (rounds 1-3; measurements)
-#endif
-constexpr bool kHalfStores = RR_TILE_HALF_STORES != 0;
 
 // One task: KC record chunks of one tile, one position per thread.  R[16] is the record the ticks work on, in place
 // (lateral in, discharge out); N[16] receives the NEXT chunk's record while the 16 ticks of this one run, so inside a task
@@ -170,7 +140,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
     if (tid < 2) lds[tid * THP + TH] = 0.0;      // the zero slots; nothing else ever writes them (first barrier: before the first tick)
     auto ring = [&](int32_t chunk) {      // the records of one chunk as a buffer: position p at byte p * kPosBytes (np * kPosBytes < 2^32: choose_schedule)
         const uint32_t c = a.rec_chunks.mod((uint32_t)chunk);
-        return make_rsrc(a.rec + rec_elem(c, a.np, 0), (uint32_t)a.np * kPosBytes - (kRecPairs ? (c & 1u) * 128u : 0u));
+        return make_rsrc(a.rec + rec_elem(c, a.np, 0), (uint32_t)a.np * kPosBytes);
     };
 
     // A workgroup takes the tiles t_last - blockIdx.x - g * gridDim.x, g = 0, 1, ... of this launch (highest level first:
@@ -196,69 +166,33 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
     };
     Task cur;
     if (!select(a.t_last - (int32_t)blockIdx.x, cur)) return;
-#ifdef RR_WAVE_TRACE
-    bool trace = a.trace && a.diag == a.trace_diag && tid == 0;
-    const bool trace_wg = trace;
-    long long *tq = a.trace + (int64_t)cur.tile * 16;
-#define RR_TRACE(i) do { if (trace) tq[i] = wall_clock64(); } while (0)
-#else
-#define RR_TRACE(i) do { } while (0)
-#endif
-    RR_TRACE(0);
 
-    // Eight lanes fetch (store) the eight 16-byte pieces of one record (four lanes one 64-byte sector in the sector form): in
+    // Eight lanes fetch (store) the eight 16-byte pieces of one record: in
     // flight a lane's N[] holds OTHER positions' pieces; receive() hands them to their owners through the wave's staging area.
     double R[kRec], N[kRec];
-    // load j of a record, sector form: (i = j / 2: half wave and group of 16 positions, half = j % 2: which 64-byte sector), so the two
-    // sectors of a 128-byte line are requested by consecutive loads
+    // load j of a record: positions 8 j ... 8 j + 7 of the wave, eight lanes per 128-byte record
     auto issue_load = [&](__amdgpu_buffer_rsrc_t src, int32_t b0, int32_t b1, int j, bool real) {
         const int32_t t = fresh(tid), ln = t & 63;      // addresses are rebuilt at every use, not kept in registers across the task
-        if (kLineLoads) {      // load j: positions 8 j ... 8 j + 7 of the wave, eight lanes per 128-byte record
-            const int32_t pos = min(b0 + (t - ln) + 8 * j + (ln >> 3), b1 - 1);
-            load_f64x2(src, real ? (uint32_t)pos * kPosBytes + (uint32_t)((ln & 7) * 16) : kDropAccess, N[2 * j], N[2 * j + 1]);
-            return;
-        }
-        const int i = j >> 1, half = j & 1;
-        const int32_t pos = min(b0 + (t - ln) + (i >> 1) * kStageLanes + 16 * (i & 1) + (ln >> 2), b1 - 1);
-        load_f64x2(src, real ? (uint32_t)pos * kPosBytes + (uint32_t)(half * 64 + (ln & 3) * 16) : kDropAccess,
-                   N[8 * half + 2 * i], N[8 * half + 2 * i + 1]);
+        const int32_t pos = min(b0 + (t - ln) + 8 * j + (ln >> 3), b1 - 1);
+        load_f64x2(src, real ? (uint32_t)pos * kPosBytes + (uint32_t)((ln & 7) * 16) : kDropAccess, N[2 * j], N[2 * j + 1]);
     };
     auto receive = [&]() {
         const int32_t tl = fresh(tid), lane = tl & 63;
         double *stage = stage_of(tl);
-        if (kLineLoads) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {      // the records of half a wave at a time: loads 4 h ... 4 h + 3
+        for (int h = 0; h < 2; ++h) {      // the records of half a wave at a time: loads 4 h ... 4 h + 3
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    reinterpret_cast<double2 *>(stage + (8 * g + (lane >> 3)) * kStageStrideOut)[lane & 7] =
-                        make_double2(N[2 * (4 * h + g)], N[2 * (4 * h + g) + 1]);
-                wave_lds_fence();
-                if (lane / kStageLanes == h) {
-                    const double2 *src = reinterpret_cast<const double2 *>(stage + (lane % kStageLanes) * kStageStrideOut);
+            for (int g = 0; g < 4; ++g)
+                reinterpret_cast<double2 *>(stage + (8 * g + (lane >> 3)) * kStageStrideOut)[lane & 7] =
+                    make_double2(N[2 * (4 * h + g)], N[2 * (4 * h + g) + 1]);
+            wave_lds_fence();
+            if (lane / kStageLanes == h) {
+                const double2 *src = reinterpret_cast<const double2 *>(stage + (lane % kStageLanes) * kStageStrideOut);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { const double2 v = src[j]; R[2 * j] = v.x; R[2 * j + 1] = v.y; }
-                }
-                wave_lds_fence();
+                for (int j = 0; j < 8; ++j) { const double2 v = src[j]; R[2 * j] = v.x; R[2 * j + 1] = v.y; }
             }
-            return;
+            wave_lds_fence();
         }
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-#pragma unroll
-                for (int g = 0; g < 2; ++g)
-                    reinterpret_cast<double2 *>(stage + (16 * g + (lane >> 2)) * kStageStride)[lane & 3] =
-                        make_double2(N[8 * half + 2 * (2 * h + g)], N[8 * half + 2 * (2 * h + g) + 1]);
-                wave_lds_fence();
-                if (lane / kStageLanes == h) {
-                    const double2 *src = reinterpret_cast<const double2 *>(stage + (lane % kStageLanes) * kStageStride);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { const double2 v = src[j]; R[8 * half + 2 * j] = v.x; R[8 * half + 2 * j + 1] = v.y; }
-                }
-                wave_lds_fence();
-            }
     };
 
     // State of a position.  A slot past the end of the tile keeps lag -1: no upstream range, never active, publishes 0.0
@@ -290,9 +224,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
     // everything but the 8 record loads has arrived (gfx9 encoding: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 |
     // vmcnt[5:4] << 14); a real s_waitcnt, so hipcc knows that no state register is pending inside the tick loop
     __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
-    RR_TRACE(1);
     receive();          // the first tile's first record: the only record load nothing overlaps
-    RR_TRACE(2);
     const bool has_lat = a.has_lat != 0;   // channel-only routing: the records only carry discharge
 
     for (;;) {
@@ -312,39 +244,6 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
         Task nxt;
         const bool has_next = select(cur.tile - (int32_t)gridDim.x, nxt);
 
-        // Eight slots of the record are final: write that 64-byte sector.  Half a wave at a time parks its sectors in
-        // the wave's staging area, then all 64 lanes store them, four lanes per sector.
-        auto store_half = [&](__amdgpu_buffer_rsrc_t dst, int half) {
-            const int32_t tl = fresh(tid), lane = tl & 63;
-            double *stage = stage_of(tl);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (lane / kStageLanes == h) {
-                    double2 *mine = reinterpret_cast<double2 *>(stage + (lane % kStageLanes) * kStageStride);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) mine[j] = make_double2(R[8 * half + 2 * j], R[8 * half + 2 * j + 1]);
-                    int32_t *word = reinterpret_cast<int32_t *>(mine + 4);
-                    word[0] = (lg < 0 || (lg & (kGhostBit | kTileGhostBit))) ? 1 : 0;   // not this tile's to write
-                    if (!SUB) word[1] = (lg >= 0 && (lg & kTileExportBit)) ? fresh(xp) : -1;      // position of the ghost that mirrors this reach
-                }
-                wave_lds_fence();
-                const int32_t t = fresh(tid), ln = t & 63;
-                const uint32_t first = (uint32_t)(b0 + (t - ln) + h * kStageLanes) * kPosBytes + (uint32_t)half * 64u;
-#pragma unroll
-                for (int g = 0; g < 2; ++g) {       // lanes 4i .. 4i+3: the four 16-byte pieces of position 16 g + i
-                    const int pm = 16 * g + (ln >> 2), piece = ln & 3;
-                    const double2 *theirs = reinterpret_cast<const double2 *>(stage + pm * kStageStride);
-                    const double2 v = theirs[piece];
-                    const bool skip = reinterpret_cast<const int32_t *>(theirs + 4)[0] != 0;
-                    store_f64x2(dst, skip ? kDropAccess : first + (uint32_t)pm * kPosBytes + (uint32_t)piece * 16u, v);
-                    if (!SUB) {     // the same sector into the record of the ghost that mirrors the reach (always issued, see store_f64)
-                        const int32_t gx = reinterpret_cast<const int32_t *>(theirs + 4)[1];
-                        store_f64x2(dst, gx < 0 ? kDropAccess : (uint32_t)gx * kPosBytes + (uint32_t)half * 64u + (uint32_t)piece * 16u, v);
-                    }
-                }
-                wave_lds_fence();
-            }
-        };
         // The whole record at once: half a wave parks its 32 records, then all 64 lanes store them, eight lanes per 128-byte
         // line -- both sectors of a line in one instruction, so no line is ever written back half filled.
         auto store_record = [&](__amdgpu_buffer_rsrc_t dst) {
@@ -436,7 +335,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                 wr[t] = qk;
                 // With sub-steps a record slot holds a row mean, not the tick's discharge: a reach mirrored by a ghost of another
                 // tile sends 8 bytes per tick into the ghost's record, always issued (see store_f64).  Without, the ghost gets a
-                // copy of the whole record in store_half.
+                // copy of the whole record in store_record.
                 if (SUB) store_f64(rec_cur, (lgk >= 0 && (lgk & kTileExportBit)) ? (uint32_t)fresh(xp) * kPosBytes + (uint32_t)s * 8u : kDropAccess, qk);
                 barrier_lds();
             }
@@ -458,15 +357,15 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
         bool ghostm = false;                          // NOLAT: this position is a ghost (its record slot is its forcing)
         auto lds_at = [&](int parity, int32_t byte) -> double & { return *reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + parity * (THP * 8) + byte); };
         // record loads of the short path: one address register per chunk, the piece of load j is an immediate / scalar offset
-        auto issue_load_plain = [&](__amdgpu_buffer_rsrc_t src, int32_t voff, int j) {
-            const int i = j >> 1, half = j & 1;
-            const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(src, voff, kLineLoads ? j * 8 * (int)kPosBytes : ((i >> 1) * kStageLanes + 16 * (i & 1)) * (int)kPosBytes + half * 64, (RR_NT_MASK & kNtTileLoad) ? 2 : 0);
+        auto issue_load_plain = [&](__amdgpu_buffer_rsrc_t src, uint32_t voff, int j) {
+            // the piece's offset is part of the per-lane offset (a compile-time constant per unrolled load, folded into the
+            // instruction's immediate where it fits): the range check of a raw buffer covers that sum, not a scalar offset
+            const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(src, (int)(voff + (uint32_t)j * 8u * kPosBytes), 0, 0);
             double2 v;
             __builtin_memcpy(&v, &bits, sizeof v);
-            if (kLineLoads) { N[2 * j] = v.x; N[2 * j + 1] = v.y; }
-            else { N[8 * half + 2 * i] = v.x; N[8 * half + 2 * i + 1] = v.y; }
+            N[2 * j] = v.x; N[2 * j + 1] = v.y;
         };
-        auto ticks_plain = [&](auto tested, int32_t tau0, int half, __amdgpu_buffer_rsrc_t rec_next, int32_t nvoff) {
+        auto ticks_plain = [&](auto tested, int32_t tau0, int half, __amdgpu_buffer_rsrc_t rec_next, uint32_t nvoff) {
 #pragma unroll
             for (int s8 = 0; s8 < 8; ++s8) {
                 const int s = 8 * half + s8;      // tau0 is a multiple of 16: the parity of the tick is the parity of s
@@ -479,11 +378,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                     auto aux_at = [&](int k) -> double & { return *reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + kAux + k * (TH * 8) + own_b); };
                     const double s_hw = (lds_at((s + 1) & 1, hw0_b) + lds_at((s + 1) & 1, hw1_b)) + lds_at((s + 1) & 1, hw2_b);
                     const double qc = aux_at(3);
-#if RR_UNIT_COEF_LDS
-                    const double r = __builtin_fma(aux_at(0), s_hw + s_cur, __builtin_fma(aux_at(1), s_hw + aux_at(4), aux_at(2) * qc));
-#else
                     const double r = __builtin_fma(c1, s_hw + s_cur, __builtin_fma(c2, s_hw + aux_at(4), c3 * qc));
-#endif
                     qk = r + R[s];
                     if (decltype(tested)::value) {
                         const bool active = (uint32_t)(tau0 + s - lagm) < (uint32_t)total;
@@ -542,40 +437,30 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                 } else {
                     up0_b = (cnt >= 1 ? u0s : TH) * 8; up1_b = (cnt >= 2 ? u0s + 1 : TH) * 8; up2_b = (cnt >= 3 ? u0s + 2 : TH) * 8;
                 }
-                const int32_t nvoff = kLineLoads ? (nb0 + (t - ln) + (ln >> 3)) * (int32_t)kPosBytes + (ln & 7) * 16 : (nb0 + (t - ln) + (ln >> 2)) * (int32_t)kPosBytes + (ln & 3) * 16;
+                const uint32_t nvoff = (uint32_t)(nb0 + (t - ln) + (ln >> 3)) * kPosBytes + (uint32_t)(ln & 7) * 16u;      // unsigned: 2^25 positions x 128 B
                 const __amdgpu_buffer_rsrc_t src = (!last || has_next) ? rec_next : make_rsrc(a.rec, 0u);
                 if (kind == 1) {
                     ticks_plain(std::false_type(), tau0, 0, src, nvoff);
-                    if (kHalfStores) store_half(rec_cur, 0);
                     ticks_plain(std::false_type(), tau0, 1, src, nvoff);
                 } else {
                     lagm = lg < 0 ? 0x40000000 : (fresh(lg) & kLagMask);      // a slot past the end of the tile is never active
                     ticks_plain(std::true_type(), tau0, 0, src, nvoff);
                     if (kind & kTileExports) store_exports(tau0, 0);
-                    if (kHalfStores) store_half(rec_cur, 0);
                     ticks_plain(std::true_type(), tau0, 1, src, nvoff);
                     if (kind & kTileExports) store_exports(tau0, 1);
                 }
             } else {
                 ticks(tau0, 0, rec_next, nb0, nb1, !last || has_next);
-                if (cc == 0) RR_TRACE(3);
-                if (kHalfStores) store_half(rec_cur, 0);
                 ticks(tau0, 1, rec_next, nb0, nb1, false);
-                if (cc == 0) RR_TRACE(6);
             }
-            if (!kHalfStores && !kLineStores) store_half(rec_cur, 0);
-            if (!kHalfStores && kLineStores) store_record(rec_cur);
-            else store_half(rec_cur, 1);
-            if (cc == 0) RR_TRACE(7);
+            store_record(rec_cur);      // after the sixteenth tick: whole lines, never a half-filled write-back
             // the next tile's state: small, and only the wait for it is exposed between two tiles.  LEAN asks for it after the
             // chunk loop: requested inside, its thirteen registers are live across every chunk beside both record buffers, and
             // what the allocator spills it reloads behind a wait for every load in flight
             if (!LEAN && last && has_next) load_state(nxt, st);
             receive();      // the record that has had 16 ticks to arrive (zeros after the last chunk of the last tile)
-            if (cc == 0) RR_TRACE(8);
             rec_cur = rec_next;
         }
-        RR_TRACE(12);
         if (lg >= 0) {
             const int32_t p = b0 + tid;
             const double *aux = lds + 2 * THP + (TH / 64) * (kStageLanes * kStageStrideOut);
@@ -584,15 +469,9 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
             if (SUB) a.si[p] = isum;
         }
         if (LEAN && has_next) load_state(nxt, st);
-        RR_TRACE(13);
-#ifdef RR_WAVE_TRACE
-        trace = false;      // the first tile of the workgroup only
-        if (!has_next && trace_wg) tq[14] = wall_clock64();     // ... and when the workgroup leaves
-#endif
         if (!has_next) break;
         cur = nxt;
     }
-#undef RR_TRACE
 }
 
 // sq = q0 at every position (a ghost starts from the state of the reach it mirrors), ss = sum of the upstream q0

@@ -43,13 +43,7 @@ __global__ __launch_bounds__(kBlock) void k_uh_convolve(const double *__restrict
 // column sits in registers (static indices: the tap loop is unrolled over the padded length NK), the last NK
 // lateral values in an LDS ring [slot][lane] (conflict-free), so HBM sees each lateral row and each output row
 // exactly once and the kernel taps once per segment -- k_uh_convolve re-reads the taps for every 8 rows.
-#ifndef RR_UH_THREADS
-#define RR_UH_THREADS 128
-#endif
-#ifndef RR_UH48
-#define RR_UH48 64, 48, 8, 2
-#endif
-constexpr int kUhThreads = RR_UH_THREADS;
+constexpr int kUhThreads = 128;
 constexpr int kUhTailThreads = 64;
 
 // NK window slots (power of two), R outputs per pass (every window value read from LDS feeds R accumulators),

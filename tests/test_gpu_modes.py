@@ -20,10 +20,10 @@ def csc_from_down(down_index):
     return indptr, down_index[has].astype(np.int32)
 
 
-KNOBS = ('RR_WAVE', 'RR_WAVE_K', 'RR_WAVE_THREADS', 'RR_TILE_BLOCK')
+KNOBS = ('RR_WAVE', 'RR_WAVE_K', 'RR_TILE_BLOCK')
 # tile capacity 64 / 333 on these networks: hundreds of tiles, 10-30 tile levels, thousands of ghosts
-SHAPES = [{'RR_WAVE': '0'}, {'RR_WAVE': '1', 'RR_WAVE_K': '16'}, {'RR_WAVE': '1', 'RR_WAVE_K': '32', 'RR_WAVE_THREADS': '1024'},
-          {'RR_WAVE': '1', 'RR_TILE_BLOCK': '64', 'RR_WAVE_K': '16', 'RR_WAVE_THREADS': '256'},
+SHAPES = [{'RR_WAVE': '0'}, {'RR_WAVE': '1', 'RR_WAVE_K': '16'}, {'RR_WAVE': '1', 'RR_WAVE_K': '32'},
+          {'RR_WAVE': '1', 'RR_TILE_BLOCK': '64', 'RR_WAVE_K': '16'},
           {'RR_WAVE': '1', 'RR_TILE_BLOCK': '333', 'RR_WAVE_K': '64'}, {'RR_WAVE': '1', 'RR_WAVE_K': '128'},
           {'RR_WAVE': '1', 'RR_WAVE_K': '256', 'RR_TILE_BLOCK': '200'}]
 

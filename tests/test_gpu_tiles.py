@@ -10,7 +10,7 @@ from river_route_amd import synth
 from river_route_amd.engine import DeviceBuffer, Plan, partition_forest, uh_convolve
 
 pytestmark = pytest.mark.gpu
-KNOBS = ('RR_WAVE', 'RR_WAVE_K', 'RR_WAVE_THREADS', 'RR_TILE_BLOCK') + ('RR_REC_STREAM', 'RR_TILE_LEAN', 'RR_UH_PAIRS')
+KNOBS = ('RR_WAVE', 'RR_WAVE_K', 'RR_TILE_BLOCK', 'RR_TILE_LEAN', 'RR_UH_PAIRS', 'RR_DIRECT')
 
 
 def csc_from_down(down_index):
@@ -27,8 +27,8 @@ def set_env(monkeypatch, env):
 
 
 @pytest.mark.parametrize('n,T,env,wide', [(300_000, 80, {'RR_WAVE': '1'}, False), (1_000_000, 80, {'RR_WAVE': '1'}, False),
-                                           (300_000, 70, {'RR_WAVE': '1', 'RR_WAVE_THREADS': '1024', 'RR_WAVE_K': '32'}, False),
-                                           (60_000, 50, {'RR_WAVE': '1', 'RR_TILE_BLOCK': '64', 'RR_WAVE_THREADS': '256', 'RR_WAVE_K': '16'}, False),
+                                           (300_000, 70, {'RR_WAVE': '1', 'RR_WAVE_K': '32'}, False),
+                                           (60_000, 50, {'RR_WAVE': '1', 'RR_TILE_BLOCK': '64', 'RR_WAVE_K': '16'}, False),
                                            (120_000, 70, {'RR_WAVE': '1', 'RR_TILE_LEAN': '0'}, False),      # the general tick for every tile
                                            (120_000, 70, {'RR_WAVE': '1'}, True)])      # confluences of four to eight reaches: their tiles go to the general kernel beside the short tick
 def test_unit_route_dev_time_tiled_vs_oracle(monkeypatch, n, T, env, wide):
@@ -569,11 +569,10 @@ def _wide_network(n, seed=5, fan=8):
     return down.astype(np.int64)
 
 
-@pytest.mark.parametrize('env', [{}, {'RR_REC_STREAM': '1'}, {'RR_TILE_LEAN': '0'}])
+@pytest.mark.parametrize('env', [{}, {'RR_TILE_LEAN': '0'}])
 def test_confluences_of_four_and_more_vs_oracle(monkeypatch, env):
     """The short tick reads three upstream values; a tile that holds a reach with more goes to the companion launch of the
-    general kernel in the same step (TileArgs::tile_filter).  Also: the record passes on the second stream (RR_REC_STREAM=1)
-    and the general kernel alone (RR_TILE_LEAN=0) on the same network."""
+    general kernel in the same step (TileArgs::tile_filter).  Also: the general kernel alone (RR_TILE_LEAN=0) on the same network."""
     set_env(monkeypatch, env)
     n, T = 150_000, 130
     down = _wide_network(n)
