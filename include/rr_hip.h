@@ -114,9 +114,12 @@ int rr_plan_set_unit_weights(rr_plan *plan, const double *c1, const double *a_da
  * call (T runoff rows x nsub sub-steps; rr_muskingum_route*: T = num_output_steps, nsub = num_routing_per_output), after
  * rr_plan_set_coeffs and rr_plan_set_boundary / rr_plan_set_options: one call per input file is the reference's pattern
  * (river_route/routers/TransformMuskingum.py:108-148), and the routers reserve in _hook_before_route.  Memory only
- * grows; a smaller call fits a larger reservation.  host_rows != 0 also prepares the staging of the host-pointer entry
- * points (pinned buffers and device rings of the PCIe pipeline).
- * info (may be NULL): [0] 1 = time-tiled kernel, 0 = streaming kernel; [1] routing ticks per launch K; [2] chunks of the
+ * grows; a smaller call fits a larger reservation.  host_rows: bit 0 also prepares the staging of the host-pointer entry
+ * points (pinned buffers and device rings of the PCIe pipeline); RR_ROWS_NOT_PLAIN: the rows of the call are not plain
+ * float64 rows in device arrays (float32 rows, fused convolution, gridded runoff: rr_*_f32*_dev, rr_unit_route_uh*_dev,
+ * rr_rapid_route_runoff_dev), so the direct row path -- which rr_rapid_route_dev and rr_stream_begin take where the params
+ * order numbers small subtrees contiguously, see rr_plan_direct_info -- does not apply and the record ring is needed.
+ * info (may be NULL): [0] 2 = direct row path, 1 = time-tiled kernel, 0 = streaming kernel; [1] routing ticks (rows) per launch K; [2] chunks of the
  * record ring (16 ticks each); [3] bytes of routing work memory now held on the device; [4] bytes of device staging and
  * [5] of pinned host staging of the host-pointer path; [6] depth of the routing pipeline in ticks (network depth + tile
  * levels x K: a call's first output row leaves this many ticks after its first input row entered); [7] bytes of the record
@@ -124,7 +127,24 @@ int rr_plan_set_unit_weights(rr_plan *plan, const double *c1, const double *a_da
 #define RR_MODE_RAPID 0
 #define RR_MODE_MUSKINGUM 1
 #define RR_MODE_UNIT 2
+#define RR_ROWS_NOT_PLAIN 2
 int rr_plan_reserve(rr_plan *plan, int mode, int64_t T, int64_t nsub, int host_rows, int64_t info[8]);
+
+/* The direct row path: where the params order numbers every small subtree contiguously -- any depth-first
+ * post-order does (a valid order for tools.adjacency_matrix, river_route/tools.py:103-104) -- RapidMuskingum calls with one
+ * sub-step per row on float64 device rows (rr_rapid_route_dev, rr_stream_begin) are routed straight from and to the caller's rows
+ * by column-range tiles: no record ring and no permutation pass for 95 % of the columns.
+ * info: [0] 1 = applies to this plan; [1] direct tiles; [2] holes (columns of skeleton reaches); [3] outlets that feed the
+ * skeleton; [4] positions, [5] tiles, [6] tile levels of the skeleton; [7] rows of the LDS window.  why (may be NULL): the
+ * reason it does not apply.  rr_plan_direct_layout: tile arrays [tiles], per-column arrays [n]; any pointer may be NULL. */
+int rr_plan_direct_info(const rr_plan *plan, int64_t info[8], char *why, int64_t why_cap);
+int rr_plan_direct_layout(const rr_plan *plan, int32_t *tile_c0, int32_t *tile_nc, int32_t *tile_lag_lo, int32_t *tile_span,
+                          int32_t *delay, int32_t *up3, int32_t *xinfo);
+/* Which routing kernel the last call on this plan ran. */
+#define RR_KERNEL_TICK 0
+#define RR_KERNEL_TILE 1
+#define RR_KERNEL_DIRECT 2
+int rr_plan_last_kernel(const rr_plan *plan);
 
 /* Tuning / measurement.  rows_per_chunk: time rows moved per permutation launch of the streaming kernel (default 16).
  * sample_every >= 16: HIP-event brackets on the call's stream around sampled routing launches (every fourth launch of the

@@ -77,6 +77,9 @@ _SIGNATURES = {
     'rr_plan_layout': (C.c_int, [_vp, _vp, _vp, _vp]),
     'rr_plan_tile_info': (C.c_int, [_vp, _vp]),
     'rr_plan_tile_layout': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'rr_plan_direct_info': (C.c_int, [_vp, _vp, _vp, _i64]),
+    'rr_plan_direct_layout': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'rr_plan_last_kernel': (C.c_int, [_vp]),
     'rr_plan_set_coeffs': (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     'rr_plan_set_unit_weights': (C.c_int, [_vp, _vp, _vp]),
     'rr_plan_reserve': (C.c_int, [_vp, C.c_int, _i64, _i64, C.c_int, _vp]),

@@ -13,7 +13,7 @@
 // Layout: rr_plan.hpp.  No CPU fallback anywhere in this file.
 //
 // One translation unit, in this order: rr_common.hpp (constants, index helpers), rr_kernels_tick.hpp, rr_kernels_tile.hpp,
-// rr_kernels_uh.hpp, rr_kernels_rec.hpp, rr_kernels_runoff.hpp (device code), rr_exec.hpp (plan object, executor), then the
+// rr_kernels_uh.hpp, rr_kernels_rec.hpp, rr_kernels_runoff.hpp, rr_kernels_direct.hpp (device code), rr_exec.hpp (plan object, executor), then the
 // C ABI below.
 #include "rr_common.hpp"
 #include "rr_kernels_tick.hpp"
@@ -21,6 +21,7 @@
 #include "rr_kernels_uh.hpp"
 #include "rr_kernels_rec.hpp"
 #include "rr_kernels_runoff.hpp"
+#include "rr_kernels_direct.hpp"
 #include "rr_exec.hpp"
 
 // ------------------------------------------------------------------------------------------------
@@ -49,7 +50,9 @@ void rr_plan_destroy(rr_plan *P)
                         P->d_tmeta, P->d_pmeta,
                         P->d_tperm, P->d_tinv, P->d_inner_idx, P->d_colmeta, P->d_ghostmeta, P->d_c4_params,
                         P->d_c3, P->d_c4, P->d_x, P->d_isum, P->d_qch, P->d_a2, P->d_c1own, P->d_z, P->d_ring, P->d_stage, P->d_mrows,
-                        P->d_slot_a[0], P->d_slot_a[1], P->d_slot_b[0], P->d_slot_b[1], P->d_m_index[0], P->d_m_index[1]};
+                        P->d_slot_a[0], P->d_slot_a[1], P->d_slot_b[0], P->d_slot_b[1], P->d_m_index[0], P->d_m_index[1],
+                        P->d_dtiles, P->d_dlane, P->d_dcoef, P->d_dq, P->d_ktmeta, P->d_kpmeta, P->d_kperm, P->d_kholecol, P->d_kcoef, P->d_ksq, P->d_kss, P->d_ksi,
+                        P->d_kholemeta};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         P->pipe.destroy();
         for (hipEvent_t e : P->ev) (void)hipEventDestroy(e);
@@ -67,7 +70,8 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
     if (!P) return fail(RR_E_ALLOC, "rr_plan_create: out of memory");
     // Run-time switches, all for tests (each is exercised by tests/test_gpu_*.py): RR_WAVE=0 the streaming kernel for every call,
     // =1 the time-tiled one wherever it applies; RR_WAVE_K ticks per task; RR_TILE_BLOCK tile capacity (many small tiles);
-    // RR_TILE_LEAN=0 the general tick; RR_UH_PAIRS=0 one record batch per fused-convolution launch; RR_VERBOSE=1 logs the schedule.
+    // RR_TILE_LEAN=0 the general tick; RR_UH_PAIRS=0 one record batch per fused-convolution launch; RR_DIRECT=0 records also where the
+    // params order would allow the direct row path; RR_VERBOSE=1 logs the schedule.
     if (const char *e = getenv("RR_WAVE")) { P->wave_enabled = atoi(e) != 0; P->wave_forced = atoi(e) == 1; }
     if (const char *e = getenv("RR_WAVE_K")) P->wave_K = std::max(kRec, atoi(e) / kRec * kRec);
     std::string err;
@@ -84,6 +88,10 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         std::vector<int32_t> lag_of((size_t)n);
         for (int64_t i = 0; i < n; ++i) lag_of[i] = P->h.lag[P->h.inv[i]];
         rr::build_tile_plan(P->h.down, lag_of, block, P->tp);
+        // the direct row path where the params order numbers small subtrees contiguously (any depth-first post-order); `why` says why not
+        if (const char *e = getenv("RR_DIRECT")) P->direct_enabled = atoi(e) != 0;
+        rr::build_direct_plan(P->h.down, lag_of, std::min<int32_t>(kDirectLanes, block), kDirectMaxWindow, block, P->dp);
+        for (int32_t sp : P->dp.tile_span) P->direct_window = std::max(P->direct_window, sp + 1);
     }
     if (device != RR_DEVICE_NONE) {
         int count = rr_device_count();
@@ -148,6 +156,50 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
             if (!rc) rc = dev_alloc(&P->d_full, n);
             if (!rc) rc = dev_alloc(&P->d_chan, n);
         }
+        if (!rc && P->dp.ok) {      // direct row path: per-column constants, the skeleton's tile arrays, the holes' out-pass
+            const rr::DirectPlan &D = P->dp;
+            const rr::TilePlan &K = D.skel;
+            if (hipFuncSetAttribute((const void *)k_direct<kDirectLanes, kDirectAhead>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)direct_lds_bytes(kDirectMaxWindow)) != hipSuccess) {
+                (void)hipGetLastError();
+                P->direct_enabled = false;
+            }
+            std::vector<DirectTile> dt((size_t)D.n_tiles);
+            for (int32_t t = 0; t < D.n_tiles; ++t) dt[t] = DirectTile{D.tile_c0[t], D.tile_nc[t], D.tile_lag_lo[t], D.tile_span[t]};
+            std::vector<int4> dl((size_t)n);
+            for (int64_t i = 0; i < n; ++i) dl[i] = make_int4(D.delay[i], D.up3[i], D.xinfo[i], H.lag[H.inv[i]]);
+            rc = dev_alloc(&P->d_dtiles, D.n_tiles);
+            if (!rc) rc = dev_upload(P->d_dtiles, dt);
+            if (!rc) rc = dev_alloc(&P->d_dlane, n);
+            if (!rc) rc = dev_upload(P->d_dlane, dl);
+            if (!rc) rc = dev_alloc(&P->d_dcoef, 4 * n);
+            if (!rc) rc = dev_alloc(&P->d_dq, n);
+            std::vector<TileMeta> tm((size_t)K.n_tiles);
+            for (int32_t t = 0; t < K.n_tiles; ++t) {
+                tm[t] = TileMeta{K.tile_ptr[t], K.tile_ptr[t + 1], K.tile_level[t], K.tile_lag_lo[t], K.tile_lag_hi[t], K.tile_flags[t], 0, 0};
+                P->n_kwide += (K.tile_flags[t] & kTileWide) ? 1 : 0;
+            }
+            std::vector<int4> pm((size_t)K.np);
+            for (int64_t p = 0; p < K.np; ++p) pm[p] = make_int4(K.lag[p], K.cfirst[p], K.xpos[p], (int32_t)K.ccnt[p]);
+            std::vector<int2> hm;
+            std::vector<int32_t> hc;
+            for (int64_t i = 0; i < n; ++i)
+                if (D.big[i]) { hm.push_back(make_int2(K.inv[i], K.lag[K.inv[i]] & kLagMask)); hc.push_back((int32_t)i); }
+            P->n_kholes = (int64_t)hm.size();
+            if (!rc) rc = dev_alloc(&P->d_ktmeta, K.n_tiles);
+            if (!rc) rc = dev_upload(P->d_ktmeta, tm);
+            if (!rc) rc = dev_alloc(&P->d_kpmeta, K.np);
+            if (!rc) rc = dev_upload(P->d_kpmeta, pm);
+            if (!rc) rc = dev_alloc(&P->d_kperm, K.np);
+            if (!rc) rc = dev_upload(P->d_kperm, K.perm);
+            if (!rc) rc = dev_alloc(&P->d_kcoef, 3 * K.np);
+            if (!rc) rc = dev_alloc(&P->d_ksq, K.np);
+            if (!rc) rc = dev_alloc(&P->d_kss, K.np);
+            if (!rc) rc = dev_alloc(&P->d_ksi, K.np);
+            if (!rc) rc = dev_alloc(&P->d_kholemeta, P->n_kholes);
+            if (!rc) rc = dev_upload(P->d_kholemeta, hm);
+            if (!rc) rc = dev_alloc(&P->d_kholecol, P->n_kholes);
+            if (!rc) rc = dev_upload(P->d_kholecol, hc);
+        }
         if (!rc) rc = dev_alloc(&P->d_w, n);
         if (!rc) rc = dev_alloc(&P->d_c1row_h, n);
         if (!rc) rc = dev_alloc(&P->d_c2, n);
@@ -207,6 +259,33 @@ int rr_plan_tile_layout(const rr_plan *P, int32_t *tile_ptr, int32_t *tile_level
     return RR_OK;
 }
 
+int rr_plan_direct_info(const rr_plan *P, int64_t info[8], char *why, int64_t why_cap)
+{
+    if (!P || !info) return fail(RR_E_INVALID, "rr_plan_direct_info: null argument");
+    const rr::DirectPlan &D = P->dp;
+    info[0] = D.ok ? 1 : 0; info[1] = D.n_tiles; info[2] = D.n_holes; info[3] = D.n_exports; info[4] = D.skel.np; info[5] = D.skel.n_tiles;
+    info[6] = D.skel.n_levels; info[7] = P->direct_window;
+    if (why && why_cap > 0) { std::strncpy(why, D.why.c_str(), (size_t)why_cap - 1); why[why_cap - 1] = 0; }
+    return RR_OK;
+}
+
+int rr_plan_direct_layout(const rr_plan *P, int32_t *tile_c0, int32_t *tile_nc, int32_t *tile_lag_lo, int32_t *tile_span, int32_t *delay, int32_t *up3, int32_t *xinfo)
+{
+    if (!P) return fail(RR_E_INVALID, "rr_plan_direct_layout: null plan");
+    const rr::DirectPlan &D = P->dp;
+    if (!D.ok) return fail(RR_E_UNSUPPORTED, "rr_plan_direct_layout: the direct row path does not apply to this plan: " + D.why);
+    auto copy = [](auto *dst, const auto &src) { if (dst && !src.empty()) std::memcpy(dst, src.data(), src.size() * sizeof(src[0])); };
+    copy(tile_c0, D.tile_c0); copy(tile_nc, D.tile_nc); copy(tile_lag_lo, D.tile_lag_lo); copy(tile_span, D.tile_span);
+    copy(delay, D.delay); copy(up3, D.up3); copy(xinfo, D.xinfo);
+    return RR_OK;
+}
+
+int rr_plan_last_kernel(const rr_plan *P)
+{
+    if (!P) return -1;
+    return P->ses.rows_direct ? RR_KERNEL_DIRECT : (P->ses.wave ? RR_KERNEL_TILE : RR_KERNEL_TICK);
+}
+
 int rr_plan_set_options(rr_plan *P, int64_t rows_per_chunk, int64_t sample_every)
 {
     if (!P) return fail(RR_E_INVALID, "rr_plan_set_options: null plan");
@@ -253,6 +332,19 @@ int rr_plan_set_coeffs(rr_plan *P, const double *lhs_off_data, const double *c2,
             P->h_coef[3 * p] = c1row[H.inv[i]]; P->h_coef[3 * p + 1] = c2[i]; P->h_coef[3 * p + 2] = c3[i];
         }
         rc = upload_tile_coef(P);
+    }
+    if (!rc && P->dp.ok) {      // direct row path: {c1row, c2, c3, c4dt} per column; the skeleton's positions as k_tile wants them (a ghost computes nothing)
+        std::vector<double> dc(4 * (size_t)n);
+        for (int64_t i = 0; i < n; ++i) { dc[4 * i] = c1row[H.inv[i]]; dc[4 * i + 1] = c2[i]; dc[4 * i + 2] = c3[i]; dc[4 * i + 3] = c4_dt ? c4_dt[i] : 0.0; }
+        rc = dev_upload(P->d_dcoef, dc);
+        const rr::TilePlan &K = P->dp.skel;
+        std::vector<double> kc(3 * (size_t)K.np, 0.0);
+        for (int64_t p = 0; p < K.np; ++p) {
+            if (K.lag[p] & kTileGhostBit) continue;
+            const int32_t i = K.perm[p];
+            kc[3 * p] = c1row[H.inv[i]]; kc[3 * p + 1] = c2[i]; kc[3 * p + 2] = c3[i];
+        }
+        if (!rc) rc = dev_upload(P->d_kcoef, kc);
     }
     if (!rc) rc = dev_upload(P->d_c2, a2);
     if (!rc) rc = dev_upload(P->d_c3, a3);
@@ -303,16 +395,18 @@ int rr_plan_reserve(rr_plan *P, int mode, int64_t T, int64_t nsub, int host_rows
     const Mode m = mode == RR_MODE_RAPID ? Mode::Rapid : (mode == RR_MODE_MUSKINGUM ? Mode::Muskingum : Mode::Unit);
     Schedule sch;
     // host rows reach the time-tiled kernel through the PCIe pipeline's device rings; where it does not apply they stream
-    rc = reserve_core(P, m, T, nsub, false, false, &sch);
-    if (rc == RR_OK && host_rows && !sch.tiled) rc = reserve_core(P, m, T, nsub, true, true, &sch);
-    if (rc == RR_OK && host_rows && sch.tiled) rc = host_pipe_prepare(P);
+    const bool host = (host_rows & 1) != 0, plain = !host && (host_rows & RR_ROWS_NOT_PLAIN) == 0;      // plain float64 rows in device arrays: the direct row path applies
+    rc = reserve_core(P, m, T, nsub, false, false, &sch, plain);
+    if (rc == RR_OK && host && !sch.tiled) rc = reserve_core(P, m, T, nsub, true, true, &sch);
+    if (rc == RR_OK && host && sch.tiled) rc = host_pipe_prepare(P);
     if (rc) return rc;
     if (info) {
-        info[0] = sch.tiled ? 1 : 0; info[1] = sch.tiled ? sch.KC * kRec : 1; info[2] = sch.chunks;
+        info[0] = sch.direct ? 2 : (sch.tiled ? 1 : 0); info[1] = (sch.tiled || sch.direct) ? sch.KC * kRec : 1; info[2] = sch.chunks;
         info[3] = (P->ring_cap + P->mrows_cap + P->stage_cap) * (int64_t)sizeof(double);
-        info[4] = host_rows && sch.tiled ? 2 * P->pipe.dev_cap * (int64_t)sizeof(double) : 0;
-        info[5] = host_rows && sch.tiled ? 2 * HostPipe::kPinned * P->pipe.pin_cap * (int64_t)sizeof(double) : 0;
-        info[6] = sch.tiled ? P->h.depth - 1 + (int64_t)P->tp.n_levels * sch.KC * kRec : P->h.depth - 1;      // pipeline depth in ticks
+        info[4] = host && sch.tiled ? 2 * P->pipe.dev_cap * (int64_t)sizeof(double) : 0;
+        info[5] = host && sch.tiled ? 2 * HostPipe::kPinned * P->pipe.pin_cap * (int64_t)sizeof(double) : 0;
+        info[6] = sch.direct ? P->h.depth - 1 + (int64_t)P->dp.skel.n_levels * sch.KC * kRec
+                             : (sch.tiled ? P->h.depth - 1 + (int64_t)P->tp.n_levels * sch.KC * kRec : P->h.depth - 1);      // pipeline depth in ticks
         info[7] = sch.ring * (int64_t)sizeof(double);
     }
     return RR_OK;
@@ -324,7 +418,7 @@ int rr_plan_profile(rr_plan *P, double prof[10])
     for (int k = 0; k < 10; ++k) prof[k] = 0.0;
     prof[0] = (double)P->prof_launches;
     prof[8] = (double)P->prof_brackets;
-    prof[9] = P->ses.wave ? (double)(P->ses.KC * kRec) : 1.0;
+    prof[9] = (P->ses.wave || P->ses.rows_direct) ? (double)(P->ses.KC * kRec) : 1.0;
     prof[7] = (double)P->prof_reach_steps;
     if (P->device < 0 || !P->ev_first || P->prof_launches == 0) return RR_OK;
     HIPCHK(hipSetDevice(P->device));
@@ -424,7 +518,7 @@ int rr_stream_begin(rr_plan *P, int has_lateral, const double *q_t, const double
     Rows io; io.dev_in = has_lateral ? lateral : nullptr; io.rows_in = lat_rows; io.dev_out = discharge; io.rows_out = out_rows;
     const Mode mode = has_lateral ? Mode::Rapid : Mode::Muskingum;
     if (P->ses.open) return fail(RR_E_STATE, "a routing call is already open on this plan (rr_stream_end it first)");
-    rc = prepare_call(P, mode, T, nsub, false, false, true);
+    rc = prepare_call(P, mode, T, nsub, false, false, true, has_lateral != 0);
     if (rc) return rc;
     if (P->h.n > 0 && T > 0) {
         rc = launch_state_in(P, mode, q_t, (hipStream_t)stream);

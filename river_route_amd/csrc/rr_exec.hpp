@@ -51,6 +51,10 @@ struct Session {
     int64_t ghost_batches = 0;    // batches of the boundary (ghost) series turned into records
     int64_t ghost_slack = 0, export_skew = 0;      // boundary reaches of a partitioned network in the time-tiled schedule (level skew included)
     TileArgs ta{};
+    // direct row path (rr_kernels_direct.hpp): K rows per task, the skeleton behind it on records
+    bool rows_direct = false;
+    int64_t n_tasks = 0;          // direct launches: rows [d K, (d + 1) K) in launch d
+    DirectArgs da{};
     bool bracket_open = false;
     int64_t bracket_reaches = 0;
     size_t max_samples = 0;
@@ -144,6 +148,20 @@ struct rr_plan {
 
     Session ses;
     HostPipe pipe;      // staging of the host-pointer entry points (allocated at first use)
+    // direct row path: column-range tiles where the params order numbers small subtrees contiguously (rr_plan.hpp: DirectPlan)
+    rr::DirectPlan dp;
+    bool direct_enabled = true, direct_now = false;      // RR_DIRECT=0 (tests): records for every call
+    int direct_window = 1;               // rows of the LDS window: largest span + 1 of the plan's tiles
+    DirectTile *d_dtiles = nullptr;
+    int4 *d_dlane = nullptr;
+    double *d_dcoef = nullptr, *d_dq = nullptr;
+    TileMeta *d_ktmeta = nullptr;        // the skeleton's tiles (TileArgs of its k_tile launches)
+    int4 *d_kpmeta = nullptr;
+    int32_t *d_kperm = nullptr, *d_kholecol = nullptr;
+    double *d_kcoef = nullptr, *d_ksq = nullptr, *d_kss = nullptr, *d_ksi = nullptr;
+    int2 *d_kholemeta = nullptr;         // per hole {position in the skeleton, lag}: the out-pass that patches the holes
+    int64_t n_kholes = 0;
+    int32_t n_kwide = 0;
     bool lean_enabled = true;           // RR_TILE_LEAN=0 (tests): the general tick for every call
     bool uh_pairs = true;               // the fused convolution takes two record batches per launch where it can (RR_UH_PAIRS=0: tests)
     bool perm_ready = false;            // the streaming kernel's tiled permutations are on the device
@@ -290,16 +308,38 @@ int64_t pick_KC(const rr_plan *P, int64_t total_ticks)
 // The choice is a pure function of the plan, the call's shape and kc_cap (lowered only when the device refuses an
 // allocation), so rr_plan_reserve and the call it prepares for agree on it.
 struct Schedule {
+    bool direct = false;              // direct row path: KC = rows per task / 16, chunks / ring = the skeleton's record ring
     bool tiled = false;
     int64_t KC = 1, chunks = 0;       // time-tiled: record chunks per task, chunks of the record ring
     int64_t ring = 0;                 // doubles of P->d_ring: record ring, or the work rows of the streaming kernel
     int64_t mrows = 0, stage = 0;     // streaming kernel: doubles of the permutation's intermediate rows / of the host staging rows
 };
 
-Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io)
+// Rows per task of the direct path: a task costs its tile `span` ticks of fill and drain (lanes start one after the other), every
+// tile level of the skeleton one task of pipeline; short calls take short tasks.
+int64_t pick_direct_K(const rr_plan *P, int64_t T)
+{
+    if (P->wave_K > 0) return P->wave_K;
+    return T >= 8192 ? 512 : (T >= 2048 ? 256 : (T >= 512 ? 128 : 64));
+}
+
+Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, bool plain_rows = false)
 {
     Schedule sch;
     const int64_t total = T * nsub, dmax = P->h.depth - 1, n = P->h.n;
+    // The direct row path: RapidMuskingum, one sub-step per row, float64 rows in device arrays, one weight per reach, no
+    // boundary reaches -- the headline's call -- on a params order that numbers small subtrees contiguously.
+    if (plain_rows && P->direct_enabled && P->dp.ok && mode == Mode::Rapid && nsub == 1 && P->weights_uniform && !force_streaming && !host_io &&
+        P->n_ghost == 0 && P->n_export == 0 && P->wave_enabled && total >= 32 && n < (int64_t{1} << 29)) {
+        const int64_t K = pick_direct_K(P, T), levels = P->dp.skel.n_levels, np = P->dp.skel.np;
+        sch.direct = true; sch.KC = K / kRec;
+        if (np > 0) {      // a record lives from the launch that forwards its first row to the out-pass behind the skeleton's last level
+            sch.chunks = std::min<int64_t>(((levels + 1) * K + 2 * dmax + kRecRows + 2 * kRec) / kRec + 2, (total + dmax) / kRec + 2);
+            sch.ring = sch.chunks * kRec * np;
+        }
+        if (np < (int64_t{1} << 25) && (P->dev_total_bytes == 0 || sch.ring * 8 <= (int64_t)(P->dev_total_bytes / 2))) return sch;
+        sch = Schedule();
+    }
     bool ok = P->wave_enabled && P->tp.ok && P->weights_uniform && n > 0 && !force_streaming && P->tp.np < (int64_t{1} << 25) &&
               !P->export_inside && P->kc_cap >= 1 && !(mode == Mode::Unit && P->unit_general);
     if (ok && !P->wave_forced) ok = total >= 32;
@@ -338,20 +378,21 @@ int host_pipe_prepare(rr_plan *P);
 
 // Sizes and allocates what a call of this shape works in.  The only place on a route call's path that allocates: the
 // host-pointer entry points come here by themselves, the *_dev ones expect rr_plan_reserve to have been here.
-int reserve_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, Schedule *out)
+int reserve_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, Schedule *out, bool plain_rows = false)
 {
     if (P->h.n == 0 || T <= 0) { if (out) *out = Schedule(); return RR_OK; }
     Schedule sch;
     for (;;) {
-        sch = choose_schedule(P, mode, T, nsub, force_streaming, host_io);
+        sch = choose_schedule(P, mode, T, nsub, force_streaming, host_io, plain_rows);
         if (ensure_cap(&P->d_ring, &P->ring_cap, sch.ring) == RR_OK) break;
         (void)hipGetLastError();
+        if (sch.direct) return fail(RR_E_ALLOC, "route: the skeleton's record ring does not fit on the device");
         if (!sch.tiled) return fail(RR_E_ALLOC, "route: the work rows of the streaming kernel do not fit on the device");
         P->kc_cap = sch.KC / 2;      // shorter tasks, a smaller ring; 0: this plan streams
     }
     int rc = ensure_cap(&P->d_mrows, &P->mrows_cap, sch.mrows);
     if (!rc) rc = ensure_cap(&P->d_stage, &P->stage_cap, sch.stage);
-    if (!rc && !sch.tiled && !P->perm_ready) rc = upload_tiled_permutations(P);
+    if (!rc && !sch.tiled && !sch.direct && !P->perm_ready) rc = upload_tiled_permutations(P);
     if (!rc && sch.tiled && host_io) rc = host_pipe_prepare(P);
     if (rc) return rc;
     // events: first / last of a call, the sampled launches (rr_plan_set_options), the second stream's
@@ -359,6 +400,7 @@ int reserve_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_stre
     const int64_t K = sch.KC * kRec, total_ticks = T * nsub + P->h.depth - 1;
     size_t samples = P->sample_every >= kSampleGroup ? (size_t)std::min<int64_t>(4096, total_ticks / P->sample_every + 1) : 0;
     if (sch.tiled && samples > 0) samples = (size_t)std::min<int64_t>(4096, ((total_ticks + K - 1) / K + P->tp.n_levels) / 4 + 1);
+    if (sch.direct && samples > 0) samples = (size_t)std::min<int64_t>(4096, (T + K - 1) / K + 1);      // every direct launch
     while (P->ev.size() < 2 * samples) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); P->ev.push_back(e); }
     if (out) *out = sch;
     return RR_OK;
@@ -366,22 +408,22 @@ int reserve_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_stre
 
 // The schedule of the call about to start.  strict (the *_dev entry points, which only enqueue): everything must have been
 // reserved; otherwise it is reserved here.
-int prepare_call(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, bool strict)
+int prepare_call(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, bool strict, bool plain_rows = false)
 {
     Schedule sch;
     if (!strict) {
-        int rc = reserve_core(P, mode, T, nsub, force_streaming, host_io, &sch);
+        int rc = reserve_core(P, mode, T, nsub, force_streaming, host_io, &sch, plain_rows);
         if (rc) return rc;
     } else {
-        sch = choose_schedule(P, mode, T, nsub, force_streaming, host_io);
+        sch = choose_schedule(P, mode, T, nsub, force_streaming, host_io, plain_rows);
         const size_t samples = P->sample_every >= kSampleGroup ? 1 : 0;
         if (P->h.n > 0 && T > 0 && (sch.ring > P->ring_cap || sch.mrows > P->mrows_cap || sch.stage > P->stage_cap || !P->ev_first || P->ev.size() < 2 * samples ||
-                                    (!sch.tiled && !P->perm_ready && sch.mrows > 0)))
+                                    (!sch.tiled && !sch.direct && !P->perm_ready && sch.mrows > 0)))
             return fail(RR_E_STATE, "this call needs " + std::to_string((sch.ring + sch.mrows + sch.stage) * 8) + " bytes of work memory on the device (" +
                                         std::to_string((P->ring_cap + P->mrows_cap + P->stage_cap) * 8) + " reserved): call rr_plan_reserve(plan, mode, " +
                                         std::to_string(T) + ", " + std::to_string(nsub) + ", ...) first; the *_dev entry points only enqueue work");
     }
-    P->wave_now = sch.tiled; P->next_KC = sch.KC; P->next_chunks = sch.chunks;
+    P->wave_now = sch.tiled; P->direct_now = sch.direct; P->next_KC = sch.KC; P->next_chunks = sch.chunks;
     return RR_OK;
 }
 
@@ -409,8 +451,9 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         return fail(RR_E_UNSUPPORTED, "more than 2^31 routing ticks or rows in one call: split it into several calls");
     S.has_in = mode != Mode::Muskingum;
     const bool host_io = io.host_out != nullptr || io.host_in != nullptr;
-    S.wave = use_wave(P, mode);
-    S.direct = H.identity && !host_io && !S.wave;   // engine order == params order: the streaming kernel reads the caller's arrays
+    S.rows_direct = P->direct_now;
+    S.wave = use_wave(P, mode) && !S.rows_direct;
+    S.direct = H.identity && !host_io && !S.wave && !S.rows_direct;   // engine order == params order: the streaming kernel reads the caller's arrays
     const int64_t C = std::max<int64_t>(1, P->chunk_rows);
 
     P->prof_launches = P->prof_samples = P->prof_brackets = 0;
@@ -423,7 +466,31 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
     if (P->n_export > 0 && !export_series) { S.open = false; return fail(RR_E_INVALID, "plan has export reaches but no export series was given"); }
     if (io.dev_out32 && !S.wave) { S.open = false; return fail(RR_E_UNSUPPORTED, "float32 output needs the time-tiled kernel"); }
 
-    if (S.wave) { S.KC = P->next_KC; S.rec_chunks = P->next_chunks; }     // ring sized by choose_schedule, allocated by rr_plan_reserve
+    if (S.wave || S.rows_direct) { S.KC = P->next_KC; S.rec_chunks = P->next_chunks; }     // ring sized by choose_schedule, allocated by rr_plan_reserve
+    if (S.rows_direct) {
+        if (io.dev_in32 || io.dev_out32 || io.uh_kernel || io.runoff || !io.dev_in || !io.dev_out || mode != Mode::Rapid || nsub != 1 || ghost_series || export_series) {
+            S.open = false;
+            return fail(RR_E_STATE, "route: the direct row path was chosen for a call it does not take");      // (choose_schedule's plain_rows)
+        }
+        const rr::TilePlan &TP = P->dp.skel;
+        const int64_t K = S.KC * kRec;
+        S.n_tasks = (S.T + K - 1) / K;
+        S.n_macro = (S.total_ticks + K - 1) / K;
+        S.n_diags = std::max<int64_t>(S.n_tasks, TP.n_tiles > 0 ? S.n_macro + TP.n_levels - 1 : 0);
+        S.n_out_batches = TP.np > 0 ? (S.total + kRecRows - 1) / kRecRows : 0;
+        DirectArgs &da = S.da;
+        da.tiles = P->d_dtiles; da.n_tiles = P->dp.n_tiles; da.lane = P->d_dlane; da.coef = P->d_dcoef; da.q = P->d_dq;
+        da.in = io.dev_in; da.out = io.dev_out; da.n = n; da.in_rows = (uint32_t)io.rows_in; da.out_rows = (uint32_t)io.rows_out;
+        da.rec = P->d_ring; da.rec_chunks = (uint32_t)std::max<int64_t>(1, S.rec_chunks); da.np = (int32_t)TP.np;
+        da.K = (int32_t)K; da.total = (int32_t)S.T;
+        TileArgs &w = S.ta;      // the skeleton's k_tile launches
+        w.tiles = P->d_ktmeta; w.pos = P->d_kpmeta; w.coef = P->d_kcoef;
+        w.sq = P->d_ksq; w.ss = P->d_kss; w.si = P->d_ksi; w.sqch = nullptr;
+        w.exports = nullptr; w.n_export = 0;
+        w.rec = P->d_ring; w.rec_chunks = Div32((uint32_t)std::max<int64_t>(1, S.rec_chunks));
+        w.np = (int32_t)TP.np; w.KC = (int32_t)S.KC; w.n_macro = (int32_t)S.n_macro; w.total = (int32_t)S.total;
+        w.has_lat = 1; w.nsub = Div32(1u); w.inv_nsub = 1.0;
+    }
     if (S.wave) {
         const rr::TilePlan &TP = P->tp;
         const int64_t K = S.KC * kRec;
@@ -449,12 +516,16 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         w.np = (int32_t)TP.np; w.KC = (int32_t)S.KC; w.n_macro = (int32_t)S.n_macro; w.total = (int32_t)S.total;
         w.has_lat = S.has_in ? 1 : 0; w.nsub = Div32((uint32_t)nsub); w.inv_nsub = 1.0 / (double)nsub;
     }
-    if (getenv("RR_VERBOSE"))
+    if (getenv("RR_VERBOSE") && S.rows_direct)
+        fprintf(stderr, "rr: n=%lld T=%lld direct rows: K=%lld tiles=%d window=%d holes=%lld outlets=%lld; skeleton: positions=%lld tiles=%d levels=%d ring_chunks=%lld (%.1f GB)\n",
+                (long long)n, (long long)T, (long long)(S.KC * kRec), P->dp.n_tiles, P->direct_window, (long long)P->dp.n_holes, (long long)P->dp.n_exports,
+                (long long)P->dp.skel.np, P->dp.skel.n_tiles, P->dp.skel.n_levels, (long long)S.rec_chunks, (double)S.rec_chunks * kRec * P->dp.skel.np * 8 / 1e9);
+    else if (getenv("RR_VERBOSE"))
         fprintf(stderr, "rr: n=%lld T=%lld nsub=%lld tiled=%d K=%lld tiles=%d levels=%d block=%d ghosts=%lld ring_chunks=%lld (%.1f GB) lds=%zu\n",
                 (long long)n, (long long)T, (long long)nsub, (int)S.wave, (long long)(S.KC * kRec), P->tp.n_tiles, P->tp.n_levels, P->tp.block,
                 (long long)P->tp.n_ghost, (long long)S.rec_chunks, S.wave ? (double)S.rec_chunks * kRec * P->tp.np * 8 / 1e9 : 0.0,
                 tile_lds_bytes(P->wave_threads));
-    if (!S.wave) {
+    if (!S.wave && !S.rows_direct) {
         // work ring in engine order: lateral rows come in, discharge rows overwrite them in place; rows stay until the
         // outlet-most reaches have passed them
         const int64_t lag_rows = (dmax + nsub - 1) / nsub;
@@ -480,6 +551,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
     }
     S.max_samples = P->sample_every >= kSampleGroup ? (size_t)std::min<int64_t>(4096, S.total_ticks / P->sample_every + 1) : 0;
     if (S.wave && S.max_samples > 0) S.max_samples = (size_t)std::min<int64_t>(4096, S.n_diags / 4 + 1);     // every fourth launch
+    if (S.rows_direct && S.max_samples > 0) S.max_samples = (size_t)std::min<int64_t>(4096, S.n_tasks);            // every direct launch
     S.max_samples = std::min(S.max_samples, P->ev.size() / 2);      // events are made by rr_plan_reserve, never here
     if (!P->ev_first) { S.open = false; return fail(RR_E_STATE, "route: the plan's events were not reserved"); }
     HIPCHK(hipEventRecord(P->ev_first, stream));
@@ -609,12 +681,12 @@ tile_kernel_t tile_kernel(bool unit, bool sub, bool lean = false, bool nolat = f
 
 // Launch d of the time-tiled schedule: the tasks (tile, macro-chunk d - level) of every tile whose macro-chunk exists.
 // Tiles are stored by level, so they are one contiguous range; a tile with no active position returns at once.
-int session_launch_diag(rr_plan *P, int64_t d)
+// TP / w / wide tiles: the plan's own tiles, or the skeleton of the direct row path (its levels start at 1).
+int launch_tile_diag(rr_plan *P, const rr::TilePlan &TP, TileArgs &w, int32_t n_wide, const double *coef, const double *coef_unit, int64_t d, bool sampled)
 {
     Session &S = P->ses;
-    const rr::TilePlan &TP = P->tp;
     const int64_t l_lo = std::max<int64_t>(0, d - (S.n_macro - 1)), l_hi = std::min<int64_t>(TP.n_levels - 1, d);
-    if (l_hi < l_lo) { ++P->prof_launches; return RR_OK; }
+    if (l_hi < l_lo) return RR_OK;
     int64_t t_lo = TP.level_start[l_lo], t_hi = TP.level_start[l_hi + 1];
     // tiles are sorted by their smallest lag inside a level; while the pipeline fills, the tiles of level 0 that
     // have not started yet are a suffix of it
@@ -625,13 +697,12 @@ int session_launch_diag(rr_plan *P, int64_t d)
         while (hi > t_lo && (d + 1) * K <= TP.tile_lag_lo[hi - 1]) --hi;
         if (t_hi <= end0) t_hi = hi;     // only level 0 in this launch: trim; otherwise the idle ones just return
     }
-    if (t_hi <= t_lo) { ++P->prof_launches; return RR_OK; }
-    TileArgs &w = S.ta;
+    if (t_hi <= t_lo) return RR_OK;
     w.diag = (int32_t)d; w.t_first = (int32_t)t_lo; w.t_last = (int32_t)t_hi - 1;
     // every fourth launch is bracketed by HIP events, full or not (fill and drain launches run fewer tiles), so the
     // sampled average is the average rocprofv3 reports for the kernel; the position-ticks of a sample are those of the
     // tiles that run a task in it
-    const bool sample = S.max_samples > 0 && (P->prof_launches % 4) == 0 && (size_t)P->prof_brackets < S.max_samples;
+    const bool sample = sampled && S.max_samples > 0 && (P->prof_launches % 4) == 0 && (size_t)P->prof_brackets < S.max_samples;
     if (sample) HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets], S.stream));
     // one workgroup per resident slot (16 waves per CU); each walks its share of the launch's tiles
     const dim3 g((unsigned)std::min<int64_t>(t_hi - t_lo, (int64_t)P->cu_count * (1024 / P->wave_threads)));
@@ -641,10 +712,10 @@ int session_launch_diag(rr_plan *P, int64_t d)
     const bool unit = S.mode == Mode::Unit;
     const bool lean = S.nsub == 1 && P->lean_enabled;      // every router's default (dt_routing = dt_runoff); sub-steps keep the general tick
     w.tile_filter = lean ? 1 : 0;
-    w.coef = (lean && unit) ? P->d_coef_unit : P->d_coef;
+    w.coef = (lean && unit) ? coef_unit : coef;
     hipLaunchKernelGGL(tile_kernel(unit, S.nsub > 1, lean, S.mode == Mode::Muskingum), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
-    if (lean && P->n_wide_tiles > 0) {
-        w.tile_filter = 2; w.coef = P->d_coef;
+    if (lean && n_wide > 0) {
+        w.tile_filter = 2; w.coef = coef;
         hipLaunchKernelGGL(tile_kernel(unit, false, false), g, dim3((unsigned)P->wave_threads), lds_bytes, S.stream, w);
     }
     if (sample) {
@@ -661,8 +732,14 @@ int session_launch_diag(rr_plan *P, int64_t d)
         P->prof_samples += K;
         ++P->prof_brackets;
     }
-    ++P->prof_launches;
     return RR_OK;
+}
+
+int session_launch_diag(rr_plan *P, int64_t d)
+{
+    int rc = launch_tile_diag(P, P->tp, P->ses.ta, P->n_wide_tiles, P->d_coef, P->d_coef_unit, d, true);
+    ++P->prof_launches;
+    return rc;
 }
 
 // Boundary inflow of a partitioned network: the ghost series (total sub-steps x ghosts, row = sub-step) is a matrix of
@@ -819,6 +896,74 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
     return RR_OK;
 }
 
+// The direct row path (rr_kernels_direct.hpp).  Launch d: k_direct routes rows [d K, (d + 1) K) of every small subtree straight from
+// and to the caller's rows, forwarding the skeleton's lateral inflow and the subtrees' outflow into the skeleton's records; then
+// the skeleton's tiles of level l run macro-chunk d - l on those records (levels start at 1: what they read was written by an
+// earlier launch); rows all of whose skeleton reaches are final get their holes patched from the records (k_rec_out over the
+// holes' columns), 128 rows at a time, which also frees their ring slots.
+int session_advance_direct(rr_plan *P, int64_t rows_ready)
+{
+    Session &S = P->ses;
+    const rr::TilePlan &TP = P->dp.skel;
+    const int64_t dmax = P->h.depth - 1, levels = TP.n_levels, K = S.KC * kRec, n = P->h.n;
+    rows_ready = std::min(rows_ready, S.T);
+    const bool skel = TP.n_tiles > 0;
+    for (;;) {
+        bool progressed = false;
+        while (S.diag < S.n_diags) {
+            const int64_t d = S.diag;
+            if (d < S.n_tasks && rows_ready < std::min((d + 1) * K, S.T)) break;
+            if (skel) {      // this launch writes record slots up to tick (d + 1) K + dmax: whatever they held one revolution earlier must have left
+                const int64_t top = std::min((d + 1) * K + dmax, S.total_ticks) / kRec;
+                if (top >= S.rec_chunks && S.ticks_stored < std::min(S.total, kRec * (top - S.rec_chunks + 1))) break;
+            }
+            if (d < S.n_tasks) {
+                const bool sample = S.max_samples > 0 && (size_t)P->prof_brackets < S.max_samples;
+                if (sample) HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets], S.stream));
+                S.da.m = (int32_t)d;
+                const dim3 g((unsigned)std::min<int64_t>(P->dp.n_tiles, (int64_t)P->cu_count));
+                hipLaunchKernelGGL((k_direct<kDirectLanes, kDirectAhead>), g, dim3(kDirectLanes), direct_lds_bytes(P->direct_window), S.stream, S.da);
+                if (sample) {
+                    HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));
+                    P->ev_reaches.push_back(n * (std::min((d + 1) * K, S.T) - d * K));
+                    P->prof_samples += K;
+                    ++P->prof_brackets;
+                }
+            }
+            if (skel) { int rc = launch_tile_diag(P, TP, S.ta, P->n_kwide, P->d_kcoef, P->d_kcoef, d, false); if (rc) return rc; }
+            ++P->prof_launches;
+            ++S.diag;
+            progressed = true;
+        }
+        S.rows_loaded = std::min(S.diag, S.n_tasks) * K < S.T ? std::min(S.diag, S.n_tasks) * K : S.T;
+        // rows the direct tiles have written, and of those the rows whose skeleton reaches are final too
+        int64_t done = S.rows_loaded;
+        if (skel) {
+            const int64_t m_done = S.diag - levels;      // the tiles of the last level have finished macro-chunk diag - levels
+            int64_t sk = S.diag >= S.n_diags ? S.total : (m_done >= 0 ? std::max<int64_t>(0, (m_done + 1) * K - dmax) : 0);
+            done = std::min(done, std::min(sk, S.total));
+            while (S.out_batches < S.n_out_batches && done >= std::min(kRecRows * (S.out_batches + 1), S.total)) {
+                RecPermArgs ra{};
+                ra.rec = P->d_ring; ra.rec_chunks = Div32((uint32_t)S.rec_chunks); ra.n = P->n_kholes; ra.np = TP.np; ra.T = S.T; ra.total = S.total;
+                ra.batch = S.out_batches; ra.nsub = Div32(1u); ra.colmeta = P->d_kholemeta; ra.cols = P->d_kholecol; ra.scale = nullptr;
+                ra.rows = RowView{S.io.dev_out, n, 0, (uint32_t)std::max<int64_t>(1, S.io.rows_out)};
+                ra.factor = Div32(1u); ra.clamp = 1; ra.swizzle = 0;
+                if (P->n_kholes > 0)
+                    hipLaunchKernelGGL((k_rec_out<false, false>), dim3((unsigned)((P->n_kholes + kRecOutCols - 1) / kRecOutCols)), dim3(kRecOutThreads), 0, S.stream, ra);
+                ++S.out_batches;
+                S.ticks_stored = std::min(S.total, kRecRows * S.out_batches);
+                progressed = true;
+            }
+            S.rows_stored = S.ticks_stored;
+        } else {
+            S.rows_stored = S.ticks_stored = done;
+        }
+        if (!progressed) break;
+    }
+    if (S.diag >= S.n_diags) S.tau = S.total_ticks;
+    return RR_OK;
+}
+
 // Runs every tick whose inputs are present: lateral rows [0, rows_ready) and ghost sub-steps [0, ghost_ready).
 // On return *export_ready = number of leading sub-steps of the export series that are final.
 int session_advance(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, int64_t *export_ready)
@@ -829,6 +974,7 @@ int session_advance(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, int64_t
     if (export_ready) *export_ready = 0;
     if (n == 0 || S.total == 0) { if (export_ready) *export_ready = S.total; return RR_OK; }
     if (S.wave) return session_advance_tile(P, rows_ready, std::min(ghost_ready, S.total), export_ready);
+    if (S.rows_direct) { if (export_ready) *export_ready = S.total; return session_advance_direct(P, rows_ready); }
     rows_ready = std::min(rows_ready, S.T);
     ghost_ready = std::min(ghost_ready, S.total);
     // a ghost at lag L is read at tick tau for sub-step tau - L: ticks below ghost_ready + min lag are safe
@@ -911,6 +1057,13 @@ int check_route_args(rr_plan *P, bool need_c4, int64_t T, int64_t nsub)
 int launch_state_in(rr_plan *P, Mode mode, const double *d_q, hipStream_t stream)
 {
     const int64_t n = P->h.n;
+    if (P->direct_now) {      // the lanes carry their discharge in params order; the skeleton's positions and ghosts as k_tile wants them
+        HIPCHK(hipMemcpyAsync(P->d_dq, d_q, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        const int64_t np = P->dp.skel.np;
+        if (np > 0)
+            hipLaunchKernelGGL(k_tile_state_in, grid1(np), dim3(kBlock), 0, stream, P->d_ksq, P->d_kss, P->d_ksi, d_q, P->d_kperm, P->d_kpmeta, (int32_t)np);
+        return RR_OK;
+    }
     if (use_wave(P, mode)) {
         const int64_t np = P->tp.np;
         hipLaunchKernelGGL(k_tile_state_in, grid1(np), dim3(kBlock), 0, stream, P->d_sq, P->d_ss, P->d_si, d_q, P->d_tperm,
@@ -925,6 +1078,12 @@ int launch_state_in(rr_plan *P, Mode mode, const double *d_q, hipStream_t stream
 void launch_state_out(rr_plan *P, Mode mode, double *d_q, int64_t total, hipStream_t stream)
 {
     const int64_t n = P->h.n;
+    if (P->direct_now) {
+        (void)hipMemcpyAsync(d_q, P->d_dq, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream);
+        const int64_t np = P->dp.skel.np;
+        if (np > 0) hipLaunchKernelGGL(k_skel_state_out, grid1(np), dim3(kBlock), 0, stream, d_q, (const double *)P->d_ksq, P->d_kperm, P->d_kpmeta, (int32_t)np);
+        return;
+    }
     if (use_wave(P, mode)) {
         hipLaunchKernelGGL(k_tile_state_out, grid1(n), dim3(kBlock), 0, stream, d_q, (const double *)P->d_sq, P->d_tinv,
                            (int32_t)n);
@@ -1096,7 +1255,8 @@ int rapid_like(rr_plan *P, Mode mode, double *q_t, const Rows &io_in, int64_t T,
     // host rows reach the time-tiled kernel through the PCIe pipeline's device rings; where it does not apply they are
     // routed chunk by chunk by the streaming kernel
     {   // host rows reach the time-tiled kernel through the PCIe pipeline's device rings (they are "device rows" to the schedule)
-        int rc = prepare_call(P, mode, T, nsub, false, false, !host_rows);
+        const bool plain = !host_rows && io.dev_in && io.dev_out && !io.dev_in32 && !io.dev_out32 && !io.uh_kernel && !io.runoff;      // float64 rows in device arrays: the direct row path applies
+        int rc = prepare_call(P, mode, T, nsub, false, false, !host_rows, plain);
         if (rc == RR_OK && host_rows && !P->wave_now) rc = prepare_call(P, mode, T, nsub, true, true, false);
         if (rc == RR_OK && host_rows && P->wave_now) rc = host_pipe_prepare(P);
         if (rc) return rc;

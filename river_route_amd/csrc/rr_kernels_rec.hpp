@@ -34,6 +34,7 @@ struct RecPermArgs {
     const float *rows_in32;   // k_rec_in<..., IN32>: the source rows are float32 (a qlateral file stored that way: 4 B read instead of 8, exact in float64); same shape as `rows`
     float *rows32;            // k_rec_out: float32 destination with `factor` rows averaged (router post-processing), or NULL
     Div32 factor;
+    const int32_t *cols;      // k_rec_out: column of the destination rows each of the n records' columns goes to (the holes of the direct row path), or NULL: column i
     int32_t swizzle;          // column tiles in XCD-contiguous order (rr_common.hpp: xcd_swizzle)
     int32_t clamp;            // k_rec_out: 0 records hold final values (sub-steps), 1 clamp at zero, 2 clamp all but headwater columns (UnitMuskingum)
 };
@@ -337,6 +338,7 @@ __global__ __launch_bounds__(kRecOutThreads) void k_rec_out(const RecPermArgs a)
     if (i >= a.n) return;
     const int32_t my = a.colmeta[i].y;
     const int o = my & 15;
+    const int64_t io = a.cols ? a.cols[i] : i;      // destination column; the float32 rows' pitch is the float64 rows' (rows.ld)
     // single sub-step: the records hold the unclamped discharge (a ghost's record is a copy of its reach's); the reference's
     // clip at zero (_numba_kernels.py:80) happens here.  UnitMuskingum leaves its headwaters' lateral inflow as it is (:122-123).
     const bool clamp = !SUB && (a.clamp == 1 || (a.clamp == 2 && !(my & kColHeadwater)));
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(kRecOutThreads) void k_rec_out(const RecPermArgs a)
             const int nsub = SUB ? (int)a.nsub.d : 1;
             double acc = out(recs[c][o + q * step + nsub - 1]);
             for (int j = 1; j < (int)a.factor.d; ++j) acc += out(recs[c][o + q * step + j * nsub + nsub - 1]);
-            a.rows32[(q0 + q) * a.n + i] = (float)(a.factor.d > 1 ? acc / (double)a.factor.d : acc);
+            a.rows32[(q0 + q) * a.rows.ld + io] = (float)(a.factor.d > 1 ? acc / (double)a.factor.d : acc);
         }
     } else {
         for (int r = tid / kRecOutCols; r < kRecRows; r += kRecOutThreads / kRecOutCols) {
@@ -359,9 +361,9 @@ __global__ __launch_bounds__(kRecOutThreads) void k_rec_out(const RecPermArgs a)
             if (SUB) {
                 uint32_t sub;
                 const uint32_t row = a.nsub.div((uint32_t)tick, sub);
-                if (sub + 1 == a.nsub.d) a.rows.row(row)[i] = recs[c][o + r];
+                if (sub + 1 == a.nsub.d) a.rows.row(row)[io] = recs[c][o + r];
             } else {
-                a.rows.row(tick)[i] = out(recs[c][o + r]);
+                a.rows.row(tick)[io] = out(recs[c][o + r]);
             }
         }
     }

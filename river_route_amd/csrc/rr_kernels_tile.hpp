@@ -521,6 +521,13 @@ __global__ __launch_bounds__(kBlock) void k_tile_unit_state_out(double *q_ch, do
     q_ch[k] = sqch[p];
 }
 
+// the skeleton of the direct row path: every position that is not a ghost hands its reach's discharge back
+__global__ __launch_bounds__(kBlock) void k_skel_state_out(double *q_t, const double *sq, const int32_t *perm, const int4 *pos, int32_t np)
+{
+    const int32_t p = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (p < np && !(pos[p].x & (kGhostBit | kTileGhostBit))) q_t[perm[p]] = sq[p];
+}
+
 __global__ __launch_bounds__(kBlock) void k_tile_state_out(double *q_t, const double *sq, const int32_t *inv, int32_t n)
 {
     const int32_t i = (int32_t)(blockIdx.x * kBlock + threadIdx.x);

@@ -199,7 +199,8 @@ void partition_forest(const std::vector<int32_t> &down, int32_t n_parts, int32_t
 }
 
 
-void build_tile_plan(const std::vector<int32_t> &down, const std::vector<int32_t> &lag_of, int32_t block, TilePlan &T)
+void build_tile_plan(const std::vector<int32_t> &down, const std::vector<int32_t> &lag_of, int32_t block, TilePlan &T,
+                     const std::vector<uint8_t> *big_in, bool skeleton_only)
 {
     T = TilePlan();
     T.block = block;
@@ -216,14 +217,14 @@ void build_tile_plan(const std::vector<int32_t> &down, const std::vector<int32_t
 
     std::vector<int64_t> sub(n, 1);
     for (int64_t c = 0; c < n; ++c) if (down[c] >= 0) sub[down[c]] += sub[c];
-    auto big = [&](int64_t v) { return sub[v] > block; };
+    auto big = [&](int64_t v) { return big_in ? (*big_in)[v] != 0 : sub[v] > block; };
     auto small_root = [&](int64_t v) { return !big(v) && (down[v] < 0 || big(down[v])); };
 
     std::vector<int32_t> tile_of_reach(n, -1);
     // ---- level 0: complete small subtrees, packed in order of their outlets' lag; a tile that the next subtree does not
     // fit is topped up from the following kWindow subtrees (largest fit first) before it is closed
     std::vector<int32_t> roots;
-    for (int64_t v = 0; v < n; ++v) if (small_root(v)) roots.push_back((int32_t)v);
+    if (!skeleton_only) for (int64_t v = 0; v < n; ++v) if (small_root(v)) roots.push_back((int32_t)v);
     std::stable_sort(roots.begin(), roots.end(), [&](int32_t a, int32_t b) { return lag_of[a] < lag_of[b]; });
     int32_t n_tiles = 0;
     {
@@ -305,8 +306,9 @@ void build_tile_plan(const std::vector<int32_t> &down, const std::vector<int32_t
         }
         for (int32_t v : bigs) tile_of_reach[v] = tile_of_piece[piece_root[v]];
     }
-    for (int64_t v = n - 1; v >= 0; --v)      // small subtrees inherit the tile of their outlet
-        if (!big(v) && !small_root(v)) tile_of_reach[v] = tile_of_reach[down[v]];
+    if (!skeleton_only)
+        for (int64_t v = n - 1; v >= 0; --v)      // small subtrees inherit the tile of their outlet
+            if (!big(v) && !small_root(v)) tile_of_reach[v] = tile_of_reach[down[v]];
     (void)n_level0;
 
     // ---- positions: breadth-first from each tile's outlets, upstream positions contiguous, headwater tributaries first
@@ -318,10 +320,10 @@ void build_tile_plan(const std::vector<int32_t> &down, const std::vector<int32_t
     for (int32_t l = 0; l < T.n_levels; ++l) T.level_start[l + 1] += T.level_start[l];
     std::vector<int32_t> root_ptr((size_t)n_tiles + 1, 0);
     auto tile_root = [&](int64_t v) { return down[v] < 0 || tile_of_reach[down[v]] != tile_of_reach[v]; };
-    for (int64_t v = 0; v < n; ++v) if (tile_root(v)) ++root_ptr[tile_of_reach[v] + 1];
+    for (int64_t v = 0; v < n; ++v) if (tile_of_reach[v] >= 0 && tile_root(v)) ++root_ptr[tile_of_reach[v] + 1];
     for (int32_t t = 0; t < n_tiles; ++t) root_ptr[t + 1] += root_ptr[t];
     std::vector<int32_t> root_list(root_ptr[n_tiles]), rfill(root_ptr.begin(), root_ptr.end() - 1);
-    for (int64_t v = n - 1; v >= 0; --v) if (tile_root(v)) root_list[rfill[tile_of_reach[v]]++] = (int32_t)v;    // outlet-most first
+    for (int64_t v = n - 1; v >= 0; --v) if (tile_of_reach[v] >= 0 && tile_root(v)) root_list[rfill[tile_of_reach[v]]++] = (int32_t)v;    // outlet-most first
 
     T.inv.assign(n, -1);
     T.tile_ptr.assign((size_t)n_tiles + 1, 0);
@@ -366,11 +368,91 @@ void build_tile_plan(const std::vector<int32_t> &down, const std::vector<int32_t
     T.xpos.assign(T.np, -1);
     T.tile_of.assign(T.np, 0);
     for (int32_t t = 0; t < n_tiles; ++t) for (int32_t p = T.tile_ptr[t]; p < T.tile_ptr[t + 1]; ++p) T.tile_of[p] = t;
+    if (skeleton_only) T.ext_ghost.assign(n, -1);
     for (int32_t g : ghost_positions) {
         const int32_t src = T.inv[T.perm[g]];
+        if (src < 0) { T.ext_ghost[T.perm[g]] = g; continue; }      // mirrors a reach outside the plan: whoever routes it writes the record
         T.xpos[g] = src; T.xpos[src] = g; T.lag[src] |= kTileExport;
     }
     T.ok = true;
+}
+
+void build_direct_plan(const std::vector<int32_t> &down, const std::vector<int32_t> &lag_of, int32_t lanes, int32_t wmax, int32_t skel_block,
+                       DirectPlan &D)
+{
+    D = DirectPlan();
+    D.lanes = lanes; D.wmax = wmax;
+    const int64_t n = (int64_t)down.size();
+    if (n == 0) { D.why = "empty network"; return; }
+    if (lanes > 1023) { D.why = "more lanes than a lane number holds"; return; }
+    // subtree size, height (levels) and smallest index; upstream reaches have smaller indices
+    std::vector<int32_t> sub(n, 1), height(n, 1), first(n), indeg(n, 0);
+    for (int64_t v = 0; v < n; ++v) first[v] = (int32_t)v;
+    for (int64_t c = 0; c < n; ++c)
+        if (down[c] >= 0) {
+            const int32_t d = down[c];
+            sub[d] += sub[c]; height[d] = std::max(height[d], height[c] + 1); first[d] = std::min(first[d], first[c]); ++indeg[d];
+        }
+    D.big.assign(n, 0);
+    for (int64_t v = 0; v < n; ++v) D.big[v] = (sub[v] > lanes || height[v] > wmax) ? 1 : 0;
+    auto small_root = [&](int64_t v) { return !D.big[v] && (down[v] < 0 || D.big[down[v]]); };
+    for (int64_t v = 0; v < n; ++v) {
+        if (D.big[v]) continue;
+        if (indeg[v] > 3) { D.why = "a reach of a small subtree has more than three upstream reaches"; return; }
+        if (small_root(v) && first[v] != (int32_t)v - sub[v] + 1) { D.why = "a small subtree is not a contiguous range of the params order"; return; }
+    }
+    // tiles: consecutive units (a whole small subtree, or one hole) while the lanes and the lag window last
+    D.delay.assign(n, 0); D.up3.assign(n, 0x3FFFFFFF); D.xinfo.assign(n, -1);
+    std::vector<int32_t> tile_of(n, -1);
+    int64_t c = 0;
+    while (c < n) {
+        const int64_t c0 = c;
+        int32_t lo = std::numeric_limits<int32_t>::max(), hi = -1;
+        while (c < n) {
+            int64_t c1;
+            int32_t ulo = lo, uhi = hi;
+            if (D.big[c]) c1 = c + 1;
+            else {      // the small subtree that STARTS here: its outlet is the first small root at or after c whose range begins at c
+                int64_t r = c;
+                while (!small_root(r)) r = down[r];      // c is the first (deepest-first) reach of exactly one small subtree
+                if (first[r] != c) { D.why = "internal: a small subtree does not start where the previous unit ended"; return; }
+                c1 = r + 1;
+                for (int64_t v = c; v < c1; ++v) { ulo = std::min(ulo, lag_of[v]); uhi = std::max(uhi, lag_of[v]); }
+            }
+            if (c1 - c0 > lanes || (uhi >= 0 && uhi - ulo + 1 > wmax)) break;
+            lo = ulo; hi = uhi; c = c1;
+        }
+        if (c == c0) { D.why = "internal: a unit does not fit an empty tile"; return; }
+        const int32_t t = D.n_tiles++;
+        D.tile_c0.push_back((int32_t)c0); D.tile_nc.push_back((int32_t)(c - c0));
+        D.tile_lag_lo.push_back(hi < 0 ? 0 : lo); D.tile_span.push_back(hi < 0 ? 0 : hi - lo);
+        for (int64_t v = c0; v < c; ++v) {
+            tile_of[v] = t;
+            if (D.big[v]) { D.delay[v] = kDirectHole; ++D.n_holes; }
+            else D.delay[v] = lag_of[v] - lo;
+        }
+    }
+    // upstream lanes (a small reach's upstream reaches are in its subtree, hence in its tile): headwater tributaries first, then
+    // ascending index -- the order in which k_tile and k_tick add them, so that the three kernels agree bit for bit
+    std::vector<int32_t> filled(n, 0);
+    for (int pass = 0; pass < 2; ++pass)
+        for (int64_t u = 0; u < n; ++u) {
+            const int32_t d = down[u];
+            if (d < 0 || D.big[d] || (indeg[u] == 0) != (pass == 0)) continue;
+            const int32_t lane = (int32_t)(u - D.tile_c0[tile_of[d]]);
+            const int k = filled[d]++;
+            D.up3[d] = (D.up3[d] & ~(0x3FF << (10 * k))) | (lane << (10 * k));
+        }
+    // tall subtrees (long unbranched runs) make most of a chain-like network skeleton: the record path routes that better
+    if (D.n_holes * 10 > n) { D.why = "more than a tenth of the reaches have subtrees too large or too tall for a direct tile"; return; }
+    // the skeleton keeps records
+    build_tile_plan(down, lag_of, skel_block, D.skel, &D.big, true);
+    if (!D.skel.ok) { D.why = "the skeleton does not tile"; return; }
+    for (int64_t v = 0; v < n; ++v) {
+        if (D.big[v]) D.xinfo[v] = D.skel.inv[v];
+        else if (small_root(v) && down[v] >= 0) { D.xinfo[v] = D.skel.ext_ghost[v]; ++D.n_exports; if (D.xinfo[v] < 0) { D.why = "internal: an outlet below the skeleton has no ghost"; return; } }
+    }
+    D.ok = true;
 }
 
 int build_host_plan(int64_t n, const int32_t *indptr, const int32_t *indices, HostPlan &P, std::string &err)

@@ -94,10 +94,44 @@ struct TilePlan {
     std::vector<uint32_t> ccnt;        // [np] upstream positions | headwater tributaries among them << 16
     std::vector<int32_t> xpos;         // [np] kTileExport: position of the mirroring ghost; kTileGhost: position of the mirrored reach; else -1
     std::vector<int32_t> tile_of;      // [np]
+    std::vector<int32_t> ext_ghost;    // skeleton-only plans: [n] position of the ghost that mirrors reach i where i is NOT in the plan, else -1
 };
 // down[i]: downstream reach or -1 (upstream reaches have smaller indices); lag_of[i]: levels between reach i and the
 // farthest headwater of the network.
-void build_tile_plan(const std::vector<int32_t> &down, const std::vector<int32_t> &lag_of, int32_t block, TilePlan &out);
+// big (optional, [n]): which reaches form the skeleton (default: more than `block` reaches upstream).  skeleton_only: only those
+// get positions; every other reach that flows into one is mirrored by a ghost whose record somebody else writes
+// (TilePlan::ext_ghost), tile levels start at 1.
+void build_tile_plan(const std::vector<int32_t> &down, const std::vector<int32_t> &lag_of, int32_t block, TilePlan &out,
+                     const std::vector<uint8_t> *big = nullptr, bool skeleton_only = false);
+
+// ---- direct tiles: rows in params order read and written by the routing kernel itself ----
+//
+// Where the params order numbers every small subtree contiguously (any depth-first post-order does: a subtree is then a
+// column range ending at its outlet), a tile is a RANGE of columns [c0, c0 + nc): lane = column.  The tile's lanes are whole
+// small subtrees -- at most `lanes` reaches and at most `wmax` levels high, so that the lags of a tile span less than wmax --
+// and the columns of skeleton reaches that lie between them (HOLES: a reach with a large or tall subtree comes right after its
+// last tributary's subtree).  A tile has no ghost and no level: a lane's upstream lanes are in the tile.  The kernel reads a
+// row segment per tick, holds it in an LDS window until the lane whose turn it is has routed it (delay = lag - smallest lag of
+// the tile), and writes finished row segments back: no record ring, no permutation pass for these columns.  The skeleton
+// (TilePlan, skeleton_only) keeps records: a hole lane forwards its column's lateral inflow to the skeleton position's record,
+// the outlet of a small subtree sends its discharge to the ghost that mirrors it there, and a small pass patches the holes of
+// the output rows from the skeleton's records.
+constexpr int32_t kDirectHole = 1 << 30;      // delay[] flag: the column belongs to the skeleton
+struct DirectPlan {
+    bool ok = false;
+    std::string why;                   // not ok: the first reason
+    int32_t lanes = 0, wmax = 0;
+    int32_t n_tiles = 0;
+    int64_t n_holes = 0, n_exports = 0;
+    std::vector<int32_t> tile_c0, tile_nc, tile_lag_lo, tile_span;   // [n_tiles]; span = largest - smallest lag of the tile's lanes
+    std::vector<int32_t> delay;        // [n] lag - tile_lag_lo of the column's tile, or kDirectHole
+    std::vector<int32_t> up3;          // [n] three 10-bit lane numbers of the upstream reaches (0x3FF: none)
+    std::vector<int32_t> xinfo;        // [n] hole: position of the reach in `skel`; outlet of a small subtree below a skeleton reach: position of its ghost there; else -1
+    std::vector<uint8_t> big;          // [n] 1: skeleton
+    TilePlan skel;                     // the skeleton's tiles (levels from 1)
+};
+void build_direct_plan(const std::vector<int32_t> &down, const std::vector<int32_t> &lag_of, int32_t lanes, int32_t wmax, int32_t skel_block,
+                       DirectPlan &out);
 
 // Returns 0 or an RR_E_* code with a message in err.
 int build_host_plan(int64_t n, const int32_t *indptr, const int32_t *indices, HostPlan &plan, std::string &err);

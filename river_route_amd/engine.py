@@ -163,14 +163,37 @@ class Plan:
                                        int(num_substeps)))
 
     # -- work memory --
-    def reserve(self, mode: int, T: int, num_substeps: int = 1, host_rows: bool = False) -> dict:
+    def reserve(self, mode: int, T: int, num_substeps: int = 1, host_rows: bool = False, plain_rows: bool = True) -> dict:
         """rr_plan_reserve: allocate what route calls of up to T rows x num_substeps sub-steps work in (the record ring, events,
         with host_rows the PCIe staging).  The *_dev entry points of the C ABI only enqueue and fail with RR_E_STATE when this
-        has not been done; the methods below call it for the shape they are given (no-op once large enough)."""
+        has not been done; the methods below call it for the shape they are given (no-op once large enough).  plain_rows=False:
+        the call's rows are not plain float64 device rows (float32 rows, fused convolution, gridded runoff), so the direct row
+        path does not apply (RR_ROWS_NOT_PLAIN)."""
         info = np.zeros(8, dtype=np.int64)
-        check(_lib.lib().rr_plan_reserve(self._h, int(mode), int(T), int(num_substeps), int(bool(host_rows)), ptr(info)))
-        return dict(tiled=bool(info[0]), ticks_per_launch=int(info[1]), ring_chunks=int(info[2]), work_bytes=int(info[3]),
+        check(_lib.lib().rr_plan_reserve(self._h, int(mode), int(T), int(num_substeps), int(bool(host_rows)) | (0 if plain_rows else 2), ptr(info)))
+        return dict(tiled=int(info[0]) == 1, direct=int(info[0]) == 2, ticks_per_launch=int(info[1]), ring_chunks=int(info[2]), work_bytes=int(info[3]),
                     staging_bytes=int(info[4]), pinned_bytes=int(info[5]), pipeline_ticks=int(info[6]), ring_bytes=int(info[7]))
+
+    def direct_info(self) -> dict:
+        """Whether the direct row path applies to this plan (the params order numbers small subtrees contiguously) and its shape,
+        see rr_plan_direct_info."""
+        info = np.zeros(8, dtype=np.int64)
+        why = C.create_string_buffer(256)
+        check(_lib.lib().rr_plan_direct_info(self._h, ptr(info), C.cast(why, C.c_void_p), 256))
+        return dict(ok=bool(info[0]), tiles=int(info[1]), holes=int(info[2]), outlets=int(info[3]), skeleton_positions=int(info[4]),
+                    skeleton_tiles=int(info[5]), skeleton_levels=int(info[6]), window_rows=int(info[7]), why=why.value.decode())
+
+    def direct_layout(self) -> dict:
+        """Arrays of the direct row path's layout, see rr_plan_direct_layout."""
+        nt = self.direct_info()['tiles']
+        out = dict(tile_c0=np.empty(nt, np.int32), tile_nc=np.empty(nt, np.int32), tile_lag_lo=np.empty(nt, np.int32), tile_span=np.empty(nt, np.int32),
+                   delay=np.empty(self.n, np.int32), up3=np.empty(self.n, np.int32), xinfo=np.empty(self.n, np.int32))
+        check(_lib.lib().rr_plan_direct_layout(self._h, *(ptr(out[k]) for k in ('tile_c0', 'tile_nc', 'tile_lag_lo', 'tile_span', 'delay', 'up3', 'xinfo'))))
+        return out
+
+    def last_kernel(self) -> str:
+        """'tick' (streaming), 'tile' (time-tiled over records) or 'direct' (direct row path): what the last call ran."""
+        return ('tick', 'tile', 'direct')[int(_lib.lib().rr_plan_last_kernel(self._h))]
 
     # -- device-pointer routing (enqueue only) --
     def rapid_route_dev(self, q_t, qlateral, ql_rows, discharge, out_rows, T, num_substeps, stream=None) -> None:
@@ -193,14 +216,14 @@ class Plan:
 
     # -- device-pointer routing with the routers' post-processing fused in: float32 rows, `factor` routed rows averaged --
     def rapid_route_f32_dev(self, q_t, qlateral, ql_rows, discharge32, T, num_substeps, factor=1, stream=None) -> None:
-        self.reserve(MODE_RAPID, T, num_substeps)
+        self.reserve(MODE_RAPID, T, num_substeps, plain_rows=False)
         check(_lib.lib().rr_rapid_route_f32_dev(self._h, ptr(q_t), ptr(qlateral), int(ql_rows), ptr(discharge32), int(T),
                                                 int(num_substeps), int(factor), stream))
 
     def rapid_route_f32in_dev(self, q_t, qlateral32, ql_rows, T, num_substeps, discharge=None, out_rows=0, discharge32=None, factor=1,
                               stream=None) -> None:
         """rr_rapid_route_f32in_dev: float32 lateral rows in (exact in float64); exactly one of discharge / discharge32."""
-        self.reserve(MODE_RAPID, T, num_substeps)
+        self.reserve(MODE_RAPID, T, num_substeps, plain_rows=False)
         check(_lib.lib().rr_rapid_route_f32in_dev(self._h, ptr(q_t), ptr(qlateral32), int(ql_rows), ptr(discharge), int(out_rows),
                                                   ptr(discharge32), int(factor), int(T), int(num_substeps), stream))
 
@@ -217,7 +240,7 @@ class Plan:
     def rapid_route_runoff_dev(self, q_t, n_points, indptr, indices, weights, runoff, runoff_is_f32, stride_t, stride_p, area, flags, T,
                                discharge=None, discharge32=None, factor=1, stream=None) -> None:
         """Gridded runoff -> records -> routing in one call (rr_rapid_route_runoff_dev); exactly one of discharge / discharge32."""
-        self.reserve(MODE_RAPID, T, 1)
+        self.reserve(MODE_RAPID, T, 1, plain_rows=False)
         check(_lib.lib().rr_rapid_route_runoff_dev(self._h, ptr(q_t), int(n_points), ptr(indptr), ptr(indices), ptr(weights), ptr(runoff),
                                                    int(bool(runoff_is_f32)), int(stride_t), int(stride_p), ptr(area), int(flags),
                                                    ptr(discharge), ptr(discharge32), int(factor), int(T), stream))

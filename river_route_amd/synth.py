@@ -109,7 +109,9 @@ def synth_network(n: int, seed: int = NETWORK_SEED, params_seed: int = PARAMS_SE
     """
     n-reach random-topology network.  order: 'random' (random topological order, default),
     'bfs' (the engine's own order: farthest-from-outlet level first; needs no permutation pass on the GPU),
-    'levels' (sorted by distance from the headwaters).
+    'levels' (sorted by distance from the headwaters), 'postorder' (depth-first post-order: every reach right after the
+    subtrees of its tributaries -- a common numbering of hydrography tables, and the one in which every sub-basin is a run of
+    consecutive columns: the engine's direct row path applies).
     """
     if n < 1:
         raise ValueError('n must be >= 1')
@@ -157,6 +159,26 @@ def synth_network_chain(n: int, seed: int = NETWORK_SEED, p_chain: float = 0.0, 
     return _network_from_parents(np.asarray(parent, dtype=np.int64), seed, params_seed, order)
 
 
+def _postorder(parent: np.ndarray) -> np.ndarray:
+    """Depth-first post-order of a forest given by parent pointers: tributaries in ascending node number, outlets likewise."""
+    n = parent.shape[0]
+    order = np.argsort(parent, kind='stable')              # children grouped by parent, ascending inside a group
+    counts = np.bincount(parent[parent >= 0], minlength=n)
+    start = np.concatenate([[0], np.cumsum(counts)]) + int((parent < 0).sum())     # the outlets (parent -1) sort first
+    kids, first, cnt = order.tolist(), start.tolist(), counts.tolist()
+    out = []
+    for root in order[:int((parent < 0).sum())].tolist():
+        stack = [(root, 0)]
+        while stack:
+            v, i = stack.pop()
+            if i < cnt[v]:
+                stack.append((v, i + 1))
+                stack.append((kids[first[v] + i], 0))
+            else:
+                out.append(v)
+    return np.asarray(out, dtype=np.int64)
+
+
 def _network_from_parents(parent: np.ndarray, seed: int, params_seed: int, order: str) -> SynthNetwork:
     n = parent.shape[0]
     levels = _levels_from_headwaters(parent)
@@ -186,6 +208,8 @@ def _network_from_parents(parent: np.ndarray, seed: int, params_seed: int, order
         indptr = np.concatenate([[0], np.cumsum(has)]).astype(np.int32)
         with Plan(indptr, down[has].astype(np.int32), device=RR_DEVICE_NONE) as plan:
             perm = first[plan.layout()[0].astype(np.int64)]
+    elif order == 'postorder':
+        perm = _postorder(parent)
     else:
         raise ValueError(f'unknown order {order!r}')
 
