@@ -51,7 +51,7 @@ void rr_plan_destroy(rr_plan *P)
                         P->d_tperm, P->d_tinv, P->d_inner_idx, P->d_colmeta, P->d_ghostmeta, P->d_c4_params,
                         P->d_c3, P->d_c4, P->d_x, P->d_isum, P->d_qch, P->d_a2, P->d_c1own, P->d_z, P->d_ring, P->d_stage, P->d_mrows,
                         P->d_slot_a[0], P->d_slot_a[1], P->d_slot_b[0], P->d_slot_b[1], P->d_m_index[0], P->d_m_index[1],
-                        P->d_dtiles, P->d_dlane, P->d_dcoef, P->d_dq, P->d_ktmeta, P->d_kpmeta, P->d_kperm, P->d_kholecol, P->d_kcoef, P->d_ksq, P->d_kss, P->d_ksi,
+                        P->d_dtiles, P->d_dlane, P->d_dsend_ptr, P->d_dsend_lane, P->d_dcoef, P->d_dq, P->d_ktmeta, P->d_kpmeta, P->d_kperm, P->d_kholecol, P->d_kcoef, P->d_ksq, P->d_kss, P->d_ksi,
                         P->d_kholemeta};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         P->pipe.destroy();
@@ -90,8 +90,9 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         rr::build_tile_plan(P->h.down, lag_of, block, P->tp);
         // the direct row path where the params order numbers small subtrees contiguously (any depth-first post-order); `why` says why not
         if (const char *e = getenv("RR_DIRECT")) P->direct_enabled = atoi(e) != 0;
-        rr::build_direct_plan(P->h.down, lag_of, std::min<int32_t>(kDirectLanes, block), kDirectMaxWindow, block, P->dp);
-        for (int32_t sp : P->dp.tile_span) P->direct_window = std::max(P->direct_window, sp + 1);
+        rr::build_direct_plan(P->h.down, lag_of, std::min<int32_t>(kDirectLanes, block), kDirectMaxWindow - 2, block, P->dp);
+        P->direct_window = 3;
+        for (int32_t sp : P->dp.tile_span) P->direct_window = std::max(P->direct_window, sp + 3);
     }
     if (device != RR_DEVICE_NONE) {
         int count = rr_device_count();
@@ -159,7 +160,7 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         if (!rc && P->dp.ok) {      // direct row path: per-column constants, the skeleton's tile arrays, the holes' out-pass
             const rr::DirectPlan &D = P->dp;
             const rr::TilePlan &K = D.skel;
-            if (hipFuncSetAttribute((const void *)k_direct<kDirectLanes, kDirectAhead>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)direct_lds_bytes(kDirectMaxWindow)) != hipSuccess) {
+            if (hipFuncSetAttribute((const void *)k_direct<kDirectAhead>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)direct_lds_bytes(kDirectMaxWindow)) != hipSuccess) {
                 (void)hipGetLastError();
                 P->direct_enabled = false;
             }
@@ -171,6 +172,10 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
             if (!rc) rc = dev_upload(P->d_dtiles, dt);
             if (!rc) rc = dev_alloc(&P->d_dlane, n);
             if (!rc) rc = dev_upload(P->d_dlane, dl);
+            if (!rc) rc = dev_alloc(&P->d_dsend_ptr, D.n_tiles + 1);
+            if (!rc) rc = dev_upload(P->d_dsend_ptr, D.send_ptr);
+            if (!rc) rc = dev_alloc(&P->d_dsend_lane, (int64_t)D.send_lane.size());
+            if (!rc) rc = dev_upload(P->d_dsend_lane, D.send_lane);
             if (!rc) rc = dev_alloc(&P->d_dcoef, 4 * n);
             if (!rc) rc = dev_alloc(&P->d_dq, n);
             std::vector<TileMeta> tm((size_t)K.n_tiles);

@@ -154,6 +154,7 @@ struct rr_plan {
     int direct_window = 1;               // rows of the LDS window: largest span + 1 of the plan's tiles
     DirectTile *d_dtiles = nullptr;
     int4 *d_dlane = nullptr;
+    int32_t *d_dsend_ptr = nullptr, *d_dsend_lane = nullptr;
     double *d_dcoef = nullptr, *d_dq = nullptr;
     TileMeta *d_ktmeta = nullptr;        // the skeleton's tiles (TileArgs of its k_tile launches)
     int4 *d_kpmeta = nullptr;
@@ -480,6 +481,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         S.n_out_batches = TP.np > 0 ? (S.total + kRecRows - 1) / kRecRows : 0;
         DirectArgs &da = S.da;
         da.tiles = P->d_dtiles; da.n_tiles = P->dp.n_tiles; da.lane = P->d_dlane; da.coef = P->d_dcoef; da.q = P->d_dq;
+        da.send_ptr = P->d_dsend_ptr; da.send_lane = P->d_dsend_lane;
         da.in = io.dev_in; da.out = io.dev_out; da.n = n; da.in_rows = (uint32_t)io.rows_in; da.out_rows = (uint32_t)io.rows_out;
         da.rec = P->d_ring; da.rec_chunks = (uint32_t)std::max<int64_t>(1, S.rec_chunks); da.np = (int32_t)TP.np;
         da.K = (int32_t)K; da.total = (int32_t)S.T;
@@ -922,7 +924,7 @@ int session_advance_direct(rr_plan *P, int64_t rows_ready)
                 if (sample) HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets], S.stream));
                 S.da.m = (int32_t)d;
                 const dim3 g((unsigned)std::min<int64_t>(P->dp.n_tiles, (int64_t)P->cu_count));
-                hipLaunchKernelGGL((k_direct<kDirectLanes, kDirectAhead>), g, dim3(kDirectLanes), direct_lds_bytes(P->direct_window), S.stream, S.da);
+                hipLaunchKernelGGL((k_direct<kDirectAhead>), g, dim3(kDirectThreads), direct_lds_bytes(P->direct_window), S.stream, S.da);
                 if (sample) {
                     HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));
                     P->ev_reaches.push_back(n * (std::min((d + 1) * K, S.T) - d * K));

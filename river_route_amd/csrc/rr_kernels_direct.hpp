@@ -11,25 +11,34 @@ namespace {
 // lane = column, and the tile reads and writes row segments itself.
 //
 // Lane with lag L routes row r at tick r + L (section 3: its upstream lanes are one tick ahead), so at one tick the lanes of a
-// tile work on different rows: delay = L - (smallest lag of the tile) rows behind the first.  A row segment is loaded once, one
-// coalesced 8-byte load per lane PF ticks ahead, and parked in an LDS window F[slot][lane] of span + 1 rows (span = largest delay):
-// lane reads F[own slot] when its turn comes, writes its discharge back in place, and when the slowest lane has done a row the
-// segment is stored, coalesced.  Each lane touches only its own column of the window: no synchronisation beyond the tick's barrier.
+// tile work on different rows: delay = L - (smallest lag of the tile) rows behind the first.  A row segment is loaded once,
+// coalesced, PF ticks ahead, and parked in an LDS window F[slot][lane] of span + 3 rows (span = largest delay): a lane reads
+// F[its slot] when its turn comes and writes its discharge back in place; when the slowest lane has done a row the segment is
+// stored, coalesced.  Each lane touches only its own column of the window.
 //
 // One task = one tile x K rows [m K, (m + 1) K): lanes start one after the other (K + span ticks, the first and last `span` of them
 // with idle lanes), so the window is empty at both ends and nothing but the lanes' last discharge is carried from task to task.
 // A tile holds whole small subtrees, so it has no ghost, no level and no dependency on another tile: every launch runs every tile.
 //
-// The skeleton (reaches with large or tall subtrees: 4-5 %) keeps records and k_tile.  Its columns lie between the subtrees'
-// columns (HOLES): the hole lane forwards its column's lateral inflow, scaled, into the skeleton position's record; the outlet lane
-// of a small subtree writes its discharge into the record of the ghost that mirrors it in the skeleton; k_rec_out, given the
-// holes' columns, patches the output rows from the skeleton's records afterwards (the direct tile stores 0 there).
+// A tick is bound by instruction issue and LDS latency, not by arithmetic: one wave per SIMD issues a vector instruction every
+// ~4 cycles, and the first version -- every lane loading, routing, forwarding and storing -- ran 110 instructions and two LDS
+// round trips per tick: 816 cycles.  So the workgroup is SPECIALISED: waves 0-3 route (lane = column: five LDS reads, five
+// multiply-adds, two LDS writes), wave 4 brings the rows in (two 16-byte loads per lane and tick, scaled by c4dt into the window
+// one tick before the first lane needs them), wave 5 takes finished rows out (one tick after the last lane wrote them), wave 6
+// forwards what the skeleton needs: the work of a tick is spread over seven instruction streams that meet at the tick's barrier.
+//
+// The skeleton (reaches with large or tall subtrees: 5 %) keeps records and k_tile.  Its columns lie between the subtrees'
+// columns (HOLES).  Wave 6 copies a hole's scaled lateral inflow from the window into the skeleton position's record, and the
+// discharge of an outlet lane (a small subtree's last reach) into the record of the ghost that mirrors it in the skeleton, 8 bytes
+// per tick and sender; k_rec_out, given the holes' columns, patches the output rows from the skeleton's records afterwards.
 struct DirectTile { int32_t c0, nc, lag_lo, span; };
 struct DirectArgs {
     const DirectTile *tiles;
     int32_t n_tiles;
     const int4 *lane;           // per column {delay | kDirectHole, upstream lanes (3 x 10 bits), xinfo, lag}
     const double *coef;         // per column {c1row, c2, c3, c4dt}
+    const int32_t *send_ptr;    // per tile: its senders in send_lane
+    const int32_t *send_lane;   // lane | kDirectHole
     double *q;                  // per column: carried discharge
     const double *in;           // lateral rows (in_rows x n), read cyclically
     double *out;                // discharge rows (out_rows x n), written cyclically
@@ -42,125 +51,187 @@ struct DirectArgs {
 };
 constexpr int32_t kDirectHoleBit = rr::kDirectHole;
 constexpr int kDirectLanes = 256, kDirectAhead = 16;
+constexpr int kDirectThreads = kDirectLanes + 3 * 64;      // four routing waves + in, out, send
+constexpr int kDirectMaxWindow = 72;      // rows of the LDS window, span + 3: 2 x 258 + 72 x 256 doubles = 151.6 KB of the CU's 160
 constexpr size_t direct_lds_bytes(int window_rows) { return (size_t)(2 * (kDirectLanes + kTilePad) + (int64_t)window_rows * kDirectLanes) * sizeof(double); }
-constexpr int kDirectMaxWindow = 72;      // rows: 2 x 258 + 72 x 256 doubles = 151.6 KB of the CU's 160
 
-__device__ __forceinline__ double load_f64(__amdgpu_buffer_rsrc_t r, uint32_t byte_off)
+__device__ __forceinline__ double2 load_f64x2_(__amdgpu_buffer_rsrc_t r, uint32_t byte_off)
 {
-    const u32x2 bits = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
-    double v;
+    const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    double2 v;
     __builtin_memcpy(&v, &bits, sizeof v);
     return v;
 }
 
-template <int TH, int PF>
-__global__ __launch_bounds__(TH, 1) void k_direct(const DirectArgs a)
+template <int PF>
+__global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    constexpr int THP = TH + kTilePad;
+    constexpr int TH = kDirectLanes, THP = TH + kTilePad;
     static_assert(PF % 2 == 0, "the parity of a tick is the parity of its place in a chunk");
     char *const X = reinterpret_cast<char *>(lds);                  // [2][THP] discharges of the last two ticks, each followed by a slot that holds 0.0
-    char *const F = reinterpret_cast<char *>(lds + 2 * THP);        // [span + 1][TH] the row window
-    const int tid = threadIdx.x;
+    char *const F = reinterpret_cast<char *>(lds + 2 * THP);        // [span + 3][TH] the row window
+    const int tid = threadIdx.x, role = tid >> 6 < 4 ? 0 : (tid >> 6) - 3, ln = tid & 63;      // 0 route, 1 in, 2 out, 3 send
     if (tid < 2) lds[tid * THP + TH] = 0.0;
     const int32_t r0 = a.m * a.K, nrows = min(a.K, a.total - r0);
     const uint32_t row_bytes = (uint32_t)a.n * 8u;                  // n < 2^29 (choose_schedule)
+    constexpr int kRowB = TH * 8;                                    // bytes of a window row
 
     for (int32_t t = (int32_t)blockIdx.x; t < a.n_tiles; t += (int32_t)gridDim.x) {
         const DirectTile tm = a.tiles[t];
-        const bool live = tid < tm.nc;
-        const int32_t col = tm.c0 + (live ? tid : 0);
-        const int4 lm = a.lane[col];
-        const bool hole = !live || (lm.x & kDirectHoleBit) != 0;
-        const int32_t delta = hole ? 0x40000000 : lm.x;              // a hole is never active
-        const int32_t xpos = live ? lm.z : -1;                        // hole: its skeleton position; outlet of a subtree: its ghost there
-        const double c1 = hole ? 0.0 : a.coef[4 * (int64_t)col], c2 = hole ? 0.0 : a.coef[4 * (int64_t)col + 1],
-                     c3 = hole ? 0.0 : a.coef[4 * (int64_t)col + 2], c4 = a.coef[4 * (int64_t)col + 3];
-        const double q0 = hole ? 0.0 : a.q[col];
-        const int32_t up0_b = (lm.y & 0x3FF) == 0x3FF || hole ? TH * 8 : (lm.y & 0x3FF) * 8,
-                      up1_b = ((lm.y >> 10) & 0x3FF) == 0x3FF || hole ? TH * 8 : ((lm.y >> 10) & 0x3FF) * 8,
-                      up2_b = ((lm.y >> 20) & 0x3FF) == 0x3FF || hole ? TH * 8 : ((lm.y >> 20) & 0x3FF) * 8;
-        const uint32_t voff = live ? (uint32_t)col * 8u : kDropAccess;
-        const int32_t span = tm.span, wrap = (span + 1) * (TH * 8);   // bytes of the window in use
-        // the record slot of this lane's tick: row + lag, i.e. (r0 + k - delay) + lag at tick k (a hole forwards the row that arrives: no delay)
-        const bool sends = xpos >= 0;
-        uint32_t xchunk = 0, xslot = 0;
-        if (sends) {
-            const uint32_t tg = (uint32_t)(r0 + lm.w - (hole ? 0 : delta));
-            xslot = tg & 15u;
-            xchunk = (tg >> 4) % a.rec_chunks;
-        }
-        const bool wave_sends = __builtin_amdgcn_ballot_w64(sends) != 0;
-
+        const int32_t span = tm.span, wrap = (span + 3) * kRowB;     // bytes of the window in use
+        // local tick k: row k + 1 arrives (wave 4), lane with delay d routes row k - d (waves 0-3), row k - 1 - span leaves (wave 5),
+        // the values of tick k - 1 are forwarded (wave 6); n_ticks of them, in chunks of PF
+        const int32_t n_ticks = nrows + span + 2;
         __syncthreads();      // every wave has left the previous tile
-        *reinterpret_cast<double *>(X + tid * 8) = q0;
-        *reinterpret_cast<double *>(X + THP * 8 + tid * 8) = q0;
-        // rows r0 ... r0 + PF - 1 on their way
-        double P[PF];
-        uint32_t rin = (uint32_t)r0 % a.in_rows;
-        auto request = [&](int32_t k) {      // row r0 + k, or nothing past the task's rows
-            const __amdgpu_buffer_rsrc_t src = make_rsrc(a.in + (int64_t)rin * a.n, row_bytes);
-            const double v = load_f64(src, k < nrows ? voff : kDropAccess);
-            rin = rin + 1 == a.in_rows ? 0 : rin + 1;
-            return v;
-        };
-#pragma unroll
-        for (int j = 0; j < PF; ++j) P[j] = request(j);
-        uint32_t rout = (uint32_t)r0 % a.out_rows;
-        int32_t in_b = 0;                                              // window slot of the row that arrives this tick, in bytes
-        int32_t own_b = delta >= 0x40000000 ? 0 : (delta == 0 ? 0 : wrap - delta * (TH * 8));      // ... of the row this lane routes this tick
-        double s_prev = 0.0;
-        __syncthreads();
 
-        auto ticks = [&](auto tested, int32_t k0) {
+        if (role == 0) {
+            // ---------------------------------------------------------------- routing lanes: lane = column
+            const bool live = tid < tm.nc;
+            const int32_t col = tm.c0 + (live ? tid : 0);
+            const int4 lm = a.lane[col];
+            const bool idle = !live || (lm.x & kDirectHoleBit) != 0;      // a hole's column only passes through the window
+            const int32_t delta = idle ? 0x40000000 : lm.x;
+            const double c1 = idle ? 0.0 : a.coef[4 * (int64_t)col], c2 = idle ? 0.0 : a.coef[4 * (int64_t)col + 1], c3 = idle ? 0.0 : a.coef[4 * (int64_t)col + 2];
+            const double q0 = idle ? 0.0 : a.q[col];
+            const int32_t u0 = lm.y & 0x3FF, u1 = (lm.y >> 10) & 0x3FF, u2 = (lm.y >> 20) & 0x3FF;
+            const int32_t up0_b = (u0 == 0x3FF || idle ? TH : u0) * 8, up1_b = (u1 == 0x3FF || idle ? TH : u1) * 8, up2_b = (u2 == 0x3FF || idle ? TH : u2) * 8;
+            *reinterpret_cast<double *>(X + tid * 8) = q0;
+            *reinterpret_cast<double *>(X + THP * 8 + tid * 8) = q0;
+            int32_t own_b = idle || delta == 0 ? 0 : wrap - delta * kRowB;      // window slot of the row this lane routes this tick: (k - delta) mod (span + 3)
+            if (!idle && delta > 0 && own_b < 0) own_b += wrap;                   // (delta <= span < span + 3)
+            double s_prev = 0.0;
+            __syncthreads();      // the discharges carried in, and row 0 in the window (wave 4)
+            auto ticks = [&](auto tested, int32_t k0) {
 #pragma unroll
-            for (int s = 0; s < PF; ++s) {
-                const int32_t k = k0 + s;
-                const int prev = ((s + 1) & 1) * (THP * 8), cur = (s & 1) * (THP * 8);
-                // the row that arrives: into the window, the next one requested
-                const double lat_in = P[s] * c4;
-                P[s] = request(k + PF);
-                *reinterpret_cast<double *>(F + in_b + tid * 8) = hole ? 0.0 : lat_in;
-                // this lane's tick: _numba_kernels.py:63-84 in gather form, the arithmetic of k_tile's short tick
-                const double q_old = *reinterpret_cast<const double *>(X + prev + tid * 8);
-                const double s_cur = (*reinterpret_cast<const double *>(X + prev + up0_b) + *reinterpret_cast<const double *>(X + prev + up1_b)) +
-                                     *reinterpret_cast<const double *>(X + prev + up2_b);
-                double *mine = reinterpret_cast<double *>(F + own_b + tid * 8);
-                const double lat = *mine;
-                double qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev, __builtin_fma(c3, q_old, lat)));
-                bool active = true;
-                if (decltype(tested)::value) {
-                    active = (uint32_t)(k - delta) < (uint32_t)nrows;
-                    qk = active ? qk : q_old;
-                    *mine = active ? qk : lat;
-                } else {
-                    *mine = qk;
+                for (int s = 0; s < PF; ++s) {
+                    const int prev = ((s + 1) & 1) * (THP * 8), cur = (s & 1) * (THP * 8);
+                    // _numba_kernels.py:63-84 in gather form, the arithmetic of k_tile's short tick operation for operation
+                    const double q_old = *reinterpret_cast<const double *>(X + prev + tid * 8);
+                    const double s_cur = (*reinterpret_cast<const double *>(X + prev + up0_b) + *reinterpret_cast<const double *>(X + prev + up1_b)) +
+                                         *reinterpret_cast<const double *>(X + prev + up2_b);
+                    double *mine = reinterpret_cast<double *>(F + own_b + tid * 8);
+                    const double lat = *mine;
+                    double qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev, __builtin_fma(c3, q_old, lat)));
+                    if (decltype(tested)::value) {      // an idle lane keeps its discharge and hands its window slot back as it found it (nobody else writes it this tick)
+                        const bool active = (uint32_t)(k0 + s - delta) < (uint32_t)nrows;
+                        qk = active ? qk : q_old;
+                        *mine = active ? qk : lat;
+                    } else {
+                        *mine = qk;
+                    }
+                    s_prev = s_cur;
+                    *reinterpret_cast<double *>(X + cur + tid * 8) = qk;
+                    own_b = own_b + kRowB == wrap ? 0 : own_b + kRowB;
+                    barrier_lds();
                 }
-                s_prev = s_cur;
-                *reinterpret_cast<double *>(X + cur + tid * 8) = qk;
-                if (wave_sends) {      // wave-uniform: most waves hold neither a hole nor an outlet
-                    const bool now = sends && (hole ? k < nrows : active);
-                    if (now) a.rec[((int64_t)xchunk * a.np + xpos) * kRec + xslot] = hole ? lat_in : qk;
-                    xslot = (xslot + 1) & 15u;      // the slot moves with the tick
-                    if (xslot == 0) xchunk = xchunk + 1 == a.rec_chunks ? 0 : xchunk + 1;
-                }
-                // the row the slowest lane has just done leaves: it sits where the next row will arrive
-                in_b = in_b + TH * 8 == wrap ? 0 : in_b + TH * 8;
-                own_b = own_b + TH * 8 == wrap ? 0 : own_b + TH * 8;
-                const double done = *reinterpret_cast<const double *>(F + in_b + tid * 8);
-                const bool leaves = k >= span && k - span < nrows;
-                const __amdgpu_buffer_rsrc_t dst = make_rsrc(a.out + (int64_t)rout * a.n, row_bytes);
-                store_f64(dst, leaves ? voff : kDropAccess, done > 0.0 ? done : 0.0);      // the reference's clip at zero (_numba_kernels.py:84)
-                if (leaves) rout = rout + 1 == a.out_rows ? 0 : rout + 1;
-                barrier_lds();
+            };
+            for (int32_t k0 = 0; k0 < n_ticks; k0 += PF) {
+                if (k0 >= span && k0 + PF <= nrows) ticks(std::false_type(), k0);      // every lane busy on every tick of the chunk
+                else ticks(std::true_type(), k0);
             }
-        };
-        const int32_t n_ticks = nrows + span;
-        for (int32_t k0 = 0; k0 < n_ticks; k0 += PF) {
-            if (k0 >= span && k0 + PF <= nrows) ticks(std::false_type(), k0);      // every lane busy on every tick of the chunk
-            else ticks(std::true_type(), k0);
+            if (!idle) a.q[col] = *reinterpret_cast<const double *>(X + THP * 8 + tid * 8);      // PF is even: the last tick wrote buffer 1
+        } else if (role == 1) {
+            // ---------------------------------------------------------------- wave 4: rows in.  Lane -> columns 2 ln, 2 ln + 1 and 128 + 2 ln, 128 + 2 ln + 1
+            const int32_t ca = 2 * ln, cb = TH / 2 + 2 * ln;
+            auto c4_of = [&](int32_t c) { return c < tm.nc ? a.coef[4 * (int64_t)(tm.c0 + c) + 3] : 0.0; };
+            const double c4a0 = c4_of(ca), c4a1 = c4_of(ca + 1), c4b0 = c4_of(cb), c4b1 = c4_of(cb + 1);
+            // a 16-byte load may reach past the tile's last column (the next tile's, or -- past the row's end -- zeros): never used
+            const uint32_t va = ca < tm.nc ? (uint32_t)(tm.c0 + ca) * 8u : kDropAccess, vb = cb < tm.nc ? (uint32_t)(tm.c0 + cb) * 8u : kDropAccess;
+            uint32_t rin = (uint32_t)r0 % a.in_rows;
+            const double *row = a.in + (int64_t)rin * a.n;
+            double2 Pa[PF], Pb[PF];
+            auto request = [&](int32_t arrival, double2 &pa, double2 &pb) {      // row r0 + arrival, or nothing past the task's rows
+                const __amdgpu_buffer_rsrc_t src = make_rsrc(row, row_bytes);
+                pa = load_f64x2_(src, arrival < nrows ? va : kDropAccess);
+                pb = load_f64x2_(src, arrival < nrows ? vb : kDropAccess);
+                ++rin; row += a.n;
+                if (rin == a.in_rows) { rin = 0; row = a.in; }
+            };
+#pragma unroll
+            for (int j = 0; j < PF; ++j) request(j, Pa[j], Pb[j]);
+            int32_t in_b = 0;
+            auto park = [&](const double2 &pa, const double2 &pb) {      // into the window, scaled (the ring of k_tile holds c4dt * lateral too)
+                *reinterpret_cast<double2 *>(F + in_b + ca * 8) = make_double2(pa.x * c4a0, pa.y * c4a1);
+                *reinterpret_cast<double2 *>(F + in_b + cb * 8) = make_double2(pb.x * c4b0, pb.y * c4b1);
+                in_b = in_b + kRowB == wrap ? 0 : in_b + kRowB;
+            };
+            park(Pa[0], Pb[0]);      // row 0, before the first tick
+            request(PF, Pa[0], Pb[0]);
+            __syncthreads();
+            for (int32_t k0 = 0; k0 < n_ticks; k0 += PF) {
+#pragma unroll
+                for (int s = 0; s < PF; ++s) {      // tick k0 + s: row k0 + s + 1 arrives, row k0 + s + 1 + PF is requested
+                    park(Pa[(s + 1) % PF], Pb[(s + 1) % PF]);
+                    request(k0 + s + 1 + PF, Pa[(s + 1) % PF], Pb[(s + 1) % PF]);
+                    barrier_lds();
+                }
+            }
+        } else if (role == 2) {
+            // ---------------------------------------------------------------- wave 5: rows out.  The same columns as wave 4
+            const int32_t ca = 2 * ln, cb = TH / 2 + 2 * ln;
+            // whole 16-byte pieces inside the tile; the piece that holds the tile's last column when nc is odd goes as 8 bytes
+            const uint32_t va = ca + 1 < tm.nc ? (uint32_t)(tm.c0 + ca) * 8u : kDropAccess, vb = cb + 1 < tm.nc ? (uint32_t)(tm.c0 + cb) * 8u : kDropAccess;
+            const bool odd_a = ca + 1 == tm.nc, odd_b = cb + 1 == tm.nc;
+            const uint32_t vo = (odd_a || odd_b) ? (uint32_t)(tm.c0 + tm.nc - 1) * 8u : kDropAccess;
+            uint32_t rout = (uint32_t)r0 % a.out_rows;
+            double *row = a.out + (int64_t)rout * a.n;
+            int32_t out_b = 0;
+            auto clip = [](double x) { return x > 0.0 ? x : 0.0; };      // the reference's clip at zero (_numba_kernels.py:84)
+            __syncthreads();
+            for (int32_t k0 = 0; k0 < n_ticks; k0 += PF) {
+#pragma unroll
+                for (int s = 0; s < PF; ++s) {      // tick k: row k - 1 - span leaves
+                    const int32_t leaving = k0 + s - 1 - span;
+                    if (leaving >= 0 && leaving < nrows) {      // wave-uniform
+                        const double2 xa = *reinterpret_cast<const double2 *>(F + out_b + ca * 8), xb = *reinterpret_cast<const double2 *>(F + out_b + cb * 8);
+                        const __amdgpu_buffer_rsrc_t dst = make_rsrc(row, row_bytes);
+                        store_f64x2(dst, va, make_double2(clip(xa.x), clip(xa.y)));
+                        store_f64x2(dst, vb, make_double2(clip(xb.x), clip(xb.y)));
+                        store_f64(dst, vo, clip(odd_a ? xa.x : xb.x));
+                        out_b = out_b + kRowB == wrap ? 0 : out_b + kRowB;
+                        ++rout; row += a.n;
+                        if (rout == a.out_rows) { rout = 0; row = a.out; }
+                    }
+                    barrier_lds();
+                }
+            }
+        } else {
+            // ---------------------------------------------------------------- wave 6: what the skeleton needs
+            const int32_t s0 = a.send_ptr[t], ns = a.send_ptr[t + 1] - s0;
+            const bool mine = ln < ns;
+            const int32_t sl = mine ? a.send_lane[s0 + ln] : 0;
+            const bool hole = (sl & kDirectHoleBit) != 0;
+            const int32_t lane = sl & 0x3FF;
+            const int4 lm = a.lane[tm.c0 + lane];
+            const int32_t delta = hole ? 0 : lm.x;
+            // the value of local row j sits, one tick after it was made: a hole's in the window (slot j mod (span + 3)), an outlet's in the
+            // discharge buffer its tick wrote; its record slot is tick r0 + j + lag
+            int32_t src_b = hole ? 2 * THP * 8 + lane * 8 : lane * 8;      // byte offset in LDS of row (k - 1 - delta) at tick k
+            uint32_t tg = (uint32_t)(r0 + lm.w), xslot = tg & 15u, xchunk = (tg >> 4) % a.rec_chunks;
+            double *dst = a.rec + ((int64_t)xchunk * a.np + (mine ? lm.z : 0)) * kRec + xslot;
+            const int64_t chunk_step = (int64_t)a.np * kRec - 15, ring_back = (int64_t)a.rec_chunks * a.np * kRec;
+            __syncthreads();
+            for (int32_t k0 = 0; k0 < n_ticks; k0 += PF) {
+#pragma unroll
+                for (int s = 0; s < PF; ++s) {
+                    const int32_t j = k0 + s - 1 - delta;      // the local row whose value was made at tick k - 1
+                    if (mine && (uint32_t)j < (uint32_t)nrows) {
+                        const int32_t at = hole ? src_b : src_b + ((s + 1) & 1) * (THP * 8);      // tick k - 1 wrote discharge buffer (k - 1) & 1
+                        *dst = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lds) + at);
+                        if (hole) src_b = src_b + kRowB == 2 * THP * 8 + wrap + lane * 8 ? 2 * THP * 8 + lane * 8 : src_b + kRowB;
+                        if (++xslot == 16) {
+                            xslot = 0;
+                            dst += chunk_step;
+                            if (++xchunk == a.rec_chunks) { xchunk = 0; dst -= ring_back; }
+                        } else {
+                            ++dst;
+                        }
+                    }
+                    barrier_lds();
+                }
+            }
         }
-        if (!hole) a.q[col] = *reinterpret_cast<const double *>(X + THP * 8 + tid * 8);      // PF is even: the last tick wrote buffer 1
     }
 }
 

@@ -407,20 +407,21 @@ void build_direct_plan(const std::vector<int32_t> &down, const std::vector<int32
     int64_t c = 0;
     while (c < n) {
         const int64_t c0 = c;
-        int32_t lo = std::numeric_limits<int32_t>::max(), hi = -1;
+        int32_t lo = std::numeric_limits<int32_t>::max(), hi = -1, senders = 0;
         while (c < n) {
             int64_t c1;
-            int32_t ulo = lo, uhi = hi;
-            if (D.big[c]) c1 = c + 1;
+            int32_t ulo = lo, uhi = hi, us = senders;
+            if (D.big[c]) { c1 = c + 1; ++us; }
             else {      // the small subtree that STARTS here: its outlet is the first small root at or after c whose range begins at c
                 int64_t r = c;
                 while (!small_root(r)) r = down[r];      // c is the first (deepest-first) reach of exactly one small subtree
                 if (first[r] != c) { D.why = "internal: a small subtree does not start where the previous unit ended"; return; }
                 c1 = r + 1;
+                if (down[r] >= 0) ++us;
                 for (int64_t v = c; v < c1; ++v) { ulo = std::min(ulo, lag_of[v]); uhi = std::max(uhi, lag_of[v]); }
             }
-            if (c1 - c0 > lanes || (uhi >= 0 && uhi - ulo + 1 > wmax)) break;
-            lo = ulo; hi = uhi; c = c1;
+            if (c1 - c0 > lanes || (uhi >= 0 && uhi - ulo + 1 > wmax) || us > kDirectSenders) break;
+            lo = ulo; hi = uhi; senders = us; c = c1;
         }
         if (c == c0) { D.why = "internal: a unit does not fit an empty tile"; return; }
         const int32_t t = D.n_tiles++;
@@ -451,6 +452,13 @@ void build_direct_plan(const std::vector<int32_t> &down, const std::vector<int32
     for (int64_t v = 0; v < n; ++v) {
         if (D.big[v]) D.xinfo[v] = D.skel.inv[v];
         else if (small_root(v) && down[v] >= 0) { D.xinfo[v] = D.skel.ext_ghost[v]; ++D.n_exports; if (D.xinfo[v] < 0) { D.why = "internal: an outlet below the skeleton has no ghost"; return; } }
+    }
+    D.send_ptr.assign((size_t)D.n_tiles + 1, 0);
+    for (int32_t t = 0; t < D.n_tiles; ++t) {
+        for (int32_t v = D.tile_c0[t]; v < D.tile_c0[t] + D.tile_nc[t]; ++v)
+            if (D.xinfo[v] >= 0) D.send_lane.push_back((v - D.tile_c0[t]) | (D.big[v] ? kDirectHole : 0));
+        D.send_ptr[t + 1] = (int32_t)D.send_lane.size();
+        if (D.send_ptr[t + 1] - D.send_ptr[t] > kDirectSenders) { D.why = "internal: a tile has more senders than one wave forwards"; return; }
     }
     D.ok = true;
 }

@@ -128,8 +128,11 @@ struct DirectPlan {
     std::vector<int32_t> up3;          // [n] three 10-bit lane numbers of the upstream reaches (0x3FF: none)
     std::vector<int32_t> xinfo;        // [n] hole: position of the reach in `skel`; outlet of a small subtree below a skeleton reach: position of its ghost there; else -1
     std::vector<uint8_t> big;          // [n] 1: skeleton
+    std::vector<int32_t> send_ptr;     // [n_tiles + 1] the tile's senders (holes and outlets that feed the skeleton, at most kDirectSenders), in column order
+    std::vector<int32_t> send_lane;    // [senders] lane of the tile | kDirectHole
     TilePlan skel;                     // the skeleton's tiles (levels from 1)
 };
+constexpr int32_t kDirectSenders = 64;      // one wave forwards them
 void build_direct_plan(const std::vector<int32_t> &down, const std::vector<int32_t> &lag_of, int32_t lanes, int32_t wmax, int32_t skel_block,
                        DirectPlan &out);
 

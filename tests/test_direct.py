@@ -1,0 +1,256 @@
+"""The direct row path (rr::DirectPlan, k_direct): host-side invariants of the column-range layout (no GPU: plans
+are host-only) and, on the GPU box, the path against the oracle -- network sizes up to 1M reaches, tasks of 64 to 512 rows, cyclic
+forcing arrays, the skeleton's record ring gone round several times, consecutive calls -- and against the record path bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import assert_close
+from oracle import oracle
+from river_route_amd import synth
+from river_route_amd._lib import RR_DEVICE_NONE
+from river_route_amd.engine import DeviceBuffer, Plan
+
+HOLE, GHOST, MASK = 1 << 30, 1 << 28, (1 << 27) - 1
+KNOBS = ('RR_WAVE', 'RR_WAVE_K', 'RR_TILE_BLOCK', 'RR_TILE_LEAN', 'RR_UH_PAIRS', 'RR_DIRECT')
+
+
+def csc_from_down(down_index):
+    has = down_index >= 0
+    indptr = np.concatenate([[0], np.cumsum(has)]).astype(np.int32)
+    return indptr, down_index[has].astype(np.int32)
+
+
+def set_env(monkeypatch, env):
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+
+
+def check_direct_layout(down):
+    n = down.shape[0]
+    indptr, indices = csc_from_down(down)
+    with Plan(indptr, indices, device=RR_DEVICE_NONE) as plan:
+        info = plan.direct_info()
+        assert info['ok'], info['why']
+        L = plan.direct_layout()
+        perm_h, lag_h, _ = plan.layout()
+    lag_of = np.empty(n, np.int64)
+    lag_of[perm_h] = lag_h
+    c0, nc, lo, span, delay, up3, xinfo = (L[k].astype(np.int64) for k in ('tile_c0', 'tile_nc', 'tile_lag_lo', 'tile_span', 'delay', 'up3', 'xinfo'))
+    # the tiles are consecutive column ranges that cover every column once
+    assert c0[0] == 0 and np.array_equal(c0[1:], (c0 + nc)[:-1]) and c0[-1] + nc[-1] == n and nc.min() >= 1 and nc.max() <= 256
+    assert span.max() + 3 == info['window_rows'] <= 72      # the LDS window: span + 1 rows in flight, one arriving, one leaving
+    tile_of = np.repeat(np.arange(c0.size), nc)
+    hole = (delay & HOLE) != 0
+    assert hole.sum() == info['holes']
+    small = ~hole
+    # a lane's delay is its lag above the tile's smallest
+    assert np.array_equal(delay[small], lag_of[small] - lo[tile_of[small]])
+    assert np.all(delay[small] >= 0) and np.all(delay[small] <= span[tile_of[small]])
+    for t in np.unique(tile_of[small]):
+        d = delay[small & (tile_of == t)]
+        assert d.min() == 0 and d.max() == span[t]
+    # the upstream lanes of a lane: exactly the reaches that flow into it, in its tile, one tick ahead, headwaters first
+    n_up = np.bincount(down[down >= 0], minlength=n)
+    lanes = np.stack([(up3 >> (10 * k)) & 0x3FF for k in range(3)], axis=1)
+    cnt = (lanes != 0x3FF).sum(axis=1)
+    assert np.array_equal(cnt[small], n_up[small]) and np.all(cnt[hole] == 0)
+    for k in range(3):
+        sel = small & (lanes[:, k] != 0x3FF)
+        u = c0[tile_of[sel]] + lanes[sel, k]
+        assert np.array_equal(down[u], np.flatnonzero(sel)) and np.array_equal(tile_of[u], tile_of[sel])
+        assert np.array_equal(delay[u], delay[sel] - 1)
+        if k:      # filled from slot 0; a headwater never follows a reach with tributaries
+            prev = c0[tile_of[sel]] + lanes[sel, k - 1]
+            assert np.all(lanes[sel, k - 1] != 0x3FF) and np.all((n_up[prev] == 0) | (n_up[u] > 0))
+    # a hole is a reach with a large or tall subtree; its downstream reach is one too; a small reach below ... is an outlet
+    assert np.all(hole[down[hole & (down >= 0)]])
+    outlet = small & (down >= 0) & hole[np.maximum(down, 0)]
+    assert outlet.sum() == info['outlets'] and np.all(xinfo[outlet] >= 0) and np.all(xinfo[small & ~outlet] == -1)
+    assert np.unique(np.concatenate([xinfo[hole], xinfo[outlet]])).size == hole.sum() + outlet.sum()
+    # the skeleton's positions: its reaches, one ghost per outlet that feeds them, and the ghosts between its own pieces
+    assert info['skeleton_positions'] >= hole.sum() + outlet.sum() and np.concatenate([xinfo[hole], xinfo[outlet]]).max(initial=-1) < info['skeleton_positions']
+    return info, dict(tile_of=tile_of, hole=hole)
+
+
+@pytest.mark.parametrize('n,seed', [(9, 1), (300, 1), (5000, 2), (60000, 21), (250000, 13)])
+def test_postorder_networks_tile_into_column_ranges(n, seed):
+    info, _ = check_direct_layout(synth.synth_network(n, seed=seed, order='postorder').down_index)
+    if n >= 60000:
+        assert info['holes'] <= 0.06 * n and info['tiles'] <= 1.35 * n / 256
+        assert info['skeleton_levels'] <= 26
+
+
+def test_postorder_forest_with_three_way_confluences():
+    net = synth.synth_network_chain(40_000, p_chain=0.3, n_outlets=7, p_third=0.05, seed=5, order='postorder')
+    check_direct_layout(net.down_index)
+
+
+@pytest.mark.parametrize('order', ['random', 'levels', 'bfs'])
+def test_other_orders_keep_to_records(order):
+    net = synth.synth_network(20_000, seed=3, order=order)
+    indptr, indices = csc_from_down(net.down_index)
+    with Plan(indptr, indices, device=RR_DEVICE_NONE) as plan:
+        info = plan.direct_info()
+    assert not info['ok'] and 'contiguous' in info['why']
+
+
+def test_chains_and_wide_confluences_keep_to_records():
+    n = 3000
+    chain = np.arange(1, n + 1, dtype=np.int64)
+    chain[-1] = -1
+    indptr, indices = csc_from_down(chain)
+    with Plan(indptr, indices, device=RR_DEVICE_NONE) as plan:      # a chain is contiguous in any order, but every subtree taller than the window is skeleton
+        info = plan.direct_info()
+    assert not info['ok'] and 'tenth' in info['why']
+    fan = np.concatenate([np.full(5, 5), [-1]]).astype(np.int64)      # five tributaries into one reach
+    indptr, indices = csc_from_down(fan)
+    with Plan(indptr, indices, device=RR_DEVICE_NONE) as plan:
+        info = plan.direct_info()
+    assert not info['ok'] and 'three' in info['why']
+
+
+# ---------------------------------------------------------------------------------------------- on the GPU box
+
+def _case(n, seed, order='postorder', chainy=False):
+    net = (synth.synth_network_chain(n, p_chain=0.3, n_outlets=5, p_third=0.04, seed=seed, order=order) if chainy
+           else synth.synth_network(n, seed=seed, order=order))
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0)
+    return net, indptr, indices, c1, c2, c3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,T,env,chainy', [(9, 40, {}, False), (1000, 100, {}, False), (60_000, 200, {'RR_WAVE_K': '64'}, False),
+                                             (60_000, 333, {'RR_WAVE_K': '128'}, True), (300_000, 150, {}, False),
+                                             (120_000, 600, {'RR_WAVE_K': '256'}, False), (60_000, 97, {'RR_TILE_BLOCK': '64', 'RR_WAVE_K': '32'}, False)])
+def test_direct_rows_vs_oracle(monkeypatch, n, T, env, chainy):
+    """rr_rapid_route_dev on a post-order network: the direct row path runs (plan.last_kernel()), two consecutive calls (state
+    carried), non-zero initial state -- discharge rows and state against the oracle."""
+    set_env(monkeypatch, env)
+    net, indptr, indices, c1, c2, c3 = _case(n, 17, chainy=chainy)
+    lhs, c4_dt = -c1[indices], (c1 + c2) / 900.0
+    q0 = 2.0 * synth.u01(3, np.arange(n))
+    with Plan(indptr, indices) as plan:
+        assert plan.direct_info()['ok'], plan.direct_info()['why']
+        plan.set_coeffs(lhs, c2, c3, c4_dt)
+        d_q, d_ql, d_out = DeviceBuffer(n * 8).upload(q0), DeviceBuffer(T * n * 8), DeviceBuffer(T * n * 8)
+        q_ref = q0.copy()
+        for call in range(2):
+            ql = synth.synth_qlateral(n, call * T, (call + 1) * T)
+            d_ref = np.zeros((T, n))
+            oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql, d_ref, 1)
+            d_ql.upload(ql)
+            plan.rapid_route_dev(d_q, d_ql, T, d_out, T, T, 1)
+            assert plan.last_kernel() == 'direct'
+            assert_close(d_out.download(np.float64, (T, n)), d_ref, f'discharge, call {call}')
+            assert_close(d_q.download(np.float64, (n,)), q_ref, f'q_t, call {call}')
+        for b in (d_q, d_ql, d_out):
+            b.free()
+
+
+@pytest.mark.gpu
+def test_direct_rows_equal_the_record_path_bit_for_bit(monkeypatch):
+    """The same call through the direct row path and through k_tile + the record passes (RR_DIRECT=0): the two add a reach's
+    upstream discharges in the same order and evaluate the same fused multiply-adds, so every row agrees to the last bit."""
+    n, T = 200_000, 300
+    net, indptr, indices, c1, c2, c3 = _case(n, 23)
+    ql = synth.synth_qlateral(n, 0, T)
+    q0 = synth.u01(9, np.arange(n))
+    res = {}
+    for direct in ('1', '0'):
+        set_env(monkeypatch, {'RR_DIRECT': direct})
+        with Plan(indptr, indices) as plan:
+            plan.set_coeffs(-c1[indices], c2, c3, (c1 + c2) / 900.0)
+            d_q, d_ql, d_out = DeviceBuffer(n * 8).upload(q0), DeviceBuffer(ql.nbytes).upload(ql), DeviceBuffer(T * n * 8)
+            plan.rapid_route_dev(d_q, d_ql, T, d_out, T, T, 1)
+            assert plan.last_kernel() == ('direct' if direct == '1' else 'tile')
+            res[direct] = (d_out.download(np.float64, (T, n)), d_q.download(np.float64, (n,)))
+            for b in (d_q, d_ql, d_out):
+                b.free()
+    np.testing.assert_array_equal(res['1'][0], res['0'][0])
+    np.testing.assert_array_equal(res['1'][1], res['0'][1])
+
+
+@pytest.mark.gpu
+def test_direct_rows_cyclic_forcing_and_ring_goes_round_vs_oracle(monkeypatch):
+    """A long call on a cyclic forcing array (row t % rows, what bench.py feeds): the skeleton's record ring goes round four
+    times (RR_WAVE_K=64 keeps it short), 118 direct launches -- every row against the oracle fed the same rows."""
+    set_env(monkeypatch, {'RR_WAVE_K': '64'})
+    n, T, rows = 60_000, 7500, 75
+    net, indptr, indices, c1, c2, c3 = _case(n, 29)
+    lhs, c4_dt = -c1[indices], (c1 + c2) / 900.0
+    ql = synth.synth_qlateral(n, 0, rows)
+    with Plan(indptr, indices) as plan:
+        plan.set_coeffs(lhs, c2, c3, c4_dt)
+        sched = plan.reserve(0, T, 1)
+        assert sched['direct'] and sched['ring_chunks'] * 16 * 3 < T, sched
+        d_q, d_ql, d_out = DeviceBuffer(n * 8).upload(np.zeros(n)), DeviceBuffer(ql.nbytes).upload(ql), DeviceBuffer(T * n * 8)
+        plan.rapid_route_dev(d_q, d_ql, rows, d_out, T, T, 1)
+        assert plan.last_kernel() == 'direct'
+        got, q_got = d_out.download(np.float64, (T, n)), d_q.download(np.float64, (n,))
+        for b in (d_q, d_ql, d_out):
+            b.free()
+    q_ref = np.zeros(n)
+    for r0 in range(0, T, rows):      # the oracle over the same cyclic rows, block by block
+        d_ref = np.zeros((rows, n))
+        oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql, d_ref, 1)
+        assert_close(got[r0:r0 + rows], d_ref, f'rows {r0}..')
+    assert_close(q_got, q_ref, 'q_t')
+
+
+@pytest.mark.gpu
+def test_direct_rows_at_1m_reaches_vs_oracle():
+    """BASELINE config 3's network in post-order, 640 rows in tasks of 128 (the schedule's choice for a call of that length): 4,938
+    column-range tiles, 50,021 holes patched from the skeleton's 30 tile levels -- all 1M columns of every row against the oracle."""
+    n, T = 1_000_000, 640
+    net, indptr, indices, c1, c2, c3 = _case(n, synth.NETWORK_SEED)
+    lhs, c4_dt = -c1[indices], (c1 + c2) / 900.0
+    ql = synth.synth_qlateral(n, 0, T)
+    q_ref, d_ref = np.zeros(n), np.zeros((T, n))
+    oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql, d_ref, 1)
+    with Plan(indptr, indices) as plan:
+        info = plan.direct_info()
+        assert info['ok'] and info['tiles'] > 4000 and info['skeleton_levels'] > 10
+        plan.set_coeffs(lhs, c2, c3, c4_dt)
+        d_q, d_ql, d_out = DeviceBuffer(n * 8).upload(np.zeros(n)), DeviceBuffer(ql.nbytes).upload(ql), DeviceBuffer(T * n * 8)
+        plan.rapid_route_dev(d_q, d_ql, T, d_out, T, T, 1)
+        assert plan.last_kernel() == 'direct' and plan.profile()['ticks_per_launch'] == 128
+        assert_close(d_out.download(np.float64, (T, n)), d_ref, 'discharge')
+        assert_close(d_q.download(np.float64, (n,)), q_ref, 'q_t')
+        for b in (d_q, d_ql, d_out):
+            b.free()
+
+
+@pytest.mark.gpu
+def test_calls_the_direct_path_does_not_take_fall_back_to_records(monkeypatch):
+    """On a post-order plan: sub-steps, channel-only routing and float32 rows keep to the record path, and so does a random order --
+    all against the oracle; a plan whose direct path is switched off says so."""
+    set_env(monkeypatch, {})
+    n, T = 50_000, 64
+    net, indptr, indices, c1, c2, c3 = _case(n, 31)
+    c1s, c2s, c3s = oracle.muskingum_coefficients(net.k, net.x, 450.0)
+    ql = synth.synth_qlateral(n, 0, T)
+    with Plan(indptr, indices) as plan:
+        plan.set_coeffs(-c1s[indices], c2s, c3s, (c1s + c2s) / 900.0)
+        q_ref, d_ref = np.zeros(n), np.zeros((T, n))
+        oracle.rapid_route(indptr, indices, -c1s[indices], c2s, c3s, (c1s + c2s) / 900.0, q_ref, ql, d_ref, 2)
+        d_q, d_ql, d_out = DeviceBuffer(n * 8).upload(np.zeros(n)), DeviceBuffer(ql.nbytes).upload(ql), DeviceBuffer(T * n * 8)
+        plan.rapid_route_dev(d_q, d_ql, T, d_out, T, T, 2)
+        assert plan.last_kernel() == 'tile'
+        assert_close(d_out.download(np.float64, (T, n)), d_ref, 'two sub-steps')
+        plan.set_coeffs(-c1[indices], c2, c3, (c1 + c2) / 900.0)
+        q_ref, d_ref = np.zeros(n), np.zeros((T, n))
+        oracle.rapid_route(indptr, indices, -c1[indices], c2, c3, (c1 + c2) / 900.0, q_ref, ql, d_ref, 1)
+        d_ql32, d_out32 = DeviceBuffer(T * n * 4).upload(ql.astype(np.float32)), DeviceBuffer(T * n * 4)
+        d_q.upload(np.zeros(n))
+        plan.rapid_route_f32_dev(d_q, d_ql, T, d_out32, T, 1, 1)
+        assert plan.last_kernel() == 'tile'
+        np.testing.assert_allclose(d_out32.download(np.float32, (T, n)), d_ref.astype(np.float32), rtol=1.2e-7, atol=1e-10 * np.abs(d_ref).max())
+        d_q.upload(np.zeros(n))
+        plan.rapid_route_dev(d_q, d_ql, T, d_out, T, T, 1)      # and back on the direct path, after the record path used the plan
+        assert plan.last_kernel() == 'direct'
+        assert_close(d_out.download(np.float64, (T, n)), d_ref, 'direct after records')
+        for b in (d_q, d_ql, d_out, d_ql32, d_out32):
+            b.free()
