@@ -52,8 +52,15 @@ struct DirectArgs {
 constexpr int32_t kDirectHoleBit = rr::kDirectHole;
 constexpr int kDirectLanes = 256, kDirectAhead = 16;
 constexpr int kDirectThreads = kDirectLanes + 3 * 64;      // four routing waves + in, out, send
-constexpr int kDirectMaxWindow = 72;      // rows of the LDS window, span + 3: 2 x 258 + 72 x 256 doubles = 151.6 KB of the CU's 160
-constexpr size_t direct_lds_bytes(int window_rows) { return (size_t)(2 * (kDirectLanes + kTilePad) + (int64_t)window_rows * kDirectLanes) * sizeof(double); }
+constexpr int kDirectMaxWindow = 64;      // rows of the LDS window, span + 3
+constexpr int kDirectSenders = rr::kDirectSenders;      // per tile: one lane of wave 6 each
+// LDS in doubles: X[2][258] | staging of wave 6: S[senders][2][16] values, SM[senders] record offsets, SP[senders] pending words |
+// F[window rows][256]: 4.1 + 16.9 + 131 KB = 152 KB of the CU's 160 with the largest window
+constexpr int kDirectStage = kDirectSenders * 2 * kRec + 2 * kDirectSenders;      // doubles
+constexpr size_t direct_lds_bytes(int window_rows)
+{
+    return (size_t)(2 * (kDirectLanes + kTilePad) + kDirectStage + (int64_t)window_rows * kDirectLanes) * sizeof(double);
+}
 
 __device__ __forceinline__ double2 load_f64x2_(__amdgpu_buffer_rsrc_t r, uint32_t byte_off)
 {
@@ -68,9 +75,10 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int TH = kDirectLanes, THP = TH + kTilePad;
-    static_assert(PF % 2 == 0, "the parity of a tick is the parity of its place in a chunk");
+    static_assert(PF % 2 == 0 && PF == kRec, "the parity of a tick is the parity of its place in a chunk; wave 6 writes a record per sender and chunk");
     char *const X = reinterpret_cast<char *>(lds);                  // [2][THP] discharges of the last two ticks, each followed by a slot that holds 0.0
-    char *const F = reinterpret_cast<char *>(lds + 2 * THP);        // [span + 3][TH] the row window
+    double *const S = lds + 2 * THP;                                // wave 6's staging (below)
+    char *const F = reinterpret_cast<char *>(lds + 2 * THP + kDirectStage);        // [span + 3][TH] the row window
     const int tid = threadIdx.x, role = tid >> 6 < 4 ? 0 : (tid >> 6) - 3, ln = tid & 63;      // 0 route, 1 in, 2 out, 3 send
     if (tid < 2) lds[tid * THP + TH] = 0.0;
     const int32_t r0 = a.m * a.K, nrows = min(a.K, a.total - r0);
@@ -198,6 +206,12 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             }
         } else {
             // ---------------------------------------------------------------- wave 6: what the skeleton needs
+            // Lane = sender.  Every tick it copies its value of the tick before -- a hole's scaled lateral inflow from the window, an
+            // outlet's discharge from the discharge buffer -- into its half of the staging area S[lane][parity][slot]; a record (16
+            // ticks, slot = tick % 16 with tick = row + lag: k_tile's layout) that is complete is posted in SM / SP, and every PF
+            // ticks the wave writes the posted records, eight lanes per 128-byte record (8-byte stores took a fifth of the kernel:
+            // profiles/r04_direct_role_ablation.txt).  A task's first and last record are partly the neighbouring tasks': only the
+            // slots [from, to) this task made are written.
             const int32_t s0 = a.send_ptr[t], ns = a.send_ptr[t + 1] - s0;
             const bool mine = ln < ns;
             const int32_t sl = mine ? a.send_lane[s0 + ln] : 0;
@@ -206,11 +220,40 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             const int4 lm = a.lane[tm.c0 + lane];
             const int32_t delta = hole ? 0 : lm.x;
             // the value of local row j sits, one tick after it was made: a hole's in the window (slot j mod (span + 3)), an outlet's in the
-            // discharge buffer its tick wrote; its record slot is tick r0 + j + lag
-            int32_t src_b = hole ? 2 * THP * 8 + lane * 8 : lane * 8;      // byte offset in LDS of row (k - 1 - delta) at tick k
-            uint32_t tg = (uint32_t)(r0 + lm.w), xslot = tg & 15u, xchunk = (tg >> 4) % a.rec_chunks;
-            double *dst = a.rec + ((int64_t)xchunk * a.np + (mine ? lm.z : 0)) * kRec + xslot;
-            const int64_t chunk_step = (int64_t)a.np * kRec - 15, ring_back = (int64_t)a.rec_chunks * a.np * kRec;
+            // discharge buffer its tick wrote
+            const int32_t f_b = (int32_t)(reinterpret_cast<char *>(F) - reinterpret_cast<char *>(lds));
+            int32_t src_b = hole ? f_b + lane * 8 : lane * 8;      // byte offset in LDS of local row (k - 1 - delta)'s value at tick k
+            const uint32_t tg = (uint32_t)(r0 + lm.w);             // record slot of local row 0: tick r0 + lag
+            uint32_t xslot = tg & 15u, xchunk = (tg >> 4) % a.rec_chunks, from = xslot, par = 0;
+            int64_t rec_off = ((int64_t)xchunk * a.np + (mine ? lm.z : 0)) * kRec;      // in doubles: the record being filled
+            const int64_t chunk_step = (int64_t)a.np * kRec, ring = (int64_t)a.rec_chunks * a.np * kRec;
+            double *mystage = S + ln * (2 * kRec);
+            int64_t *const SM = reinterpret_cast<int64_t *>(S + kDirectSenders * 2 * kRec);
+            int32_t *const SP = reinterpret_cast<int32_t *>(S + kDirectSenders * 2 * kRec + kDirectSenders);      // 0: nothing posted; else 1 + parity | from << 8 | to << 16
+            SP[ln] = 0;
+            auto post = [&](uint32_t to) {
+                SM[ln] = rec_off;
+                SP[ln] = (int32_t)(1u + par) | (int32_t)(from << 8) | (int32_t)(to << 16);
+            };
+            auto flush = [&]() {      // lanes 8 i .. 8 i + 7: the eight 16-byte pieces of sender (8 g + i)'s posted record
+                wave_lds_fence();
+                for (int32_t g = 0; 8 * g < ns; ++g) {
+                    const int32_t snd = 8 * g + (ln >> 3), piece = ln & 7;
+                    const int32_t word = SP[snd];
+                    if (word) {
+                        const int32_t lo = (word >> 8) & 0xFF, hi = (word >> 16) & 0xFF;
+                        const double2 v = *reinterpret_cast<const double2 *>(S + snd * (2 * kRec) + ((word & 0xFF) - 1) * kRec + 2 * piece);
+                        double *dst = a.rec + SM[snd] + 2 * piece;
+                        if (lo <= 2 * piece && 2 * piece + 2 <= hi) *reinterpret_cast<double2 *>(dst) = v;
+                        else {
+                            if (lo <= 2 * piece && 2 * piece < hi) dst[0] = v.x;
+                            if (lo <= 2 * piece + 1 && 2 * piece + 1 < hi) dst[1] = v.y;
+                        }
+                    }
+                }
+                wave_lds_fence();
+                SP[ln] = 0;
+            };
             __syncthreads();
             for (int32_t k0 = 0; k0 < n_ticks; k0 += PF) {
 #pragma unroll
@@ -218,19 +261,21 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                     const int32_t j = k0 + s - 1 - delta;      // the local row whose value was made at tick k - 1
                     if (mine && (uint32_t)j < (uint32_t)nrows) {
                         const int32_t at = hole ? src_b : src_b + ((s + 1) & 1) * (THP * 8);      // tick k - 1 wrote discharge buffer (k - 1) & 1
-                        *dst = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lds) + at);
-                        if (hole) src_b = src_b + kRowB == 2 * THP * 8 + wrap + lane * 8 ? 2 * THP * 8 + lane * 8 : src_b + kRowB;
-                        if (++xslot == 16) {
-                            xslot = 0;
-                            dst += chunk_step;
-                            if (++xchunk == a.rec_chunks) { xchunk = 0; dst -= ring_back; }
-                        } else {
-                            ++dst;
+                        mystage[par * kRec + xslot] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lds) + at);
+                        if (hole) src_b = src_b + kRowB == f_b + wrap + lane * 8 ? f_b + lane * 8 : src_b + kRowB;
+                        if (++xslot == 16) {      // complete: post it and move on to the next chunk's record
+                            post(16);
+                            xslot = 0; from = 0; par ^= 1u;
+                            rec_off += chunk_step;
+                            if (++xchunk == a.rec_chunks) { xchunk = 0; rec_off -= ring; }
                         }
                     }
+                    if (s == PF - 1) flush();      // a sender completes at most one record in PF = 16 ticks
                     barrier_lds();
                 }
             }
+            if (mine && xslot > from) post(xslot);      // the task's last record: the slots it made
+            flush();
         }
     }
 }
