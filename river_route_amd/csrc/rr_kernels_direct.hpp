@@ -23,14 +23,14 @@ namespace {
 // A tick is bound by instruction issue and LDS latency, not by arithmetic: one wave per SIMD issues a vector instruction every
 // ~4 cycles, and the first version -- every lane loading, routing, forwarding and storing -- ran 110 instructions and two LDS
 // round trips per tick: 816 cycles.  So the workgroup is SPECIALISED: waves 0-3 route (lane = column: five LDS reads, five
-// multiply-adds, two LDS writes), wave 4 brings the rows in (two 16-byte loads per lane and tick, scaled by c4dt into the window
-// one tick before the first lane needs them), wave 5 takes finished rows out (one tick after the last lane wrote them), wave 6
-// forwards what the skeleton needs: the work of a tick is spread over seven instruction streams that meet at the tick's barrier.
+// multiply-adds, two LDS writes), waves 4 and 5 bring the rows in (a 16-byte load per lane and tick, 32 rows ahead, scaled by c4dt
+// into the window one tick before the first lane needs them), wave 6 takes finished rows out (one tick after the last lane wrote
+// them), wave 7 forwards what the skeleton needs: eight instruction streams, two per SIMD, that meet at the tick's barrier.
 //
 // The skeleton (reaches with large or tall subtrees: 5 %) keeps records and k_tile.  Its columns lie between the subtrees'
-// columns (HOLES).  Wave 6 copies a hole's scaled lateral inflow from the window into the skeleton position's record, and the
+// columns (HOLES).  Wave 7 copies a hole's scaled lateral inflow from the window into the skeleton position's record, and the
 // discharge of an outlet lane (a small subtree's last reach) into the record of the ghost that mirrors it in the skeleton, 8 bytes
-// per tick and sender; k_rec_out, given the holes' columns, patches the output rows from the skeleton's records afterwards.
+// per tick and sender (whole records at a time); k_rec_out, given the holes' columns, patches the output rows from the skeleton's records afterwards.
 struct DirectTile { int32_t c0, nc, lag_lo, span; };
 struct DirectArgs {
     const DirectTile *tiles;
@@ -51,10 +51,10 @@ struct DirectArgs {
 };
 constexpr int32_t kDirectHoleBit = rr::kDirectHole;
 constexpr int kDirectLanes = 256, kDirectAhead = 16;
-constexpr int kDirectThreads = kDirectLanes + 3 * 64;      // four routing waves + in, out, send
+constexpr int kDirectThreads = kDirectLanes + 4 * 64;      // four routing waves + in, in, out, send: two waves per SIMD
 constexpr int kDirectMaxWindow = 64;      // rows of the LDS window, span + 3
-constexpr int kDirectSenders = rr::kDirectSenders;      // per tile: one lane of wave 6 each
-// LDS in doubles: X[2][258] | staging of wave 6: S[senders][2][16] values, SM[senders] record offsets, SP[senders] pending words |
+constexpr int kDirectSenders = rr::kDirectSenders;      // per tile: one lane of wave 7 each
+// LDS in doubles: X[2][258] | staging of wave 7: S[senders][2][16] values, SM[senders] record offsets, SP[senders] pending words |
 // F[window rows][256]: 4.1 + 16.9 + 131 KB = 152 KB of the CU's 160 with the largest window
 constexpr int kDirectStage = kDirectSenders * 2 * kRec + 2 * kDirectSenders;      // doubles
 constexpr size_t direct_lds_bytes(int window_rows)
@@ -77,9 +77,9 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
     constexpr int TH = kDirectLanes, THP = TH + kTilePad;
     static_assert(PF % 2 == 0 && PF == kRec, "the parity of a tick is the parity of its place in a chunk; wave 6 writes a record per sender and chunk");
     char *const X = reinterpret_cast<char *>(lds);                  // [2][THP] discharges of the last two ticks, each followed by a slot that holds 0.0
-    double *const S = lds + 2 * THP;                                // wave 6's staging (below)
+    double *const S = lds + 2 * THP;                                // wave 7's staging (below)
     char *const F = reinterpret_cast<char *>(lds + 2 * THP + kDirectStage);        // [span + 3][TH] the row window
-    const int tid = threadIdx.x, role = tid >> 6 < 4 ? 0 : (tid >> 6) - 3, ln = tid & 63;      // 0 route, 1 in, 2 out, 3 send
+    const int tid = threadIdx.x, wave = tid >> 6, role = wave < 4 ? 0 : (wave < 6 ? 1 : wave - 4), ln = tid & 63;      // 0 route, 1 in (two waves), 2 out, 3 send
     if (tid < 2) lds[tid * THP + TH] = 0.0;
     const int32_t r0 = a.m * a.K, nrows = min(a.K, a.total - r0);
     const uint32_t row_bytes = (uint32_t)a.n * 8u;                  // n < 2^29 (choose_schedule)
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
     for (int32_t t = (int32_t)blockIdx.x; t < a.n_tiles; t += (int32_t)gridDim.x) {
         const DirectTile tm = a.tiles[t];
         const int32_t span = tm.span, wrap = (span + 3) * kRowB;     // bytes of the window in use
-        // local tick k: row k + 1 arrives (wave 4), lane with delay d routes row k - d (waves 0-3), row k - 1 - span leaves (wave 5),
-        // the values of tick k - 1 are forwarded (wave 6); n_ticks of them, in chunks of PF
+        // local tick k: row k + 1 arrives (waves 4, 5), lane with delay d routes row k - d (waves 0-3), row k - 1 - span leaves (wave 6),
+        // the values of tick k - 1 are forwarded (wave 7); n_ticks of them, in chunks of PF
         const int32_t n_ticks = nrows + span + 2;
         __syncthreads();      // every wave has left the previous tile
 
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             int32_t own_b = idle || delta == 0 ? 0 : wrap - delta * kRowB;      // window slot of the row this lane routes this tick: (k - delta) mod (span + 3)
             if (!idle && delta > 0 && own_b < 0) own_b += wrap;                   // (delta <= span < span + 3)
             double s_prev = 0.0;
-            __syncthreads();      // the discharges carried in, and row 0 in the window (wave 4)
+            __syncthreads();      // the discharges carried in, and row 0 in the window (waves 4, 5)
             auto ticks = [&](auto tested, int32_t k0) {
 #pragma unroll
                 for (int s = 0; s < PF; ++s) {
@@ -140,43 +140,49 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             }
             if (!idle) a.q[col] = *reinterpret_cast<const double *>(X + THP * 8 + tid * 8);      // PF is even: the last tick wrote buffer 1
         } else if (role == 1) {
-            // ---------------------------------------------------------------- wave 4: rows in.  Lane -> columns 2 ln, 2 ln + 1 and 128 + 2 ln, 128 + 2 ln + 1
-            const int32_t ca = 2 * ln, cb = TH / 2 + 2 * ln;
+            // ---------------------------------------------------------------- waves 4, 5: rows in.  Wave 4 + h, lane -> columns 128 h + 2 ln, 128 h + 2 ln + 1
+            const int32_t ca = (wave - 4) * (TH / 2) + 2 * ln;
             auto c4_of = [&](int32_t c) { return c < tm.nc ? a.coef[4 * (int64_t)(tm.c0 + c) + 3] : 0.0; };
-            const double c4a0 = c4_of(ca), c4a1 = c4_of(ca + 1), c4b0 = c4_of(cb), c4b1 = c4_of(cb + 1);
+            const double c4a0 = c4_of(ca), c4a1 = c4_of(ca + 1);
             // a 16-byte load may reach past the tile's last column (the next tile's, or -- past the row's end -- zeros): never used
-            const uint32_t va = ca < tm.nc ? (uint32_t)(tm.c0 + ca) * 8u : kDropAccess, vb = cb < tm.nc ? (uint32_t)(tm.c0 + cb) * 8u : kDropAccess;
+            const uint32_t va = ca < tm.nc ? (uint32_t)(tm.c0 + ca) * 8u : kDropAccess;
             uint32_t rin = (uint32_t)r0 % a.in_rows;
             const double *row = a.in + (int64_t)rin * a.n;
-            double2 Pa[PF], Pb[PF];
-            auto request = [&](int32_t arrival, double2 &pa, double2 &pb) {      // row r0 + arrival, or nothing past the task's rows
+            // AH rows in flight: a tick cannot be shorter than the memory latency over AH (16 rows ahead held the tick at 0.21 us:
+            // 32 KB per CU in flight against ~3 us under load); the register ring is indexed statically: two chunk bodies alternate
+            constexpr int AH = 2 * PF;
+            double2 Pa[AH];
+            auto request = [&](int32_t arrival, double2 &pa) {      // row r0 + arrival, or nothing past the task's rows
                 const __amdgpu_buffer_rsrc_t src = make_rsrc(row, row_bytes);
                 pa = load_f64x2_(src, arrival < nrows ? va : kDropAccess);
-                pb = load_f64x2_(src, arrival < nrows ? vb : kDropAccess);
                 ++rin; row += a.n;
                 if (rin == a.in_rows) { rin = 0; row = a.in; }
             };
 #pragma unroll
-            for (int j = 0; j < PF; ++j) request(j, Pa[j], Pb[j]);
+            for (int j = 0; j < AH; ++j) request(j, Pa[j]);
             int32_t in_b = 0;
-            auto park = [&](const double2 &pa, const double2 &pb) {      // into the window, scaled (the ring of k_tile holds c4dt * lateral too)
+            auto park = [&](const double2 &pa) {      // into the window, scaled (the ring of k_tile holds c4dt * lateral too)
                 *reinterpret_cast<double2 *>(F + in_b + ca * 8) = make_double2(pa.x * c4a0, pa.y * c4a1);
-                *reinterpret_cast<double2 *>(F + in_b + cb * 8) = make_double2(pb.x * c4b0, pb.y * c4b1);
                 in_b = in_b + kRowB == wrap ? 0 : in_b + kRowB;
             };
-            park(Pa[0], Pb[0]);      // row 0, before the first tick
-            request(PF, Pa[0], Pb[0]);
+            park(Pa[0]);      // row 0, before the first tick
+            request(AH, Pa[0]);
             __syncthreads();
-            for (int32_t k0 = 0; k0 < n_ticks; k0 += PF) {
+            auto chunk = [&](auto half, int32_t k0) {      // ticks k0 ... k0 + PF - 1; k0 = PF (2 c + half): row k0 + s + 1 sits in P[(k0 + s + 1) % AH]
 #pragma unroll
-                for (int s = 0; s < PF; ++s) {      // tick k0 + s: row k0 + s + 1 arrives, row k0 + s + 1 + PF is requested
-                    park(Pa[(s + 1) % PF], Pb[(s + 1) % PF]);
-                    request(k0 + s + 1 + PF, Pa[(s + 1) % PF], Pb[(s + 1) % PF]);
+                for (int s = 0; s < PF; ++s) {      // tick k0 + s: row k0 + s + 1 arrives, row k0 + s + 1 + AH is requested
+                    constexpr int base = decltype(half)::value * PF;
+                    park(Pa[(base + s + 1) % AH]);
+                    request(k0 + s + 1 + AH, Pa[(base + s + 1) % AH]);
                     barrier_lds();
                 }
+            };
+            for (int32_t k0 = 0; k0 < n_ticks; k0 += 2 * PF) {
+                chunk(std::integral_constant<int, 0>(), k0);
+                if (k0 + PF < n_ticks) chunk(std::integral_constant<int, 1>(), k0 + PF);
             }
         } else if (role == 2) {
-            // ---------------------------------------------------------------- wave 5: rows out.  The same columns as wave 4
+            // ---------------------------------------------------------------- wave 6: rows out.  Lane -> columns 2 ln, 2 ln + 1 and 128 + 2 ln, 128 + 2 ln + 1
             const int32_t ca = 2 * ln, cb = TH / 2 + 2 * ln;
             // whole 16-byte pieces inside the tile; the piece that holds the tile's last column when nc is odd goes as 8 bytes
             const uint32_t va = ca + 1 < tm.nc ? (uint32_t)(tm.c0 + ca) * 8u : kDropAccess, vb = cb + 1 < tm.nc ? (uint32_t)(tm.c0 + cb) * 8u : kDropAccess;
@@ -205,7 +211,7 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                 }
             }
         } else {
-            // ---------------------------------------------------------------- wave 6: what the skeleton needs
+            // ---------------------------------------------------------------- wave 7: what the skeleton needs
             // Lane = sender.  Every tick it copies its value of the tick before -- a hole's scaled lateral inflow from the window, an
             // outlet's discharge from the discharge buffer -- into its half of the staging area S[lane][parity][slot]; a record (16
             // ticks, slot = tick % 16 with tick = row + lag: k_tile's layout) that is complete is posted in SM / SP, and every PF
