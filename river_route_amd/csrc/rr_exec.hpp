@@ -903,6 +903,9 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
 // the skeleton's tiles of level l run macro-chunk d - l on those records (levels start at 1: what they read was written by an
 // earlier launch); rows all of whose skeleton reaches are final get their holes patched from the records (k_rec_out over the
 // holes' columns), 128 rows at a time, which also frees their ring slots.
+// (The skeleton's launches and the out-pass on a second stream beside the direct launches, with or without CUs set aside for them,
+// changed nothing -- 212 to 226 ms per year against 212: profiles/r04_direct_second_stream_ab.txt -- the out-pass's scattered
+// 8-byte stores, 5 % of the columns, compete for the same memory system.)
 int session_advance_direct(rr_plan *P, int64_t rows_ready)
 {
     Session &S = P->ses;
