@@ -49,11 +49,14 @@ def parse_args():
     ap.add_argument('--reaches', type=int, default=None, help='reaches per GPU (default 1,000,000 at N = 1; 1,250,000 at N > 1: BASELINE config 5 is 10M reaches on 8 GPUs)')
     ap.add_argument('--runoff-steps', type=int, default=35_040, help='runoff steps per bench step (1 yr @ 15 min)')
     ap.add_argument('--substeps', type=int, default=1)
-    ap.add_argument('--forcing-rows', type=int, default=288,
-                    help='rows of the cyclic device-resident forcing (three days): more than the 143 rows one in-pass launch reads, so no launch reads a forcing row twice')
+    ap.add_argument('--forcing-rows', type=int, default=0,
+                    help='rows of the cyclic device-resident forcing; 0 = 288 (three days: more than the 143 rows one in-pass launch reads, so no launch reads a '
+                         'forcing row twice), 1,024 on the direct row path (8 GB: a tile comes back to a row after the chip has streamed the whole array)')
     ap.add_argument('--sink-rows', type=int, default=0,
-                    help='rows of the cyclic discharge sink; 0 = one out-pass launch (128), so that no launch writes a row twice')
-    ap.add_argument('--order', default='random', choices=['random', 'levels', 'bfs'])
+                    help='rows of the cyclic discharge sink; 0 = one out-pass launch (128), so that no launch writes a row twice; 1,024 on the direct row path')
+    ap.add_argument('--order', default='random', choices=['random', 'levels', 'bfs', 'postorder'],
+                    help="params-file order of the synthetic network; 'postorder' (depth-first post-order: every sub-basin a run of consecutive "
+                         "columns) lets the engine route straight from and to the rows (direct row path, DESIGN.md section 3d)")
     ap.add_argument('--sample-every', type=int, default=128)
     ap.add_argument('--chunk-rows', type=int, default=16)
     ap.add_argument('--cpu-baseline-steps', type=int, default=96)
@@ -68,7 +71,7 @@ def parse_args():
                     help="N = 1: skip the `secondary` entries (BASELINE configs 2 and 4 behind their own oracle gates)")
     ap.add_argument('--cpu-replicas', type=int, default=-1,
                     help="also time N independent oracle replicas on N cores (the only parallelism the reference endorses, "
-                         "docs/references/parallelism.md:67-114); 0 = off, -1 = one per core up to 16")
+                         "docs/references/parallelism.md:67-114); 0 = off, -1 = a sweep over 16 / 64 / 256 / all cores")
     a = ap.parse_args()
     if a.reaches is None:
         a.reaches = 1_000_000 if a.gpus == 1 and int(os.environ.get('WORLD_SIZE', '1')) == 1 else 1_250_000
@@ -147,16 +150,21 @@ def _replica_worker(args):
 
 def cpu_replicas(replicas, indptr, indices, lhs, c2, c3, c4_dt, ql, nsub, out_dir, seconds):
     """N independent replicas on N cores (docs/references/parallelism.md:67-114: one process per ensemble member or
-    watershed is the only parallelism the reference endorses).  Shorter forcing so N copies fit host memory."""
+    watershed is the only parallelism the reference endorses), at several widths up to the box's core count: the line shows
+    where the host saturates (every replica streams its own 1M-reach arrays through the memory system) and reports the best
+    aggregate.  Shorter forcing so N copies fit host memory; before this process touches the GPU (the replicas fork)."""
     import multiprocessing as mp
     cores = os.cpu_count() or 1
-    N = min(cores, 16) if replicas < 0 else min(replicas, cores)
-    rows = ql[:min(ql.shape[0], 16)]
-    with mp.get_context('fork').Pool(N) as pool:
-        res = pool.map(_replica_worker, [(indptr, indices, lhs, c2, c3, c4_dt, rows, nsub, out_dir, min(seconds, 4.0))] * N)
-    total = sum(r[0] for r in res) / max(r[1] for r in res)
-    return {'value': total, 'unit': 'reach-steps/s', 'cores': N,
-            'sample': f'{N} independent single-thread replicas of the same network, {rows.shape[0]} forcing rows each'}
+    widths = sorted({min(w, cores) for w in ((16, 64, 256, cores) if replicas < 0 else (replicas,))})
+    rows = ql[:min(ql.shape[0], 8)]
+    sweep = []
+    for N in widths:
+        with mp.get_context('fork').Pool(N) as pool:
+            res = pool.map(_replica_worker, [(indptr, indices, lhs, c2, c3, c4_dt, rows, nsub, out_dir, min(seconds, 3.0))] * N)
+        sweep.append({'replicas': N, 'value': sum(r[0] for r in res) / max(r[1] for r in res)})
+    best = max(sweep, key=lambda e: e['value'])
+    return {'value': best['value'], 'unit': 'reach-steps/s', 'cores': best['replicas'], 'host_cores': cores, 'sweep': sweep,
+            'sample': f'independent single-thread replicas of the same network, {rows.shape[0]} forcing rows each, ~3 s per width; best of {[e["replicas"] for e in sweep]}'}
 
 
 def bench_unit(args, device_index):
@@ -238,6 +246,9 @@ def bench_unit(args, device_index):
     if base is not None and prof['ticks_per_launch'] > 1 and chk_kernel <= 1:
         raise SystemExit('bench.py: the parity gate did not run the timed kernel; refusing to report a number')
     roofline = roofline_from_profile(prof, nsub, HBM_PEAK_GBS, copy_gbs=copy_bandwidth(device_index), unit=True)
+    whole_path(roofline, prof, plan.profile_aux(), plan.last_kernel(), float(n) * T * nsub * args.steps / elapsed, None)
+    if roofline is not None and 'k_rec_in' in roofline['path']['kernels']:
+        roofline['path']['kernels'][f'k_rec_in_uh (convolution fused, {n_ks} taps)'] = roofline['path']['kernels'].pop('k_rec_in')
     line = {'metric': 'reach-steps/sec', 'value': float(n) * T * nsub * args.steps / elapsed, 'unit': 'reach-steps/s',
             'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
@@ -316,7 +327,7 @@ def main():
 
     from river_route_amd import synth
     n, T, nsub, dt = args.reaches, args.runoff_steps, args.substeps, 900.0
-    rows = min(args.forcing_rows, T)
+    rows = min(args.forcing_rows or 288, T)
     net = indptr = indices = c1 = c2 = c3 = base = None
     if world == 1 and args.workload == 'rapid':
         net = synth.synth_network(n, order=args.order)
@@ -412,7 +423,7 @@ def secondary_lines(args, device_index):
     net = synth.synth_network(a.reaches, order=a.order)
     indptr, indices = csc_from_down(net.down_index)
     c1, c2, c3 = muskingum_coefficients(net.k, net.x, 900.0)
-    base = None if a.no_cpu_baseline else cpu_baseline(net, indptr, indices, c1, c2, c3, 900.0, a.substeps, min(a.cpu_baseline_steps, a.forcing_rows), 1.0, 0)
+    base = None if a.no_cpu_baseline else cpu_baseline(net, indptr, indices, c1, c2, c3, 900.0, a.substeps, min(a.cpu_baseline_steps, a.forcing_rows or 288), 1.0, 0)
     line = bench_rapid(a, device_index, net, indptr, indices, c1, c2, c3, base)
     line['config']['baseline_config'] = 2
     out.append(line)
@@ -422,6 +433,150 @@ def secondary_lines(args, device_index):
     line['config']['baseline_config'] = 4
     out.append(line)
     out.append(bench_rapid_f32(args, device_index))
+    # the headline's network with its params file in depth-first post-order: the direct row path (no record ring and no permutation
+    # pass for 95 % of the columns)
+    a = copy.copy(args)
+    a.order, a.cpu_baseline_seconds, a.cpu_replicas = 'postorder', 1.0, 0
+    net = synth.synth_network(a.reaches, order=a.order)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = muskingum_coefficients(net.k, net.x, 900.0)
+    base = None if a.no_cpu_baseline else cpu_baseline(net, indptr, indices, c1, c2, c3, 900.0, a.substeps, a.cpu_baseline_steps, 1.0, 0)
+    line = bench_rapid(a, device_index, net, indptr, indices, c1, c2, c3, base)
+    line['config']['variant_of_baseline_config'] = 3
+    out.append(line)
+    del net, indptr, indices, c1, c2, c3, base
+    out.extend(bench_dropin(args, device_index))
+    return out
+
+
+def _rss_gb():
+    import resource
+    return round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 2)      # high-water mark of this process, GB
+
+
+def bench_dropin(args, device_index, T: int = 744):
+    """What a drop-in caller gets, PCIe and files included (the shape of the reference's own harness, tests/test_zbenchmarks.py:29-152:
+    wall time and peak memory of route-from-qlateral, route-from-depths, end to end through .route()), each checked against the oracle
+    on its first rows: (i) kernels.rapid_route with numpy arrays -- the three-line swap of INTEGRATION.md, host pointers through the
+    C ABI; (ii) RapidMuskingum(config).route() from a float32 qlateral netCDF to a discharge netCDF; (iii) UnitMuskingum(config)
+    .route() from runoff depths.  One month of hourly rows (744) on the headline's network.  `value` is reach-steps per second of wall time."""
+    import shutil
+    import tempfile
+    import pandas as pd
+    from scipy.io import netcdf_file
+    import scipy.sparse
+    from oracle import oracle
+    import river_route_amd as rr
+    from river_route_amd import kernels, synth
+    try:
+        import pyarrow  # noqa: F401
+    except ImportError:      # this image has pandas without a parquet engine: params / state tables travel as pickles (as in tests/conftest.py)
+        pd.read_parquet = lambda path, columns=None, **kw: (pd.read_pickle(path)[list(columns)] if columns is not None else pd.read_pickle(path))
+        pd.DataFrame.to_parquet = lambda self, path, **kw: self.to_pickle(path)
+    n, dt = args.reaches, 3600.0
+    net = synth.synth_network(n, order=args.order)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = muskingum_coefficients(net.k, net.x, dt)
+    lhs, c4_dt = -c1[indices], (c1 + c2) / dt
+    ql = synth.synth_qlateral(n, 0, T, dt=dt)
+    chk = 48
+    q_ref, d_ref = np.zeros(n), np.zeros((chk, n))
+    oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql[:chk], d_ref, 1)
+    scale = float(np.abs(d_ref).max())
+    out = []
+
+    def entry(what, seconds, gate, extra=None):
+        e = {'metric': 'reach-steps/sec', 'value': float(n) * T / seconds, 'unit': 'reach-steps/s', 'n_gpus': 1, 'steps': 1, 'warmup': 1,
+             'ms_per_step': seconds * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+             'config': {'workload': what, 'reaches': n, 'runoff_steps': T, 'params_order': args.order, 'timed_region': 'wall clock of the call, host arrays / files in and out',
+                        'peak_host_rss_gb': _rss_gb()},
+             'roofline': None, 'cpu_baseline': {'parity_gate': gate}}
+        if extra:
+            e['config'].update(extra)
+        out.append(e)
+
+    # (i) the kernel boundary with numpy arrays
+    d = np.zeros((T, n))
+    for rep in range(2):      # the first call builds and caches the plan, as the reference's first call compiles
+        q = np.zeros(n)
+        t0 = time.perf_counter()
+        kernels.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q, ql, d, 1)
+        sec = time.perf_counter() - t0
+    if not np.allclose(d[:chk], d_ref, rtol=1e-10, atol=1e-10 * scale):
+        raise SystemExit('bench.py: kernels.rapid_route differs from the oracle; refusing to report a number')
+    entry(f'kernels.rapid_route(numpy arrays): {n} reaches x {T} hourly rows, float64 host arrays in and out through rr_rapid_route (PCIe both ways)', sec,
+          f'first {chk} rows == oracle, rtol 1e-10')
+    kernels.clear_plan_cache()
+    del d
+
+    tmp = tempfile.mkdtemp(prefix='rr_bench_')
+    try:
+        params = os.path.join(tmp, 'params.parquet')
+        pd.DataFrame({'river_id': net.river_ids, 'downstream_river_id': net.downstream_ids, 'k': net.k, 'x': net.x}).to_parquet(params)
+        dates = (np.datetime64('2020-01-01T00:00:00', 's') + np.arange(T) * np.timedelta64(int(dt), 's')).astype('datetime64[s]').astype(np.int64).astype(np.float64)
+
+        def write_rows(path, var, rows32):
+            with netcdf_file(path, 'w', version=2) as ds:
+                ds.createDimension('time', T)
+                ds.createDimension('river_id', n)
+                tv = ds.createVariable('time', 'f8', ('time',))
+                tv.units = 'seconds since 1970-01-01 00:00:00'
+                tv[:] = dates
+                rid = ds.createVariable('river_id', 'i4', ('river_id',))
+                rid[:] = net.river_ids.astype(np.int32)
+                v = ds.createVariable(var, 'f4', ('time', 'river_id'))
+                v[:] = rows32
+
+        def read_q(path, rows):
+            with netcdf_file(path, 'r', mmap=True) as ds:
+                return np.array(ds.variables['Q'][:rows], dtype=np.float32)
+
+        # (ii) RapidMuskingum file to file, float32 lateral volumes as qlateral files store them
+        ql32 = ql.astype(np.float32)
+        qfile = os.path.join(tmp, 'qlateral.nc')
+        write_rows(qfile, 'qlateral', ql32)
+        q_ref32, d_ref32 = np.zeros(n), np.zeros((chk, n))
+        oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref32, ql32[:chk].astype(np.float64), d_ref32, 1)
+        del ql32
+        os.makedirs(os.path.join(tmp, 'rapid'))
+        t0 = time.perf_counter()
+        rr.RapidMuskingum(params_file=params, qlateral_files=[qfile], discharge_dir=os.path.join(tmp, 'rapid'), dt_routing=int(dt), log=False).route()
+        sec = time.perf_counter() - t0
+        got = read_q(os.path.join(tmp, 'rapid', 'discharge_qlateral.nc'), chk)
+        if not np.allclose(got, d_ref32.astype(np.float32), rtol=1.2e-7, atol=1e-10 * scale):
+            raise SystemExit('bench.py: RapidMuskingum(config).route() differs from the oracle; refusing to report a number')
+        entry(f'RapidMuskingum(config).route(): {n} reaches x {T} hourly rows, float32 qlateral netCDF in, float32 discharge netCDF out (params parquet read, '
+              f'network analysis, file read, upload, routing, download, file write)', sec, f'first {chk} rows of the discharge file == oracle, <= 1 ulp(float32)')
+        os.remove(qfile)
+        shutil.rmtree(os.path.join(tmp, 'rapid'))
+
+        # (iii) UnitMuskingum from runoff depths + a 48-step unit-hydrograph kernel
+        n_ks = args.uh_steps
+        kern = synth.synth_uh_kernel(n, n_ks, tr=dt)
+        kfile = os.path.join(tmp, 'uh_kernel.npz')
+        scipy.sparse.save_npz(kfile, scipy.sparse.csr_matrix(kern), compressed=False)
+        depth32 = synth.synth_runoff_depth(n, 0, T).astype(np.float32)
+        dfile = os.path.join(tmp, 'depth.nc')
+        write_rows(dfile, 'qlateral', depth32)
+        from tests_support import unit_split_arrays
+        hw_idx, inner_idx, A_in, A_hw = unit_split_arrays(indptr, indices, n)
+        c1i, c2i, c3i = c1[inner_idx], c2[inner_idx], c3[inner_idx]
+        conv = oracle.UnitHydrograph(kern).convolve(depth32[:chk].astype(np.float64))
+        qc, qf, dd = np.zeros(inner_idx.size), np.zeros(inner_idx.size), np.zeros((chk, n))
+        oracle.unit_route(A_in.indptr, A_in.indices, -c1i[A_in.indices], A_in.indptr, A_in.indices, A_in.data, A_hw.indptr, A_hw.indices, A_hw.data,
+                          c1i, c2i, c3i, hw_idx, inner_idx, qc, qf, conv, dd, 1)
+        del depth32, kern, conv
+        os.makedirs(os.path.join(tmp, 'unit'))
+        t0 = time.perf_counter()
+        rr.UnitMuskingum(params_file=params, qlateral_files=[dfile], discharge_dir=os.path.join(tmp, 'unit'), uh_kernel_file=kfile, dt_routing=int(dt), log=False).route()
+        sec = time.perf_counter() - t0
+        got = read_q(os.path.join(tmp, 'unit', 'discharge_depth.nc'), chk)
+        if not np.allclose(got, dd.astype(np.float32), rtol=1.2e-7, atol=1e-9 * float(np.abs(dd).max())):
+            raise SystemExit('bench.py: UnitMuskingum(config).route() differs from the oracle; refusing to report a number')
+        entry(f'UnitMuskingum(config).route(): {n} reaches x {T} hourly rows of float32 runoff depths + {n_ks}-step unit-hydrograph kernel (npz), float32 discharge '
+              f'netCDF out', sec, f'first {chk} rows of the discharge file == oracle (direct-form convolution + unit_route), <= 1 ulp(float32)', {'uh_steps': n_ks})
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
     return out
 
 
@@ -436,7 +591,7 @@ def bench_rapid_f32(args, device_index, factor: int = 4):
     from river_route_amd.engine import Plan
     from river_route_amd.multi_gpu import roofline_from_profile
     n, T, nsub, dt = args.reaches, args.runoff_steps, 1, 900.0
-    rows = min(args.forcing_rows, T)
+    rows = min(args.forcing_rows or 288, T)
     dev = torch.device('cuda', device_index)
     net = synth.synth_network(n, order=args.order)
     indptr, indices = csc_from_down(net.down_index)
@@ -477,6 +632,7 @@ def bench_rapid_f32(args, device_index, factor: int = 4):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     roofline = roofline_from_profile(plan.profile(), 1, HBM_PEAK_GBS)
+    whole_path(roofline, plan.profile(), plan.profile_aux(), plan.last_kernel(), float(n) * T * args.steps / elapsed, None)
     plan.close()
     return {'metric': 'reach-steps/sec', 'value': float(n) * T * args.steps / elapsed, 'unit': 'reach-steps/s', 'n_gpus': 1, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -493,14 +649,17 @@ def bench_rapid(args, local_rank, net, indptr, indices, c1, c2, c3, base):
     from river_route_amd import synth
     from river_route_amd.engine import Plan, copy_bandwidth
     n, T, nsub, dt = net.n, args.runoff_steps, args.substeps, 900.0
-    rows = min(args.forcing_rows, T)
     dev = torch.device('cuda', local_rank)
     plan = Plan(indptr, indices, device=local_rank)
     plan.set_coeffs(-c1[indices], c2, c3, (c1 + c2) / (dt * nsub))
     plan.set_options(rows_per_chunk=args.chunk_rows, sample_every=args.sample_every)
+    # The direct row path (post-order params files) reads and writes the rows from its routing kernel: a tile walks down its own
+    # columns, so the cyclic arrays must be longer than the caches hold for the whole chip (1,024 rows = 8 GB at 1M reaches).
+    direct = plan.reserve(0, T, nsub)['direct']
+    rows = min(args.forcing_rows or (1024 if direct else 288), T)
 
     ql = synth.synth_qlateral_torch(n, 0, rows, dev, dt=dt * nsub)      # the same bits as synth_qlateral (tests/test_host.py), made on the device
-    sink_rows = min(T, args.sink_rows or plan.tile_info()['batch_rows'])      # default: rows of one out-pass batch, a launch never writes a sink row twice
+    sink_rows = min(T, args.sink_rows or (1024 if direct else plan.tile_info()['batch_rows']))      # record path: rows of one out-pass batch, a launch never writes a sink row twice
     out = torch.zeros((sink_rows, n), dtype=torch.float64, device=dev)
     q_t = torch.zeros(n, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
@@ -510,8 +669,9 @@ def bench_rapid(args, local_rank, net, indptr, indices, c1, c2, c3, base):
         plan.rapid_route_dev(q_t, ql, rows, out, sink_rows, T, nsub, stream)
 
     # Parity gate before timing, through the kernels the timed passes run (the time-tiled kernel and the record
-    # permutation passes take every call of 32 sub-steps or more): all rows of the forcing routed from a zero state
-    # into a plain array, compared element by element with the oracle's first pass over the same rows.
+    # permutation passes take every call of 32 sub-steps or more; on a post-order network the direct row path does): the first
+    # rows of the forcing routed from a zero state into a plain array, compared element by element with the oracle's first pass.
+    chk_name = None
     if base is not None:
         want = base.pop('first_pass')
         chk_T = want.shape[0]
@@ -519,12 +679,12 @@ def bench_rapid(args, local_rank, net, indptr, indices, c1, c2, c3, base):
         q_t.zero_()
         plan.rapid_route_dev(q_t, ql, rows, chk_out, chk_T, chk_T, nsub, stream)
         torch.cuda.synchronize()
-        chk_kernel = plan.profile()['ticks_per_launch']
+        chk_kernel, chk_name = plan.profile()['ticks_per_launch'], plan.last_kernel()
         got = chk_out.cpu().numpy()
         if not np.allclose(got, want, rtol=1e-10, atol=1e-10 * np.abs(want).max()):
             raise SystemExit('bench.py: GPU result differs from the oracle; refusing to report a number')
         base['parity_gate'] = (f'{chk_T} rows x {n} reaches routed by the timed kernel family '
-                               f'({"k_tile, " + str(chk_kernel) + " ticks per task" if chk_kernel > 1 else "k_tick"}) == oracle, '
+                               f'({KERNEL_NAMES[chk_name] + ", " + str(chk_kernel) + " ticks per task" if chk_kernel > 1 else "k_tick"}) == oracle, '
                                f'rtol 1e-10, max |diff| {float(np.abs(got - want).max()):.3e}')
         del chk_out
 
@@ -537,33 +697,74 @@ def bench_rapid(args, local_rank, net, indptr, indices, c1, c2, c3, base):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
 
-    prof = plan.profile()      # HIP events of the last timed pass, on the engine's stream
-    if base is not None and prof['ticks_per_launch'] > 1 and chk_kernel <= 1:
+    prof, aux, kern = plan.profile(), plan.profile_aux(), plan.last_kernel()      # HIP events of the last timed pass, on the engine's stream
+    if base is not None and chk_name != kern:
         raise SystemExit('bench.py: the parity gate did not run the timed kernel; refusing to report a number')
     reach_steps = float(n) * T * nsub * args.steps
     from river_route_amd.multi_gpu import roofline_from_profile
     copy_gbs = copy_bandwidth(local_rank)
-    roofline = roofline_from_profile(prof, nsub, HBM_PEAK_GBS, *pmc_traffic(plan, n, nsub), copy_gbs=copy_gbs)
-    tiles = plan.tile_info()
+    traffic = pmc_traffic(args.order, n, T, nsub)
+    roofline = roofline_from_profile(prof, nsub, HBM_PEAK_GBS, copy_gbs=copy_gbs, kernel=kern, traffic=traffic)
+    whole_path(roofline, prof, aux, kern, reach_steps / elapsed, traffic)
+    tiles, dinfo = plan.tile_info(), plan.direct_info()
     line = {
         'metric': 'reach-steps/sec', 'value': reach_steps / elapsed, 'unit': 'reach-steps/s',
         'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
         'config': {'workload': f'RapidMuskingum, {n}-reach synthetic random-topology network '
-                               f'(depth {plan.depth}, {args.order} topological order), {T} runoff steps @ 900 s '
+                               f'(depth {plan.depth}, {"depth-first post-order" if args.order == "postorder" else args.order + " topological order"}), {T} runoff steps @ 900 s '
                                f'(1 yr @ 15 min), {nsub} sub-step(s), fp64, 1xMI355X',
                    'reaches': n, 'runoff_steps': T, 'substeps': nsub, 'network_depth': plan.depth,
                    'forcing': f'{rows}-row device-resident cyclic array', 'discharge_sink': f'{sink_rows}-row device-resident cyclic array', 'params_order': args.order,
-                   'permutation_passes_in_timed_region': True,
-                   'tiles': tiles['tiles'], 'tile_levels': tiles['levels'], 'ghost_positions': tiles['ghosts']},
+                   'routing_kernel': KERNEL_NAMES[kern],
+                   'permutation_passes_in_timed_region': kern != 'direct'},
         'roofline': roofline,
         'cpu_baseline': base,
     }
+    if kern == 'direct':
+        line['config'].update(direct_tiles=dinfo['tiles'], holes=dinfo['holes'], skeleton_positions=dinfo['skeleton_positions'],
+                              skeleton_tile_levels=dinfo['skeleton_levels'], window_rows=dinfo['window_rows'])
+    else:
+        line['config'].update(tiles=tiles['tiles'], tile_levels=tiles['levels'], ghost_positions=tiles['ghosts'])
     plan.close()
     del ql, out, q_t
     torch.cuda.empty_cache()
     return line
+
+
+KERNEL_NAMES = {'tick': 'k_tick (streaming, one launch per tick)', 'tile': 'k_tile (time-tiled over subtree tiles and records) + k_rec_in / k_rec_out',
+                'direct': 'k_direct (column-range tiles reading and writing the rows) + k_tile on the skeleton + k_rec_out over the holes'}
+
+
+def whole_path(roofline, prof, aux, kern, rate, traffic):
+    """Adds the WHOLE path to the `roofline` object (which prices the dominant kernel): every kernel of the timed pass with its
+    launches and its average duration between HIP events on the engine's stream (every fourth launch sampled; the direct launches
+    all), the bytes per reach-step the path has to move (16: a lateral value in, a discharge out) and -- from the committed
+    rocprofv3 counter passes of the same command, while the kernel sources are the ones they were taken with -- the bytes it does
+    move, and the two end-to-end fractions of the 8 TB/s peak that follow from the measured rate."""
+    if roofline is None:
+        return
+    main = {'tile': 'k_tile', 'direct': 'k_direct', 'tick': 'k_tick'}[kern]
+    kernels = {}
+    if prof['brackets'] > 0:
+        kernels[main] = {'launches': prof['launches'], 'sampled': prof['brackets'], 'avg_us': round(prof['sampled_ms'] / prof['brackets'] * 1e3, 2)}
+    if kern == 'direct':      # prof['launches'] counts the schedule's steps (direct launches, then the skeleton's drain); every direct launch is sampled
+        kernels[main]['launches'] = prof['brackets']
+    for name, a in aux.items():
+        if a['sampled'] > 0:
+            kernels[name] = {'launches': a['launches'], 'sampled': a['sampled'], 'avg_us': round(a['sampled_ms'] / a['sampled'] * 1e3, 2)}
+    for k in kernels.values():
+        k['ms_per_pass'] = round(k['launches'] * k['avg_us'] / 1e3, 2)
+    measured = None if traffic is None else traffic.get('bytes_per_reach_step')
+    roofline['path'] = {
+        'kernels': kernels, 'sum_ms_per_pass': round(sum(k['ms_per_pass'] for k in kernels.values()), 2),
+        'bytes_per_reach_step_compulsory': 16.0,
+        'bytes_per_reach_step_measured': measured,
+        'bytes_per_reach_step_by_kernel': None if traffic is None else traffic.get('by_kernel'),
+        'traffic_source': None if traffic is None else traffic.get('source'),
+        'frac_end_to_end_compulsory': round(16.0 * rate / 1e9 / HBM_PEAK_GBS, 4),
+        'frac_end_to_end_measured': None if measured is None else round(measured * rate / 1e9 / HBM_PEAK_GBS, 4)}
 
 
 def engine_sha16():
@@ -576,20 +777,27 @@ def engine_sha16():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(plan, n, nsub, kernel='k_tile', key='hbm_bytes_per_position_tick'):
-    """(bytes per position-tick, source) of the routing kernel from the committed counter passes -- only for the
-    configuration they were taken on and only while the kernel sources are the ones they were taken with."""
-    path = os.path.join(REPO, 'profiles', 'r03_pmc_traffic.json')
-    if n != 1_000_000 or nsub != 1 or any(k.startswith(('RR_WAVE', 'RR_TILE')) for k in os.environ):
-        return None, None
+def pmc_traffic(order, n, T, nsub):
+    """HBM bytes of the timed pass from the committed counter passes (profiles/r04_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE, separate runs of this bench command, every dispatch of the pass summed per kernel, FETCH_SIZE doubled as the
+    micro-architecture guide prescribes for gfx950) -- only for the configuration they were taken on and only while the kernel
+    sources are the ones they were taken with."""
+    path = os.path.join(REPO, 'profiles', 'r04_pmc_traffic.json')
+    if nsub != 1 or any(k.startswith(('RR_WAVE', 'RR_TILE', 'RR_DIRECT')) for k in os.environ):
+        return None
     try:
         with open(path) as f:
-            rec = json.load(f)
+            rec = json.load(f).get(order)
+        if not rec or rec.get('reaches') != n or rec.get('runoff_steps') != T:
+            return None
         if rec.get('engine_sha16') != engine_sha16():
-            return None, f'profiles/r03_pmc_traffic.json is from other kernel sources ({rec.get("engine_sha16")}): not used'
-        return rec['kernels'][kernel][key], f'profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, engine {rec["engine_sha16"]})'
+            return {'source': f'profiles/r04_pmc_traffic.json [{order}] is from other kernel sources ({rec.get("engine_sha16")}): not used'}
+        out = {'source': f'profiles/r04_pmc_traffic.json [{order}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the whole year, engine {rec["engine_sha16"]})',
+               'bytes_per_reach_step': rec['bytes_per_reach_step'], 'by_kernel': rec['bytes_per_reach_step_by_kernel'],
+               'main_kernel_bytes_per_launch': rec.get('main_kernel_bytes_per_full_launch')}
+        return out
     except (OSError, KeyError, ValueError):
-        return None, None
+        return None
 
 
 if __name__ == '__main__':

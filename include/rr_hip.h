@@ -140,6 +140,11 @@ int rr_plan_reserve(rr_plan *plan, int mode, int64_t T, int64_t nsub, int host_r
 int rr_plan_direct_info(const rr_plan *plan, int64_t info[8], char *why, int64_t why_cap);
 int rr_plan_direct_layout(const rr_plan *plan, int32_t *tile_c0, int32_t *tile_nc, int32_t *tile_lag_lo, int32_t *tile_span,
                           int32_t *delay, int32_t *up3, int32_t *xinfo);
+/* The kernels around the routing kernel in the last call, sampled like it (every fourth launch between HIP events on the call's
+ * stream, while rr_plan_set_options(sample_every >= 16) is in force): aux[3 k + 0] launches, [3 k + 1] launches sampled,
+ * [3 k + 2] their milliseconds, for k = 0 the in-pass (params-order rows -> records), 1 the out-pass, 2 the skeleton's routing
+ * launches of the direct row path, 3 its out-pass over the holes. */
+int rr_plan_profile_aux(rr_plan *plan, double aux[12]);
 /* Which routing kernel the last call on this plan ran. */
 #define RR_KERNEL_TICK 0
 #define RR_KERNEL_TILE 1

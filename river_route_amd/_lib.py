@@ -85,6 +85,7 @@ _SIGNATURES = {
     'rr_plan_reserve': (C.c_int, [_vp, C.c_int, _i64, _i64, C.c_int, _vp]),
     'rr_plan_set_options': (C.c_int, [_vp, _i64, _i64]),
     'rr_plan_profile': (C.c_int, [_vp, _vp]),
+    'rr_plan_profile_aux': (C.c_int, [_vp, _vp]),
     'rr_rapid_route': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64]),
     'rr_muskingum_route': (C.c_int, [_vp, _vp, _vp, _i64, _i64]),
     'rr_unit_route': (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64]),

@@ -56,6 +56,7 @@ void rr_plan_destroy(rr_plan *P)
         for (void *p : ptrs) if (p) (void)hipFree(p);
         P->pipe.destroy();
         for (hipEvent_t e : P->ev) (void)hipEventDestroy(e);
+        for (hipEvent_t e : P->aux_ev) (void)hipEventDestroy(e);
         if (P->ev_first) (void)hipEventDestroy(P->ev_first);
         if (P->ev_last) (void)hipEventDestroy(P->ev_last);
     }
@@ -440,6 +441,24 @@ int rr_plan_profile(rr_plan *P, double prof[10])
     }
     prof[1] = (double)P->prof_samples; prof[2] = sum; prof[3] = P->prof_samples ? mn : 0.0; prof[4] = mx;
     prof[5] = reaches;
+    return RR_OK;
+}
+
+int rr_plan_profile_aux(rr_plan *P, double aux[12])
+{
+    if (!P || !aux) return fail(RR_E_INVALID, "rr_plan_profile_aux: null argument");
+    for (int k = 0; k < 12; ++k) aux[k] = 0.0;
+    for (int k = 0; k < rr_plan::kAuxKinds; ++k) aux[3 * k] = (double)P->aux_launches[k];
+    if (P->device < 0 || P->aux_kind.empty()) return RR_OK;
+    HIPCHK(hipSetDevice(P->device));
+    if (P->ev_last) HIPCHK(hipEventSynchronize(P->ev_last));
+    for (size_t i = 0; i < P->aux_kind.size(); ++i) {
+        float ms = 0.f;
+        HIPCHK(hipEventSynchronize(P->aux_ev[2 * i + 1]));
+        HIPCHK(hipEventElapsedTime(&ms, P->aux_ev[2 * i], P->aux_ev[2 * i + 1]));
+        aux[3 * P->aux_kind[i] + 1] += 1.0;
+        aux[3 * P->aux_kind[i] + 2] += ms;
+    }
     return RR_OK;
 }
 

@@ -167,7 +167,12 @@ struct rr_plan {
     bool uh_pairs = true;               // the fused convolution takes two record batches per launch where it can (RR_UH_PAIRS=0: tests)
     bool perm_ready = false;            // the streaming kernel's tiled permutations are on the device
 
-    // profile of the last route call
+    // profile of the last route call: the routing kernel (ev, rr_plan_profile) and, sampled the same way, the kernels around it
+    // (aux: 0 in-pass, 1 out-pass, 2 the skeleton's k_tile launches of the direct row path, 3 its out-pass over the holes)
+    static constexpr int kAuxKinds = 4, kAuxSamples = 256;
+    std::vector<hipEvent_t> aux_ev;      // 2 per sample, made by rr_plan_reserve
+    std::vector<int> aux_kind;
+    int64_t aux_launches[kAuxKinds] = {0, 0, 0, 0};
     std::vector<hipEvent_t> ev;
     std::vector<int64_t> ev_reaches;
     hipEvent_t ev_first = nullptr, ev_last = nullptr;
@@ -280,6 +285,21 @@ int upload_tiled_permutations(rr_plan *P)
     }
     P->perm_ready = true;
     return RR_OK;
+}
+
+// Every fourth launch of a kind is bracketed by HIP events while the plan samples (rr_plan_set_options): aux_begin returns the
+// sample's number or -1.
+int aux_begin(rr_plan *P, int kind, hipStream_t stream)
+{
+    const int64_t seq = P->aux_launches[kind]++;
+    if (P->sample_every < kSampleGroup || (seq & 3) != 0 || 2 * (P->aux_kind.size() + 1) > P->aux_ev.size()) return -1;
+    if (hipEventRecord(P->aux_ev[2 * P->aux_kind.size()], stream) != hipSuccess) return -1;
+    P->aux_kind.push_back(kind);
+    return (int)P->aux_kind.size() - 1;
+}
+void aux_end(rr_plan *P, int sample, hipStream_t stream)
+{
+    if (sample >= 0) (void)hipEventRecord(P->aux_ev[2 * sample + 1], stream);
 }
 
 // ---- session -------------------------------------------------------------------------------------
@@ -403,6 +423,7 @@ int reserve_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_stre
     if (sch.tiled && samples > 0) samples = (size_t)std::min<int64_t>(4096, ((total_ticks + K - 1) / K + P->tp.n_levels) / 4 + 1);
     if (sch.direct && samples > 0) samples = (size_t)std::min<int64_t>(4096, (T + K - 1) / K + 1);      // every direct launch
     while (P->ev.size() < 2 * samples) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); P->ev.push_back(e); }
+    if (samples > 0) while (P->aux_ev.size() < 2 * rr_plan::kAuxSamples) { hipEvent_t e; HIPCHK(hipEventCreate(&e)); P->aux_ev.push_back(e); }
     if (out) *out = sch;
     return RR_OK;
 }
@@ -458,6 +479,8 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
     const int64_t C = std::max<int64_t>(1, P->chunk_rows);
 
     P->prof_launches = P->prof_samples = P->prof_brackets = 0;
+    P->aux_kind.clear();
+    for (int k = 0; k < rr_plan::kAuxKinds; ++k) P->aux_launches[k] = 0;
     P->prof_reach_steps = n * S.total;
     P->ev_reaches.clear();
     P->last_stream = stream;
@@ -798,6 +821,7 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch, int count = 1)
     const dim3 gp((unsigned)((n + (in ? kRecInCols : kRecOutCols) - 1) / (in ? kRecInCols : kRecOutCols)));
     const bool sub = S.nsub > 1;
     hipStream_t st = rec_stream(P);
+    const int aux = aux_begin(P, in ? 0 : 1, st);
     if (in && S.io.runoff) {
         const dim3 gr((unsigned)((n + kRunoffInThreads - 1) / kRunoffInThreads), (unsigned)kRecBatch);
         if (S.io.runoff->is_f32) hipLaunchKernelGGL(k_rec_in_runoff<float>, gr, dim3(kRunoffInThreads), 0, st, ra, *S.io.runoff);
@@ -819,6 +843,7 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch, int count = 1)
         if (sub) hipLaunchKernelGGL((k_rec_out<true, false>), gp, dim3(kRecOutThreads), 0, st, ra);
         else hipLaunchKernelGGL((k_rec_out<false, false>), gp, dim3(kRecOutThreads), 0, st, ra);
     }
+    aux_end(P, aux, st);
 }
 
 // Time-tiled schedule: batches of kRecRows (128) tick-rows become records as soon as their rows are there and their ring slots
@@ -935,7 +960,12 @@ int session_advance_direct(rr_plan *P, int64_t rows_ready)
                     ++P->prof_brackets;
                 }
             }
-            if (skel) { int rc = launch_tile_diag(P, TP, S.ta, P->n_kwide, P->d_kcoef, P->d_kcoef, d, false); if (rc) return rc; }
+            if (skel) {
+                const int aux = aux_begin(P, 2, S.stream);
+                int rc = launch_tile_diag(P, TP, S.ta, P->n_kwide, P->d_kcoef, P->d_kcoef, d, false);
+                if (rc) return rc;
+                aux_end(P, aux, S.stream);
+            }
             ++P->prof_launches;
             ++S.diag;
             progressed = true;
@@ -953,8 +983,10 @@ int session_advance_direct(rr_plan *P, int64_t rows_ready)
                 ra.batch = S.out_batches; ra.nsub = Div32(1u); ra.colmeta = P->d_kholemeta; ra.cols = P->d_kholecol; ra.scale = nullptr;
                 ra.rows = RowView{S.io.dev_out, n, 0, (uint32_t)std::max<int64_t>(1, S.io.rows_out)};
                 ra.factor = Div32(1u); ra.clamp = 1; ra.swizzle = 0;
+                const int aux = aux_begin(P, 3, S.stream);
                 if (P->n_kholes > 0)
                     hipLaunchKernelGGL((k_rec_out<false, false>), dim3((unsigned)((P->n_kholes + kRecOutCols - 1) / kRecOutCols)), dim3(kRecOutThreads), 0, S.stream, ra);
+                aux_end(P, aux, S.stream);
                 ++S.out_batches;
                 S.ticks_stored = std::min(S.total, kRecRows * S.out_batches);
                 progressed = true;

@@ -111,6 +111,13 @@ class Plan:
                     max_ms=float(p[4]), sampled_reaches=float(p[5]), region_ms=float(p[6]), reach_steps=float(p[7]),
                     brackets=int(p[8]), ticks_per_launch=int(p[9]))
 
+    def profile_aux(self) -> dict:
+        """rr_plan_profile_aux: the kernels around the routing kernel in the last call, {name: {launches, sampled, sampled_ms}}."""
+        a = np.zeros(12, dtype=np.float64)
+        check(_lib.lib().rr_plan_profile_aux(self._h, ptr(a)))
+        names = ('k_rec_in', 'k_rec_out', 'k_tile (skeleton)', 'k_rec_out (holes)')
+        return {nm: dict(launches=int(a[3 * k]), sampled=int(a[3 * k + 1]), sampled_ms=float(a[3 * k + 2])) for k, nm in enumerate(names) if a[3 * k] > 0}
+
     # -- coefficients --
     def set_coeffs(self, lhs_off_data, c2, c3, c4_dt=None) -> None:
         lhs = _f64(lhs_off_data, 'lhs_off_data')
