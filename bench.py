@@ -517,7 +517,7 @@ def bench_dropin(args, device_index, T: int = 744):
 
         def write_rows(path, var, rows32):
             with netcdf_file(path, 'w', version=2) as ds:
-                ds.createDimension('time', T)
+                ds.createDimension('time', None)      # record dimension: a fixed NetCDF-3 variable holds less than 2 GiB
                 ds.createDimension('river_id', n)
                 tv = ds.createVariable('time', 'f8', ('time',))
                 tv.units = 'seconds since 1970-01-01 00:00:00'

@@ -28,9 +28,9 @@ namespace {
 // them), wave 7 forwards what the skeleton needs: eight instruction streams, two per SIMD, that meet at the tick's barrier.
 //
 // The skeleton (reaches with large or tall subtrees: 5 %) keeps records and k_tile.  Its columns lie between the subtrees'
-// columns (HOLES).  Wave 7 copies a hole's scaled lateral inflow from the window into the skeleton position's record, and the
-// discharge of an outlet lane (a small subtree's last reach) into the record of the ghost that mirrors it in the skeleton, 8 bytes
-// per tick and sender (whole records at a time); k_rec_out, given the holes' columns, patches the output rows from the skeleton's records afterwards.
+// columns (HOLES).  A hole's scaled lateral inflow (waves 4, 5) and the discharge of an outlet lane (a small subtree's last reach)
+// go into small LDS rings, from which wave 7 writes whole records into the skeleton's record ring: the hole's own position, the
+// ghost that mirrors the outlet there; k_rec_out, given the holes' columns, patches the output rows from the skeleton's records afterwards.
 struct DirectTile { int32_t c0, nc, lag_lo, span; };
 struct DirectArgs {
     const DirectTile *tiles;
@@ -53,10 +53,12 @@ constexpr int32_t kDirectHoleBit = rr::kDirectHole;
 constexpr int kDirectLanes = 256, kDirectAhead = 16;
 constexpr int kDirectThreads = kDirectLanes + 4 * 64;      // four routing waves + in, in, out, send: two waves per SIMD
 constexpr int kDirectMaxWindow = 64;      // rows of the LDS window, span + 3
-constexpr int kDirectSenders = rr::kDirectSenders;      // per tile: one lane of wave 7 each
-// LDS in doubles: X[2][258] | staging of wave 7: S[senders][2][16] values, SM[senders] record offsets, SP[senders] pending words |
-// F[window rows][256]: 4.1 + 16.9 + 131 KB = 152 KB of the CU's 160 with the largest window
-constexpr int kDirectStage = kDirectSenders * 2 * kRec + 2 * kDirectSenders;      // doubles
+constexpr int kDirectSenders = rr::kDirectSenders;      // per tile
+// LDS in doubles: X[2][258] | S[senders][32]: what the skeleton needs, a ring of two records (32 ticks) per sender, filled by the
+// lanes that make the values -- the outlet's routing lane, the hole's column in waves 4 / 5 -- at slot = tick % 32 (tick = row + lag,
+// k_tile's record slot) | D[2][256]: a slot per lane that takes the store of a lane with nothing to send (no branch, no bank
+// conflict) | F[window rows][256]: 4.1 + 16.4 + 4.1 + 131 KB = 156 KB of the CU's 160 with the largest window
+constexpr int kDirectStage = kDirectSenders * 2 * kRec + 2 * kDirectLanes;      // doubles
 constexpr size_t direct_lds_bytes(int window_rows)
 {
     return (size_t)(2 * (kDirectLanes + kTilePad) + kDirectStage + (int64_t)window_rows * kDirectLanes) * sizeof(double);
@@ -77,13 +79,15 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
     constexpr int TH = kDirectLanes, THP = TH + kTilePad;
     static_assert(PF % 2 == 0 && PF == kRec, "the parity of a tick is the parity of its place in a chunk; wave 6 writes a record per sender and chunk");
     char *const X = reinterpret_cast<char *>(lds);                  // [2][THP] discharges of the last two ticks, each followed by a slot that holds 0.0
-    double *const S = lds + 2 * THP;                                // wave 7's staging (below)
+    double *const S = lds + 2 * THP;                                // the senders' rings, then the dummy slots
     char *const F = reinterpret_cast<char *>(lds + 2 * THP + kDirectStage);        // [span + 3][TH] the row window
     const int tid = threadIdx.x, wave = tid >> 6, role = wave < 4 ? 0 : (wave < 6 ? 1 : wave - 4), ln = tid & 63;      // 0 route, 1 in (two waves), 2 out, 3 send
     if (tid < 2) lds[tid * THP + TH] = 0.0;
     const int32_t r0 = a.m * a.K, nrows = min(a.K, a.total - r0);
     const uint32_t row_bytes = (uint32_t)a.n * 8u;                  // n < 2^29 (choose_schedule)
     constexpr int kRowB = TH * 8;                                    // bytes of a window row
+    constexpr int kStageB = 2 * THP * 8, kDummyB = kStageB + kDirectSenders * 2 * kRec * 8;      // byte offsets in LDS of S and of the dummy slots
+    constexpr int kSenderMask = 0x7F;
 
     for (int32_t t = (int32_t)blockIdx.x; t < a.n_tiles; t += (int32_t)gridDim.x) {
         const DirectTile tm = a.tiles[t];
@@ -99,7 +103,12 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             const int32_t col = tm.c0 + (live ? tid : 0);
             const int4 lm = a.lane[col];
             const bool idle = !live || (lm.x & kDirectHoleBit) != 0;      // a hole's column only passes through the window
-            const int32_t delta = idle ? 0x40000000 : lm.x;
+            const int32_t delta = idle ? 0x40000000 : (lm.x & rr::kDirectDelayMask);
+            // an outlet that feeds the skeleton also puts its discharge into its sender ring; every lane of a tile is at the same
+            // tick (row + lag) at the same moment, so the slot is wave-uniform
+            const int32_t sender = idle ? 0 : (lm.x >> rr::kDirectSenderShift) & kSenderMask;
+            const int32_t stage_b = sender ? kStageB + (sender - 1) * (2 * kRec * 8) : kDummyB + tid * 8;      // dummy: the lane's own slot (32 of them: slot 0 ... see below)
+            const bool wave_sends = __builtin_amdgcn_ballot_w64(sender != 0) != 0;
             const double c1 = idle ? 0.0 : a.coef[4 * (int64_t)col], c2 = idle ? 0.0 : a.coef[4 * (int64_t)col + 1], c3 = idle ? 0.0 : a.coef[4 * (int64_t)col + 2];
             const double q0 = idle ? 0.0 : a.q[col];
             const int32_t u0 = lm.y & 0x3FF, u1 = (lm.y >> 10) & 0x3FF, u2 = (lm.y >> 20) & 0x3FF;
@@ -130,6 +139,12 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                     }
                     s_prev = s_cur;
                     *reinterpret_cast<double *>(X + cur + tid * 8) = qk;
+                    if (wave_sends) {      // wave-uniform
+                        const int32_t slot_b = ((r0 + tm.lag_lo + k0 + s) & 31) * 8;
+                        bool put = sender != 0;
+                        if (decltype(tested)::value) put = put && (uint32_t)(k0 + s - delta) < (uint32_t)nrows;
+                        *reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + (put ? stage_b + slot_b : kDummyB + tid * 8)) = qk;
+                    }
                     own_b = own_b + kRowB == wrap ? 0 : own_b + kRowB;
                     barrier_lds();
                 }
@@ -144,6 +159,17 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             const int32_t ca = (wave - 4) * (TH / 2) + 2 * ln;
             auto c4_of = [&](int32_t c) { return c < tm.nc ? a.coef[4 * (int64_t)(tm.c0 + c) + 3] : 0.0; };
             const double c4a0 = c4_of(ca), c4a1 = c4_of(ca + 1);
+            // a hole's scaled lateral inflow also goes into its sender ring, at slot (row + lag) % 32
+            auto hole_of = [&](int32_t c, int32_t &ring_b, int32_t &slot0) {
+                const int4 lm = a.lane[tm.c0 + (c < tm.nc ? c : 0)];
+                const bool hole = c < tm.nc && (lm.x & kDirectHoleBit) != 0 && ((lm.x >> rr::kDirectSenderShift) & kSenderMask) != 0;
+                ring_b = hole ? kStageB + (((lm.x >> rr::kDirectSenderShift) & kSenderMask) - 1) * (2 * kRec * 8) : -1;
+                slot0 = (r0 + lm.w) & 31;      // of local row 0
+            };
+            int32_t ring0, ring1, hs0, hs1;
+            hole_of(ca, ring0, hs0); hole_of(ca + 1, ring1, hs1);
+            const int32_t dummy_b = kDummyB + (TH + (wave - 4) * 64 + ln) * 8;      // (the in-waves' dummy slots follow the routing lanes')
+            const bool wave_holes = __builtin_amdgcn_ballot_w64(ring0 >= 0 || ring1 >= 0) != 0;
             // a 16-byte load may reach past the tile's last column (the next tile's, or -- past the row's end -- zeros): never used
             const uint32_t va = ca < tm.nc ? (uint32_t)(tm.c0 + ca) * 8u : kDropAccess;
             uint32_t rin = (uint32_t)r0 % a.in_rows;
@@ -161,18 +187,24 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
 #pragma unroll
             for (int j = 0; j < AH; ++j) request(j, Pa[j]);
             int32_t in_b = 0;
-            auto park = [&](const double2 &pa) {      // into the window, scaled (the ring of k_tile holds c4dt * lateral too)
-                *reinterpret_cast<double2 *>(F + in_b + ca * 8) = make_double2(pa.x * c4a0, pa.y * c4a1);
+            auto park = [&](const double2 &pa, int32_t arrival) {      // into the window, scaled (the ring of k_tile holds c4dt * lateral too)
+                const double x0 = pa.x * c4a0, x1 = pa.y * c4a1;
+                *reinterpret_cast<double2 *>(F + in_b + ca * 8) = make_double2(x0, x1);
                 in_b = in_b + kRowB == wrap ? 0 : in_b + kRowB;
+                if (wave_holes) {      // wave-uniform
+                    const bool real = arrival < nrows;
+                    *reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + (real && ring0 >= 0 ? ring0 + ((hs0 + arrival) & 31) * 8 : dummy_b)) = x0;
+                    *reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + (real && ring1 >= 0 ? ring1 + ((hs1 + arrival) & 31) * 8 : dummy_b)) = x1;
+                }
             };
-            park(Pa[0]);      // row 0, before the first tick
+            park(Pa[0], 0);      // row 0, before the first tick
             request(AH, Pa[0]);
             __syncthreads();
             auto chunk = [&](auto half, int32_t k0) {      // ticks k0 ... k0 + PF - 1; k0 = PF (2 c + half): row k0 + s + 1 sits in P[(k0 + s + 1) % AH]
 #pragma unroll
                 for (int s = 0; s < PF; ++s) {      // tick k0 + s: row k0 + s + 1 arrives, row k0 + s + 1 + AH is requested
                     constexpr int base = decltype(half)::value * PF;
-                    park(Pa[(base + s + 1) % AH]);
+                    park(Pa[(base + s + 1) % AH], k0 + s + 1);
                     request(k0 + s + 1 + AH, Pa[(base + s + 1) % AH]);
                     barrier_lds();
                 }
@@ -212,76 +244,69 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             }
         } else {
             // ---------------------------------------------------------------- wave 7: what the skeleton needs
-            // Lane = sender.  Every tick it copies its value of the tick before -- a hole's scaled lateral inflow from the window, an
-            // outlet's discharge from the discharge buffer -- into its half of the staging area S[lane][parity][slot]; a record (16
-            // ticks, slot = tick % 16 with tick = row + lag: k_tile's layout) that is complete is posted in SM / SP, and every PF
-            // ticks the wave writes the posted records, eight lanes per 128-byte record (8-byte stores took a fifth of the kernel:
-            // profiles/r04_direct_role_ablation.txt).  A task's first and last record are partly the neighbouring tasks': only the
-            // slots [from, to) this task made are written.
+            // The senders' rings fill by themselves (above); this wave writes every record that is complete -- 16 ticks, slot = tick % 16
+            // with tick = row + lag: k_tile's layout -- into the skeleton's record ring, eight lanes per 128-byte record.  Sender i has
+            // its turn when the local tick is i mod 16 (four senders a tick at most: one store instruction), once in 16 ticks, which is
+            // how often it completes a record; a ring holds two, so the one being written out is never the one being filled.  (Copying
+            // the values itself, this wave was busy 90 % of a tick and every other wave waited for it: profiles/r04_direct_wave_stamps_before.txt.)
+            // A task's first and last record are partly the neighbouring tasks': only the slots this task made are written.
             const int32_t s0 = a.send_ptr[t], ns = a.send_ptr[t + 1] - s0;
-            const bool mine = ln < ns;
-            const int32_t sl = mine ? a.send_lane[s0 + ln] : 0;
-            const bool hole = (sl & kDirectHoleBit) != 0;
-            const int32_t lane = sl & 0x3FF;
-            const int4 lm = a.lane[tm.c0 + lane];
-            const int32_t delta = hole ? 0 : lm.x;
-            // the value of local row j sits, one tick after it was made: a hole's in the window (slot j mod (span + 3)), an outlet's in the
-            // discharge buffer its tick wrote
-            const int32_t f_b = (int32_t)(reinterpret_cast<char *>(F) - reinterpret_cast<char *>(lds));
-            int32_t src_b = hole ? f_b + lane * 8 : lane * 8;      // byte offset in LDS of local row (k - 1 - delta)'s value at tick k
-            const uint32_t tg = (uint32_t)(r0 + lm.w);             // record slot of local row 0: tick r0 + lag
-            uint32_t xslot = tg & 15u, xchunk = (tg >> 4) % a.rec_chunks, from = xslot, par = 0;
-            int64_t rec_off = ((int64_t)xchunk * a.np + (mine ? lm.z : 0)) * kRec;      // in doubles: the record being filled
-            const int64_t chunk_step = (int64_t)a.np * kRec, ring = (int64_t)a.rec_chunks * a.np * kRec;
-            double *mystage = S + ln * (2 * kRec);
-            int64_t *const SM = reinterpret_cast<int64_t *>(S + kDirectSenders * 2 * kRec);
-            int32_t *const SP = reinterpret_cast<int32_t *>(S + kDirectSenders * 2 * kRec + kDirectSenders);      // 0: nothing posted; else 1 + parity | from << 8 | to << 16
-            SP[ln] = 0;
-            auto post = [&](uint32_t to) {
-                SM[ln] = rec_off;
-                SP[ln] = (int32_t)(1u + par) | (int32_t)(from << 8) | (int32_t)(to << 16);
+            const int32_t piece = ln & 7, member = ln >> 3;
+            auto write_piece = [&](int64_t off, int32_t lo, int32_t hi, const double2 &v) {      // slots [lo, hi) of the record
+                double *dst = a.rec + off + 2 * piece;
+                if (lo <= 2 * piece && 2 * piece + 2 <= hi) *reinterpret_cast<double2 *>(dst) = v;
+                else {
+                    if (lo <= 2 * piece && 2 * piece < hi) dst[0] = v.x;
+                    if (lo <= 2 * piece + 1 && 2 * piece + 1 < hi) dst[1] = v.y;
+                }
             };
-            auto flush = [&]() {      // lanes 8 i .. 8 i + 7: the eight 16-byte pieces of sender (8 g + i)'s posted record
-                wave_lds_fence();
-                for (int32_t g = 0; 8 * g < ns; ++g) {
-                    const int32_t snd = 8 * g + (ln >> 3), piece = ln & 7;
-                    const int32_t word = SP[snd];
-                    if (word) {
-                        const int32_t lo = (word >> 8) & 0xFF, hi = (word >> 16) & 0xFF;
-                        const double2 v = *reinterpret_cast<const double2 *>(S + snd * (2 * kRec) + ((word & 0xFF) - 1) * kRec + 2 * piece);
-                        double *dst = a.rec + SM[snd] + 2 * piece;
-                        if (lo <= 2 * piece && 2 * piece + 2 <= hi) *reinterpret_cast<double2 *>(dst) = v;
-                        else {
-                            if (lo <= 2 * piece && 2 * piece < hi) dst[0] = v.x;
-                            if (lo <= 2 * piece + 1 && 2 * piece + 1 < hi) dst[1] = v.y;
-                        }
+            // per turn (= local tick % 16): the sender this lane serves then
+            int32_t ring_b[PF];                       // its ring in LDS, or -1
+            uint32_t done[PF], end[PF], avail0[PF];   // ticks (row + lag) written out so far / of the task's last row + 1 / visible at local tick 0
+            uint32_t chk[PF];                         // ring chunk of the record `done` lies in
+            int64_t roff[PF];                         // ... and its offset in the record ring, in doubles
+            const int64_t chunk_step = (int64_t)a.np * kRec, ring = (int64_t)a.rec_chunks * a.np * kRec;
+#pragma unroll
+            for (int f = 0; f < PF; ++f) {
+                const int32_t i = f + PF * member;
+                const bool have = member < kDirectSenders / PF && i < ns;
+                const int32_t sl = have ? a.send_lane[s0 + i] : 0;
+                const int4 lm = a.lane[tm.c0 + (sl & 0x3FF)];
+                const bool hole = (sl & kDirectHoleBit) != 0;
+                ring_b[f] = have ? kStageB + i * (2 * kRec * 8) : -1;
+                done[f] = (uint32_t)(r0 + lm.w);
+                end[f] = done[f] + (uint32_t)nrows;
+                // what wave 7 sees at local tick k: an outlet's values of the ticks before k (every lane of the tile is at tick r0 + lag_lo + k),
+                // a hole's rows up to k (row k + 1 is parked during tick k)
+                avail0[f] = hole ? (uint32_t)(r0 + lm.w + 1) : (uint32_t)(r0 + tm.lag_lo);
+                chk[f] = (done[f] >> 4) % a.rec_chunks;
+                roff[f] = ((int64_t)chk[f] * a.np + (have ? lm.z : 0)) * kRec;
+            }
+            auto turn = [&](int f, uint32_t avail, bool last) {      // writes sender f's record if it is complete (last: whatever this task made of it)
+                if (ring_b[f] < 0) return;
+                const uint32_t upto = last ? min(end[f], (done[f] | 15u) + 1u) : (done[f] | 15u) + 1u;
+                if (done[f] < upto && upto <= min(avail, end[f])) {
+                    const double2 v = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(lds) + ring_b[f] + ((done[f] >> 4) & 1u) * (kRec * 8) + piece * 16);
+                    write_piece(roff[f], (int32_t)(done[f] & 15u), (int32_t)((upto - 1u) & 15u) + 1, v);
+                    done[f] = upto;
+                    if ((upto & 15u) == 0) {
+                        roff[f] += chunk_step;
+                        if (++chk[f] == a.rec_chunks) { chk[f] = 0; roff[f] -= ring; }
                     }
                 }
-                wave_lds_fence();
-                SP[ln] = 0;
             };
             __syncthreads();
             for (int32_t k0 = 0; k0 < n_ticks; k0 += PF) {
 #pragma unroll
                 for (int s = 0; s < PF; ++s) {
-                    const int32_t j = k0 + s - 1 - delta;      // the local row whose value was made at tick k - 1
-                    if (mine && (uint32_t)j < (uint32_t)nrows) {
-                        const int32_t at = hole ? src_b : src_b + ((s + 1) & 1) * (THP * 8);      // tick k - 1 wrote discharge buffer (k - 1) & 1
-                        mystage[par * kRec + xslot] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lds) + at);
-                        if (hole) src_b = src_b + kRowB == f_b + wrap + lane * 8 ? f_b + lane * 8 : src_b + kRowB;
-                        if (++xslot == 16) {      // complete: post it and move on to the next chunk's record
-                            post(16);
-                            xslot = 0; from = 0; par ^= 1u;
-                            rec_off += chunk_step;
-                            if (++xchunk == a.rec_chunks) { xchunk = 0; rec_off -= ring; }
-                        }
-                    }
-                    if (s == PF - 1) flush();      // a sender completes at most one record in PF = 16 ticks
+                    turn(s, avail0[s] + (uint32_t)(k0 + s), false);
                     barrier_lds();
                 }
             }
-            if (mine && xslot > from) post(xslot);      // the task's last record: the slots it made
-            flush();
+            // the records completed since their sender's last turn, then the task's last (partial) ones: everything is staged by now
+            wave_lds_fence();
+#pragma unroll
+            for (int f = 0; f < PF; ++f) { turn(f, 0xFFFFFFFFu, false); turn(f, 0xFFFFFFFFu, false); turn(f, 0xFFFFFFFFu, true); }
         }
     }
 }

@@ -456,7 +456,10 @@ void build_direct_plan(const std::vector<int32_t> &down, const std::vector<int32
     D.send_ptr.assign((size_t)D.n_tiles + 1, 0);
     for (int32_t t = 0; t < D.n_tiles; ++t) {
         for (int32_t v = D.tile_c0[t]; v < D.tile_c0[t] + D.tile_nc[t]; ++v)
-            if (D.xinfo[v] >= 0) D.send_lane.push_back((v - D.tile_c0[t]) | (D.big[v] ? kDirectHole : 0));
+            if (D.xinfo[v] >= 0) {      // the column's number among the tile's senders travels in its delay word
+                D.delay[v] |= ((int32_t)(D.send_lane.size() - D.send_ptr[t]) + 1) << kDirectSenderShift;
+                D.send_lane.push_back((v - D.tile_c0[t]) | (D.big[v] ? kDirectHole : 0));
+            }
         D.send_ptr[t + 1] = (int32_t)D.send_lane.size();
         if (D.send_ptr[t + 1] - D.send_ptr[t] > kDirectSenders) { D.why = "internal: a tile has more senders than one wave forwards"; return; }
     }

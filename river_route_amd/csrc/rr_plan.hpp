@@ -117,6 +117,7 @@ void build_tile_plan(const std::vector<int32_t> &down, const std::vector<int32_t
 // the outlet of a small subtree sends its discharge to the ghost that mirrors it there, and a small pass patches the holes of
 // the output rows from the skeleton's records.
 constexpr int32_t kDirectHole = 1 << 30;      // delay[] flag: the column belongs to the skeleton
+constexpr int32_t kDirectSenderShift = 8, kDirectDelayMask = 0xFF;      // delay[] bits 8-14: 1 + the column's number among its tile's senders (0: none); bits 0-7: the delay
 struct DirectPlan {
     bool ok = false;
     std::string why;                   // not ok: the first reason
@@ -124,7 +125,7 @@ struct DirectPlan {
     int32_t n_tiles = 0;
     int64_t n_holes = 0, n_exports = 0;
     std::vector<int32_t> tile_c0, tile_nc, tile_lag_lo, tile_span;   // [n_tiles]; span = largest - smallest lag of the tile's lanes
-    std::vector<int32_t> delay;        // [n] lag - tile_lag_lo of the column's tile, or kDirectHole
+    std::vector<int32_t> delay;        // [n] lag - tile_lag_lo of the column's tile (bits 0-7) | sender number + 1 (bits 8-14) | kDirectHole
     std::vector<int32_t> up3;          // [n] three 10-bit lane numbers of the upstream reaches (0x3FF: none)
     std::vector<int32_t> xinfo;        // [n] hole: position of the reach in `skel`; outlet of a small subtree below a skeleton reach: position of its ghost there; else -1
     std::vector<uint8_t> big;          // [n] 1: skeleton

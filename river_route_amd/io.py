@@ -141,7 +141,10 @@ def write_discharge(path, dates, q_array, river_ids, var_river_id='river_id', va
         pass
     from scipy.io import netcdf_file
     with netcdf_file(str(path), 'w', version=2) as ds:
-        ds.createDimension('time', q_array.shape[0])
+        # a fixed-size NetCDF-3 variable holds less than 2 GiB (its size field is 32 bits): beyond that `time` is the record
+        # dimension (same dimensions and variables to any reader; 1M reaches x 744 rows of float32 are 2.98 GB)
+        big = q_array.shape[0] * q_array.shape[1] * 4 >= (1 << 31) - 4
+        ds.createDimension('time', None if big else q_array.shape[0])
         ds.createDimension(var_river_id, q_array.shape[1])
         ds.runoff_file = str(routed_file)
         tv = ds.createVariable('time', 'f8', ('time',))

@@ -37,7 +37,8 @@ def check_direct_layout(down):
         perm_h, lag_h, _ = plan.layout()
     lag_of = np.empty(n, np.int64)
     lag_of[perm_h] = lag_h
-    c0, nc, lo, span, delay, up3, xinfo = (L[k].astype(np.int64) for k in ('tile_c0', 'tile_nc', 'tile_lag_lo', 'tile_span', 'delay', 'up3', 'xinfo'))
+    c0, nc, lo, span, dword, up3, xinfo = (L[k].astype(np.int64) for k in ('tile_c0', 'tile_nc', 'tile_lag_lo', 'tile_span', 'delay', 'up3', 'xinfo'))
+    delay, sender = (dword & 0xFF) | (dword & HOLE), (dword >> 8) & 0x7F      # the delay word also carries 1 + the column's number among its tile's senders
     # the tiles are consecutive column ranges that cover every column once
     assert c0[0] == 0 and np.array_equal(c0[1:], (c0 + nc)[:-1]) and c0[-1] + nc[-1] == n and nc.min() >= 1 and nc.max() <= 256
     assert span.max() + 3 == info['window_rows'] <= 72      # the LDS window: span + 1 rows in flight, one arriving, one leaving
@@ -69,6 +70,11 @@ def check_direct_layout(down):
     outlet = small & (down >= 0) & hole[np.maximum(down, 0)]
     assert outlet.sum() == info['outlets'] and np.all(xinfo[outlet] >= 0) and np.all(xinfo[small & ~outlet] == -1)
     assert np.unique(np.concatenate([xinfo[hole], xinfo[outlet]])).size == hole.sum() + outlet.sum()
+    sends = hole | outlet      # numbered 1, 2, ... in column order inside each tile, at most 64
+    assert np.all(sender[~sends] == 0) and sender.max(initial=0) <= 64
+    if sends.any():
+        first = np.r_[True, tile_of[np.flatnonzero(sends)][1:] != tile_of[np.flatnonzero(sends)][:-1]]
+        assert np.all(sender[sends][first] == 1) and np.all(np.diff(sender[sends])[~first[1:]] == 1)
     # the skeleton's positions: its reaches, one ghost per outlet that feeds them, and the ghosts between its own pieces
     assert info['skeleton_positions'] >= hole.sum() + outlet.sum() and np.concatenate([xinfo[hole], xinfo[outlet]]).max(initial=-1) < info['skeleton_positions']
     return info, dict(tile_of=tile_of, hole=hole)
