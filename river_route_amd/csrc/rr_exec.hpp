@@ -336,12 +336,12 @@ struct Schedule {
     int64_t mrows = 0, stage = 0;     // streaming kernel: doubles of the permutation's intermediate rows / of the host staging rows
 };
 
-// Rows per task of the direct path: a task costs its tile `span` ticks of fill and drain (lanes start one after the other), every
-// tile level of the skeleton one task of pipeline; short calls take short tasks.
+// Rows per task of the direct path: a task costs its tile `span` ticks of fill and drain (lanes start one after the other: 10 % at
+// 512 rows, 5 % at 1,024), every tile level of the skeleton one task of pipeline and of record ring; short calls take short tasks.
 int64_t pick_direct_K(const rr_plan *P, int64_t T)
 {
     if (P->wave_K > 0) return P->wave_K;
-    return T >= 8192 ? 512 : (T >= 2048 ? 256 : (T >= 512 ? 128 : 64));
+    return T >= 16384 ? 1024 : (T >= 8192 ? 512 : (T >= 2048 ? 256 : (T >= 512 ? 128 : 64)));
 }
 
 Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, bool plain_rows = false)
