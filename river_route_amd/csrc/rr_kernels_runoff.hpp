@@ -52,12 +52,11 @@ __global__ __launch_bounds__(kBlock) void k_runoff_to_qlateral(const int32_t *__
     }
     const double a = area ? area[r] : 1.0;
 #pragma unroll
-    for (int j = 1; j <= kRunoffRows; ++j) {
-        if (j > nt) break;
+    for (int j = 1; j <= kRunoffRows; ++j) {      // (no break: the loop must unroll for acc[] to stay in registers -- it was 144 B of scratch per thread)
         double v = (cumulative && t0 + j - 1 > 0) ? acc[j] - acc[j - 1] : acc[j];
         if (force_positive) v = v < 0.0 ? 0.0 : v;      // np.clip leaves NaN alone, as does this comparison
         if (v != v && !keep_nan) v = 0.0;
-        out[(t0 + j - 1) * n_rivers + r] = area ? v * a : v;
+        if (j <= nt) out[(t0 + j - 1) * n_rivers + r] = area ? v * a : v;
     }
 }
 

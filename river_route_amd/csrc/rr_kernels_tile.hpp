@@ -201,7 +201,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
     auto load_state = [&](const Task &t, State &s) {
         s.lg = -1; s.up = 0; s.xp = 0; s.uh = 0;
         s.c1 = s.c2 = s.c3 = s.s_prev = s.qch = s.isum = s.q = 0.0;
-        const int32_t p = t.b0 + tid;
+        const int32_t p = t.b0 + fresh(tid);      // formed here, not when the next task is chosen: kept across the chunk loop the address is spilled
         if (p < t.b1) {
             const int4 pm = a.pos[p];
             const uint32_t cc = (uint32_t)pm.w;
@@ -228,14 +228,25 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
     const bool has_lat = a.has_lat != 0;   // channel-only routing: the records only carry discharge
 
     for (;;) {
-        int32_t lg = st.lg, up = st.up, xp = st.xp, uh = st.uh, sub = 0;
+        int32_t lg = LEAN && UNIT ? 0 : st.lg, up = LEAN && UNIT ? 0 : st.up, xp = LEAN && UNIT ? 0 : st.xp, uh = LEAN && UNIT ? 0 : st.uh, sub = 0;
         double c1 = st.c1, c2 = st.c2, c3 = st.c3, s_prev = st.s_prev, qch = st.qch, isum = st.isum;
         const int32_t b0 = cur.b0, tau_begin = cur.m * K;
         lds[(size_t)((tau_begin + 1) & 1) * THP + tid] = st.q;       // tick tau_begin reads the buffer of tick tau_begin - 1
-        if (LEAN && UNIT) {      // only this thread reads and writes these slots: no barrier
+        // UnitMuskingum's short tick has six upstream slots where RapidMuskingum's has three, and no register to spare: left in
+        // registers, the position's four constant words were spilled to scratch and reloaded every chunk behind a wait for every load
+        // in flight (11 spills; profiles/r04_unit_spills.txt).  They wait in LDS instead (aux[0], aux[1]: this thread's own slots).
+        constexpr bool kParked = LEAN && UNIT;
+        int32_t *const parked = reinterpret_cast<int32_t *>(lds + 2 * THP + (TH / 64) * (kStageLanes * kStageStrideOut));
+        if (kParked) {      // only this thread reads and writes these slots: no barrier
             double *aux = lds + 2 * THP + (TH / 64) * (kStageLanes * kStageStrideOut);
-            aux[tid] = st.c1; aux[TH + tid] = st.c2; aux[2 * TH + tid] = st.c3; aux[3 * TH + tid] = st.qch; aux[4 * TH + tid] = st.s_prev;
+            reinterpret_cast<int2 *>(parked)[tid] = make_int2(st.up, st.uh);
+            reinterpret_cast<int2 *>(parked + 2 * TH)[tid] = make_int2(st.lg, st.xp);
+            aux[3 * TH + tid] = st.qch; aux[4 * TH + tid] = st.s_prev;
         }
+        auto the_up = [&]() { return kParked ? parked[2 * tid] : fresh(up); };
+        auto the_uh = [&]() { return kParked ? parked[2 * tid + 1] : fresh(uh); };
+        auto the_lg = [&]() { return kParked ? parked[2 * TH + 2 * tid] : fresh(lg); };
+        auto the_xp = [&]() { return kParked ? parked[2 * TH + 2 * tid + 1] : fresh(xp); };
         if (SUB && lg >= 0) {      // phase of the position's sub-step counter at the first tick of the task
             const int32_t ts0 = tau_begin - (lg & kLagMask);
             const uint32_t r = a.nsub.mod((uint32_t)(ts0 < 0 ? -ts0 : ts0));
@@ -256,8 +267,9 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
 #pragma unroll
                     for (int j = 0; j < 8; ++j) mine[j] = make_double2(R[2 * j], R[2 * j + 1]);
                     int32_t *word = reinterpret_cast<int32_t *>(mine + 8);
-                    word[0] = (lg < 0 || (lg & (kGhostBit | kTileGhostBit))) ? 1 : 0;   // not this tile's to write
-                    if (!SUB) word[1] = (lg >= 0 && (lg & kTileExportBit)) ? fresh(xp) : -1;      // position of the ghost that mirrors this reach
+                    const int32_t lgw = LEAN ? the_lg() : lg;
+                    word[0] = (lgw < 0 || (lgw & (kGhostBit | kTileGhostBit))) ? 1 : 0;   // not this tile's to write
+                    if (!SUB) word[1] = (lgw >= 0 && (lgw & kTileExportBit)) ? the_xp() : -1;      // position of the ghost that mirrors this reach
                 }
                 wave_lds_fence();
                 const int32_t t = fresh(tid), ln = t & 63;
@@ -408,9 +420,9 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
         // boundary exports of a partitioned network: with one sub-step per row the record slot of a tick IS the discharge of that
         // sub-step, so the export series is written from the half record that has just been completed
         auto store_exports = [&](int32_t tau0, int half) {
-            const int32_t lgk = fresh(lg);
+            const int32_t lgk = the_lg();
             if (lgk >= 0 && (lgk & kExportBit)) {
-                const int32_t ts0 = tau0 + 8 * half - (lgk & kLagMask), slot = fresh(xp);      // xp: the export slot (see TileArgs::pos)
+                const int32_t ts0 = tau0 + 8 * half - (lgk & kLagMask), slot = the_xp();      // xp: the export slot (see TileArgs::pos)
 #pragma unroll
                 for (int s8 = 0; s8 < 8; ++s8)
                     if ((uint32_t)(ts0 + s8) < (uint32_t)total) a.exports[(int64_t)(ts0 + s8) * a.n_export + slot] = R[8 * half + s8];
@@ -426,12 +438,12 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
             const int32_t nb0 = last ? nxt.b0 : b0, nb1 = last ? nxt.b1 : cur.b1;
             if constexpr (LEAN) {
                 // a position past the end of the next tile reads whatever follows it in the ring (or zeros past its end): never used
-                const int32_t t = fresh(tid), ln = t & 63, upk = fresh(up);
+                const int32_t t = fresh(tid), ln = t & 63, upk = the_up();
                 const int32_t cnt = (int32_t)((uint32_t)upk >> 16), u0s = upk & 0xFFFF;
                 own_b = t * 8;
-                if (NOLAT) { const int32_t lgs = fresh(lg); ghostm = lgs >= 0 && (lgs & (kGhostBit | kTileGhostBit)) != 0; }
+                if (NOLAT) { const int32_t lgs = the_lg(); ghostm = lgs >= 0 && (lgs & (kGhostBit | kTileGhostBit)) != 0; }
                 if (UNIT) {
-                    const int32_t nh = fresh(uh) - u0s, ni = cnt - nh, i0 = u0s + nh;      // headwater tributaries [u0s, uh), inner ones [uh, u0s + cnt)
+                    const int32_t nh = the_uh() - u0s, ni = cnt - nh, i0 = u0s + nh;      // headwater tributaries [u0s, uh), inner ones [uh, u0s + cnt)
                     hw0_b = (nh >= 1 ? u0s : TH) * 8; hw1_b = (nh >= 2 ? u0s + 1 : TH) * 8; hw2_b = (nh >= 3 ? u0s + 2 : TH) * 8;
                     up0_b = (ni >= 1 ? i0 : TH) * 8; up1_b = (ni >= 2 ? i0 + 1 : TH) * 8; up2_b = (ni >= 3 ? i0 + 2 : TH) * 8;
                 } else {
@@ -443,7 +455,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
                     ticks_plain(std::false_type(), tau0, 0, src, nvoff);
                     ticks_plain(std::false_type(), tau0, 1, src, nvoff);
                 } else {
-                    lagm = lg < 0 ? 0x40000000 : (fresh(lg) & kLagMask);      // a slot past the end of the tile is never active
+                    { const int32_t lgs = the_lg(); lagm = lgs < 0 ? 0x40000000 : (lgs & kLagMask); }      // a slot past the end of the tile is never active
                     ticks_plain(std::true_type(), tau0, 0, src, nvoff);
                     if (kind & kTileExports) store_exports(tau0, 0);
                     ticks_plain(std::true_type(), tau0, 1, src, nvoff);
@@ -461,7 +473,7 @@ __global__ __launch_bounds__(TH, 4) void k_tile(const TileArgs a)      // 16 wav
             receive();      // the record that has had 16 ticks to arrive (zeros after the last chunk of the last tile)
             rec_cur = rec_next;
         }
-        if (lg >= 0) {
+        if ((LEAN ? the_lg() : lg) >= 0) {
             const int32_t p = b0 + tid;
             const double *aux = lds + 2 * THP + (TH / 64) * (kStageLanes * kStageStrideOut);
             a.sq[p] = lds[(size_t)((tau_begin + K - 1) & 1) * THP + tid]; a.ss[p] = (LEAN && UNIT) ? aux[4 * TH + tid] : s_prev;
