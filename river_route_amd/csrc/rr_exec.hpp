@@ -337,11 +337,12 @@ struct Schedule {
 };
 
 // Rows per task of the direct path: a task costs its tile `span` ticks of fill and drain (lanes start one after the other: 10 % at
-// 512 rows, 5 % at 1,024), every tile level of the skeleton one task of pipeline and of record ring; short calls take short tasks.
+// 512 rows), every tile level of the skeleton one task of pipeline and of record ring (1,024 rows: 213 ms per year against 207,
+// profiles/r04_direct_k_and_fill.txt); short calls take short tasks.
 int64_t pick_direct_K(const rr_plan *P, int64_t T)
 {
     if (P->wave_K > 0) return P->wave_K;
-    return T >= 16384 ? 1024 : (T >= 8192 ? 512 : (T >= 2048 ? 256 : (T >= 512 ? 128 : 64)));
+    return T >= 8192 ? 512 : (T >= 2048 ? 256 : (T >= 512 ? 128 : 64));
 }
 
 Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, bool plain_rows = false)

@@ -178,6 +178,16 @@ class Plan:
         path does not apply (RR_ROWS_NOT_PLAIN)."""
         info = np.zeros(8, dtype=np.int64)
         check(_lib.lib().rr_plan_reserve(self._h, int(mode), int(T), int(num_substeps), int(bool(host_rows)) | (0 if plain_rows else 2), ptr(info)))
+        if int(info[0]) == 0 and int(T) * int(num_substeps) >= 32 and self.n > 0 and not getattr(self, '_warned_streaming', False):
+            # the time-tiled kernel takes every call of 32 sub-steps or more -- unless the network does not tile, the coefficients give the
+            # tributaries of a reach different weights, or its record ring (depth + tile levels x K tick-rows of every reach) does not fit
+            # the card: the streaming kernel then routes at about a third of the rate.  Say so once, where the routers' log shows it.
+            import logging
+            self._warned_streaming = True
+            logging.getLogger('river_route_amd').warning(
+                'routing %d reaches (network depth %d) with the streaming kernel k_tick: the time-tiled kernel does not apply to this call '
+                '(record ring too large for the device, per-edge weights, or a reach with more tributaries than a tile holds); '
+                'expect about a third of its rate', self.n, self.depth)
         return dict(tiled=int(info[0]) == 1, direct=int(info[0]) == 2, ticks_per_launch=int(info[1]), ring_chunks=int(info[2]), work_bytes=int(info[3]),
                     staging_bytes=int(info[4]), pinned_bytes=int(info[5]), pipeline_ticks=int(info[6]), ring_bytes=int(info[7]))
 

@@ -496,7 +496,7 @@ def bench_main(args, rank: int, local_rank: int, world: int, gate=None) -> None:
     r = dt / net.k
     den = r + 2.0 * (1.0 - net.x)
     c1, c2, c3 = (r - 2.0 * net.x) / den, (r + 2.0 * net.x) / den, (2.0 * (1.0 - net.x) - r) / den
-    rows = min(args.forcing_rows, T)
+    rows = min(args.forcing_rows or 288, T)
     lateral = synth.synth_qlateral_torch(n, 0, rows, torch.device('cuda', local_rank), columns=spec.real_global, dt=dt * nsub)
     eng = HipPartEngine(spec, c1, c2, c3, (c1 + c2) / (dt * nsub), np.zeros(n), lateral, T, nsub, local_rank,
                         out_rows=min(T, 128), sample_every=args.sample_every)      # sink of one out-pass batch: no row written twice by a launch
