@@ -27,10 +27,10 @@
  *     exactly as the reference passes them.  The engine keeps its own permuted device layout.
  *   - `*_dev` variants take DEVICE pointers (valid on the plan's GPU) and a hipStream_t passed as
  *     void*; they only enqueue work: nothing in them allocates or synchronises (work memory comes
- *     from rr_plan_reserve).  The record passes of a call run on a second stream of the plan, forked
- *     from and joined to the caller's stream by events: to the caller the call is ordered on its
- *     stream.  The un-suffixed variants take HOST pointers, copy in/out, and return when the results
- *     are in the caller's buffers.
+ *     from rr_plan_reserve -- a BREAK against the first versions of this ABI, see INTEGRATION.md: a
+ *     `_dev` call or rr_stream_begin* without a reservation at least as large returns RR_E_STATE).  Every
+ *     kernel of a call is enqueued on the caller's stream.  The un-suffixed variants take HOST pointers,
+ *     copy in/out, and return when the results are in the caller's buffers.
  *   - a plan is bound to one GPU and is not thread-safe; use one plan per thread/stream.
  *   - there is NO CPU fallback: without a usable gfx950 device every compute call fails with
  *     RR_E_NO_DEVICE.  rr_plan_create(device = RR_DEVICE_NONE) builds a host-only plan whose

@@ -117,14 +117,14 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             *reinterpret_cast<double *>(X + THP * 8 + tid * 8) = q0;
             int32_t own_b = idle || delta == 0 ? 0 : wrap - delta * kRowB;      // window slot of the row this lane routes this tick: (k - delta) mod (span + 3)
             if (!idle && delta > 0 && own_b < 0) own_b += wrap;                   // (delta <= span < span + 3)
-            double s_prev = 0.0;
+            double s_prev = 0.0, q_last = q0;      // the lane's own discharge one tick back stays in a register
             __syncthreads();      // the discharges carried in, and row 0 in the window (waves 4, 5)
             auto ticks = [&](auto tested, int32_t k0) {
 #pragma unroll
                 for (int s = 0; s < PF; ++s) {
                     const int prev = ((s + 1) & 1) * (THP * 8), cur = (s & 1) * (THP * 8);
                     // _numba_kernels.py:63-84 in gather form, the arithmetic of k_tile's short tick operation for operation
-                    const double q_old = *reinterpret_cast<const double *>(X + prev + tid * 8);
+                    const double q_old = q_last;
                     const double s_cur = (*reinterpret_cast<const double *>(X + prev + up0_b) + *reinterpret_cast<const double *>(X + prev + up1_b)) +
                                          *reinterpret_cast<const double *>(X + prev + up2_b);
                     double *mine = reinterpret_cast<double *>(F + own_b + tid * 8);
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                     } else {
                         *mine = qk;
                     }
-                    s_prev = s_cur;
+                    s_prev = s_cur; q_last = qk;
                     *reinterpret_cast<double *>(X + cur + tid * 8) = qk;
                     if (wave_sends) {      // wave-uniform
                         const int32_t slot_b = ((r0 + tm.lag_lo + k0 + s) & 31) * 8;

@@ -9,7 +9,7 @@ import pytest
 from conftest import assert_close
 from oracle import oracle
 from river_route_amd import synth
-from river_route_amd.engine import Plan
+from river_route_amd.engine import DeviceBuffer, Plan
 
 pytestmark = pytest.mark.gpu
 
@@ -358,3 +358,28 @@ def test_dev_entry_points_only_enqueue(monkeypatch, env):
         torch.cuda.synchronize()
     finally:
         L.rr_plan_destroy(h)
+
+
+def test_profile_names_every_kernel_of_the_path(monkeypatch):
+    """bench.py's whole-path block: with sampling on, rr_plan_profile / rr_plan_profile_aux time the routing kernel and the two
+    record passes of the last call between HIP events on its stream, and rr_plan_last_kernel says which routing kernel ran."""
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    n, T = 60_000, 1500
+    net = synth.synth_network(n, seed=5)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0)
+    ql = synth.synth_qlateral(n, 0, 64)
+    with Plan(indptr, indices) as plan:
+        plan.set_coeffs(-c1[indices], c2, c3, (c1 + c2) / 900.0)
+        plan.set_options(sample_every=128)
+        d_q, d_ql, d_out = DeviceBuffer(n * 8).upload(np.zeros(n)), DeviceBuffer(ql.nbytes).upload(ql), DeviceBuffer(128 * n * 8)
+        plan.rapid_route_dev(d_q, d_ql, 64, d_out, 128, T, 1)
+        prof, aux = plan.profile(), plan.profile_aux()
+        assert plan.last_kernel() == 'tile' and prof['brackets'] > 0 and prof['sampled_ms'] > 0
+        batches = (T + 127) // 128
+        assert aux['k_rec_in']['launches'] == (T + 14) // 128 + 1 and aux['k_rec_out']['launches'] == batches
+        for k in ('k_rec_in', 'k_rec_out'):
+            assert aux[k]['sampled'] == (aux[k]['launches'] + 3) // 4 and 0 < aux[k]['sampled_ms'] < 1e3
+        for b in (d_q, d_ql, d_out):
+            b.free()
