@@ -26,6 +26,10 @@ namespace {
 // multiply-adds, two LDS writes), waves 4 and 5 bring the rows in (a 16-byte load per lane and tick, 32 rows ahead, scaled by c4dt
 // into the window one tick before the first lane needs them), wave 6 takes finished rows out (one tick after the last lane wrote
 // them), wave 7 forwards what the skeleton needs: eight instruction streams, two per SIMD, that meet at the tick's barrier.
+// What a tick (0.196 us) answers to, measured build against build on one box (profiles/r04_direct_tick_ab.txt): the rows-in waves'
+// instruction count (38 a tick; 63 -> +34 %) and their rows in flight (16 instead of 32 -> +11 %: a loaded memory latency of ~3.5 us);
+// not the rows-out wave's count (44 or 36: 0.5 %), not wave 7's, not where the rows lie (Infinity Cache or HBM: the same), not
+// LDS round trips taken off the I/O waves' path (slower), and two workgroups of 128 lanes per CU are slower than one of 256.
 //
 // The skeleton (reaches with large or tall subtrees: 5 %) keeps records and k_tile.  Its columns lie between the subtrees'
 // columns (HOLES).  A hole's scaled lateral inflow (waves 4, 5) and the discharge of an outlet lane (a small subtree's last reach)
@@ -64,6 +68,13 @@ constexpr size_t direct_lds_bytes(int window_rows)
     return (size_t)(2 * (kDirectLanes + kTilePad) + kDirectStage + (int64_t)window_rows * kDirectLanes) * sizeof(double);
 }
 
+// the reference's clip at zero (_numba_kernels.py:84): x > 0 ? x : 0 in one instruction (the compiler's own max quiets its operand first)
+__device__ __forceinline__ double clip0(double x)
+{
+    double r;
+    asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(x));
+    return r;
+}
 __device__ __forceinline__ double2 load_f64x2_(__amdgpu_buffer_rsrc_t r, uint32_t byte_off)
 {
     const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
@@ -174,8 +185,8 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             const uint32_t va = ca < tm.nc ? (uint32_t)(tm.c0 + ca) * 8u : kDropAccess;
             uint32_t rin = (uint32_t)r0 % a.in_rows;
             const double *row = a.in + (int64_t)rin * a.n;
-            // AH rows in flight: a tick cannot be shorter than the memory latency over AH (16 rows ahead held the tick at 0.21 us:
-            // 32 KB per CU in flight against ~3 us under load); the register ring is indexed statically: two chunk bodies alternate
+            // AH rows in flight: a tick cannot be shorter than the memory latency over AH (16 rows ahead hold the tick at 0.22 us:
+            // 32 KB per CU in flight against ~3.5 us under load); the register ring is indexed statically: two chunk bodies alternate
             constexpr int AH = 2 * PF;
             double2 Pa[AH];
             auto request = [&](int32_t arrival, double2 &pa) {      // row r0 + arrival, or nothing past the task's rows
@@ -209,32 +220,32 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                     barrier_lds();
                 }
             };
-            for (int32_t k0 = 0; k0 < n_ticks; k0 += 2 * PF) {
+            // (an odd last chunk stands outside the loop: a branch around the second half inside it would leave the compiler's count of
+            // the loads in flight -- s_waitcnt vmcnt -- at the smaller of the two paths', 15 instead of 31, in every trip)
+            int32_t k0 = 0;
+            for (; k0 + PF < n_ticks; k0 += 2 * PF) {
                 chunk(std::integral_constant<int, 0>(), k0);
-                if (k0 + PF < n_ticks) chunk(std::integral_constant<int, 1>(), k0 + PF);
+                chunk(std::integral_constant<int, 1>(), k0 + PF);
             }
+            if (k0 < n_ticks) chunk(std::integral_constant<int, 0>(), k0);
         } else if (role == 2) {
             // ---------------------------------------------------------------- wave 6: rows out.  Lane -> columns 2 ln, 2 ln + 1 and 128 + 2 ln, 128 + 2 ln + 1
-            const int32_t ca = 2 * ln, cb = TH / 2 + 2 * ln;
-            // whole 16-byte pieces inside the tile; the piece that holds the tile's last column when nc is odd goes as 8 bytes
-            const uint32_t va = ca + 1 < tm.nc ? (uint32_t)(tm.c0 + ca) * 8u : kDropAccess, vb = cb + 1 < tm.nc ? (uint32_t)(tm.c0 + cb) * 8u : kDropAccess;
-            const bool odd_a = ca + 1 == tm.nc, odd_b = cb + 1 == tm.nc;
-            const uint32_t vo = (odd_a || odd_b) ? (uint32_t)(tm.c0 + tm.nc - 1) * 8u : kDropAccess;
+            // The descriptor ends behind the tile's last column: a 16-byte piece past it is dropped by the range check, and so is the
+            // second half of the piece that holds the last column of a tile with an odd number of them (the check is made per dword).
+            const uint32_t va = (uint32_t)(tm.c0 + 2 * ln) * 8u, vb = va + 128u * 8u, tile_end = (uint32_t)(tm.c0 + tm.nc) * 8u;
             uint32_t rout = (uint32_t)r0 % a.out_rows;
             double *row = a.out + (int64_t)rout * a.n;
             int32_t out_b = 0;
-            auto clip = [](double x) { return x > 0.0 ? x : 0.0; };      // the reference's clip at zero (_numba_kernels.py:84)
             __syncthreads();
             for (int32_t k0 = 0; k0 < n_ticks; k0 += PF) {
 #pragma unroll
                 for (int s = 0; s < PF; ++s) {      // tick k: row k - 1 - span leaves
                     const int32_t leaving = k0 + s - 1 - span;
                     if (leaving >= 0 && leaving < nrows) {      // wave-uniform
-                        const double2 xa = *reinterpret_cast<const double2 *>(F + out_b + ca * 8), xb = *reinterpret_cast<const double2 *>(F + out_b + cb * 8);
-                        const __amdgpu_buffer_rsrc_t dst = make_rsrc(row, row_bytes);
-                        store_f64x2(dst, va, make_double2(clip(xa.x), clip(xa.y)));
-                        store_f64x2(dst, vb, make_double2(clip(xb.x), clip(xb.y)));
-                        store_f64(dst, vo, clip(odd_a ? xa.x : xb.x));
+                        const double2 xa = *reinterpret_cast<const double2 *>(F + out_b + 2 * ln * 8), xb = *reinterpret_cast<const double2 *>(F + out_b + 2 * ln * 8 + 128 * 8);
+                        const __amdgpu_buffer_rsrc_t dst = make_rsrc(row, tile_end);
+                        store_f64x2(dst, va, make_double2(clip0(xa.x), clip0(xa.y)));
+                        store_f64x2(dst, vb, make_double2(clip0(xb.x), clip0(xb.y)));
                         out_b = out_b + kRowB == wrap ? 0 : out_b + kRowB;
                         ++rout; row += a.n;
                         if (rout == a.out_rows) { rout = 0; row = a.out; }
@@ -245,9 +256,10 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
         } else {
             // ---------------------------------------------------------------- wave 7: what the skeleton needs
             // The senders' rings fill by themselves (above); this wave writes every record that is complete -- 16 ticks, slot = tick % 16
-            // with tick = row + lag: k_tile's layout -- into the skeleton's record ring, eight lanes per 128-byte record.  Sender i has
-            // its turn when the local tick is i mod 16 (four senders a tick at most: one store instruction), once in 16 ticks, which is
-            // how often it completes a record; a ring holds two, so the one being written out is never the one being filled.  (Copying
+            // with tick = row + lag: k_tile's layout -- into the skeleton's record ring, eight lanes per 128-byte record.  The lanes
+            // form eight groups of eight, a group serves kDirectSenders / 8 senders in turn, one a tick (eight records a tick at most:
+            // one store instruction), so a sender has a turn every eight ticks and completes a record every 16; a ring holds two
+            // records, so the one being written out is never the one being filled.  (Copying
             // the values itself, this wave was busy 90 % of a tick and every other wave waited for it: profiles/r04_direct_wave_stamps_before.txt.)
             // A task's first and last record are partly the neighbouring tasks': only the slots this task made are written.
             const int32_t s0 = a.send_ptr[t], ns = a.send_ptr[t + 1] - s0;
@@ -260,16 +272,18 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                     if (lo <= 2 * piece + 1 && 2 * piece + 1 < hi) dst[1] = v.y;
                 }
             };
-            // per turn (= local tick % 16): the sender this lane serves then
-            int32_t ring_b[PF];                       // its ring in LDS, or -1
-            uint32_t done[PF], end[PF], avail0[PF];   // ticks (row + lag) written out so far / of the task's last row + 1 / visible at local tick 0
-            uint32_t chk[PF];                         // ring chunk of the record `done` lies in
-            int64_t roff[PF];                         // ... and its offset in the record ring, in doubles
+            // per turn (= local tick % NS): the sender this lane serves then
+            constexpr int NS = kDirectSenders / 8;    // senders per group of eight lanes
+            static_assert(PF % NS == 0, "a sender's turns are the ticks with tick % NS == its place in the group");
+            int32_t ring_b[NS];                       // its ring in LDS, or -1
+            uint32_t done[NS], end[NS], avail0[NS];   // ticks (row + lag) written out so far / of the task's last row + 1 / visible at local tick 0
+            uint32_t chk[NS];                         // ring chunk of the record `done` lies in
+            int64_t roff[NS];                         // ... and its offset in the record ring, in doubles
             const int64_t chunk_step = (int64_t)a.np * kRec, ring = (int64_t)a.rec_chunks * a.np * kRec;
 #pragma unroll
-            for (int f = 0; f < PF; ++f) {
-                const int32_t i = f + PF * member;
-                const bool have = member < kDirectSenders / PF && i < ns;
+            for (int f = 0; f < NS; ++f) {
+                const int32_t i = f + NS * member;
+                const bool have = i < ns;
                 const int32_t sl = have ? a.send_lane[s0 + i] : 0;
                 const int4 lm = a.lane[tm.c0 + (sl & 0x3FF)];
                 const bool hole = (sl & kDirectHoleBit) != 0;
@@ -299,14 +313,14 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             for (int32_t k0 = 0; k0 < n_ticks; k0 += PF) {
 #pragma unroll
                 for (int s = 0; s < PF; ++s) {
-                    turn(s, avail0[s] + (uint32_t)(k0 + s), false);
+                    turn(s % NS, avail0[s % NS] + (uint32_t)(k0 + s), false);
                     barrier_lds();
                 }
             }
             // the records completed since their sender's last turn, then the task's last (partial) ones: everything is staged by now
             wave_lds_fence();
 #pragma unroll
-            for (int f = 0; f < PF; ++f) { turn(f, 0xFFFFFFFFu, false); turn(f, 0xFFFFFFFFu, false); turn(f, 0xFFFFFFFFu, true); }
+            for (int f = 0; f < NS; ++f) { turn(f, 0xFFFFFFFFu, false); turn(f, 0xFFFFFFFFu, false); turn(f, 0xFFFFFFFFu, true); }
         }
     }
 }
