@@ -26,10 +26,12 @@ namespace {
 // multiply-adds, two LDS writes), waves 4 and 5 bring the rows in (a 16-byte load per lane and tick, 32 rows ahead, scaled by c4dt
 // into the window one tick before the first lane needs them), wave 6 takes finished rows out (one tick after the last lane wrote
 // them), wave 7 forwards what the skeleton needs: eight instruction streams, two per SIMD, that meet at the tick's barrier.
-// What a tick (0.196 us) answers to, measured build against build on one box (profiles/r04_direct_tick_ab.txt): the rows-in waves'
-// instruction count (38 a tick; 63 -> +34 %) and their rows in flight (16 instead of 32 -> +11 %: a loaded memory latency of ~3.5 us);
-// not the rows-out wave's count (44 or 36: 0.5 %), not wave 7's, not where the rows lie (Infinity Cache or HBM: the same), not
-// LDS round trips taken off the I/O waves' path (slower), and two workgroups of 128 lanes per CU are slower than one of 256.
+// What a tick (0.195 us) answers to, measured build against build on one box (profiles/r04_direct_tick_ab.txt): heavier rows-in
+// waves slow it down (63 instead of 38 instructions a tick: +34 %; 16 instead of 32 rows in flight: +11 %, a loaded memory latency
+// of ~3.5 us), lighter ones do not speed it up (25 instructions, or 20 / 26 on four waves that take turns), nor do a lighter rows-out
+// wave or wave 7, nor rows that lie in the Infinity Cache instead of HBM, nor LDS round trips taken off the I/O waves' path; two
+// workgroups of 128 lanes per CU are slower than one of 256.  What is left is the routing waves' own recurrence: four LDS reads, two
+// additions and three multiply-adds in a chain, two LDS writes, the wait for them and the barrier.
 //
 // The skeleton (reaches with large or tall subtrees: 5 %) keeps records and k_tile.  Its columns lie between the subtrees'
 // columns (HOLES).  A hole's scaled lateral inflow (waves 4, 5) and the discharge of an outlet lane (a small subtree's last reach)
