@@ -260,3 +260,81 @@ def test_calls_the_direct_path_does_not_take_fall_back_to_records(monkeypatch):
         assert_close(d_out.download(np.float64, (T, n)), d_ref, 'direct after records')
         for b in (d_q, d_ql, d_out, d_ql32, d_out32):
             b.free()
+
+
+@pytest.mark.gpu
+def test_direct_full_year_at_1m_sub_basins_vs_oracle(monkeypatch):
+    """The post-order line of the bench at full length against the ORACLE (the bench's own gate checks 96 rows): four sub-basins of
+    3k-6k reaches -- each with skeleton reaches, holes and outlets that feed them -- routed by the oracle on their own through
+    all 35,040 steps; the engine's rows for those columns, from two calls of 17,520 rows over the whole 1M-reach network in tasks of
+    512 rows (35 launches of k_direct per call, the skeleton's record ring, state carried between the calls, a 120-row forcing
+    ring read 146 times per call) must be theirs row by row."""
+    import torch
+    from test_gpu_tiles import _sub_basins
+    set_env(monkeypatch, {})
+    n, T, rows, calls = 1_000_000, 35_040, 120, 2
+    net, indptr, indices, c1, c2, c3 = _case(n, synth.NETWORK_SEED)
+    lhs, c4_dt = -c1[indices], (c1 + c2) / 900.0
+    cols, sub_down = _sub_basins(net.down_index, 3_000, 6_000, 4)
+    s_indptr, s_indices = csc_from_down(sub_down)
+    dev = torch.device('cuda:0')
+    ql = synth.synth_qlateral_torch(n, 0, rows, dev)
+    cols_t = torch.from_numpy(cols).to(dev)
+    ql_sub = ql[:, cols_t].cpu().numpy()
+    s_c1, s_c2, s_c3, s_c4 = c1[cols], np.ascontiguousarray(c2[cols]), np.ascontiguousarray(c3[cols]), np.ascontiguousarray(c4_dt[cols])
+    s_lhs = -s_c1[s_indices]
+    q_ref, d_ref = np.zeros(cols.size), np.zeros((rows, cols.size))
+    Tc = T // calls
+    assert Tc % rows == 0
+    worst = 0.0
+    with Plan(indptr, indices) as plan:
+        info = plan.direct_info()
+        assert info['ok'] and info['holes'] > 10_000
+        L = plan.direct_layout()
+        assert (L['delay'][cols] & HOLE).any(), 'the sub-basins hold skeleton reaches'
+        plan.set_coeffs(lhs, c2, c3, c4_dt)
+        q = torch.zeros(n, dtype=torch.float64, device=dev)
+        out = torch.empty((Tc, n), dtype=torch.float64, device=dev)
+        for call in range(calls):
+            out.fill_(-1.0)
+            plan.rapid_route_dev(q, ql, rows, out, Tc, Tc, 1, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert plan.last_kernel() == 'direct' and plan.profile()['ticks_per_launch'] == 512
+            kept = out[:, cols_t]
+            for r0 in range(0, Tc, rows):
+                oracle.rapid_route(s_indptr, s_indices, s_lhs, s_c2, s_c3, s_c4, q_ref, ql_sub, d_ref, 1)
+                got = kept[r0:r0 + rows].cpu().numpy()
+                err = np.abs(got - d_ref).max() / np.abs(d_ref).max()
+                worst = max(worst, err)
+                assert err <= 1e-10, f'call {call}, rows {r0}..{r0 + rows}: {err:.3e} of the largest discharge'
+            del kept
+        assert_close(q[cols_t].cpu().numpy(), q_ref, 'final state of the sub-basins')
+    print(f'post-order sub-basins: {cols.size} reaches x {T} steps against the oracle, worst difference {worst:.2e} of the largest discharge')
+
+
+@pytest.mark.gpu
+def test_direct_constant_forcing_settles_at_the_basin_sums(monkeypatch):
+    """The fixed-point property of test_gpu_tiles.py at full size on the direct row path: one forcing row (a ring of ONE row: the
+    rows-in waves read it 35,040 times) and a 128-row sink written 274 times; after a year every one of the 1M reaches -- small
+    subtrees, holes, skeleton -- sits at the lateral inflow accumulated over its basin (_numba_kernels.py:68-78: q = A q + ql/dt
+    is the update's fixed point)."""
+    import torch
+    set_env(monkeypatch, {})
+    n, T, sink = 1_000_000, 35_040, 128
+    net, indptr, indices, c1, c2, c3 = _case(n, synth.NETWORK_SEED)
+    row = synth.synth_qlateral(n, 0, 1)
+    acc, dl = (row[0] / 900.0).tolist(), net.down_index.tolist()
+    for i in range(n):
+        if dl[i] >= 0:
+            acc[dl[i]] += acc[i]
+    want = np.asarray(acc)
+    dev = torch.device('cuda:0')
+    with Plan(indptr, indices) as plan:
+        plan.set_coeffs(-c1[indices], c2, c3, (c1 + c2) / 900.0)
+        q = torch.zeros(n, dtype=torch.float64, device=dev)
+        out = torch.zeros((sink, n), dtype=torch.float64, device=dev)
+        plan.rapid_route_dev(q, torch.from_numpy(row).to(dev), 1, out, sink, T, 1, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert plan.last_kernel() == 'direct'
+        np.testing.assert_allclose(q.cpu().numpy(), want, rtol=1e-9, err_msg='final state')
+        np.testing.assert_allclose(out.cpu().numpy(), np.broadcast_to(want, (sink, n)), rtol=1e-9, err_msg='last 128 rows')
