@@ -91,9 +91,9 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         rr::build_tile_plan(P->h.down, lag_of, block, P->tp);
         // the direct row path where the params order numbers small subtrees contiguously (any depth-first post-order); `why` says why not
         if (const char *e = getenv("RR_DIRECT")) P->direct_enabled = atoi(e) != 0;
-        rr::build_direct_plan(P->h.down, lag_of, std::min<int32_t>(kDirectLanes, block), kDirectMaxLevels, block, P->dp);
-        P->direct_window = kDirectSlack;
-        for (int32_t sp : P->dp.tile_span) P->direct_window = std::max(P->direct_window, 2 * sp + kDirectSlack);
+        rr::build_direct_plan(P->h.down, lag_of, std::min<int32_t>(kDirectLanes, block), kDirectMaxWindow - 2, block, P->dp);
+        P->direct_window = 3;
+        for (int32_t sp : P->dp.tile_span) P->direct_window = std::max(P->direct_window, sp + 3);
     }
     if (device != RR_DEVICE_NONE) {
         int count = rr_device_count();

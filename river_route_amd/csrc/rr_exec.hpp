@@ -151,7 +151,7 @@ struct rr_plan {
     // direct row path: column-range tiles where the params order numbers small subtrees contiguously (rr_plan.hpp: DirectPlan)
     rr::DirectPlan dp;
     bool direct_enabled = true, direct_now = false;      // RR_DIRECT=0 (tests): records for every call
-    int direct_window = 1;               // rows of the LDS window: twice the largest span of the plan's tiles + kDirectSlack
+    int direct_window = 1;               // rows of the LDS window: largest span + 1 of the plan's tiles
     DirectTile *d_dtiles = nullptr;
     int4 *d_dlane = nullptr;
     int32_t *d_dsend_ptr = nullptr, *d_dsend_lane = nullptr;

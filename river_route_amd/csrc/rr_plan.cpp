@@ -401,17 +401,16 @@ void build_direct_plan(const std::vector<int32_t> &down, const std::vector<int32
         if (indeg[v] > 3) { D.why = "a reach of a small subtree has more than three upstream reaches"; return; }
         if (small_root(v) && first[v] != (int32_t)v - sub[v] + 1) { D.why = "a small subtree is not a contiguous range of the params order"; return; }
     }
-    // tiles: consecutive units (a whole small subtree, or one hole) while the lanes and the senders last.  The subtrees of a tile do
-    // not depend on each other, so each starts on its own: a lane's delay counts from the smallest lag of ITS subtree
+    // tiles: consecutive units (a whole small subtree, or one hole) while the lanes and the lag window last
     D.delay.assign(n, 0); D.up3.assign(n, 0x3FFFFFFF); D.xinfo.assign(n, -1);
     std::vector<int32_t> tile_of(n, -1);
     int64_t c = 0;
     while (c < n) {
         const int64_t c0 = c;
-        int32_t lo = std::numeric_limits<int32_t>::max(), hi = -1, senders = 0, span = 0;
+        int32_t lo = std::numeric_limits<int32_t>::max(), hi = -1, senders = 0;
         while (c < n) {
             int64_t c1;
-            int32_t ulo = std::numeric_limits<int32_t>::max(), uhi = -1, us = senders;
+            int32_t ulo = lo, uhi = hi, us = senders;
             if (D.big[c]) { c1 = c + 1; ++us; }
             else {      // the small subtree that STARTS here: its outlet is the first small root at or after c whose range begins at c
                 int64_t r = c;
@@ -421,20 +420,17 @@ void build_direct_plan(const std::vector<int32_t> &down, const std::vector<int32
                 if (down[r] >= 0) ++us;
                 for (int64_t v = c; v < c1; ++v) { ulo = std::min(ulo, lag_of[v]); uhi = std::max(uhi, lag_of[v]); }
             }
-            if (c1 - c0 > lanes || us > kDirectSenders) break;
-            if (uhi >= 0) {
-                for (int64_t v = c; v < c1; ++v) D.delay[v] = lag_of[v] - ulo;
-                lo = std::min(lo, ulo); hi = std::max(hi, uhi); span = std::max(span, uhi - ulo);
-            }
-            senders = us; c = c1;
+            if (c1 - c0 > lanes || (uhi >= 0 && uhi - ulo + 1 > wmax) || us > kDirectSenders) break;
+            lo = ulo; hi = uhi; senders = us; c = c1;
         }
         if (c == c0) { D.why = "internal: a unit does not fit an empty tile"; return; }
         const int32_t t = D.n_tiles++;
         D.tile_c0.push_back((int32_t)c0); D.tile_nc.push_back((int32_t)(c - c0));
-        D.tile_lag_lo.push_back(hi < 0 ? 0 : lo); D.tile_span.push_back(span);
+        D.tile_lag_lo.push_back(hi < 0 ? 0 : lo); D.tile_span.push_back(hi < 0 ? 0 : hi - lo);
         for (int64_t v = c0; v < c; ++v) {
             tile_of[v] = t;
             if (D.big[v]) { D.delay[v] = kDirectHole; ++D.n_holes; }
+            else D.delay[v] = lag_of[v] - lo;
         }
     }
     // upstream lanes (a small reach's upstream reaches are in its subtree, hence in its tile): headwater tributaries first, then
