@@ -277,6 +277,8 @@ def bench_unit(args, device_index):
     if year is not None:
         line['year'] = year
     plan.close()
+    del depth, out, kern, state, q_ch, q_full
+    torch.cuda.empty_cache()
     return line
 
 
