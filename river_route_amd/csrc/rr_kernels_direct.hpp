@@ -27,14 +27,15 @@ namespace {
 // into the window one tick before the first lane needs them), wave 6 takes finished rows out (one tick after the last lane wrote
 // them), wave 7 forwards what the skeleton needs: eight instruction streams, two per SIMD, that meet at the tick's barrier.
 // What a tick (0.195 us per row and CU) answers to, measured build against build on one box (profiles/r04_direct_tick_ab.txt):
-// not the instruction streams within reason (rows-in waves of 25 or 38 instructions, four of them taking turns, a lighter
-// rows-out wave or wave 7; 63 instructions do slow it down), not the barriers (TWO rows per barrier, parity-green: the same time per
-// row; bare barriers cost 13 ns), not the routing waves at all (switched off: the same time), not LDS traffic (a read less per lane:
-// the same), not the rows in flight beyond 32, their alignment, or the memory level they come from.  With the routing off the three
-// I/O roles add up: rows in alone 0.87 ms per 512 rows, rows out ~0.8, wave 7 alone 0.79 -- and a kernel that only loads and stores
-// the same row segments (profiles/microbench/row_stream_probe.hip) needs 0.73 + 0.68 = 1.42 ms: the CU's vector memory path takes
-// the loads, the row stores and the record stores one after the other, at ~87 cycles per 64 x 16-byte instruction (25 GB/s per CU,
-// which is also a plain copy's share of the chip), and wave 7's scattered 128-byte records cost as much as all the row stores.
+// not the instruction streams within reason (rows-in waves of 25 or 38 instructions, four of them taking turns, a lighter rows-out
+// wave or wave 7; 63 instructions do slow it down), not the barriers (bare ones cost 9 ns), not an LDS read less per lane, not the
+// rows in flight beyond 32, their alignment, or the memory level they come from.  Roles switched off one at a time: the routing
+// waves alone need 1.6 ms per 512 rows (0.139 us a tick: their LDS round trips), each I/O role alone 1.0-1.2, the three I/O roles
+// together 1.96, everything 2.06 -- no role's removal saves more than 8 %.  TWO rows per barrier (a variant, parity-green, kept
+// as a patch) bring the routing waves to 1.16 ms and the whole to the same 2.1: there the I/O roles together are the time.  A
+// kernel that only loads and stores the same row segments (profiles/microbench/row_stream_probe.hip) needs 0.73 + 0.68 = 1.42 ms:
+// the CU's vector memory path serves loads and stores one after the other, ~87 cycles per 64 x 16-byte instruction (22-25 GB/s
+// per CU, a plain copy's share of the chip).
 //
 // The skeleton (reaches with large or tall subtrees: 5 %) keeps records and k_tile.  Its columns lie between the subtrees'
 // columns (HOLES).  A hole's scaled lateral inflow (waves 4, 5) and the discharge of an outlet lane (a small subtree's last reach)
