@@ -67,6 +67,9 @@ def parse_args():
                     help="'unit' = BASELINE config 4 (UnitMuskingum + 48-step UH kernel); secondary line, not the headline")
     ap.add_argument('--uh-steps', type=int, default=48)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--sequential-parts', type=int, default=0,
+                    help='one GPU: the network of `--gpus P` (P x --reaches reaches, BASELINE config 5 at P = 8) cut into P parts that are routed '
+                         'one after another on this card, boundary series handed from part to part (multi_gpu.run_sequential); per-part times in the line')
     ap.add_argument('--no-secondary', action='store_true',
                     help="N = 1: skip the `secondary` entries (BASELINE configs 2 and 4 behind their own oracle gates)")
     ap.add_argument('--cpu-replicas', type=int, default=-1,
@@ -74,7 +77,7 @@ def parse_args():
                          "docs/references/parallelism.md:67-114); 0 = off, -1 = a sweep over 16 / 64 / 256 / all cores")
     a = ap.parse_args()
     if a.reaches is None:
-        a.reaches = 1_000_000 if a.gpus == 1 and int(os.environ.get('WORLD_SIZE', '1')) == 1 else 1_250_000
+        a.reaches = 1_000_000 if a.gpus == 1 and int(os.environ.get('WORLD_SIZE', '1')) == 1 and a.sequential_parts < 2 else 1_250_000
     return a
 
 
@@ -385,6 +388,9 @@ def main():
         return
     local_rank = device_index
 
+    if args.sequential_parts > 1:
+        print(json.dumps(bench_sequential_parts(args, device_index)))
+        return
     if args.workload == 'unit':
         print(json.dumps(bench_unit(args, device_index)))
         return
@@ -432,6 +438,95 @@ def part_parity_gate(eng, spec, coef, run, rows=96):
         assert np.allclose(np.maximum(E[:, :ex.size], 0.0), want[:, ex], rtol=1e-10, atol=1e-10 * scale), f'part {spec.part}: export series differs'
     return (f'first {Tg} rows of its part through the timed exchange and kernels == oracle on the part with the received boundary '
             f'series folded in, rtol 1e-10')
+
+
+def bench_sequential_parts(args, device_index, parts=None):
+    """BASELINE config 5's network and partition on ONE card: `parts` x args.reaches reaches cut by rr_partition_forest exactly as
+    `bench.py --gpus parts` cuts them, the parts routed one after another with their boundary series (the flow is one-directional:
+    docs/references/parallelism.md:67-75; multi_gpu.run_sequential).  Gate: the first 96 rows of EVERY part against the oracle on the
+    undivided network.  Timed: the year per part (warm-up + `steps` passes each); `value` = all reach-steps / the sum of the parts'
+    times -- what one card does with the 10M-reach network -- and `config.part_*` what each GPU of the N-GPU run would have to do."""
+    import torch
+    from river_route_amd import synth
+    from river_route_amd.engine import MODE_RAPID, partition_forest
+    from river_route_amd.multi_gpu import HipPartEngine, run_sequential, split_network
+    P = int(parts or args.sequential_parts)
+    n, T, nsub, dt = args.reaches * P, args.runoff_steps, args.substeps, 900.0
+    dev = torch.device('cuda', device_index)
+    t0 = time.perf_counter()
+    net = synth.synth_network(n, order=args.order)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = muskingum_coefficients(net.k, net.x, dt / nsub)
+    c4_dt = (c1 + c2) / dt
+    part_of, sizes = partition_forest(indptr, indices, P)
+    specs = [split_network(net.down_index, part_of, p, P) for p in range(P)]
+    setup_s = time.perf_counter() - t0
+    gate = None
+    if not args.no_cpu_baseline and nsub == 1:
+        from oracle import oracle
+        Tg = 96
+        q_ref, d_ref = np.zeros(n), np.zeros((Tg, n))
+        t0 = time.perf_counter()
+        for r0 in range(0, Tg, 16):
+            ql = synth.synth_qlateral_torch(n, r0, r0 + 16, dev, dt=dt).cpu().numpy()
+            oracle.rapid_route(indptr, indices, -c1[indices], c2, c3, c4_dt, q_ref, ql, d_ref[r0:r0 + 16], 1)
+            del ql
+        oracle_s = time.perf_counter() - t0
+        worst = [0.0]
+
+        def check(spec, eng):
+            torch.cuda.synchronize()
+            got, want = eng.discharge.cpu().numpy()[:, spec.n_ghost:], d_ref[:, spec.real_global]
+            scale = float(np.abs(want).max())
+            if not (np.allclose(got, want, rtol=1e-10, atol=1e-10 * scale) and np.allclose(eng.final_state(), q_ref[spec.real_global], rtol=1e-10, atol=1e-10 * scale)):
+                raise SystemExit(f'bench.py: part {spec.part} of the partitioned network differs from the oracle on the undivided network; refusing to report a number')
+            worst[0] = max(worst[0], float(np.abs(got - want).max()) / scale)
+
+        run_sequential(specs, lambda sp: HipPartEngine(sp, c1, c2, c3, c4_dt, np.zeros(n), synth.synth_qlateral_torch(n, 0, Tg, dev, columns=sp.real_global, dt=dt),
+                                                       Tg, 1, device_index, out_rows=Tg), Tg, 1, check)
+        gate = (f'{Tg} rows of every one of the {P} parts (boundary series handed from part to part) == oracle on the undivided {n}-reach network, '
+                f'rtol 1e-10, worst difference {worst[0]:.2e} of the largest discharge; oracle {n * Tg / oracle_s:.3e} reach-steps/s on 1 host core')
+        del d_ref
+    rows = min(args.forcing_rows or 288, T)
+    per_part = []
+
+    def make(sp):
+        lateral = synth.synth_qlateral_torch(n, 0, rows, dev, columns=sp.real_global, dt=dt)
+        eng = HipPartEngine(sp, c1, c2, c3, c4_dt, np.zeros(n), lateral, T, nsub, device_index, out_rows=min(T, args.sink_rows or 128), sample_every=args.sample_every)
+        eng.sched = eng.plan.reserve(MODE_RAPID, T, nsub)
+        return eng
+
+    def route(eng, T_, S_):
+        ts = []
+        for rep in range(args.warmup + args.steps):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            eng.begin(); eng.advance(T_, S_); eng.end()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        eng.pass_s = ts[args.warmup:]
+
+    def visit(sp, eng):
+        prof, tiles = eng.plan.profile(), eng.plan.tile_info()
+        aux = eng.plan.profile_aux()
+        launch_us = prof['sampled_ms'] / max(1, prof['brackets']) * 1e3
+        per_part.append({'part': sp.part, 'reaches': int(sp.real_global.size), 'boundary_inflows': sp.n_ghost, 'exports': int(sp.export_global.size),
+                         'feeds': [d for d, _ in sp.downstream_parts], 'fed_by': [u for u, _ in sp.upstream_parts], 'depth': eng.plan.depth,
+                         'tiles': tiles['tiles'], 'tile_levels': tiles['levels'], 'kernel': eng.plan.last_kernel(), 'ticks_per_launch': eng.sched['ticks_per_launch'],
+                         'ring_gb': round(eng.sched['ring_bytes'] / 1e9, 1), 'ms_per_year': [round(t * 1e3, 1) for t in eng.pass_s],
+                         'routing_launch_us': round(launch_us, 1), 'routing_launches': prof['launches'],
+                         'passes_us': {k: round(v['sampled_ms'] / max(1, v['sampled']) * 1e3, 1) for k, v in aux.items()}})
+
+    run_sequential(specs, make, T, nsub, visit, route)
+    total_s = sum(sum(p['ms_per_year']) for p in per_part) * 1e-3
+    return {'metric': 'reach-steps/sec', 'value': float(n) * T * nsub * args.steps / total_s, 'unit': 'reach-steps/s', 'n_gpus': 1, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': total_s / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {'workload': f'RapidMuskingum, ONE {n}-reach synthetic network (BASELINE config 5 at 8 x 1.25M) cut into {P} parts by rr_partition_forest, the parts '
+                                   f'routed one after another on ONE MI355X with their boundary series, {T} runoff steps @ 900 s, {nsub} sub-step(s), fp64',
+                       'reaches': n, 'parts': P, 'runoff_steps': T, 'substeps': nsub, 'params_order': args.order, 'setup_s': round(setup_s, 1), 'per_part': per_part,
+                       'baseline_config': 5},
+            'roofline': None, 'cpu_baseline': None if gate is None else {'parity_gate': gate}}
 
 
 def secondary_lines(args, device_index):

@@ -261,7 +261,14 @@ int rr_plan_set_boundary(rr_plan *plan, int64_t n_ghost, const int64_t *ghost_re
                          const int64_t *export_reaches);
 
 /* Opens a routing call on device arrays (has_lateral = 1: RapidMuskingum, 0: channel-only Muskingum).
- * q_t[n]: initial state (ghost entries = the upstream reach's initial discharge). */
+ * q_t[n]: initial state (ghost entries = the upstream reach's initial discharge).
+ * lateral / discharge are read / written cyclically (step t: row t % lat_rows, row t % out_rows).  A caller that REFILLS a lateral
+ * ring shorter than the call between two rr_stream_advance calls may announce at most lat_rows rows beyond those the engine has
+ * taken; the engine takes them in whole batches -- 128 tick-rows (+ 15 of overlap) on the record path, K rows on the direct row path,
+ * where K (rr_plan_reserve's info[1]) is capped to the largest multiple of 16 that fits BOTH rings (rings of fewer than 32 rows keep
+ * to records) -- so a refilled ring must hold at least one such batch.  On the direct row path the columns of skeleton reaches are
+ * patched into a discharge row info[6] (the pipeline's depth) rows after the row was first written: a cyclic discharge ring that the
+ * caller drains while the call is open must be that long (or T rows), or the call must be reserved with RR_ROWS_NOT_PLAIN. */
 int rr_stream_begin(rr_plan *plan, int has_lateral, const double *q_t, const double *lateral, int64_t lat_rows,
                     double *discharge, int64_t out_rows, int64_t T, int64_t nsub, const double *ghost_series,
                     double *export_series, void *stream);

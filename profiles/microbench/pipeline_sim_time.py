@@ -9,6 +9,10 @@ Cost model, calibrated on one card (profiles/r03_*: 1M reaches, K = 64):
   record passes:  (t_in + t_out) per 128 rows, scaled by the part's columns / 1M, spread over the launches of those rows
 
     python profiles/microbench/pipeline_sim_time.py [reaches per GPU] [t_launch_us t_in_us t_out_us]
+    python profiles/microbench/pipeline_sim_time.py --measured profiles/r05_parts_10M.json
+        round 5: every part's launch costs are scaled so that the part ALONE takes what it was MEASURED to take on one card
+        (`bench.py --sequential-parts 8`: each of the 8 parts of the 10M-reach network routed for the year with its real boundary
+        series); what stays simulated is only the overlap between the GPUs -- who waits for whose boundary series, and how long.
 """
 import sys
 import numpy as np
@@ -63,7 +67,7 @@ def part_model(spec, T, K, t_task, t_in, t_out):
                 n=int(spec.real_global.size), ghosts=spec.n_ghost, ups=[s for s, _ in spec.upstream_parts])
 
 
-def simulate(n, parts, T=35040, K=0, exchange=128, t_launch=234.0, t_in=415.0, t_out=435.0, hop_us=30.0):
+def simulate(n, parts, T=35040, K=0, exchange=128, t_launch=234.0, t_in=415.0, t_out=435.0, hop_us=30.0, measured=None):
     net = synth.synth_network(n, order='random')
     has = net.down_index >= 0
     indptr = np.concatenate([[0], np.cumsum(has)]).astype(np.int32)
@@ -71,6 +75,10 @@ def simulate(n, parts, T=35040, K=0, exchange=128, t_launch=234.0, t_in=415.0, t
     part_of, _ = partition_forest(indptr, indices, parts)
     t_task = t_launch / 4.0
     P = [part_model(split_network(net.down_index, part_of, p, parts), T, K, t_task, t_in, t_out) for p in range(parts)]
+    if measured is not None:      # the part alone takes its measured time; the shape of its launches (fill, drain) is the model's
+        for m, rec in zip(P, measured):
+            assert rec['reaches'] == m['n'] and rec['ticks_per_launch'] == m['K'], (rec, m['n'], m['K'])
+            m['cost'] = m['cost'] * (1e3 * sum(rec['ms_per_year']) / len(rec['ms_per_year']) / m['cost'].sum())
     finish = [None] * parts
     for p, m in enumerate(P):      # parts are numbered upstream-first
         done = np.zeros(m['n_diags'])
@@ -101,6 +109,13 @@ def simulate(n, parts, T=35040, K=0, exchange=128, t_launch=234.0, t_in=415.0, t
 
 
 if __name__ == '__main__':
+    if len(sys.argv) > 2 and sys.argv[1] == '--measured':
+        import json
+        line = json.load(open(sys.argv[2]))
+        cfg = line['config']
+        print(f"part times measured on one card ({sys.argv[2]}: {cfg['parts']} parts of the {cfg['reaches']}-reach network, one after another):")
+        simulate(cfg['reaches'], cfg['parts'], T=cfg['runoff_steps'], measured=cfg['per_part'])
+        sys.exit(0)
     per = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000
     kw = {}
     if len(sys.argv) > 4:

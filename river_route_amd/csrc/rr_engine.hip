@@ -542,7 +542,7 @@ int rr_stream_begin(rr_plan *P, int has_lateral, const double *q_t, const double
     Rows io; io.dev_in = has_lateral ? lateral : nullptr; io.rows_in = lat_rows; io.dev_out = discharge; io.rows_out = out_rows;
     const Mode mode = has_lateral ? Mode::Rapid : Mode::Muskingum;
     if (P->ses.open) return fail(RR_E_STATE, "a routing call is already open on this plan (rr_stream_end it first)");
-    rc = prepare_call(P, mode, T, nsub, false, false, true, has_lateral != 0);
+    rc = prepare_call(P, mode, T, nsub, false, false, true, has_lateral != 0, lat_rows, out_rows);
     if (rc) return rc;
     if (P->h.n > 0 && T > 0) {
         rc = launch_state_in(P, mode, q_t, (hipStream_t)stream);

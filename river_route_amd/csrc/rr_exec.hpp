@@ -345,7 +345,12 @@ int64_t pick_direct_K(const rr_plan *P, int64_t T)
     return T >= 8192 ? 512 : (T >= 2048 ? 256 : (T >= 512 ? 128 : 64));
 }
 
-Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, bool plain_rows = false)
+// ring_in / ring_out (streaming calls, rr_stream_begin): rows of the caller's cyclic lateral / discharge arrays where those are shorter
+// than the call (0: they hold every row).  A caller may refill such a ring between two rr_stream_advance calls, so a direct task must
+// not span more rows than the ring holds: K is capped (a ring of fewer than 32 rows keeps to records, which take rows in batches of 128
+// tick-rows the caller announces one by one).
+Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, bool plain_rows = false,
+                         int64_t ring_in = 0, int64_t ring_out = 0)
 {
     Schedule sch;
     const int64_t total = T * nsub, dmax = P->h.depth - 1, n = P->h.n;
@@ -353,13 +358,16 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
     // boundary reaches -- the headline's call -- on a params order that numbers small subtrees contiguously.
     if (plain_rows && P->direct_enabled && P->dp.ok && mode == Mode::Rapid && nsub == 1 && P->weights_uniform && !force_streaming && !host_io &&
         P->n_ghost == 0 && P->n_export == 0 && P->wave_enabled && total >= 32 && n < (int64_t{1} << 29)) {
-        const int64_t K = pick_direct_K(P, T), levels = P->dp.skel.n_levels, np = P->dp.skel.np;
+        int64_t K = pick_direct_K(P, T);
+        const int64_t levels = P->dp.skel.n_levels, np = P->dp.skel.np;
+        if (ring_in > 0 && ring_in < T) K = std::min(K, ring_in / kRec * kRec);
+        if (ring_out > 0 && ring_out < T) K = std::min(K, ring_out / kRec * kRec);
         sch.direct = true; sch.KC = K / kRec;
         if (np > 0) {      // a record lives from the launch that forwards its first row to the out-pass behind the skeleton's last level
             sch.chunks = std::min<int64_t>(((levels + 1) * K + 2 * dmax + kRecRows + 2 * kRec) / kRec + 2, (total + dmax) / kRec + 2);
             sch.ring = sch.chunks * kRec * np;
         }
-        if (np < (int64_t{1} << 25) && (P->dev_total_bytes == 0 || sch.ring * 8 <= (int64_t)(P->dev_total_bytes / 2))) return sch;
+        if (K >= 2 * kRec && np < (int64_t{1} << 25) && (P->dev_total_bytes == 0 || sch.ring * 8 <= (int64_t)(P->dev_total_bytes / 2))) return sch;
         sch = Schedule();
     }
     bool ok = P->wave_enabled && P->tp.ok && P->weights_uniform && n > 0 && !force_streaming && P->tp.np < (int64_t{1} << 25) &&
@@ -431,14 +439,15 @@ int reserve_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_stre
 
 // The schedule of the call about to start.  strict (the *_dev entry points, which only enqueue): everything must have been
 // reserved; otherwise it is reserved here.
-int prepare_call(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, bool strict, bool plain_rows = false)
+int prepare_call(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, bool strict, bool plain_rows = false,
+                 int64_t ring_in = 0, int64_t ring_out = 0)
 {
     Schedule sch;
     if (!strict) {
         int rc = reserve_core(P, mode, T, nsub, force_streaming, host_io, &sch, plain_rows);
         if (rc) return rc;
     } else {
-        sch = choose_schedule(P, mode, T, nsub, force_streaming, host_io, plain_rows);
+        sch = choose_schedule(P, mode, T, nsub, force_streaming, host_io, plain_rows, ring_in, ring_out);
         const size_t samples = P->sample_every >= kSampleGroup ? 1 : 0;
         if (P->h.n > 0 && T > 0 && (sch.ring > P->ring_cap || sch.mrows > P->mrows_cap || sch.stage > P->stage_cap || !P->ev_first || P->ev.size() < 2 * samples ||
                                     (!sch.tiled && !sch.direct && !P->perm_ready && sch.mrows > 0)))
@@ -493,7 +502,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
 
     if (S.wave || S.rows_direct) { S.KC = P->next_KC; S.rec_chunks = P->next_chunks; }     // ring sized by choose_schedule, allocated by rr_plan_reserve
     if (S.rows_direct) {
-        if (io.dev_in32 || io.dev_out32 || io.uh_kernel || io.runoff || !io.dev_in || !io.dev_out || mode != Mode::Rapid || nsub != 1 || ghost_series || export_series) {
+        if (io.dev_in32 || io.dev_out32 || io.uh_kernel || io.runoff || !io.dev_in || !io.dev_out || mode != Mode::Rapid || nsub != 1 || P->n_ghost > 0 || P->n_export > 0) {
             S.open = false;
             return fail(RR_E_STATE, "route: the direct row path was chosen for a call it does not take");      // (choose_schedule's plain_rows)
         }
@@ -761,6 +770,14 @@ int launch_tile_diag(rr_plan *P, const rr::TilePlan &TP, TileArgs &w, int32_t n_
     return RR_OK;
 }
 
+// Whether launch d of a tile plan has any tile to run (launch_tile_diag returns early otherwise).
+bool tile_diag_launches(const rr_plan *P, const rr::TilePlan &TP, int64_t d)
+{
+    const Session &S = P->ses;
+    const int64_t l_lo = std::max<int64_t>(0, d - (S.n_macro - 1)), l_hi = std::min<int64_t>(TP.n_levels - 1, d);
+    return l_hi >= l_lo && TP.level_start[l_hi + 1] > TP.level_start[l_lo];
+}
+
 int session_launch_diag(rr_plan *P, int64_t d)
 {
     int rc = launch_tile_diag(P, P->tp, P->ses.ta, P->n_wide_tiles, P->d_coef, P->d_coef_unit, d, true);
@@ -961,11 +978,11 @@ int session_advance_direct(rr_plan *P, int64_t rows_ready)
                     ++P->prof_brackets;
                 }
             }
-            if (skel) {
+            if (skel && tile_diag_launches(P, TP, d)) {      // (an empty bracket would be counted as a launch of the skeleton)
                 const int aux = aux_begin(P, 2, S.stream);
                 int rc = launch_tile_diag(P, TP, S.ta, P->n_kwide, P->d_kcoef, P->d_kcoef, d, false);
+                aux_end(P, aux, S.stream);      // before rc is looked at: rr_plan_profile_aux reads both events of every sample
                 if (rc) return rc;
-                aux_end(P, aux, S.stream);
             }
             ++P->prof_launches;
             ++S.diag;

@@ -31,7 +31,7 @@ import numpy as np
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 
 __all__ = ['PartSpec', 'split_network', 'HipPartEngine', 'HipUnitPartEngine', 'part_driver', 'run_distributed', 'run_in_process',
-           'bench_main']
+           'run_sequential', 'bench_main']
 
 
 @dataclass
@@ -169,6 +169,13 @@ class HipPartEngine:
 
     def final_state(self) -> np.ndarray:
         return self.q_t.cpu().numpy()[self.spec.n_ghost:]
+
+    def close(self) -> None:
+        """Hands the plan's device memory (record ring included) and the part's rows back; the export series stays with whoever
+        holds it (run_sequential: the parts downstream)."""
+        self.plan.close()
+        self.lateral = self.discharge = self.ghost_series = self.q0 = self.q_t = None
+        self.torch.cuda.empty_cache()
 
 
 class HipUnitPartEngine:
@@ -411,6 +418,38 @@ def run_in_process(engines, specs, T: int, nsub: int, chunk_rows: int) -> None:
                 break
         if not progressed:
             raise RuntimeError('run_in_process: parts are deadlocked (no message can be delivered)')
+
+
+def run_sequential(specs, make_engine, T: int, nsub: int, visit=None, route=None) -> None:
+    """The parts of a cut network routed ONE AFTER ANOTHER on one GPU.  Discharge only flows downstream
+    (docs/references/math.md:57-59, docs/references/parallelism.md:67-75), and the parts are numbered upstream-first, so part p
+    can be routed through its whole call once the parts before it have been: their export series (kept on the device, a few MB)
+    are its ghost series.  `specs`: every part's PartSpec in part order; `make_engine(spec)` builds the part's engine (its plan
+    and record ring exist only while the part is routed: a network whose parts each fit the card routes on it whatever its
+    size); `visit(spec, engine)` sees the finished engine before it is closed; `route(engine, T, S)` replaces the one
+    begin / advance / end (bench.py times several passes per part).  What bench.py --sequential-parts and the BASELINE config 5
+    test run: the same engines, kernels and boundary series as the distributed run, without the exchange."""
+    S = int(T) * int(nsub)
+    exports = {}
+    for spec in specs:
+        if any(src >= spec.part for src, _ in spec.upstream_parts):
+            raise ValueError('run_sequential: parts must be numbered upstream-first')
+        eng = make_engine(spec)
+        for src, cols in spec.upstream_parts:
+            ecols = next(c for dst, c in specs[src].downstream_parts if dst == spec.part)
+            eng.ghost_series[:S, cols] = exports[src][:S, ecols]
+        if route is not None:
+            route(eng, int(T), S)
+        else:
+            eng.begin()
+            eng.advance(T, S)
+            eng.end()
+        if spec.downstream_parts:
+            exports[spec.part] = eng.export_series
+        if visit is not None:
+            visit(spec, eng)
+        if hasattr(eng, 'close'):
+            eng.close()
 
 
 TILE_STATE_BYTES = 72.0      # per position and task: lag, first upstream, counts, ghost link (16), ss, sq, c1, c2, c3 read (40), sq, ss written (16)
