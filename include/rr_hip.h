@@ -298,6 +298,14 @@ int rr_stream_end_unit(rr_plan *plan, double *q_ch, double *q_full);
 int rr_partition_forest(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indices, int32_t n_parts,
                         int32_t *part_of, int64_t *part_sizes);
 
+/* Depth-first post-order of a river network given as one downstream ROW index per reach (-1 at outlets), rows in ANY order:
+ * order[k] = the row that comes k-th.  Every reach follows the whole sub-basin of each of its tributaries, so every sub-basin is a run
+ * of consecutive rows -- still a valid order for river_route/tools.py:103-104 (upstream before downstream), and the one in which
+ * rr_rapid_route_dev / rr_stream_begin route straight from and to the caller's rows (rr_plan_direct_info).  A reach's tributaries
+ * are visited largest sub-basin first, outlets in ascending row index.  RR_E_INVALID for an index out of range or a cycle.
+ * Host-only, needs no GPU. */
+int rr_postorder(int64_t n, const int64_t *down_index, int64_t *order);
+
 /* ---- router post-processing on the device (river_route/routers/TransformMuskingum.py:128-142) ----
  * out[o, i] = (float) mean_{j < factor} discharge[o * factor + j, i]; num_rows must be a multiple of factor.
  * Halves (or better) the bytes that leave the GPU: the reference's routers hand float32 to their writer. */

@@ -108,6 +108,7 @@ _SIGNATURES = {
     'rr_stream_begin_unit': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     'rr_stream_end_unit': (C.c_int, [_vp, _vp, _vp]),
     'rr_partition_forest': (C.c_int, [_i64, _vp, _vp, C.c_int32, _vp, _vp]),
+    'rr_postorder': (C.c_int, [_i64, _vp, _vp]),
     'rr_resample_cast_dev': (C.c_int, [C.c_int, _vp, _i64, _i64, _i64, _vp, _vp]),
     'rr_runoff_to_qlateral': (C.c_int, [C.c_int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, C.c_int, _i64, _i64, _vp, C.c_int, _vp]),
     'rr_runoff_to_qlateral_dev': (C.c_int, [C.c_int, _i64, _i64, _i64, _vp, _vp, _vp, _vp, C.c_int, _i64, _i64, _vp,

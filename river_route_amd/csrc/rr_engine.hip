@@ -620,6 +620,13 @@ int rr_partition_forest(int64_t n, const int32_t *csc_indptr, const int32_t *csc
     return RR_OK;
 }
 
+int rr_postorder(int64_t n, const int64_t *down_index, int64_t *order)
+{
+    if (n < 0 || (n > 0 && (!down_index || !order))) return fail(RR_E_INVALID, "rr_postorder: bad argument");
+    if (!rr::postorder(down_index, n, order)) return fail(RR_E_INVALID, "rr_postorder: a downstream index is out of range, or the network has a cycle");
+    return RR_OK;
+}
+
 // ---- device-pointer entry points ----
 
 int rr_rapid_route_dev(rr_plan *P, double *q_t, const double *qlateral, int64_t ql_rows, double *discharge,

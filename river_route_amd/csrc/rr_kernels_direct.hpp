@@ -89,6 +89,17 @@ __device__ __forceinline__ double2 load_f64x2_(__amdgpu_buffer_rsrc_t r, uint32_
     return v;
 }
 
+// Row segments leave with the non-temporal hint: a tile's first and last 128-byte line are shared with its neighbours, which run on
+// other XCDs, so those lines reach memory in two parts either way; streamed past the L2 they cost less (a store-only probe of the same
+// segments: 790 against 1,027 us; the year at 1M reaches 199.9 against 204.6 ms, profiles/r05_direct_ab_nt.txt).  Non-temporal LOADS of the
+// rows were slower (212.9 ms), tiles dealt to the XCDs in column order changed nothing (204.0).
+__device__ __forceinline__ void store_f64x2_nt(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, double2 v)
+{
+    u32x4 bits;
+    __builtin_memcpy(&bits, &v, sizeof bits);
+    __builtin_amdgcn_raw_buffer_store_b128(bits, r, (int)byte_off, 0, 2);      // aux: nt
+}
+
 template <int PF>
 __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a)
 {
@@ -250,8 +261,8 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                     if (leaving >= 0 && leaving < nrows) {      // wave-uniform
                         const double2 xa = *reinterpret_cast<const double2 *>(F + out_b + 2 * ln * 8), xb = *reinterpret_cast<const double2 *>(F + out_b + 2 * ln * 8 + 128 * 8);
                         const __amdgpu_buffer_rsrc_t dst = make_rsrc(row, tile_end);
-                        store_f64x2(dst, va, make_double2(clip0(xa.x), clip0(xa.y)));
-                        store_f64x2(dst, vb, make_double2(clip0(xb.x), clip0(xb.y)));
+                        store_f64x2_nt(dst, va, make_double2(clip0(xa.x), clip0(xa.y)));
+                        store_f64x2_nt(dst, vb, make_double2(clip0(xb.x), clip0(xb.y)));
                         out_b = out_b + kRowB == wrap ? 0 : out_b + kRowB;
                         ++rout; row += a.n;
                         if (rout == a.out_rows) { rout = 0; row = a.out; }

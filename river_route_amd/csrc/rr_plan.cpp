@@ -466,6 +466,43 @@ void build_direct_plan(const std::vector<int32_t> &down, const std::vector<int32
     D.ok = true;
 }
 
+bool postorder(const int64_t *down, int64_t n, int64_t *order)
+{
+    if (n == 0) return true;
+    // upstream lists, then sub-basin sizes by peeling headwaters (no order is assumed)
+    std::vector<int64_t> up_ptr(n + 1, 0), pending(n, 0), sub(n, 1);
+    for (int64_t i = 0; i < n; ++i) {
+        if (down[i] >= n || down[i] == i) return false;
+        if (down[i] >= 0) ++up_ptr[down[i] + 1];
+    }
+    for (int64_t i = 0; i < n; ++i) { pending[i] = up_ptr[i + 1]; up_ptr[i + 1] += up_ptr[i]; }
+    std::vector<int64_t> up_idx(up_ptr[n]), fill(up_ptr.begin(), up_ptr.end() - 1), queue;
+    for (int64_t i = 0; i < n; ++i) if (down[i] >= 0) up_idx[fill[down[i]]++] = i;
+    queue.reserve(n);
+    for (int64_t i = 0; i < n; ++i) if (pending[i] == 0) queue.push_back(i);
+    for (size_t h = 0; h < queue.size(); ++h) {
+        const int64_t v = queue[h], d = down[v];
+        if (d >= 0) { sub[d] += sub[v]; if (--pending[d] == 0) queue.push_back(d); }
+    }
+    if ((int64_t)queue.size() != n) return false;      // a cycle keeps its reaches pending
+    // largest sub-basin first: the small tributaries of a reach then sit right before it, and the direct row path's column-range
+    // tiles come out fuller (1M-reach random network: 4,986 tiles against 5,196 with the smallest first, 5,033 in index order)
+    for (int64_t v = 0; v < n; ++v)
+        std::sort(up_idx.begin() + up_ptr[v], up_idx.begin() + up_ptr[v + 1], [&](int64_t a, int64_t b) { return sub[a] != sub[b] ? sub[a] > sub[b] : a < b; });
+    int64_t k = 0;
+    std::vector<std::pair<int64_t, int64_t>> stack;      // (reach, next tributary)
+    for (int64_t root = 0; root < n; ++root) {
+        if (down[root] >= 0) continue;
+        stack.emplace_back(root, up_ptr[root]);
+        while (!stack.empty()) {
+            auto &top = stack.back();
+            if (top.second < up_ptr[top.first + 1]) { const int64_t c = up_idx[top.second++]; stack.emplace_back(c, up_ptr[c]); }
+            else { order[k++] = top.first; stack.pop_back(); }
+        }
+    }
+    return k == n;
+}
+
 int build_host_plan(int64_t n, const int32_t *indptr, const int32_t *indices, HostPlan &P, std::string &err)
 {
     if (n < 0 || (n > 0 && (!indptr))) { err = "rr_plan_create: null csc_indptr or negative n"; return RR_E_INVALID; }

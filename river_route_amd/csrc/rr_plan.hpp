@@ -137,6 +137,10 @@ constexpr int32_t kDirectSenders = 64;      // one wave forwards them
 void build_direct_plan(const std::vector<int32_t> &down, const std::vector<int32_t> &lag_of, int32_t lanes, int32_t wmax, int32_t skel_block,
                        DirectPlan &out);
 
+// Depth-first post-order of a forest given by downstream indices in any order (include/rr_hip.h: rr_postorder).  False: an index out of
+// range or a cycle.
+bool postorder(const int64_t *down, int64_t n, int64_t *order);
+
 // Returns 0 or an RR_E_* code with a message in err.
 int build_host_plan(int64_t n, const int32_t *indptr, const int32_t *indices, HostPlan &plan, std::string &err);
 

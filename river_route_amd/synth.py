@@ -160,23 +160,13 @@ def synth_network_chain(n: int, seed: int = NETWORK_SEED, p_chain: float = 0.0, 
 
 
 def _postorder(parent: np.ndarray) -> np.ndarray:
-    """Depth-first post-order of a forest given by parent pointers: tributaries in ascending node number, outlets likewise."""
-    n = parent.shape[0]
-    order = np.argsort(parent, kind='stable')              # children grouped by parent, ascending inside a group
-    counts = np.bincount(parent[parent >= 0], minlength=n)
-    start = np.concatenate([[0], np.cumsum(counts)]) + int((parent < 0).sum())     # the outlets (parent -1) sort first
-    kids, first, cnt = order.tolist(), start.tolist(), counts.tolist()
-    out = []
-    for root in order[:int((parent < 0).sum())].tolist():
-        stack = [(root, 0)]
-        while stack:
-            v, i = stack.pop()
-            if i < cnt[v]:
-                stack.append((v, i + 1))
-                stack.append((kids[first[v] + i], 0))
-            else:
-                out.append(v)
-    return np.asarray(out, dtype=np.int64)
+    """Depth-first post-order of a forest given by parent pointers, as tools.postorder numbers it (rr_postorder: a reach's
+    tributaries largest sub-basin first, outlets in ascending node number)."""
+    from . import _lib
+    down = np.ascontiguousarray(parent, dtype=np.int64)
+    order = np.empty(down.shape[0], dtype=np.int64)
+    _lib.check(_lib.lib().rr_postorder(down.shape[0], _lib.ptr(down), _lib.ptr(order)))
+    return order
 
 
 def _network_from_parents(parent: np.ndarray, seed: int, params_seed: int, order: str) -> SynthNetwork:

@@ -7,7 +7,7 @@ from __future__ import annotations
 import numpy as np
 import scipy.sparse
 
-__all__ = ['adjacency_matrix', 'engine_order', 'connectivity_to_digraph', 'upstream_of', 'subset_configs_to_river']
+__all__ = ['adjacency_matrix', 'engine_order', 'postorder', 'connectivity_to_digraph', 'upstream_of', 'subset_configs_to_river']
 
 
 def adjacency_matrix(river_ids: np.ndarray, downstream_ids: np.ndarray) -> scipy.sparse.csc_matrix:
@@ -52,6 +52,39 @@ def engine_order(river_ids: np.ndarray, downstream_ids: np.ndarray) -> np.ndarra
     A = adjacency_matrix(river_ids, downstream_ids)
     with Plan(A.indptr, A.indices, device=_lib.RR_DEVICE_NONE) as plan:
         return plan.layout()[0].astype(np.int64)
+
+
+def postorder(river_ids: np.ndarray, downstream_ids: np.ndarray) -> np.ndarray:
+    """
+    Row order that sorts a network table into depth-first post-order: `order[k]` is the row that comes k-th, every reach right after
+    the sub-basins of its tributaries (largest first).  The rows may come in ANY order -- unlike `adjacency_matrix` this needs no
+    topological sort, it makes one.  A params table (and the columns of its qlateral / state files) re-sorted with it,
+    `table.iloc[order]`, is still valid for the reference (upstream before downstream, river_route/tools.py:103-104), and every
+    sub-basin becomes a run of consecutive rows: the engine then routes RapidMuskingum straight from and to the (time, river) rows,
+    without its record ring and permutation passes (the direct row path, `Plan.direct_info()`).
+    Raises ValueError for a downstream id that is not a river id (as `adjacency_matrix` does) and for a network with a cycle.
+    """
+    from . import _lib
+    rid = np.asarray(river_ids).astype(np.int64, copy=False).ravel()
+    did = np.asarray(downstream_ids).astype(np.int64, copy=False).ravel()
+    n = rid.shape[0]
+    if did.shape[0] != n:
+        raise ValueError('river_ids and downstream_ids must have the same length')
+    by_id = np.argsort(rid, kind='stable')
+    sorted_ids = rid[by_id]
+    has = did >= 0
+    pos = np.searchsorted(sorted_ids, did[has], side='right') - 1
+    known = (pos >= 0) & (sorted_ids[np.maximum(pos, 0)] == did[has])
+    if not known.all():
+        raise ValueError(f'Unknown downstream_river_id: {int(did[has][np.flatnonzero(~known)[0]])}')
+    down = np.full(n, -1, dtype=np.int64)
+    down[has] = by_id[pos]
+    order = np.empty(n, dtype=np.int64)
+    try:
+        _lib.check(_lib.lib().rr_postorder(n, _lib.ptr(down), _lib.ptr(order)))
+    except _lib.RRError as e:
+        raise ValueError(f'the river network is not a forest: {e.message}') from e
+    return order
 
 
 def connectivity_to_digraph(river_ids: np.ndarray, downstream_ids: np.ndarray):

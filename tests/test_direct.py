@@ -93,6 +93,45 @@ def test_postorder_forest_with_three_way_confluences():
     check_direct_layout(net.down_index)
 
 
+@pytest.mark.parametrize('n,chainy', [(1, False), (9, False), (5000, False), (120_000, False), (40_000, True)])
+def test_tools_postorder_sorts_any_table_into_column_range_order(n, chainy):
+    """tools.postorder on a network table whose rows come in ANY order (not even topologically sorted): the re-sorted table is
+    accepted by adjacency_matrix (river_route/tools.py:103-104), every sub-basin is a run of consecutive rows, and the plan built on
+    it takes the direct row path."""
+    from river_route_amd import tools
+    net = (synth.synth_network_chain(n, p_chain=0.4, n_outlets=6, p_third=0.05, seed=8) if chainy else synth.synth_network(n, seed=6))
+    shuffle = np.random.default_rng(5).permutation(n)
+    rid, did = net.river_ids[shuffle], net.downstream_ids[shuffle]
+    order = tools.postorder(rid, did)
+    assert np.array_equal(np.sort(order), np.arange(n))
+    rid, did = rid[order], did[order]
+    A = tools.adjacency_matrix(rid, did)      # raises unless upstream comes before downstream
+    down = np.full(n, -1, dtype=np.int64)
+    coo = A.tocoo()
+    down[coo.col] = coo.row
+    sub = np.ones(n, dtype=np.int64)
+    first = np.arange(n)
+    for c in range(n):      # upstream first
+        if down[c] >= 0:
+            sub[down[c]] += sub[c]
+            first[down[c]] = min(first[down[c]], first[c])
+    assert np.array_equal(first, np.arange(n) - sub + 1), 'every sub-basin is the run of rows that ends at its outlet'
+    if n >= 5000:
+        info, _ = check_direct_layout(down)
+        assert info['ok']
+
+
+def test_tools_postorder_rejects_what_is_not_a_forest():
+    from river_route_amd import tools
+    with pytest.raises(ValueError, match='Unknown downstream_river_id: 99'):
+        tools.postorder(np.array([1, 2, 3]), np.array([2, 99, -1]))
+    with pytest.raises(ValueError, match='not a forest'):
+        tools.postorder(np.array([1, 2, 3, 4]), np.array([2, 3, 1, -1]))      # 1 -> 2 -> 3 -> 1
+    with pytest.raises(ValueError, match='not a forest'):
+        tools.postorder(np.array([7]), np.array([7]))
+    assert tools.postorder(np.array([], dtype=np.int64), np.array([], dtype=np.int64)).size == 0
+
+
 @pytest.mark.parametrize('order', ['random', 'levels', 'bfs'])
 def test_other_orders_keep_to_records(order):
     net = synth.synth_network(20_000, seed=3, order=order)
@@ -342,3 +381,69 @@ def test_direct_constant_forcing_settles_at_the_basin_sums(monkeypatch):
         np.testing.assert_allclose(out.cpu().numpy(), np.broadcast_to(want, (sink, n)), rtol=1e-9, err_msg='last 128 rows')
     del out, q
     torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_stream_session_takes_the_direct_path_vs_oracle(monkeypatch):
+    """rr_stream_begin / advance / end on a post-order network: HipPartEngine hands over ghost and export buffers even
+    where the part has no boundary reach (one part = the whole network) -- the call takes the direct row path and reproduces the oracle."""
+    import torch
+    from river_route_amd.engine import partition_forest
+    from river_route_amd.multi_gpu import HipPartEngine, split_network
+    set_env(monkeypatch, {})
+    n, T = 80_000, 200
+    net, indptr, indices, c1, c2, c3 = _case(n, 41)
+    lhs, c4_dt = -c1[indices], (c1 + c2) / 900.0
+    q0 = synth.u01(4, np.arange(n))
+    ql = synth.synth_qlateral(n, 0, T)
+    q_ref, d_ref = q0.copy(), np.zeros((T, n))
+    oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql, d_ref, 1)
+    part_of, _ = partition_forest(indptr, indices, 1)
+    spec = split_network(net.down_index, part_of, 0, 1)
+    eng = HipPartEngine(spec, c1, c2, c3, c4_dt, q0, ql, T, 1, 0, out_rows=T)
+    eng.begin()
+    for rows in (64, 130, T):      # rows announced in three steps
+        eng.advance(rows, rows)
+    eng.end()
+    torch.cuda.synchronize()
+    assert eng.plan.last_kernel() == 'direct'
+    assert_close(eng.discharge.cpu().numpy(), d_ref, 'discharge')
+    assert_close(eng.final_state(), q_ref, 'state')
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_stream_session_with_a_refilled_lateral_ring_shorter_than_a_task(monkeypatch):
+    """A caller that REFILLS a 48-row cyclic lateral ring between rr_stream_advance calls (step t reads row t % 48): the direct
+    task is capped to the ring (K = 48 instead of 64; 32 for a ring of 40 rows), so no launch reads a slot that has been refilled.
+    Every row against the oracle."""
+    import torch
+    set_env(monkeypatch, {})
+    n, T = 60_000, 300
+    net, indptr, indices, c1, c2, c3 = _case(n, 43)
+    lhs, c4_dt = -c1[indices], (c1 + c2) / 900.0
+    ql = synth.synth_qlateral(n, 0, T)
+    q_ref, d_ref = np.zeros(n), np.zeros((T, n))
+    oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql, d_ref, 1)
+    dev = torch.device('cuda:0')
+    for ring, K in ((48, 48), (40, 32)):
+        with Plan(indptr, indices) as plan:
+            plan.set_coeffs(lhs, c2, c3, c4_dt)
+            q = torch.zeros(n, dtype=torch.float64, device=dev)
+            lat = torch.zeros((ring, n), dtype=torch.float64, device=dev)
+            out = torch.zeros((T, n), dtype=torch.float64, device=dev)
+            stream = torch.cuda.current_stream().cuda_stream
+            plan.stream_begin(q, lat, ring, out, T, T, 1, stream=stream)
+            fed = 0
+            while fed < T:      # a whole task at a time: what is announced is taken at once, and never more than the ring holds
+                step = min(K, T - fed)
+                rows = torch.from_numpy(ql[fed:fed + step]).to(dev)
+                idx = torch.arange(fed, fed + step, device=dev) % ring
+                lat[idx] = rows      # on the call's stream: ordered behind the launches that read the old rows
+                fed += step
+                plan.stream_advance(fed, fed)
+            plan.stream_end(q)
+            torch.cuda.synchronize()
+            assert plan.last_kernel() == 'direct' and plan.profile()['ticks_per_launch'] == K
+            assert_close(out.cpu().numpy(), d_ref, f'discharge, ring of {ring} rows')
+            assert_close(q.cpu().numpy(), q_ref, 'state')
