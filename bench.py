@@ -63,8 +63,9 @@ def parse_args():
     ap.add_argument('--cpu-baseline-seconds', type=float, default=12.0)
     ap.add_argument('--exchange-rows', type=int, default=128,
                     help='N>1: runoff steps per boundary-series message')
-    ap.add_argument('--workload', default='rapid', choices=['rapid', 'unit'],
-                    help="'unit' = BASELINE config 4 (UnitMuskingum + 48-step UH kernel); secondary line, not the headline")
+    ap.add_argument('--workload', default='rapid', choices=['rapid', 'unit', 'rapid_f32'],
+                    help="'unit' = BASELINE config 4 (UnitMuskingum + 48-step UH kernel), 'rapid_f32' = the headline's year with float32 rows in and "
+                         "hourly float32 means out; secondary lines, not the headline (run alone for the counter passes)")
     ap.add_argument('--uh-steps', type=int, default=48)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--sequential-parts', type=int, default=0,
@@ -244,7 +245,7 @@ def bench_unit(args, device_index):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     from river_route_amd.engine import copy_bandwidth
-    from river_route_amd.multi_gpu import roofline_from_profile
+    from river_route_amd.measure import roofline_from_profile
     prof = plan.profile()
     aux = plan.profile_aux()
     # a year as the reference runs it: ten files of T steps, one call each, the discharge and the convolution's tail carried from
@@ -266,8 +267,9 @@ def bench_unit(args, device_index):
                 'note': 'ten consecutive calls of the block above, discharge state and convolution tail carried between them'}
     if base is not None and prof['ticks_per_launch'] > 1 and chk_kernel <= 1:
         raise SystemExit('bench.py: the parity gate did not run the timed kernel; refusing to report a number')
-    roofline = roofline_from_profile(prof, nsub, HBM_PEAK_GBS, copy_gbs=copy_bandwidth(device_index), unit=True)
-    whole_path(roofline, prof, aux, plan.last_kernel(), float(n) * T * nsub * args.steps / elapsed, None)
+    traffic = pmc_traffic(args.order, n, T, nsub, key='config4') if n_ks == 48 else None
+    roofline = roofline_from_profile(prof, nsub, HBM_PEAK_GBS, copy_gbs=copy_bandwidth(device_index), unit=True, traffic=traffic)
+    whole_path(roofline, prof, aux, plan.last_kernel(), float(n) * T * nsub * args.steps / elapsed, traffic)
     if roofline is not None and 'k_rec_in' in roofline['path']['kernels']:
         roofline['path']['kernels'][f'k_rec_in_uh (convolution fused, {n_ks} taps)'] = roofline['path']['kernels'].pop('k_rec_in')
     line = {'metric': 'reach-steps/sec', 'value': float(n) * T * nsub * args.steps / elapsed, 'unit': 'reach-steps/s',
@@ -393,6 +395,9 @@ def main():
         return
     if args.workload == 'unit':
         print(json.dumps(bench_unit(args, device_index)))
+        return
+    if args.workload == 'rapid_f32':
+        print(json.dumps(bench_rapid_f32(args, device_index)))
         return
     line = bench_rapid(args, device_index, net, indptr, indices, c1, c2, c3, base)
     if not args.no_secondary and n == 1_000_000 and T == 35_040 and nsub == 1:
@@ -706,7 +711,7 @@ def bench_rapid_f32(args, device_index, factor: int = 4):
     import torch
     from river_route_amd import synth
     from river_route_amd.engine import Plan
-    from river_route_amd.multi_gpu import roofline_from_profile
+    from river_route_amd.measure import roofline_from_profile
     n, T, nsub, dt = args.reaches, args.runoff_steps, 1, 900.0
     rows = min(args.forcing_rows or 288, T)
     dev = torch.device('cuda', device_index)
@@ -748,8 +753,9 @@ def bench_rapid_f32(args, device_index, factor: int = 4):
         one_pass()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    roofline = roofline_from_profile(plan.profile(), 1, HBM_PEAK_GBS)
-    whole_path(roofline, plan.profile(), plan.profile_aux(), plan.last_kernel(), float(n) * T * args.steps / elapsed, None)
+    traffic = pmc_traffic(args.order, n, T, 1, key='f32') if factor == 4 else None
+    roofline = roofline_from_profile(plan.profile(), 1, HBM_PEAK_GBS, traffic=traffic)
+    whole_path(roofline, plan.profile(), plan.profile_aux(), plan.last_kernel(), float(n) * T * args.steps / elapsed, traffic)
     plan.close()
     return {'metric': 'reach-steps/sec', 'value': float(n) * T * args.steps / elapsed, 'unit': 'reach-steps/s', 'n_gpus': 1, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -818,9 +824,9 @@ def bench_rapid(args, local_rank, net, indptr, indices, c1, c2, c3, base):
     if base is not None and chk_name != kern:
         raise SystemExit('bench.py: the parity gate did not run the timed kernel; refusing to report a number')
     reach_steps = float(n) * T * nsub * args.steps
-    from river_route_amd.multi_gpu import roofline_from_profile
+    from river_route_amd.measure import roofline_from_profile
     copy_gbs = copy_bandwidth(local_rank)
-    traffic = pmc_traffic(args.order, n, T, nsub)
+    traffic = pmc_traffic(args.order, n, T, nsub, key='config2' if n == 100_000 and args.order == 'random' else None)
     roofline = roofline_from_profile(prof, nsub, HBM_PEAK_GBS, copy_gbs=copy_gbs, kernel=kern, traffic=traffic)
     whole_path(roofline, prof, aux, kern, reach_steps / elapsed, traffic)
     tiles, dinfo = plan.tile_info(), plan.direct_info()
@@ -850,71 +856,10 @@ def bench_rapid(args, local_rank, net, indptr, indices, c1, c2, c3, base):
     return line
 
 
+from river_route_amd.measure import engine_sha16, pmc_traffic, whole_path      # noqa: E402  (HIP-event profile + counter passes -> the `roofline` object)
+
 KERNEL_NAMES = {'tick': 'k_tick (streaming, one launch per tick)', 'tile': 'k_tile (time-tiled over subtree tiles and records) + k_rec_in / k_rec_out',
                 'direct': 'k_direct (column-range tiles reading and writing the rows) + k_tile on the skeleton + k_rec_out over the holes'}
-
-
-def whole_path(roofline, prof, aux, kern, rate, traffic):
-    """Adds the WHOLE path to the `roofline` object (which prices the dominant kernel): every kernel of the timed pass with its
-    launches and its average duration between HIP events on the engine's stream (every fourth launch sampled; the direct launches
-    all), the bytes per reach-step the path has to move (16: a lateral value in, a discharge out) and -- from the committed
-    rocprofv3 counter passes of the same command, while the kernel sources are the ones they were taken with -- the bytes it does
-    move, and the two end-to-end fractions of the 8 TB/s peak that follow from the measured rate."""
-    if roofline is None:
-        return
-    main = {'tile': 'k_tile', 'direct': 'k_direct', 'tick': 'k_tick'}[kern]
-    kernels = {}
-    if prof['brackets'] > 0:
-        kernels[main] = {'launches': prof['launches'], 'sampled': prof['brackets'], 'avg_us': round(prof['sampled_ms'] / prof['brackets'] * 1e3, 2)}
-    if kern == 'direct':      # prof['launches'] counts the schedule's steps (direct launches, then the skeleton's drain); every direct launch is sampled
-        kernels[main]['launches'] = prof['brackets']
-    for name, a in aux.items():
-        if a['sampled'] > 0:
-            kernels[name] = {'launches': a['launches'], 'sampled': a['sampled'], 'avg_us': round(a['sampled_ms'] / a['sampled'] * 1e3, 2)}
-    for k in kernels.values():
-        k['ms_per_pass'] = round(k['launches'] * k['avg_us'] / 1e3, 2)
-    measured = None if traffic is None else traffic.get('bytes_per_reach_step')
-    roofline['path'] = {
-        'kernels': kernels, 'sum_ms_per_pass': round(sum(k['ms_per_pass'] for k in kernels.values()), 2),
-        'bytes_per_reach_step_compulsory': 16.0,
-        'bytes_per_reach_step_measured': measured,
-        'bytes_per_reach_step_by_kernel': None if traffic is None else traffic.get('by_kernel'),
-        'traffic_source': None if traffic is None else traffic.get('source'),
-        'frac_end_to_end_compulsory': round(16.0 * rate / 1e9 / HBM_PEAK_GBS, 4),
-        'frac_end_to_end_measured': None if measured is None else round(measured * rate / 1e9 / HBM_PEAK_GBS, 4)}
-
-
-def engine_sha16():
-    import hashlib
-    h = hashlib.sha256()
-    csrc = os.path.join(REPO, 'river_route_amd', 'csrc')
-    for name in sorted(f for f in os.listdir(csrc) if f.endswith(('.hip', '.hpp', '.cpp'))):      # every source of librr_hip.so
-        with open(os.path.join(csrc, name), 'rb') as f:
-            h.update(f.read())
-    return h.hexdigest()[:16]
-
-
-def pmc_traffic(order, n, T, nsub):
-    """HBM bytes of the timed pass from the committed counter passes (profiles/r04_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE and
-    --pmc WRITE_SIZE, separate runs of this bench command, every dispatch of the pass summed per kernel, FETCH_SIZE doubled as the
-    micro-architecture guide prescribes for gfx950) -- only for the configuration they were taken on and only while the kernel
-    sources are the ones they were taken with."""
-    path = os.path.join(REPO, 'profiles', 'r04_pmc_traffic.json')
-    if nsub != 1 or any(k.startswith(('RR_WAVE', 'RR_TILE', 'RR_DIRECT')) for k in os.environ):
-        return None
-    try:
-        with open(path) as f:
-            rec = json.load(f).get(order)
-        if not rec or rec.get('reaches') != n or rec.get('runoff_steps') != T:
-            return None
-        if rec.get('engine_sha16') != engine_sha16():
-            return {'source': f'profiles/r04_pmc_traffic.json [{order}] is from other kernel sources ({rec.get("engine_sha16")}): not used'}
-        out = {'source': f'profiles/r04_pmc_traffic.json [{order}] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the whole year, engine {rec["engine_sha16"]})',
-               'bytes_per_reach_step': rec['bytes_per_reach_step'], 'by_kernel': rec['bytes_per_reach_step_by_kernel'],
-               'main_kernel_bytes_per_launch': rec.get('main_kernel_bytes_per_full_launch')}
-        return out
-    except (OSError, KeyError, ValueError):
-        return None
 
 
 if __name__ == '__main__':

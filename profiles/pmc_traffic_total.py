@@ -1,9 +1,9 @@
 """Reduce two rocprofv3 counter passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE; separate runs of the same one-pass bench command) to the
-HBM bytes the WHOLE timed pass moves, per kernel and per reach-step, and merge them into profiles/r04_pmc_traffic.json under the
+HBM bytes the WHOLE timed pass moves, per kernel and per reach-step, and merge them into profiles/r05_pmc_traffic.json under the
 params order they were taken on.
 
     python profiles/pmc_traffic_total.py <fetch counter_collection.csv> <write counter_collection.csv> --order random|postorder \
-        --reaches 1000000 --runoff-steps 35040 [--main k_tile|k_direct] [--json profiles/r04_pmc_traffic.json]
+        --reaches 1000000 --runoff-steps 35040 [--main k_tile|k_direct] [--json profiles/r05_pmc_traffic.json]
 
 gfx950 correction (/opt/skills/guides/MI355X_MICROARCH.md, HBM/rocprofv3 section): FETCH_SIZE counts half of a coalesced read
 stream -> doubled; WRITE_SIZE exact.  Raw counters are KiB.  FETCH_SIZE is the L2's fabric-side request count: reads served by the
@@ -40,12 +40,12 @@ def load(path, counter):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('fetch_csv'); ap.add_argument('write_csv')
-    ap.add_argument('--order', required=True)
+    ap.add_argument('--order', required=True, help="the entry's name: random | postorder (the headline's network), config2 | config4 | f32 (secondary lines)")
     ap.add_argument('--reaches', type=int, default=1_000_000)
     ap.add_argument('--runoff-steps', type=int, default=35_040)
     ap.add_argument('--main', default='k_tile')
     ap.add_argument('--command', default='')
-    ap.add_argument('--json', default=os.path.join(REPO, 'profiles', 'r04_pmc_traffic.json'))
+    ap.add_argument('--json', default=os.path.join(REPO, 'profiles', 'r05_pmc_traffic.json'))
     a = ap.parse_args()
     fetch, write = load(a.fetch_csv, 'FETCH_SIZE'), load(a.write_csv, 'WRITE_SIZE')
     reach_steps = float(a.reaches) * a.runoff_steps

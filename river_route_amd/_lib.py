@@ -29,19 +29,34 @@ class RRError(RuntimeError):
         self.message = message
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile librr_hip.so for gfx950 with hipcc (cross-compiles without a GPU). Returns the path."""
+SANITIZED_LIB_PATH = os.path.join(_HERE, 'librr_hip_asan.so')
+
+
+def sanitizer_runtime() -> str | None:
+    """The AddressSanitizer runtime of the compiler hipcc drives (to be preloaded into a python that loads the sanitized build)."""
+    import glob
+    found = sorted(glob.glob('/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so'))
+    return found[-1] if found else None
+
+
+def build(force: bool = False, verbose: bool = False, sanitize: bool = False) -> str:
+    """Compile librr_hip.so for gfx950 with hipcc (cross-compiles without a GPU). Returns the path.
+    sanitize: the HOST code (network analysis, tile / direct planners, partitioner, executor: rr_plan.cpp and the host half of
+    rr_engine.hip) under AddressSanitizer + UndefinedBehaviorSanitizer into librr_hip_asan.so -- device code is compiled as usual
+    (-fno-gpu-sanitize: no GPU sanitizer on this pool).  tests/test_sanitize.py runs the host-only planner tests against it."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith('.hpp')] + [os.path.join(os.path.dirname(_HERE), 'include', 'rr_hip.h')]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
-        return LIB_PATH
+    target = SANITIZED_LIB_PATH if sanitize else LIB_PATH
+    if not force and os.path.exists(target) and all(os.path.getmtime(target) >= os.path.getmtime(d) for d in deps):
+        return target
     hipcc = os.environ.get('HIPCC') or ('/opt/rocm/bin/hipcc' if os.path.exists('/opt/rocm/bin/hipcc') else 'hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wall', '-Wno-unused-result',
-           *srcs, '-o', LIB_PATH]
+    opt = ['-O1', '-g', '-fsanitize=address,undefined', '-fno-gpu-sanitize', '-fno-omit-frame-pointer', '-shared-libsan'] if sanitize else ['-O3']
+    cmd = [hipcc, '--offload-arch=gfx950', *opt, '-std=c++17', '-fPIC', '-shared', '-pthread', '-Wall', '-Wno-unused-result',
+           *srcs, '-o', target]
     if verbose:
         print(' '.join(cmd))
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return target
 
 
 def _preload_hip_runtime() -> None:

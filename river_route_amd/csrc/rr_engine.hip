@@ -52,7 +52,7 @@ void rr_plan_destroy(rr_plan *P)
                         P->d_c3, P->d_c4, P->d_x, P->d_isum, P->d_qch, P->d_a2, P->d_c1own, P->d_z, P->d_ring, P->d_stage, P->d_mrows,
                         P->d_slot_a[0], P->d_slot_a[1], P->d_slot_b[0], P->d_slot_b[1], P->d_m_index[0], P->d_m_index[1],
                         P->d_dtiles, P->d_dlane, P->d_dsend_ptr, P->d_dsend_lane, P->d_dcoef, P->d_dq, P->d_ktmeta, P->d_kpmeta, P->d_kperm, P->d_kholecol, P->d_kcoef, P->d_ksq, P->d_kss, P->d_ksi,
-                        P->d_kholemeta};
+                        P->d_kholemeta, P->d_kghostmeta};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         P->pipe.destroy();
         for (hipEvent_t e : P->ev) (void)hipEventDestroy(e);
@@ -91,6 +91,7 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
         rr::build_tile_plan(P->h.down, lag_of, block, P->tp);
         // the direct row path where the params order numbers small subtrees contiguously (any depth-first post-order); `why` says why not
         if (const char *e = getenv("RR_DIRECT")) P->direct_enabled = atoi(e) != 0;
+        P->direct_block = block;
         rr::build_direct_plan(P->h.down, lag_of, std::min<int32_t>(kDirectLanes, block), kDirectMaxWindow - 2, block, P->dp);
         P->direct_window = 3;
         for (int32_t sp : P->dp.tile_span) P->direct_window = std::max(P->direct_window, sp + 3);
@@ -158,54 +159,7 @@ int rr_plan_create(int64_t n, const int32_t *csc_indptr, const int32_t *csc_indi
             if (!rc) rc = dev_alloc(&P->d_full, n);
             if (!rc) rc = dev_alloc(&P->d_chan, n);
         }
-        if (!rc && P->dp.ok) {      // direct row path: per-column constants, the skeleton's tile arrays, the holes' out-pass
-            const rr::DirectPlan &D = P->dp;
-            const rr::TilePlan &K = D.skel;
-            if (hipFuncSetAttribute((const void *)k_direct<kDirectAhead>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)direct_lds_bytes(kDirectMaxWindow)) != hipSuccess) {
-                (void)hipGetLastError();
-                P->direct_enabled = false;
-            }
-            std::vector<DirectTile> dt((size_t)D.n_tiles);
-            for (int32_t t = 0; t < D.n_tiles; ++t) dt[t] = DirectTile{D.tile_c0[t], D.tile_nc[t], D.tile_lag_lo[t], D.tile_span[t]};
-            std::vector<int4> dl((size_t)n);
-            for (int64_t i = 0; i < n; ++i) dl[i] = make_int4(D.delay[i], D.up3[i], D.xinfo[i], H.lag[H.inv[i]]);
-            rc = dev_alloc(&P->d_dtiles, D.n_tiles);
-            if (!rc) rc = dev_upload(P->d_dtiles, dt);
-            if (!rc) rc = dev_alloc(&P->d_dlane, n);
-            if (!rc) rc = dev_upload(P->d_dlane, dl);
-            if (!rc) rc = dev_alloc(&P->d_dsend_ptr, D.n_tiles + 1);
-            if (!rc) rc = dev_upload(P->d_dsend_ptr, D.send_ptr);
-            if (!rc) rc = dev_alloc(&P->d_dsend_lane, (int64_t)D.send_lane.size());
-            if (!rc) rc = dev_upload(P->d_dsend_lane, D.send_lane);
-            if (!rc) rc = dev_alloc(&P->d_dcoef, 4 * n);
-            if (!rc) rc = dev_alloc(&P->d_dq, n);
-            std::vector<TileMeta> tm((size_t)K.n_tiles);
-            for (int32_t t = 0; t < K.n_tiles; ++t) {
-                tm[t] = TileMeta{K.tile_ptr[t], K.tile_ptr[t + 1], K.tile_level[t], K.tile_lag_lo[t], K.tile_lag_hi[t], K.tile_flags[t], 0, 0};
-                P->n_kwide += (K.tile_flags[t] & kTileWide) ? 1 : 0;
-            }
-            std::vector<int4> pm((size_t)K.np);
-            for (int64_t p = 0; p < K.np; ++p) pm[p] = make_int4(K.lag[p], K.cfirst[p], K.xpos[p], (int32_t)K.ccnt[p]);
-            std::vector<int2> hm;
-            std::vector<int32_t> hc;
-            for (int64_t i = 0; i < n; ++i)
-                if (D.big[i]) { hm.push_back(make_int2(K.inv[i], K.lag[K.inv[i]] & kLagMask)); hc.push_back((int32_t)i); }
-            P->n_kholes = (int64_t)hm.size();
-            if (!rc) rc = dev_alloc(&P->d_ktmeta, K.n_tiles);
-            if (!rc) rc = dev_upload(P->d_ktmeta, tm);
-            if (!rc) rc = dev_alloc(&P->d_kpmeta, K.np);
-            if (!rc) rc = dev_upload(P->d_kpmeta, pm);
-            if (!rc) rc = dev_alloc(&P->d_kperm, K.np);
-            if (!rc) rc = dev_upload(P->d_kperm, K.perm);
-            if (!rc) rc = dev_alloc(&P->d_kcoef, 3 * K.np);
-            if (!rc) rc = dev_alloc(&P->d_ksq, K.np);
-            if (!rc) rc = dev_alloc(&P->d_kss, K.np);
-            if (!rc) rc = dev_alloc(&P->d_ksi, K.np);
-            if (!rc) rc = dev_alloc(&P->d_kholemeta, P->n_kholes);
-            if (!rc) rc = dev_upload(P->d_kholemeta, hm);
-            if (!rc) rc = dev_alloc(&P->d_kholecol, P->n_kholes);
-            if (!rc) rc = dev_upload(P->d_kholecol, hc);
-        }
+        if (!rc) rc = upload_direct_plan(P);      // direct row path: per-column constants, the skeleton's tile arrays, the holes' out-pass
         if (!rc) rc = dev_alloc(&P->d_w, n);
         if (!rc) rc = dev_alloc(&P->d_c1row_h, n);
         if (!rc) rc = dev_alloc(&P->d_c2, n);
@@ -339,18 +293,10 @@ int rr_plan_set_coeffs(rr_plan *P, const double *lhs_off_data, const double *c2,
         }
         rc = upload_tile_coef(P);
     }
-    if (!rc && P->dp.ok) {      // direct row path: {c1row, c2, c3, c4dt} per column; the skeleton's positions as k_tile wants them (a ghost computes nothing)
-        std::vector<double> dc(4 * (size_t)n);
-        for (int64_t i = 0; i < n; ++i) { dc[4 * i] = c1row[H.inv[i]]; dc[4 * i + 1] = c2[i]; dc[4 * i + 2] = c3[i]; dc[4 * i + 3] = c4_dt ? c4_dt[i] : 0.0; }
-        rc = dev_upload(P->d_dcoef, dc);
-        const rr::TilePlan &K = P->dp.skel;
-        std::vector<double> kc(3 * (size_t)K.np, 0.0);
-        for (int64_t p = 0; p < K.np; ++p) {
-            if (K.lag[p] & kTileGhostBit) continue;
-            const int32_t i = K.perm[p];
-            kc[3 * p] = c1row[H.inv[i]]; kc[3 * p + 1] = c2[i]; kc[3 * p + 2] = c3[i];
-        }
-        if (!rc) rc = dev_upload(P->d_kcoef, kc);
+    {   // direct row path: {c1row, c2, c3, c4dt} per column, kept on the host too (rr_plan_set_boundary lays the direct plan out again)
+        P->h_dcoef.assign(4 * (size_t)n, 0.0);
+        for (int64_t i = 0; i < n; ++i) { P->h_dcoef[4 * i] = c1row[H.inv[i]]; P->h_dcoef[4 * i + 1] = c2[i]; P->h_dcoef[4 * i + 2] = c3[i]; P->h_dcoef[4 * i + 3] = c4_dt ? c4_dt[i] : 0.0; }
+        if (!rc) rc = upload_direct_coef(P);
     }
     if (!rc) rc = dev_upload(P->d_c2, a2);
     if (!rc) rc = dev_upload(P->d_c3, a3);
@@ -467,7 +413,9 @@ int rr_plan_profile_aux(rr_plan *P, double aux[12])
 int rr_plan_set_boundary(rr_plan *P, int64_t n_ghost, const int64_t *ghost_reaches, int64_t n_export,
                          const int64_t *export_reaches)
 {
-    int rc = need_device(P);
+    if (!P) return fail(RR_E_INVALID, "null plan");
+    const bool host_only = P->device < 0;      // a host-only plan takes the boundary too: its layouts can be inspected (rr_plan_direct_info)
+    int rc = host_only ? RR_OK : need_device(P);
     if (rc) return rc;
     const rr::HostPlan &H = P->h;
     const int64_t n = H.n;
@@ -495,15 +443,31 @@ int rr_plan_set_boundary(rr_plan *P, int64_t n_ghost, const int64_t *ghost_reach
         bidx[p] = (int32_t)e;
         emax = std::max<int64_t>(emax, H.lag[p]);
     }
-    rc = dev_upload(P->d_lag, lag);
-    if (!rc) rc = dev_upload(P->d_bidx, bidx);
-    if (rc) return rc;
+    if (!host_only) {
+        rc = dev_upload(P->d_lag, lag);
+        if (!rc) rc = dev_upload(P->d_bidx, bidx);
+        if (rc) return rc;
+    }
     P->n_ghost = n_ghost; P->n_export = n_export;
     P->ghost_min_lag = n_ghost ? gmin : 0;
     P->export_max_lag = n_export ? emax : 0;
     P->ghost_reach.assign(n_ghost, 0); P->export_reach.assign(n_export, 0);
     for (int64_t g = 0; g < n_ghost; ++g) P->ghost_reach[g] = (int32_t)ghost_reaches[g];
     for (int64_t e = 0; e < n_export; ++e) P->export_reach[e] = (int32_t)export_reaches[e];
+    {   // the direct row path, laid out again around the boundary reaches: a ghost's column is passed through (its series becomes the record
+        // of the skeleton's ghost that mirrors it), an export is stored by the skeleton's kernel or by its lane (rr_plan.hpp: build_direct_plan)
+        std::vector<uint8_t> gmask((size_t)n, 0);
+        std::vector<int32_t> eslot((size_t)n, -1), lag_of((size_t)n);
+        for (int64_t g = 0; g < n_ghost; ++g) gmask[ghost_reaches[g]] = 1;
+        for (int64_t e = 0; e < n_export; ++e) eslot[export_reaches[e]] = (int32_t)e;
+        for (int64_t i = 0; i < n; ++i) lag_of[i] = H.lag[H.inv[i]];
+        rr::build_direct_plan(H.down, lag_of, std::min<int32_t>(kDirectLanes, P->direct_block), kDirectMaxWindow - 2, P->direct_block, P->dp,
+                              n_ghost ? &gmask : nullptr, n_export ? &eslot : nullptr);
+        rc = upload_direct_plan(P);
+        if (!rc) rc = upload_direct_coef(P);
+        if (rc) return rc;
+    }
+    if (host_only) return RR_OK;
     if (P->tp.ok) {      // the same flags and slots in the tile layout
         const rr::TilePlan &TP = P->tp;
         // flags in the tile layout; an export reach's slot in the export series travels in xpos[], the word a reach mirrored

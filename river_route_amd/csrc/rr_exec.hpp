@@ -54,6 +54,9 @@ struct Session {
     // direct row path (rr_kernels_direct.hpp): K rows per task, the skeleton behind it on records
     bool rows_direct = false;
     int64_t n_tasks = 0;          // direct launches: rows [d K, (d + 1) K) in launch d
+    int64_t d_done = 0;           // direct launches made
+    int64_t KS = 1;               // record chunks per task of the skeleton's launches (KS divides KC; shorter where the part feeds another GPU)
+    bool export_lanes = false, export_skel = false;    // a boundary export is routed by a lane of a direct tile (final as soon as its rows are routed) / by the skeleton
     DirectArgs da{};
     bool bracket_open = false;
     int64_t bracket_reaches = 0;
@@ -122,7 +125,7 @@ struct rr_plan {
     bool wave_enabled = true, wave_forced = false, wave_now = false, weights_uniform = false;
     int wave_threads = 512;
     int64_t wave_K = 0;          // ticks per task (multiple of 16); 0 = chosen per call
-    int64_t next_KC = 1, next_chunks = 0;   // prepare_call: task length and record ring of the call about to start
+    int64_t next_KC = 1, next_KS = 1, next_chunks = 0;   // prepare_call: task length(s) and record ring of the call about to start
     int64_t kc_cap = int64_t{1} << 20;      // longest task (record chunks) the device had room for; 0: no record ring fits, the plan streams
     TileMeta *d_tmeta = nullptr;     // per tile (rr_kernels_tile.hpp)
     int4 *d_pmeta = nullptr;         // per position {lag | flags, first upstream position, xpos, upstream counts}
@@ -161,6 +164,9 @@ struct rr_plan {
     int32_t *d_kperm = nullptr, *d_kholecol = nullptr;
     double *d_kcoef = nullptr, *d_ksq = nullptr, *d_kss = nullptr, *d_ksi = nullptr;
     int2 *d_kholemeta = nullptr;         // per hole {position in the skeleton, lag}: the out-pass that patches the holes
+    int2 *d_kghostmeta = nullptr;        // per boundary ghost {position of the skeleton's ghost that mirrors it, lag}: the in-pass of the ghost series
+    std::vector<double> h_dcoef;         // {c1row, c2, c3, c4dt} per column as rr_plan_set_coeffs got them
+    int32_t direct_block = 0;            // tile capacity the plan was built with (rr_plan_set_boundary lays the direct plan out again)
     int64_t n_kholes = 0;
     int32_t n_kwide = 0;
     bool lean_enabled = true;           // RR_TILE_LEAN=0 (tests): the general tick for every call
@@ -256,6 +262,99 @@ int upload_tile_coef(rr_plan *P)
     return dev_upload(P->d_coef_unit, coef);
 }
 
+// The direct row path's device arrays (rr::DirectPlan): per-column constants, the skeleton's tile arrays, the columns of the holes' out-pass.
+// Called by rr_plan_create and again by rr_plan_set_boundary, which lays the plan out anew around the boundary reaches.
+int upload_direct_plan(rr_plan *P)
+{
+    void *old[] = {P->d_dtiles, P->d_dlane, P->d_dsend_ptr, P->d_dsend_lane, P->d_dcoef, P->d_dq, P->d_ktmeta, P->d_kpmeta, P->d_kperm, P->d_kholecol, P->d_kcoef,
+                   P->d_ksq, P->d_kss, P->d_ksi, P->d_kholemeta, P->d_kghostmeta};
+    for (void *p : old) if (p) (void)hipFree(p);
+    P->d_dtiles = nullptr; P->d_dlane = nullptr; P->d_dsend_ptr = P->d_dsend_lane = nullptr; P->d_dcoef = P->d_dq = nullptr; P->d_ktmeta = nullptr; P->d_kpmeta = nullptr;
+    P->d_kperm = P->d_kholecol = nullptr; P->d_kcoef = P->d_ksq = P->d_kss = P->d_ksi = nullptr; P->d_kholemeta = P->d_kghostmeta = nullptr;
+    P->n_kholes = 0; P->n_kwide = 0;
+    P->direct_window = 3;
+    for (int32_t sp : P->dp.tile_span) P->direct_window = std::max(P->direct_window, sp + 3);
+    if (!P->dp.ok || P->device < 0) return RR_OK;
+    const rr::HostPlan &H = P->h;
+    const rr::DirectPlan &D = P->dp;
+    const rr::TilePlan &K = D.skel;
+    const int64_t n = H.n;
+    if (hipFuncSetAttribute((const void *)k_direct<kDirectAhead>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)direct_lds_bytes(kDirectMaxWindow)) != hipSuccess) {
+        (void)hipGetLastError();
+        P->direct_enabled = false;
+    }
+    std::vector<DirectTile> dt((size_t)D.n_tiles);
+    for (int32_t t = 0; t < D.n_tiles; ++t) dt[t] = DirectTile{D.tile_c0[t], D.tile_nc[t], D.tile_lag_lo[t], D.tile_span[t]};
+    std::vector<int4> dl((size_t)n);
+    for (int64_t i = 0; i < n; ++i) dl[i] = make_int4(D.delay[i], D.up3[i], D.xinfo[i], H.lag[H.inv[i]]);
+    int rc = dev_alloc(&P->d_dtiles, D.n_tiles);
+    if (!rc) rc = dev_upload(P->d_dtiles, dt);
+    if (!rc) rc = dev_alloc(&P->d_dlane, n);
+    if (!rc) rc = dev_upload(P->d_dlane, dl);
+    if (!rc) rc = dev_alloc(&P->d_dsend_ptr, D.n_tiles + 1);
+    if (!rc) rc = dev_upload(P->d_dsend_ptr, D.send_ptr);
+    if (!rc) rc = dev_alloc(&P->d_dsend_lane, (int64_t)D.send_lane.size());
+    if (!rc) rc = dev_upload(P->d_dsend_lane, D.send_lane);
+    if (!rc) rc = dev_alloc(&P->d_dcoef, 4 * n);
+    if (!rc) rc = dev_alloc(&P->d_dq, n);
+    std::vector<TileMeta> tm((size_t)K.n_tiles);
+    std::vector<int32_t> klag(K.lag), kxpos(K.xpos), kflags(K.tile_flags);
+    // boundary exports among the skeleton's reaches: flagged as in the plan's own tiles (rr_plan_set_boundary); the slot in the export
+    // series travels in xpos[] (an export is an outlet of its part: no ghost of another tile mirrors it -- checked by build_direct_plan)
+    for (size_t e = 0; e < P->export_reach.size(); ++e) {
+        const int32_t i = P->export_reach[e];
+        if (!D.big[i]) continue;
+        const int32_t p = K.inv[i];
+        klag[p] |= kExportBit; kxpos[p] = (int32_t)e; kflags[K.tile_of[p]] |= kTileExports;
+    }
+    for (int32_t t = 0; t < K.n_tiles; ++t) {
+        tm[t] = TileMeta{K.tile_ptr[t], K.tile_ptr[t + 1], K.tile_level[t], K.tile_lag_lo[t], K.tile_lag_hi[t], kflags[t], 0, 0};
+        P->n_kwide += (kflags[t] & kTileWide) ? 1 : 0;
+    }
+    std::vector<int4> pm((size_t)K.np);
+    for (int64_t p = 0; p < K.np; ++p) pm[p] = make_int4(klag[p], K.cfirst[p], kxpos[p], (int32_t)K.ccnt[p]);
+    std::vector<int2> hm, gm;
+    std::vector<int32_t> hc;
+    for (int64_t i = 0; i < n; ++i)
+        if (D.big[i]) { hm.push_back(make_int2(K.inv[i], K.lag[K.inv[i]] & kLagMask)); hc.push_back((int32_t)i); }
+    for (int32_t i : P->ghost_reach) { const int32_t g = K.ext_ghost[i]; gm.push_back(make_int2(g, K.lag[g] & kLagMask)); }
+    P->n_kholes = (int64_t)hm.size();
+    if (!rc) rc = dev_alloc(&P->d_ktmeta, K.n_tiles);
+    if (!rc) rc = dev_upload(P->d_ktmeta, tm);
+    if (!rc) rc = dev_alloc(&P->d_kpmeta, K.np);
+    if (!rc) rc = dev_upload(P->d_kpmeta, pm);
+    if (!rc) rc = dev_alloc(&P->d_kperm, K.np);
+    if (!rc) rc = dev_upload(P->d_kperm, K.perm);
+    if (!rc) rc = dev_alloc(&P->d_kcoef, 3 * K.np);
+    if (!rc) rc = dev_alloc(&P->d_ksq, K.np);
+    if (!rc) rc = dev_alloc(&P->d_kss, K.np);
+    if (!rc) rc = dev_alloc(&P->d_ksi, K.np);
+    if (!rc) rc = dev_alloc(&P->d_kholemeta, P->n_kholes);
+    if (!rc) rc = dev_upload(P->d_kholemeta, hm);
+    if (!rc) rc = dev_alloc(&P->d_kholecol, P->n_kholes);
+    if (!rc) rc = dev_upload(P->d_kholecol, hc);
+    if (!rc) rc = dev_alloc(&P->d_kghostmeta, (int64_t)gm.size());
+    if (!rc) rc = dev_upload(P->d_kghostmeta, gm);
+    return rc;
+}
+
+// Coefficients of the direct row path from the host copy rr_plan_set_coeffs keeps: per column for the lanes, per position for the skeleton
+// (a ghost position computes nothing: zeros, as in upload_tile_coef).
+int upload_direct_coef(rr_plan *P)
+{
+    if (!P->dp.ok || P->device < 0 || P->h_dcoef.empty()) return RR_OK;
+    int rc = dev_upload(P->d_dcoef, P->h_dcoef);
+    const rr::TilePlan &K = P->dp.skel;
+    std::vector<double> kc(3 * (size_t)K.np, 0.0);
+    for (int64_t p = 0; p < K.np; ++p) {
+        if (K.lag[p] & kTileGhostBit) continue;
+        const int64_t i = K.perm[p];
+        kc[3 * p] = P->h_dcoef[4 * i]; kc[3 * p + 1] = P->h_dcoef[4 * i + 1]; kc[3 * p + 2] = P->h_dcoef[4 * i + 2];
+    }
+    if (!rc) rc = dev_upload(P->d_kcoef, kc);
+    return rc;
+}
+
 // The two-phase tiled permutation params order <-> lag order of the streaming kernel (k_perm_a / k_perm_b).  Built when a
 // call first streams: the time-tiled kernel, which takes almost every call, has its own record passes.
 int upload_tiled_permutations(rr_plan *P)
@@ -330,6 +429,7 @@ int64_t pick_KC(const rr_plan *P, int64_t total_ticks)
 // allocation), so rr_plan_reserve and the call it prepares for agree on it.
 struct Schedule {
     bool direct = false;              // direct row path: KC = rows per task / 16, chunks / ring = the skeleton's record ring
+    int64_t KS = 1;                   // direct row path: record chunks per task of the skeleton's launches
     bool tiled = false;
     int64_t KC = 1, chunks = 0;       // time-tiled: record chunks per task, chunks of the record ring
     int64_t ring = 0;                 // doubles of P->d_ring: record ring, or the work rows of the streaming kernel
@@ -354,17 +454,23 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
 {
     Schedule sch;
     const int64_t total = T * nsub, dmax = P->h.depth - 1, n = P->h.n;
-    // The direct row path: RapidMuskingum, one sub-step per row, float64 rows in device arrays, one weight per reach, no
-    // boundary reaches -- the headline's call -- on a params order that numbers small subtrees contiguously.
+    // The direct row path: RapidMuskingum, one sub-step per row, float64 rows in device arrays, one weight per reach -- the
+    // headline's call -- on a params order that numbers small subtrees contiguously (boundary reaches of a partitioned network
+    // included: rr_plan_set_boundary lays the direct plan out around them).
     if (plain_rows && P->direct_enabled && P->dp.ok && mode == Mode::Rapid && nsub == 1 && P->weights_uniform && !force_streaming && !host_io &&
-        P->n_ghost == 0 && P->n_export == 0 && P->wave_enabled && total >= 32 && n < (int64_t{1} << 29)) {
+        P->wave_enabled && total >= 32 && n < (int64_t{1} << 29)) {
         int64_t K = pick_direct_K(P, T);
         const int64_t levels = P->dp.skel.n_levels, np = P->dp.skel.np;
         if (ring_in > 0 && ring_in < T) K = std::min(K, ring_in / kRec * kRec);
         if (ring_out > 0 && ring_out < T) K = std::min(K, ring_out / kRec * kRec);
         sch.direct = true; sch.KC = K / kRec;
+        // The skeleton's own tasks: as long as the lanes' (every tile level costs one task of pipeline and of record ring) -- except in a part
+        // that feeds another GPU, whose boundary series every level delays by one task: 64 ticks there (as kc_long below), several of the
+        // skeleton's launches per direct launch.  KS divides KC.
+        sch.KS = sch.KC;
+        if (P->n_export > 0 && P->wave_K <= 0) for (sch.KS = std::min<int64_t>(sch.KC, 4); sch.KC % sch.KS; --sch.KS) {}
         if (np > 0) {      // a record lives from the launch that forwards its first row to the out-pass behind the skeleton's last level
-            sch.chunks = std::min<int64_t>(((levels + 1) * K + 2 * dmax + kRecRows + 2 * kRec) / kRec + 2, (total + dmax) / kRec + 2);
+            sch.chunks = std::min<int64_t>((levels * sch.KS * kRec + 2 * K + 2 * dmax + kRecRows + 2 * kRec) / kRec + 2, (total + dmax) / kRec + 2);
             sch.ring = sch.chunks * kRec * np;
         }
         if (K >= 2 * kRec && np < (int64_t{1} << 25) && (P->dev_total_bytes == 0 || sch.ring * 8 <= (int64_t)(P->dev_total_bytes / 2))) return sch;
@@ -455,7 +561,7 @@ int prepare_call(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_stre
                                         std::to_string((P->ring_cap + P->mrows_cap + P->stage_cap) * 8) + " reserved): call rr_plan_reserve(plan, mode, " +
                                         std::to_string(T) + ", " + std::to_string(nsub) + ", ...) first; the *_dev entry points only enqueue work");
     }
-    P->wave_now = sch.tiled; P->direct_now = sch.direct; P->next_KC = sch.KC; P->next_chunks = sch.chunks;
+    P->wave_now = sch.tiled; P->direct_now = sch.direct; P->next_KC = sch.KC; P->next_KS = sch.KS; P->next_chunks = sch.chunks;
     return RR_OK;
 }
 
@@ -502,28 +608,38 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
 
     if (S.wave || S.rows_direct) { S.KC = P->next_KC; S.rec_chunks = P->next_chunks; }     // ring sized by choose_schedule, allocated by rr_plan_reserve
     if (S.rows_direct) {
-        if (io.dev_in32 || io.dev_out32 || io.uh_kernel || io.runoff || !io.dev_in || !io.dev_out || mode != Mode::Rapid || nsub != 1 || P->n_ghost > 0 || P->n_export > 0) {
+        if (io.dev_in32 || io.dev_out32 || io.uh_kernel || io.runoff || !io.dev_in || !io.dev_out || mode != Mode::Rapid || nsub != 1) {
             S.open = false;
             return fail(RR_E_STATE, "route: the direct row path was chosen for a call it does not take");      // (choose_schedule's plain_rows)
         }
         const rr::TilePlan &TP = P->dp.skel;
         const int64_t K = S.KC * kRec;
+        S.KS = std::max<int64_t>(1, P->next_KS);
         S.n_tasks = (S.T + K - 1) / K;
-        S.n_macro = (S.total_ticks + K - 1) / K;
-        S.n_diags = std::max<int64_t>(S.n_tasks, TP.n_tiles > 0 ? S.n_macro + TP.n_levels - 1 : 0);
+        S.n_macro = (S.total_ticks + S.KS * kRec - 1) / (S.KS * kRec);      // of the skeleton's launches
+        S.n_diags = TP.n_tiles > 0 ? S.n_macro + TP.n_levels - 1 : 0;
+        S.n_in_batches = (S.total + 14) / kRecRows + 1;      // of the boundary series (if any)
         S.n_out_batches = TP.np > 0 ? (S.total + kRecRows - 1) / kRecRows : 0;
+        S.export_skew = 0; S.export_lanes = S.export_skel = false;
+        for (int32_t i : P->export_reach) {
+            if (!P->dp.big[i]) { S.export_lanes = true; continue; }
+            S.export_skel = true;
+            const int32_t p = TP.inv[i];
+            S.export_skew = std::max<int64_t>(S.export_skew, (int64_t)TP.tile_level[TP.tile_of[p]] * S.KS * kRec + (TP.lag[p] & kLagMask));
+        }
         DirectArgs &da = S.da;
         da.tiles = P->d_dtiles; da.n_tiles = P->dp.n_tiles; da.lane = P->d_dlane; da.coef = P->d_dcoef; da.q = P->d_dq;
         da.send_ptr = P->d_dsend_ptr; da.send_lane = P->d_dsend_lane;
         da.in = io.dev_in; da.out = io.dev_out; da.n = n; da.in_rows = (uint32_t)io.rows_in; da.out_rows = (uint32_t)io.rows_out;
         da.rec = P->d_ring; da.rec_chunks = (uint32_t)std::max<int64_t>(1, S.rec_chunks); da.np = (int32_t)TP.np;
         da.K = (int32_t)K; da.total = (int32_t)S.T;
+        da.exports = export_series; da.n_export = (int32_t)P->n_export;
         TileArgs &w = S.ta;      // the skeleton's k_tile launches
         w.tiles = P->d_ktmeta; w.pos = P->d_kpmeta; w.coef = P->d_kcoef;
         w.sq = P->d_ksq; w.ss = P->d_kss; w.si = P->d_ksi; w.sqch = nullptr;
-        w.exports = nullptr; w.n_export = 0;
+        w.exports = export_series; w.n_export = (int32_t)P->n_export;
         w.rec = P->d_ring; w.rec_chunks = Div32((uint32_t)std::max<int64_t>(1, S.rec_chunks));
-        w.np = (int32_t)TP.np; w.KC = (int32_t)S.KC; w.n_macro = (int32_t)S.n_macro; w.total = (int32_t)S.total;
+        w.np = (int32_t)TP.np; w.KC = (int32_t)S.KS; w.n_macro = (int32_t)S.n_macro; w.total = (int32_t)S.total;
         w.has_lat = 1; w.nsub = Div32(1u); w.inv_nsub = 1.0;
     }
     if (S.wave) {
@@ -725,7 +841,7 @@ int launch_tile_diag(rr_plan *P, const rr::TilePlan &TP, TileArgs &w, int32_t n_
     int64_t t_lo = TP.level_start[l_lo], t_hi = TP.level_start[l_hi + 1];
     // tiles are sorted by their smallest lag inside a level; while the pipeline fills, the tiles of level 0 that
     // have not started yet are a suffix of it
-    const int64_t K = S.KC * kRec;
+    const int64_t K = (int64_t)w.KC * kRec;      // (the skeleton of the direct row path may run shorter tasks than its lanes)
     if (l_lo == 0) {
         const int64_t end0 = TP.level_start[1];
         int64_t hi = std::min<int64_t>(t_hi, end0);
@@ -791,8 +907,9 @@ void launch_ghost_permute(rr_plan *P, int64_t batch)
 {
     Session &S = P->ses;
     RecPermArgs ra{};
-    ra.rec = P->d_ring; ra.rec_chunks = Div32((uint32_t)S.rec_chunks); ra.n = P->n_ghost; ra.np = P->tp.np; ra.T = S.total; ra.total = S.total;
-    ra.batch = batch; ra.nsub = Div32(1u); ra.colmeta = P->d_ghostmeta; ra.scale = nullptr;
+    // (direct row path: the ghosts' records are those of the skeleton's positions that mirror them)
+    ra.rec = P->d_ring; ra.rec_chunks = Div32((uint32_t)S.rec_chunks); ra.n = P->n_ghost; ra.np = S.rows_direct ? P->dp.skel.np : P->tp.np; ra.T = S.total; ra.total = S.total;
+    ra.batch = batch; ra.nsub = Div32(1u); ra.colmeta = S.rows_direct ? P->d_kghostmeta : P->d_ghostmeta; ra.scale = nullptr;
     ra.rows = RowView{const_cast<double *>(S.ghost_series), P->n_ghost, 0, (uint32_t)S.total};
     ra.factor = Div32(1u);
     hipLaunchKernelGGL(k_rec_in<false>, dim3((unsigned)((P->n_ghost + kRecInCols - 1) / kRecInCols)), dim3(kRecInThreads), 0, rec_stream(P), ra);
@@ -949,51 +1066,74 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
 // (The skeleton's launches and the out-pass on a second stream beside the direct launches, with or without CUs set aside for them,
 // changed nothing -- 212 to 226 ms per year against 212: profiles/r04_direct_second_stream_ab.txt -- the out-pass's scattered
 // 8-byte stores, 5 % of the columns, compete for the same memory system.)
-int session_advance_direct(rr_plan *P, int64_t rows_ready)
+int session_advance_direct(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, int64_t *export_ready)
 {
     Session &S = P->ses;
     const rr::TilePlan &TP = P->dp.skel;
-    const int64_t dmax = P->h.depth - 1, levels = TP.n_levels, K = S.KC * kRec, n = P->h.n;
+    const int64_t dmax = P->h.depth - 1, levels = TP.n_levels, K = S.KC * kRec, KS = S.KS * kRec, per = K / KS, n = P->h.n;
     rows_ready = std::min(rows_ready, S.T);
-    const bool skel = TP.n_tiles > 0;
+    const bool skel = TP.n_tiles > 0, ghosts = skel && P->n_ghost > 0;
+    // a record slot is recycled only after every tick-row it can hold has left (the same rule as session_advance_tile's)
+    auto slot_free = [&](int64_t j) {
+        const int64_t must_have_left = kRecRows * (j + 1) + kRec - kRec * S.rec_chunks;
+        return must_have_left <= 0 || S.ticks_stored >= std::min(S.total, must_have_left);
+    };
     for (;;) {
         bool progressed = false;
-        while (S.diag < S.n_diags) {
-            const int64_t d = S.diag;
-            if (d < S.n_tasks && rows_ready < std::min((d + 1) * K, S.T)) break;
+        while (S.d_done < S.n_tasks) {
+            const int64_t d = S.d_done;
+            if (rows_ready < std::min((d + 1) * K, S.T)) break;
             if (skel) {      // this launch writes record slots up to tick (d + 1) K + dmax: whatever they held one revolution earlier must have left
                 const int64_t top = std::min((d + 1) * K + dmax, S.total_ticks) / kRec;
                 if (top >= S.rec_chunks && S.ticks_stored < std::min(S.total, kRec * (top - S.rec_chunks + 1))) break;
             }
-            if (d < S.n_tasks) {
-                const bool sample = S.max_samples > 0 && (size_t)P->prof_brackets < S.max_samples;
-                if (sample) HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets], S.stream));
-                S.da.m = (int32_t)d;
-                const dim3 g((unsigned)std::min<int64_t>(P->dp.n_tiles, (int64_t)P->cu_count));
-                hipLaunchKernelGGL((k_direct<kDirectAhead>), g, dim3(kDirectThreads), direct_lds_bytes(P->direct_window), S.stream, S.da);
-                if (sample) {
-                    HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));
-                    P->ev_reaches.push_back(n * (std::min((d + 1) * K, S.T) - d * K));
-                    P->prof_samples += K;
-                    ++P->prof_brackets;
-                }
+            const bool sample = S.max_samples > 0 && (size_t)P->prof_brackets < S.max_samples;
+            if (sample) HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets], S.stream));
+            S.da.m = (int32_t)d;
+            const dim3 g((unsigned)std::min<int64_t>(P->dp.n_tiles, (int64_t)P->cu_count));
+            hipLaunchKernelGGL((k_direct<kDirectAhead>), g, dim3(kDirectThreads), direct_lds_bytes(P->direct_window), S.stream, S.da);
+            if (sample) {
+                HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));
+                P->ev_reaches.push_back(n * (std::min((d + 1) * K, S.T) - d * K));
+                P->prof_samples += K;
+                ++P->prof_brackets;
             }
-            if (skel && tile_diag_launches(P, TP, d)) {      // (an empty bracket would be counted as a launch of the skeleton)
+            ++P->prof_launches;
+            ++S.d_done;
+            progressed = true;
+        }
+        const int64_t rows_routed = S.d_done >= S.n_tasks ? S.T : S.d_done * K;      // by the lanes
+        S.rows_loaded = rows_routed;
+        // The boundary series of a partitioned network becomes the records of the skeleton's ghosts that mirror the boundary reaches,
+        // 128 tick-rows at a time (k_rec_in's batches), never ahead of the rows the lanes have routed: the ring's slots up to there are free.
+        while (ghosts && S.ghost_batches < S.n_in_batches) {
+            const int64_t need = std::min(kRecRows * (S.ghost_batches + 1), S.total);
+            if (ghost_ready < need || need > rows_routed || !slot_free(S.ghost_batches)) break;
+            launch_ghost_permute(P, S.ghost_batches);
+            ++S.ghost_batches;
+            progressed = true;
+        }
+        const int64_t ghost_loaded = !ghosts || S.ghost_batches >= S.n_in_batches ? S.total : std::max<int64_t>(0, kRecRows * S.ghost_batches - 15);
+        // The skeleton's launch j runs its tiles of level l (from 1) on macro-chunk j - l, KS ticks each: what they read -- the records the
+        // lanes forwarded and the boundary records, ticks below j KS -- is there once the lanes have routed that many rows.
+        while (skel && S.diag < S.n_diags) {
+            const int64_t j = S.diag;
+            if (S.d_done < S.n_tasks && j > S.d_done * per - 1) break;
+            if (ghost_loaded < std::min(S.total, j * KS)) break;
+            if (tile_diag_launches(P, TP, j)) {      // (an empty bracket would be counted as a launch of the skeleton)
                 const int aux = aux_begin(P, 2, S.stream);
-                int rc = launch_tile_diag(P, TP, S.ta, P->n_kwide, P->d_kcoef, P->d_kcoef, d, false);
+                int rc = launch_tile_diag(P, TP, S.ta, P->n_kwide, P->d_kcoef, P->d_kcoef, j, false);
                 aux_end(P, aux, S.stream);      // before rc is looked at: rr_plan_profile_aux reads both events of every sample
                 if (rc) return rc;
             }
-            ++P->prof_launches;
             ++S.diag;
             progressed = true;
         }
-        S.rows_loaded = std::min(S.diag, S.n_tasks) * K < S.T ? std::min(S.diag, S.n_tasks) * K : S.T;
         // rows the direct tiles have written, and of those the rows whose skeleton reaches are final too
-        int64_t done = S.rows_loaded;
+        int64_t done = rows_routed;
         if (skel) {
             const int64_t m_done = S.diag - levels;      // the tiles of the last level have finished macro-chunk diag - levels
-            int64_t sk = S.diag >= S.n_diags ? S.total : (m_done >= 0 ? std::max<int64_t>(0, (m_done + 1) * K - dmax) : 0);
+            int64_t sk = S.diag >= S.n_diags ? S.total : (m_done >= 0 ? std::max<int64_t>(0, (m_done + 1) * KS - dmax) : 0);
             done = std::min(done, std::min(sk, S.total));
             while (S.out_batches < S.n_out_batches && done >= std::min(kRecRows * (S.out_batches + 1), S.total)) {
                 RecPermArgs ra{};
@@ -1015,7 +1155,12 @@ int session_advance_direct(rr_plan *P, int64_t rows_ready)
         }
         if (!progressed) break;
     }
-    if (S.diag >= S.n_diags) S.tau = S.total_ticks;
+    if (S.d_done >= S.n_tasks && S.diag >= S.n_diags) S.tau = S.total_ticks;
+    if (export_ready) {      // a lane's export is final with its row; a skeleton reach's once its tile's level has passed the tick
+        int64_t e = S.d_done >= S.n_tasks ? S.total : S.d_done * K;
+        if (S.export_skel) e = std::min(e, S.diag >= S.n_diags ? S.total : S.diag * KS - S.export_skew);
+        *export_ready = P->n_export > 0 ? std::max<int64_t>(0, std::min(e, S.total)) : S.total;
+    }
     return RR_OK;
 }
 
@@ -1029,7 +1174,7 @@ int session_advance(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, int64_t
     if (export_ready) *export_ready = 0;
     if (n == 0 || S.total == 0) { if (export_ready) *export_ready = S.total; return RR_OK; }
     if (S.wave) return session_advance_tile(P, rows_ready, std::min(ghost_ready, S.total), export_ready);
-    if (S.rows_direct) { if (export_ready) *export_ready = S.total; return session_advance_direct(P, rows_ready); }
+    if (S.rows_direct) return session_advance_direct(P, rows_ready, std::min(ghost_ready, S.total), export_ready);
     rows_ready = std::min(rows_ready, S.T);
     ghost_ready = std::min(ghost_ready, S.total);
     // a ghost at lag L is read at tick tau for sub-step tau - L: ticks below ghost_ready + min lag are safe

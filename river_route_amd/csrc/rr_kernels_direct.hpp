@@ -58,6 +58,8 @@ struct DirectArgs {
     uint32_t rec_chunks;
     int32_t np;
     int32_t m, K, total;        // this launch: rows [m K, min((m + 1) K, total))
+    double *exports;            // boundary series another GPU reads (a partitioned network's exports that lanes route): (total, n_export)
+    int32_t n_export;
 };
 constexpr int32_t kDirectHoleBit = rr::kDirectHole;
 constexpr int kDirectLanes = 256, kDirectAhead = 16;
@@ -137,6 +139,9 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             const int32_t sender = idle ? 0 : (lm.x >> rr::kDirectSenderShift) & kSenderMask;
             const int32_t stage_b = sender ? kStageB + (sender - 1) * (2 * kRec * 8) : kDummyB + tid * 8;      // dummy: the lane's own slot (32 of them: slot 0 ... see below)
             const bool wave_sends = __builtin_amdgcn_ballot_w64(sender != 0) != 0;
+            // a boundary export of a partitioned network that a lane routes: its discharge after every step, unclamped, into its column of the export series
+            const int32_t exp_slot = (!idle && (lm.x & rr::kDirectExport)) ? lm.z : -1;
+            const bool wave_exports = __builtin_amdgcn_ballot_w64(exp_slot >= 0) != 0;
             const double c1 = idle ? 0.0 : a.coef[4 * (int64_t)col], c2 = idle ? 0.0 : a.coef[4 * (int64_t)col + 1], c3 = idle ? 0.0 : a.coef[4 * (int64_t)col + 2];
             const double q0 = idle ? 0.0 : a.q[col];
             const int32_t u0 = lm.y & 0x3FF, u1 = (lm.y >> 10) & 0x3FF, u2 = (lm.y >> 20) & 0x3FF;
@@ -172,6 +177,10 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                         bool put = sender != 0;
                         if (decltype(tested)::value) put = put && (uint32_t)(k0 + s - delta) < (uint32_t)nrows;
                         *reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + (put ? stage_b + slot_b : kDummyB + tid * 8)) = qk;
+                    }
+                    if (wave_exports) {      // wave-uniform; a few lanes of a few tiles
+                        const int32_t row = k0 + s - delta;
+                        if (exp_slot >= 0 && (uint32_t)row < (uint32_t)nrows) a.exports[(int64_t)(r0 + row) * a.n_export + exp_slot] = qk;
                     }
                     own_b = own_b + kRowB == wrap ? 0 : own_b + kRowB;
                     barrier_lds();

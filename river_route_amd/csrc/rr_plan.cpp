@@ -378,7 +378,7 @@ void build_tile_plan(const std::vector<int32_t> &down, const std::vector<int32_t
 }
 
 void build_direct_plan(const std::vector<int32_t> &down, const std::vector<int32_t> &lag_of, int32_t lanes, int32_t wmax, int32_t skel_block,
-                       DirectPlan &D)
+                       DirectPlan &D, const std::vector<uint8_t> *ghost, const std::vector<int32_t> *export_slot)
 {
     D = DirectPlan();
     D.lanes = lanes; D.wmax = wmax;
@@ -396,7 +396,16 @@ void build_direct_plan(const std::vector<int32_t> &down, const std::vector<int32
     D.big.assign(n, 0);
     for (int64_t v = 0; v < n; ++v) D.big[v] = (sub[v] > lanes || height[v] > wmax) ? 1 : 0;
     auto small_root = [&](int64_t v) { return !D.big[v] && (down[v] < 0 || D.big[down[v]]); };
+    auto is_ghost = [&](int64_t v) { return ghost && (*ghost)[v] != 0; };
+    // A boundary ghost's column lies wherever the caller put it (first, in a partitioned network's parts), not next to the reach it flows
+    // into, so that reach cannot be a lane: it and what lies downstream of it joins the skeleton (in the part that holds the main stems
+    // that is where the ghosts enter anyway; the few reaches at the upper ends of the stems, whose own sub-basins were cut away, are added).
+    if (ghost)
+        for (int64_t v = 0; v < n; ++v)
+            if (is_ghost(v)) for (int64_t w = down[v]; w >= 0 && !D.big[w]; w = down[w]) D.big[w] = 1;
     for (int64_t v = 0; v < n; ++v) {
+        if (is_ghost(v) && (indeg[v] != 0 || down[v] < 0)) { D.why = "a boundary ghost is not a headwater with a downstream reach"; return; }
+        if (export_slot && (*export_slot)[v] >= 0 && down[v] >= 0) { D.why = "a boundary export has a downstream reach in this plan"; return; }
         if (D.big[v]) continue;
         if (indeg[v] > 3) { D.why = "a reach of a small subtree has more than three upstream reaches"; return; }
         if (small_root(v) && first[v] != (int32_t)v - sub[v] + 1) { D.why = "a small subtree is not a contiguous range of the params order"; return; }
@@ -417,8 +426,8 @@ void build_direct_plan(const std::vector<int32_t> &down, const std::vector<int32
                 while (!small_root(r)) r = down[r];      // c is the first (deepest-first) reach of exactly one small subtree
                 if (first[r] != c) { D.why = "internal: a small subtree does not start where the previous unit ended"; return; }
                 c1 = r + 1;
-                if (down[r] >= 0) ++us;
-                for (int64_t v = c; v < c1; ++v) { ulo = std::min(ulo, lag_of[v]); uhi = std::max(uhi, lag_of[v]); }
+                if (down[r] >= 0 && !is_ghost(r)) ++us;
+                if (!is_ghost(r)) for (int64_t v = c; v < c1; ++v) { ulo = std::min(ulo, lag_of[v]); uhi = std::max(uhi, lag_of[v]); }      // (a ghost is a unit of one idle column)
             }
             if (c1 - c0 > lanes || (uhi >= 0 && uhi - ulo + 1 > wmax) || us > kDirectSenders) break;
             lo = ulo; hi = uhi; senders = us; c = c1;
@@ -430,6 +439,7 @@ void build_direct_plan(const std::vector<int32_t> &down, const std::vector<int32
         for (int64_t v = c0; v < c; ++v) {
             tile_of[v] = t;
             if (D.big[v]) { D.delay[v] = kDirectHole; ++D.n_holes; }
+            else if (is_ghost(v)) D.delay[v] = kDirectHole;      // passed through, not routed: its value arrives in the skeleton's record ring
             else D.delay[v] = lag_of[v] - lo;
         }
     }
@@ -451,12 +461,19 @@ void build_direct_plan(const std::vector<int32_t> &down, const std::vector<int32
     if (!D.skel.ok) { D.why = "the skeleton does not tile"; return; }
     for (int64_t v = 0; v < n; ++v) {
         if (D.big[v]) D.xinfo[v] = D.skel.inv[v];
-        else if (small_root(v) && down[v] >= 0) { D.xinfo[v] = D.skel.ext_ghost[v]; ++D.n_exports; if (D.xinfo[v] < 0) { D.why = "internal: an outlet below the skeleton has no ghost"; return; } }
+        else if (small_root(v) && down[v] >= 0) {
+            if (D.skel.ext_ghost[v] < 0) { D.why = "internal: an outlet below the skeleton has no ghost"; return; }
+            if (is_ghost(v)) continue;      // the in-pass of the boundary series writes that ghost's record (rr_exec.hpp), no lane sends
+            D.xinfo[v] = D.skel.ext_ghost[v]; ++D.n_exports;
+        }
     }
+    if (export_slot)
+        for (int64_t v = 0; v < n; ++v)
+            if ((*export_slot)[v] >= 0 && !D.big[v]) { D.delay[v] |= kDirectExport; D.xinfo[v] = (*export_slot)[v]; }      // (an outlet: it sends nothing, xinfo is free)
     D.send_ptr.assign((size_t)D.n_tiles + 1, 0);
     for (int32_t t = 0; t < D.n_tiles; ++t) {
         for (int32_t v = D.tile_c0[t]; v < D.tile_c0[t] + D.tile_nc[t]; ++v)
-            if (D.xinfo[v] >= 0) {      // the column's number among the tile's senders travels in its delay word
+            if (D.xinfo[v] >= 0 && !(D.delay[v] & kDirectExport)) {      // the column's number among the tile's senders travels in its delay word
                 D.delay[v] |= ((int32_t)(D.send_lane.size() - D.send_ptr[t]) + 1) << kDirectSenderShift;
                 D.send_lane.push_back((v - D.tile_c0[t]) | (D.big[v] ? kDirectHole : 0));
             }

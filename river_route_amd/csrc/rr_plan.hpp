@@ -118,6 +118,7 @@ void build_tile_plan(const std::vector<int32_t> &down, const std::vector<int32_t
 // the output rows from the skeleton's records.
 constexpr int32_t kDirectHole = 1 << 30;      // delay[] flag: the column belongs to the skeleton
 constexpr int32_t kDirectSenderShift = 8, kDirectDelayMask = 0xFF;      // delay[] bits 8-14: 1 + the column's number among its tile's senders (0: none); bits 0-7: the delay
+constexpr int32_t kDirectExport = 1 << 15;    // delay[] flag: a boundary export of a partitioned network routed by a lane; xinfo = its column in the export series
 struct DirectPlan {
     bool ok = false;
     std::string why;                   // not ok: the first reason
@@ -134,8 +135,13 @@ struct DirectPlan {
     TilePlan skel;                     // the skeleton's tiles (levels from 1)
 };
 constexpr int32_t kDirectSenders = 64;      // one wave forwards them
+// Boundary reaches of a partitioned network (optional, both [n]): ghost[i] != 0 -- the reach's discharge is prescribed (it is routed on
+// another GPU): its column is passed through like a hole's and nobody sends for it (the boundary series is turned into the record of the
+// skeleton's ghost that mirrors it by the in-pass); it must be a headwater of this network, and the reaches downstream of it join the skeleton.
+// export_slot[i] >= 0 -- the reach's discharge also goes to that column of the export series: a skeleton reach's by the skeleton's
+// kernel, a lane's by the lane (kDirectExport); it must be an outlet of this network.
 void build_direct_plan(const std::vector<int32_t> &down, const std::vector<int32_t> &lag_of, int32_t lanes, int32_t wmax, int32_t skel_block,
-                       DirectPlan &out);
+                       DirectPlan &out, const std::vector<uint8_t> *ghost = nullptr, const std::vector<int32_t> *export_slot = nullptr);
 
 // Depth-first post-order of a forest given by downstream indices in any order (include/rr_hip.h: rr_postorder).  False: an index out of
 // range or a cycle.

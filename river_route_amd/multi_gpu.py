@@ -452,57 +452,6 @@ def run_sequential(specs, make_engine, T: int, nsub: int, visit=None, route=None
             eng.close()
 
 
-TILE_STATE_BYTES = 72.0      # per position and task: lag, first upstream, counts, ghost link (16), ss, sq, c1, c2, c3 read (40), sq, ss written (16)
-
-
-def roofline_from_profile(prof: dict, nsub: int, peak_gbs: float = 8000.0, copy_gbs=None, unit: bool = False, kernel: str = None, traffic: dict = None):
-    """`roofline` object of bench.py from Plan.profile() for the dominant kernel.
-
-    Time-tiled kernel (k_tile; a launch advances its tiles by K ticks): ALGORITHMIC bytes of a launch = positions x
-    (16 B x K: the record of every position read once and written once, a ghost's by the tile that owns its reach) +
-    positions x 72 B (80 with the channel state of UnitMuskingum) of state and coefficients once per task; `frac` =
-    those bytes / HIP-event time of the sampled launches / peak, a fraction of the roofline by construction.
-    Every fourth launch is sampled, fill and drain launches included, so `avg_launch_us` is the average rocprofv3
-    reports for the kernel.  Direct row path (k_direct; a launch routes K rows of every column): 16 B per reach-row (the lateral
-    value read, the discharge written) + 64 B of per-column constants and state per task; every launch is sampled.
-    `traffic` = HBM bytes per full launch measured by separate rocprofv3 --pmc passes, with the file it came from.
-    `streaming_model_*` prices the same launches at SURVEY section 8(d)'s contract figure (72 B per reach sub-step + 16 B
-    per reach row: what a kernel that keeps nothing on chip between ticks would move); a time-tiled kernel undercuts
-    it, so that figure may exceed the peak and is NOT the roofline fraction."""
-    if prof['sampled'] <= 0 or prof['sampled_ms'] <= 0:
-        return None
-    tpl = max(1, prof['ticks_per_launch'])
-    launches = prof['sampled'] / tpl
-    avg_ms = prof['sampled_ms'] / launches
-    pos_ticks = prof['sampled_reaches'] / launches          # position-ticks (time-tiled), reach-rows (direct) or reach-ticks (streaming) per launch
-    streaming = (72.0 + 16.0 / nsub) * pos_ticks
-    if kernel == 'direct':
-        alg = pos_ticks * (16.0 + 64.0 / tpl)
-        name = f'k_direct (direct row path over column-range tiles, {tpl} rows per task)'
-    elif tpl > 1:
-        alg = pos_ticks * (16.0 + (TILE_STATE_BYTES + (8.0 if unit else 0.0)) / tpl)
-        name = f'k_tile (time-tiled routing over subtree tiles, {tpl} ticks per task)'
-    else:
-        alg = streaming
-        name = 'k_tick (streaming routing)'
-    sec = avg_ms * 1e-3
-    per_launch = None if not traffic else traffic.get('main_kernel_bytes_per_launch')
-    out = {'bound': 'hbm', 'achieved': round(alg / sec / 1e9, 1), 'peak': peak_gbs, 'unit': 'GB/s',
-           'frac': round(alg / sec / 1e9 / peak_gbs, 4), 'traffic': None if per_launch is None else round(per_launch),
-           'traffic_source': None if not traffic else traffic.get('source'),
-           'kernel': name, 'ticks_per_launch': tpl, 'avg_launch_us': round(avg_ms * 1e3, 3),
-           'algorithmic_bytes_per_launch': round(alg),
-           'algorithmic_bytes_per_position_tick': round(alg / pos_ticks, 3),
-           'measured_hbm_gbps': None if per_launch is None else round(per_launch / sec / 1e9, 1),
-           'frac_measured_traffic': None if per_launch is None else round(per_launch / sec / 1e9 / peak_gbs, 4),
-           'peak_measured_copy': None if copy_gbs is None else round(copy_gbs, 1),
-           'frac_of_measured_copy': None if copy_gbs is None else round(alg / sec / 1e9 / copy_gbs, 4),
-           'streaming_model_gbps': round(streaming / sec / 1e9, 1),
-           'launches_per_pass': prof['launches'], 'launches_sampled': int(launches),
-           'pass_region_ms': round(prof['region_ms'], 3)}
-    return out
-
-
 # ------------------------------------------------------------------------------------------------ bench.py --gpus N
 
 def bench_main(args, rank: int, local_rank: int, world: int, gate=None) -> None:
@@ -588,6 +537,7 @@ def bench_main(args, rank: int, local_rank: int, world: int, gate=None) -> None:
     gathered = [torch.zeros_like(info) for _ in range(world)]
     dist.all_gather(gathered, info)
     if rank == 0:
+        from .measure import roofline_from_profile
         roofline = roofline_from_profile(prof, nsub)
         line = {
             'metric': 'reach-steps/sec', 'value': float(n) * T * nsub * args.steps / elapsed,

@@ -447,3 +447,70 @@ def test_stream_session_with_a_refilled_lateral_ring_shorter_than_a_task(monkeyp
             assert plan.last_kernel() == 'direct' and plan.profile()['ticks_per_launch'] == K
             assert_close(out.cpu().numpy(), d_ref, f'discharge, ring of {ring} rows')
             assert_close(q.cpu().numpy(), q_ref, 'state')
+
+
+def test_parts_of_a_cut_postorder_network_lay_out_around_their_boundary_reaches():
+    """rr_plan_set_boundary lays the direct plan out again: a ghost's column (first in a part's local order, far from the reach it
+    flows into) is passed through, the reaches below it join the skeleton, an export is a lane's or the skeleton's."""
+    from river_route_amd.engine import partition_forest
+    from river_route_amd.multi_gpu import split_network
+    n, parts = 400_000, 4
+    net = synth.synth_network(n, seed=4, order='postorder')
+    indptr, indices = csc_from_down(net.down_index)
+    part_of, _ = partition_forest(indptr, indices, parts)
+    for p in (0, parts - 1):
+        spec = split_network(net.down_index, part_of, p, parts)
+        with Plan(spec.indptr, spec.indices, device=RR_DEVICE_NONE) as plan:
+            export_local = spec.n_ghost + np.searchsorted(spec.real_global, spec.export_global)
+            plan.set_boundary(np.arange(spec.n_ghost), export_local)
+            info = plan.direct_info()
+            assert info['ok'], info['why']
+            L = plan.direct_layout()
+        word = L['delay'].astype(np.int64)
+        assert np.all((word[:spec.n_ghost] & HOLE) != 0) and np.all(((word[:spec.n_ghost] >> 8) & 0x7F) == 0), 'a ghost is passed through and sends nothing'
+        below = spec.down_local[:spec.n_ghost]
+        assert np.all((word[below] & HOLE) != 0) and np.all(L['xinfo'][below] >= 0), 'the reach a ghost flows into is a skeleton reach'
+        lane_export = (word[export_local] & (1 << 15)) != 0
+        assert np.array_equal(L['xinfo'][export_local][lane_export], np.flatnonzero(lane_export)), 'a lane export carries its column of the export series'
+        assert np.all((word[export_local][~lane_export] & HOLE) != 0), 'the other exports are skeleton reaches'
+        if p == 0:
+            assert lane_export.any() and not lane_export.all(), 'this case has both kinds'
+
+
+def _route_parts_on_the_direct_path(n, parts, T, chunk, seed, expect_direct):
+    from river_route_amd.engine import partition_forest
+    from river_route_amd.multi_gpu import HipPartEngine, run_in_process, split_network
+    net, indptr, indices, c1, c2, c3 = _case(n, seed)
+    c4_dt = (c1 + c2) / 900.0
+    q0 = 4.0 * synth.u01(8, np.arange(n))
+    ql = synth.synth_qlateral(n, 0, T)
+    q_ref, d_ref = q0.copy(), np.zeros((T, n))
+    oracle.rapid_route(indptr, indices, -c1[indices], c2, c3, c4_dt, q_ref, ql, d_ref, 1)
+    part_of, _ = partition_forest(indptr, indices, parts)
+    specs = [split_network(net.down_index, part_of, p, parts) for p in range(parts)]
+    engines = [HipPartEngine(s, c1, c2, c3, c4_dt, q0, ql[:, s.real_global], T, 1, 0, out_rows=T) for s in specs]
+    run_in_process(engines, specs, T, 1, chunk)
+    kernels = [e.plan.last_kernel() for e in engines]
+    q, d = np.zeros(n), np.zeros((T, n))
+    for s, e in zip(specs, engines):
+        q[s.real_global] = e.final_state()
+        d[:, s.real_global] = e.discharge.cpu().numpy()[:, s.n_ghost:]
+        e.close()
+    assert_close(q, q_ref, 'state')
+    assert_close(d, d_ref, 'discharge')
+    assert kernels == expect_direct, kernels
+    return specs
+
+
+@pytest.mark.gpu
+def test_partitioned_postorder_network_on_the_direct_path_vs_oracle(monkeypatch):
+    """Parts of a cut post-order network through rr_stream_begin / advance / end with their boundary series exchanged in batches
+    (multi_gpu.run_in_process: the distributed driver without the network): the leaf parts' exports -- lanes' and skeleton reaches' --
+    feed the trunk part's ghosts, every part on the direct row path, against the oracle on the undivided network.  At 200k reaches
+    the trunk part is mostly main stem and keeps to records (its ghosts then go through the record path's in-pass)."""
+    set_env(monkeypatch, {})
+    specs = _route_parts_on_the_direct_path(1_000_000, 4, 300, 64, 4, ['direct'] * 4)
+    assert specs[-1].n_ghost > 100
+    _route_parts_on_the_direct_path(200_000, 8, 200, 32, 4, ['direct'] * 7 + ['tile'])
+    set_env(monkeypatch, {'RR_WAVE_K': '64'})      # short tasks: the skeleton's ring goes round, exports trail by fewer rows
+    _route_parts_on_the_direct_path(400_000, 4, 700, 48, 6, ['direct'] * 4)
