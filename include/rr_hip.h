@@ -115,10 +115,11 @@ int rr_plan_set_unit_weights(rr_plan *plan, const double *c1, const double *a_da
  * rr_plan_set_coeffs and rr_plan_set_boundary / rr_plan_set_options: one call per input file is the reference's pattern
  * (river_route/routers/TransformMuskingum.py:108-148), and the routers reserve in _hook_before_route.  Memory only
  * grows; a smaller call fits a larger reservation.  host_rows: bit 0 also prepares the staging of the host-pointer entry
- * points (pinned buffers and device rings of the PCIe pipeline); RR_ROWS_NOT_PLAIN: the rows of the call are not plain
- * float64 rows in device arrays (float32 rows, fused convolution, gridded runoff: rr_*_f32*_dev, rr_unit_route_uh*_dev,
- * rr_rapid_route_runoff_dev), so the direct row path -- which rr_rapid_route_dev and rr_stream_begin take where the params
- * order numbers small subtrees contiguously, see rr_plan_direct_info -- does not apply and the record ring is needed.
+ * points (pinned buffers and device rings of the PCIe pipeline); RR_ROWS_NOT_PLAIN: the call does not hand over lateral rows
+ * in a device array (fused convolution, gridded runoff: rr_unit_route_uh*_dev, rr_rapid_route_runoff_dev), so the direct row path
+ * -- which rr_rapid_route*_dev and rr_stream_begin take where the params order numbers small subtrees contiguously, see
+ * rr_plan_direct_info -- does not apply and the record ring is needed; RR_ROWS_F32_OUT: the call writes float32 rows
+ * (rr_*_route_f32*_dev: the direct task is then a multiple of 128 rows).
  * info (may be NULL): [0] 2 = direct row path, 1 = time-tiled kernel, 0 = streaming kernel; [1] routing ticks (rows) per launch K; [2] chunks of the
  * record ring (16 ticks each); [3] bytes of routing work memory now held on the device; [4] bytes of device staging and
  * [5] of pinned host staging of the host-pointer path; [6] depth of the routing pipeline in ticks (network depth + tile
@@ -128,6 +129,7 @@ int rr_plan_set_unit_weights(rr_plan *plan, const double *c1, const double *a_da
 #define RR_MODE_MUSKINGUM 1
 #define RR_MODE_UNIT 2
 #define RR_ROWS_NOT_PLAIN 2
+#define RR_ROWS_F32_OUT 4
 int rr_plan_reserve(rr_plan *plan, int mode, int64_t T, int64_t nsub, int host_rows, int64_t info[8]);
 
 /* The direct row path: where the params order numbers every small subtree contiguously -- any depth-first

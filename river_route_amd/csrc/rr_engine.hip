@@ -347,8 +347,8 @@ int rr_plan_reserve(rr_plan *P, int mode, int64_t T, int64_t nsub, int host_rows
     const Mode m = mode == RR_MODE_RAPID ? Mode::Rapid : (mode == RR_MODE_MUSKINGUM ? Mode::Muskingum : Mode::Unit);
     Schedule sch;
     // host rows reach the time-tiled kernel through the PCIe pipeline's device rings; where it does not apply they stream
-    const bool host = (host_rows & 1) != 0, plain = !host && (host_rows & RR_ROWS_NOT_PLAIN) == 0;      // plain float64 rows in device arrays: the direct row path applies
-    rc = reserve_core(P, m, T, nsub, false, false, &sch, plain);
+    const bool host = (host_rows & 1) != 0, plain = !host && (host_rows & RR_ROWS_NOT_PLAIN) == 0;      // rows in device arrays (float64 or float32): the direct row path applies
+    rc = reserve_core(P, m, T, nsub, false, false, &sch, plain, (host_rows & RR_ROWS_F32_OUT) != 0);
     if (rc == RR_OK && host && !sch.tiled) rc = reserve_core(P, m, T, nsub, true, true, &sch);
     if (rc == RR_OK && host && sch.tiled) rc = host_pipe_prepare(P);
     if (rc) return rc;
@@ -629,11 +629,12 @@ int rr_unit_route_dev(rr_plan *P, double *q_ch, double *q_full, const double *co
 
 // float32 output fused into the record pass (k_rec_out): applies when the call is time-tiled and factor x sub-steps divides
 // the tick-rows of a batch (128); otherwise RR_E_UNSUPPORTED and the caller uses the float64 form + rr_resample_cast_dev.
-static int f32_output_applies(rr_plan *P, Mode mode, int64_t T, int64_t nsub, int64_t factor)
+static int f32_output_applies(rr_plan *P, Mode mode, int64_t T, int64_t nsub, int64_t factor, bool plain = false)
 {
     if (factor < 1 || T % factor != 0) return fail(RR_E_INVALID, "float32 output: the number of rows must be a multiple of factor >= 1");
     if (kRecRows % (factor * nsub) != 0) return fail(RR_E_UNSUPPORTED, "float32 output: factor x sub-steps must divide the rows of a record batch (128)");
-    if (!choose_schedule(P, mode, T, nsub, false, false).tiled) return fail(RR_E_UNSUPPORTED, "float32 output needs the time-tiled kernel, which this call does not get");
+    const Schedule sch = choose_schedule(P, mode, T, nsub, false, false, plain, 0, 0, true);
+    if (!sch.tiled && !sch.direct) return fail(RR_E_UNSUPPORTED, "float32 output needs the time-tiled kernel or the direct row path, which this call does not get");
     return RR_OK;
 }
 
@@ -645,7 +646,7 @@ int rr_rapid_route_f32_dev(rr_plan *P, double *q_t, const double *qlateral, int6
     if (P->h.n > 0 && T > 0 && (!q_t || !qlateral || !discharge32 || ql_rows < 1))
         return fail(RR_E_INVALID, "rr_rapid_route_f32_dev: null array or empty row count");
     if (P->h.n == 0 || T == 0) return RR_OK;
-    rc = f32_output_applies(P, Mode::Rapid, T, nsub, factor);
+    rc = f32_output_applies(P, Mode::Rapid, T, nsub, factor, true);
     if (rc) return rc;
     Rows io; io.dev_in = qlateral; io.rows_in = ql_rows; io.dev_out32 = discharge32; io.out_factor = factor; io.rows_out = T / factor;
     return rapid_like(P, Mode::Rapid, q_t, io, T, nsub, (hipStream_t)stream, false);
@@ -660,8 +661,8 @@ int rr_rapid_route_f32in_dev(rr_plan *P, double *q_t, const float *qlateral32, i
     if (P->h.n > 0 && T > 0 && (!q_t || !qlateral32 || ql_rows < 1 || (!discharge && !discharge32) || (discharge && discharge32) || (discharge && out_rows < 1)))
         return fail(RR_E_INVALID, "rr_rapid_route_f32in_dev: null array, empty row count, or both or neither output");
     if (P->h.n == 0 || T == 0) return RR_OK;
-    if (f32) { rc = f32_output_applies(P, Mode::Rapid, T, nsub, factor); if (rc) return rc; }
-    else if (!choose_schedule(P, Mode::Rapid, T, nsub, false, false).tiled) return fail(RR_E_UNSUPPORTED, "rr_rapid_route_f32in_dev needs the time-tiled kernel, which this call does not get");
+    if (f32) { rc = f32_output_applies(P, Mode::Rapid, T, nsub, factor, true); if (rc) return rc; }
+    else { const Schedule sch = choose_schedule(P, Mode::Rapid, T, nsub, false, false, true); if (!sch.tiled && !sch.direct) return fail(RR_E_UNSUPPORTED, "rr_rapid_route_f32in_dev needs the time-tiled kernel or the direct row path, which this call does not get"); }
     Rows io; io.dev_in32 = qlateral32; io.dev_in = P->d_c4_params; io.rows_in = ql_rows;      // (dev_in only has to be non-NULL for the executor)
     if (f32) { io.dev_out32 = discharge32; io.out_factor = factor; io.rows_out = T / factor; }
     else { io.dev_out = discharge; io.rows_out = out_rows; }

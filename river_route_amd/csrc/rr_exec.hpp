@@ -262,6 +262,13 @@ int upload_tile_coef(rr_plan *P)
     return dev_upload(P->d_coef_unit, coef);
 }
 
+typedef void (*direct_kernel_t)(const DirectArgs);
+direct_kernel_t direct_kernel(bool in32, bool out32)
+{
+    return in32 ? (out32 ? (direct_kernel_t)k_direct<kDirectAhead, true, true> : (direct_kernel_t)k_direct<kDirectAhead, true, false>)
+                : (out32 ? (direct_kernel_t)k_direct<kDirectAhead, false, true> : (direct_kernel_t)k_direct<kDirectAhead, false, false>);
+}
+
 // The direct row path's device arrays (rr::DirectPlan): per-column constants, the skeleton's tile arrays, the columns of the holes' out-pass.
 // Called by rr_plan_create and again by rr_plan_set_boundary, which lays the plan out anew around the boundary reaches.
 int upload_direct_plan(rr_plan *P)
@@ -279,10 +286,11 @@ int upload_direct_plan(rr_plan *P)
     const rr::DirectPlan &D = P->dp;
     const rr::TilePlan &K = D.skel;
     const int64_t n = H.n;
-    if (hipFuncSetAttribute((const void *)k_direct<kDirectAhead>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)direct_lds_bytes(kDirectMaxWindow)) != hipSuccess) {
-        (void)hipGetLastError();
-        P->direct_enabled = false;
-    }
+    for (int v = 0; v < 4; ++v)      // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
+        if (hipFuncSetAttribute((const void *)direct_kernel((v & 1) != 0, (v & 2) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)direct_lds_bytes(kDirectMaxWindow)) != hipSuccess) {
+            (void)hipGetLastError();
+            P->direct_enabled = false;
+        }
     std::vector<DirectTile> dt((size_t)D.n_tiles);
     for (int32_t t = 0; t < D.n_tiles; ++t) dt[t] = DirectTile{D.tile_c0[t], D.tile_nc[t], D.tile_lag_lo[t], D.tile_span[t]};
     std::vector<int4> dl((size_t)n);
@@ -449,8 +457,10 @@ int64_t pick_direct_K(const rr_plan *P, int64_t T)
 // than the call (0: they hold every row).  A caller may refill such a ring between two rr_stream_advance calls, so a direct task must
 // not span more rows than the ring holds: K is capped (a ring of fewer than 32 rows keeps to records, which take rows in batches of 128
 // tick-rows the caller announces one by one).
+// out32 (float32 output fused in, rr_*_f32*_dev): the direct task is a multiple of 128 rows, so that every output row -- the mean of
+// `factor` routed rows, factor divides 128 -- lies inside one task.
 Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, bool plain_rows = false,
-                         int64_t ring_in = 0, int64_t ring_out = 0)
+                         int64_t ring_in = 0, int64_t ring_out = 0, bool out32 = false)
 {
     Schedule sch;
     const int64_t total = T * nsub, dmax = P->h.depth - 1, n = P->h.n;
@@ -458,11 +468,12 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
     // headline's call -- on a params order that numbers small subtrees contiguously (boundary reaches of a partitioned network
     // included: rr_plan_set_boundary lays the direct plan out around them).
     if (plain_rows && P->direct_enabled && P->dp.ok && mode == Mode::Rapid && nsub == 1 && P->weights_uniform && !force_streaming && !host_io &&
-        P->wave_enabled && total >= 32 && n < (int64_t{1} << 29)) {
+        P->wave_enabled && total >= 8 && n < (int64_t{1} << 29)) {
         int64_t K = pick_direct_K(P, T);
         const int64_t levels = P->dp.skel.n_levels, np = P->dp.skel.np;
         if (ring_in > 0 && ring_in < T) K = std::min(K, ring_in / kRec * kRec);
         if (ring_out > 0 && ring_out < T) K = std::min(K, ring_out / kRec * kRec);
+        if (out32) K = std::max<int64_t>(kRecRows, K / kRecRows * kRecRows);
         sch.direct = true; sch.KC = K / kRec;
         // The skeleton's own tasks: as long as the lanes' (every tile level costs one task of pipeline and of record ring) -- except in a part
         // that feeds another GPU, whose boundary series every level delays by one task: 64 ticks there (as kc_long below), several of the
@@ -514,12 +525,12 @@ int host_pipe_prepare(rr_plan *P);
 
 // Sizes and allocates what a call of this shape works in.  The only place on a route call's path that allocates: the
 // host-pointer entry points come here by themselves, the *_dev ones expect rr_plan_reserve to have been here.
-int reserve_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, Schedule *out, bool plain_rows = false)
+int reserve_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, Schedule *out, bool plain_rows = false, bool out32 = false)
 {
     if (P->h.n == 0 || T <= 0) { if (out) *out = Schedule(); return RR_OK; }
     Schedule sch;
     for (;;) {
-        sch = choose_schedule(P, mode, T, nsub, force_streaming, host_io, plain_rows);
+        sch = choose_schedule(P, mode, T, nsub, force_streaming, host_io, plain_rows, 0, 0, out32);
         if (ensure_cap(&P->d_ring, &P->ring_cap, sch.ring) == RR_OK) break;
         (void)hipGetLastError();
         if (sch.direct) return fail(RR_E_ALLOC, "route: the skeleton's record ring does not fit on the device");
@@ -546,14 +557,14 @@ int reserve_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_stre
 // The schedule of the call about to start.  strict (the *_dev entry points, which only enqueue): everything must have been
 // reserved; otherwise it is reserved here.
 int prepare_call(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, bool strict, bool plain_rows = false,
-                 int64_t ring_in = 0, int64_t ring_out = 0)
+                 int64_t ring_in = 0, int64_t ring_out = 0, bool out32 = false)
 {
     Schedule sch;
     if (!strict) {
-        int rc = reserve_core(P, mode, T, nsub, force_streaming, host_io, &sch, plain_rows);
+        int rc = reserve_core(P, mode, T, nsub, force_streaming, host_io, &sch, plain_rows, out32);
         if (rc) return rc;
     } else {
-        sch = choose_schedule(P, mode, T, nsub, force_streaming, host_io, plain_rows, ring_in, ring_out);
+        sch = choose_schedule(P, mode, T, nsub, force_streaming, host_io, plain_rows, ring_in, ring_out, out32);
         const size_t samples = P->sample_every >= kSampleGroup ? 1 : 0;
         if (P->h.n > 0 && T > 0 && (sch.ring > P->ring_cap || sch.mrows > P->mrows_cap || sch.stage > P->stage_cap || !P->ev_first || P->ev.size() < 2 * samples ||
                                     (!sch.tiled && !sch.direct && !P->perm_ready && sch.mrows > 0)))
@@ -604,13 +615,14 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
     if (n == 0 || S.total == 0) return RR_OK;
     if (P->n_ghost > 0 && !ghost_series) { S.open = false; return fail(RR_E_INVALID, "plan has ghost reaches but no ghost series was given"); }
     if (P->n_export > 0 && !export_series) { S.open = false; return fail(RR_E_INVALID, "plan has export reaches but no export series was given"); }
-    if (io.dev_out32 && !S.wave) { S.open = false; return fail(RR_E_UNSUPPORTED, "float32 output needs the time-tiled kernel"); }
+    if (io.dev_out32 && !S.wave && !S.rows_direct) { S.open = false; return fail(RR_E_UNSUPPORTED, "float32 output needs the time-tiled kernel or the direct row path"); }
 
     if (S.wave || S.rows_direct) { S.KC = P->next_KC; S.rec_chunks = P->next_chunks; }     // ring sized by choose_schedule, allocated by rr_plan_reserve
     if (S.rows_direct) {
-        if (io.dev_in32 || io.dev_out32 || io.uh_kernel || io.runoff || !io.dev_in || !io.dev_out || mode != Mode::Rapid || nsub != 1) {
+        if (io.uh_kernel || io.runoff || (!io.dev_in && !io.dev_in32) || (!io.dev_out && !io.dev_out32) || mode != Mode::Rapid || nsub != 1 ||
+            (io.dev_out32 && (io.out_factor < 1 || (S.KC * kRec) % io.out_factor != 0 || T % io.out_factor != 0))) {
             S.open = false;
-            return fail(RR_E_STATE, "route: the direct row path was chosen for a call it does not take");      // (choose_schedule's plain_rows)
+            return fail(RR_E_STATE, "route: the direct row path was chosen for a call it does not take");      // (choose_schedule's plain_rows / out32)
         }
         const rr::TilePlan &TP = P->dp.skel;
         const int64_t K = S.KC * kRec;
@@ -630,7 +642,8 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         DirectArgs &da = S.da;
         da.tiles = P->d_dtiles; da.n_tiles = P->dp.n_tiles; da.lane = P->d_dlane; da.coef = P->d_dcoef; da.q = P->d_dq;
         da.send_ptr = P->d_dsend_ptr; da.send_lane = P->d_dsend_lane;
-        da.in = io.dev_in; da.out = io.dev_out; da.n = n; da.in_rows = (uint32_t)io.rows_in; da.out_rows = (uint32_t)io.rows_out;
+        da.in = io.dev_in; da.out = io.dev_out; da.n = n; da.in_rows = (uint32_t)io.rows_in; da.out_rows = (uint32_t)std::max<int64_t>(1, io.rows_out);
+        da.in32 = io.dev_in32; da.out32 = io.dev_out32; da.factor = (int32_t)std::max<int64_t>(1, io.out_factor);
         da.rec = P->d_ring; da.rec_chunks = (uint32_t)std::max<int64_t>(1, S.rec_chunks); da.np = (int32_t)TP.np;
         da.K = (int32_t)K; da.total = (int32_t)S.T;
         da.exports = export_series; da.n_export = (int32_t)P->n_export;
@@ -1091,7 +1104,7 @@ int session_advance_direct(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, 
             if (sample) HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets], S.stream));
             S.da.m = (int32_t)d;
             const dim3 g((unsigned)std::min<int64_t>(P->dp.n_tiles, (int64_t)P->cu_count));
-            hipLaunchKernelGGL((k_direct<kDirectAhead>), g, dim3(kDirectThreads), direct_lds_bytes(P->direct_window), S.stream, S.da);
+            hipLaunchKernelGGL(direct_kernel(S.da.in32 != nullptr, S.da.out32 != nullptr), g, dim3(kDirectThreads), direct_lds_bytes(P->direct_window), S.stream, S.da);
             if (sample) {
                 HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));
                 P->ev_reaches.push_back(n * (std::min((d + 1) * K, S.T) - d * K));
@@ -1140,10 +1153,12 @@ int session_advance_direct(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, 
                 ra.rec = P->d_ring; ra.rec_chunks = Div32((uint32_t)S.rec_chunks); ra.n = P->n_kholes; ra.np = TP.np; ra.T = S.T; ra.total = S.total;
                 ra.batch = S.out_batches; ra.nsub = Div32(1u); ra.colmeta = P->d_kholemeta; ra.cols = P->d_kholecol; ra.scale = nullptr;
                 ra.rows = RowView{S.io.dev_out, n, 0, (uint32_t)std::max<int64_t>(1, S.io.rows_out)};
-                ra.factor = Div32(1u); ra.clamp = 1; ra.swizzle = 0;
+                ra.rows32 = S.io.dev_out32;
+                ra.factor = Div32((uint32_t)std::max<int64_t>(1, S.io.out_factor)); ra.clamp = 1; ra.swizzle = 0;
                 const int aux = aux_begin(P, 3, S.stream);
-                if (P->n_kholes > 0)
-                    hipLaunchKernelGGL((k_rec_out<false, false>), dim3((unsigned)((P->n_kholes + kRecOutCols - 1) / kRecOutCols)), dim3(kRecOutThreads), 0, S.stream, ra);
+                const dim3 gh((unsigned)((P->n_kholes + kRecOutCols - 1) / kRecOutCols));
+                if (P->n_kholes > 0 && ra.rows32) hipLaunchKernelGGL((k_rec_out<false, true>), gh, dim3(kRecOutThreads), 0, S.stream, ra);
+                else if (P->n_kholes > 0) hipLaunchKernelGGL((k_rec_out<false, false>), gh, dim3(kRecOutThreads), 0, S.stream, ra);
                 aux_end(P, aux, S.stream);
                 ++S.out_batches;
                 S.ticks_stored = std::min(S.total, kRecRows * S.out_batches);
@@ -1455,8 +1470,8 @@ int rapid_like(rr_plan *P, Mode mode, double *q_t, const Rows &io_in, int64_t T,
     // host rows reach the time-tiled kernel through the PCIe pipeline's device rings; where it does not apply they are
     // routed chunk by chunk by the streaming kernel
     {   // host rows reach the time-tiled kernel through the PCIe pipeline's device rings (they are "device rows" to the schedule)
-        const bool plain = !host_rows && io.dev_in && io.dev_out && !io.dev_in32 && !io.dev_out32 && !io.uh_kernel && !io.runoff;      // float64 rows in device arrays: the direct row path applies
-        int rc = prepare_call(P, mode, T, nsub, false, false, !host_rows, plain);
+        const bool plain = !host_rows && (io.dev_in || io.dev_in32) && (io.dev_out || io.dev_out32) && !io.uh_kernel && !io.runoff;      // rows in device arrays, float64 or float32: the direct row path applies
+        int rc = prepare_call(P, mode, T, nsub, false, false, !host_rows, plain, 0, 0, io.dev_out32 != nullptr);
         if (rc == RR_OK && host_rows && !P->wave_now) rc = prepare_call(P, mode, T, nsub, true, true, false);
         if (rc == RR_OK && host_rows && P->wave_now) rc = host_pipe_prepare(P);
         if (rc) return rc;

@@ -60,6 +60,9 @@ struct DirectArgs {
     int32_t m, K, total;        // this launch: rows [m K, min((m + 1) K, total))
     double *exports;            // boundary series another GPU reads (a partitioned network's exports that lanes route): (total, n_export)
     int32_t n_export;
+    const float *in32;          // IN32: float32 lateral rows instead of `in` (as qlateral files store them; exact in float64)
+    float *out32;               // OUT32: float32 discharge rows, each the mean of `factor` routed rows (TransformMuskingum.py:128-142), (total / factor, n), not cyclic
+    int32_t factor;
 };
 constexpr int32_t kDirectHoleBit = rr::kDirectHole;
 constexpr int kDirectLanes = 256, kDirectAhead = 16;
@@ -83,6 +86,20 @@ __device__ __forceinline__ double clip0(double x)
     asm("v_max_f64 %0, %1, 0" : "=v"(r) : "v"(x));
     return r;
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 load_f32x2_(__amdgpu_buffer_rsrc_t r, uint32_t byte_off)
+{
+    const u32x2 bits = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
+    f32x2 v;
+    __builtin_memcpy(&v, &bits, sizeof v);
+    return v;
+}
+__device__ __forceinline__ void store_f32x2_nt(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, f32x2 v)
+{
+    u32x2 bits;
+    __builtin_memcpy(&bits, &v, sizeof bits);
+    __builtin_amdgcn_raw_buffer_store_b64(bits, r, (int)byte_off, 0, 2);      // aux: nt
+}
 __device__ __forceinline__ double2 load_f64x2_(__amdgpu_buffer_rsrc_t r, uint32_t byte_off)
 {
     const u32x4 bits = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
@@ -102,7 +119,11 @@ __device__ __forceinline__ void store_f64x2_nt(__amdgpu_buffer_rsrc_t r, uint32_
     __builtin_amdgcn_raw_buffer_store_b128(bits, r, (int)byte_off, 0, 2);      // aux: nt
 }
 
-template <int PF>
+// IN32: the lateral rows are float32 (the in-waves load 8 bytes per lane and convert; float32 -> float64 is exact, so the results are those
+// of the float64 copy bit for bit).  OUT32: the routers' post-processing in the rows-out wave -- the mean over `factor` consecutive rows
+// (sequential sum, one division, as numpy reduces a strided axis) and the float32 cast; K is a multiple of factor (choose_schedule), so
+// every output row lies inside one task.
+template <int PF, bool IN32 = false, bool OUT32 = false>
 __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -208,24 +229,27 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             const int32_t dummy_b = kDummyB + (TH + (wave - 4) * 64 + ln) * 8;      // (the in-waves' dummy slots follow the routing lanes')
             const bool wave_holes = __builtin_amdgcn_ballot_w64(ring0 >= 0 || ring1 >= 0) != 0;
             // a 16-byte load may reach past the tile's last column (the next tile's, or -- past the row's end -- zeros): never used
-            const uint32_t va = ca < tm.nc ? (uint32_t)(tm.c0 + ca) * 8u : kDropAccess;
+            const uint32_t va = ca < tm.nc ? (uint32_t)(tm.c0 + ca) * (IN32 ? 4u : 8u) : kDropAccess;
             uint32_t rin = (uint32_t)r0 % a.in_rows;
-            const double *row = a.in + (int64_t)rin * a.n;
+            const char *row = IN32 ? reinterpret_cast<const char *>(a.in32 + (int64_t)rin * a.n) : reinterpret_cast<const char *>(a.in + (int64_t)rin * a.n);
+            const uint32_t in_row_bytes = IN32 ? row_bytes / 2u : row_bytes;
             // AH rows in flight: a tick cannot be shorter than the memory latency over AH (16 rows ahead hold the tick at 0.22 us:
             // 32 KB per CU in flight against ~3.5 us under load); the register ring is indexed statically: two chunk bodies alternate
             constexpr int AH = 2 * PF;
-            double2 Pa[AH];
-            auto request = [&](int32_t arrival, double2 &pa) {      // row r0 + arrival, or nothing past the task's rows
-                const __amdgpu_buffer_rsrc_t src = make_rsrc(row, row_bytes);
-                pa = load_f64x2_(src, arrival < nrows ? va : kDropAccess);
-                ++rin; row += a.n;
-                if (rin == a.in_rows) { rin = 0; row = a.in; }
+            typedef typename std::conditional<IN32, f32x2, double2>::type Pt;
+            Pt Pa[AH];
+            auto request = [&](int32_t arrival, Pt &pa) {      // row r0 + arrival, or nothing past the task's rows
+                const __amdgpu_buffer_rsrc_t src = make_rsrc(row, in_row_bytes);
+                if constexpr (IN32) pa = load_f32x2_(src, arrival < nrows ? va : kDropAccess);
+                else pa = load_f64x2_(src, arrival < nrows ? va : kDropAccess);
+                ++rin; row += in_row_bytes;
+                if (rin == a.in_rows) { rin = 0; row = IN32 ? reinterpret_cast<const char *>(a.in32) : reinterpret_cast<const char *>(a.in); }
             };
 #pragma unroll
             for (int j = 0; j < AH; ++j) request(j, Pa[j]);
             int32_t in_b = 0;
-            auto park = [&](const double2 &pa, int32_t arrival) {      // into the window, scaled (the ring of k_tile holds c4dt * lateral too)
-                const double x0 = pa.x * c4a0, x1 = pa.y * c4a1;
+            auto park = [&](const Pt &pa, int32_t arrival) {      // into the window, scaled (the ring of k_tile holds c4dt * lateral too)
+                const double x0 = (double)pa.x * c4a0, x1 = (double)pa.y * c4a1;
                 *reinterpret_cast<double2 *>(F + in_b + ca * 8) = make_double2(x0, x1);
                 in_b = in_b + kRowB == wrap ? 0 : in_b + kRowB;
                 if (wave_holes) {      // wave-uniform
@@ -258,9 +282,14 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             // ---------------------------------------------------------------- wave 6: rows out.  Lane -> columns 2 ln, 2 ln + 1 and 128 + 2 ln, 128 + 2 ln + 1
             // The descriptor ends behind the tile's last column: a 16-byte piece past it is dropped by the range check, and so is the
             // second half of the piece that holds the last column of a tile with an odd number of them (the check is made per dword).
-            const uint32_t va = (uint32_t)(tm.c0 + 2 * ln) * 8u, vb = va + 128u * 8u, tile_end = (uint32_t)(tm.c0 + tm.nc) * 8u;
-            uint32_t rout = (uint32_t)r0 % a.out_rows;
-            double *row = a.out + (int64_t)rout * a.n;
+            constexpr uint32_t kOutB = OUT32 ? 4u : 8u;
+            const uint32_t va = (uint32_t)(tm.c0 + 2 * ln) * kOutB, vb = va + 128u * kOutB, tile_end = (uint32_t)(tm.c0 + tm.nc) * kOutB;
+            uint32_t rout = OUT32 ? 0u : (uint32_t)r0 % a.out_rows;
+            double *row = OUT32 ? nullptr : a.out + (int64_t)rout * a.n;
+            float *row32 = OUT32 ? a.out32 + (int64_t)(r0 / a.factor) * a.n : nullptr;      // r0 = m K is a multiple of factor
+            double2 sa = make_double2(0.0, 0.0), sb = sa;      // OUT32: the sums of the output row being formed
+            int32_t cnt = 0;
+            const double fdiv = (double)a.factor;
             int32_t out_b = 0;
             __syncthreads();
             for (int32_t k0 = 0; k0 < n_ticks; k0 += PF) {
@@ -269,12 +298,29 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                     const int32_t leaving = k0 + s - 1 - span;
                     if (leaving >= 0 && leaving < nrows) {      // wave-uniform
                         const double2 xa = *reinterpret_cast<const double2 *>(F + out_b + 2 * ln * 8), xb = *reinterpret_cast<const double2 *>(F + out_b + 2 * ln * 8 + 128 * 8);
-                        const __amdgpu_buffer_rsrc_t dst = make_rsrc(row, tile_end);
-                        store_f64x2_nt(dst, va, make_double2(clip0(xa.x), clip0(xa.y)));
-                        store_f64x2_nt(dst, vb, make_double2(clip0(xb.x), clip0(xb.y)));
+                        if constexpr (OUT32) {
+                            const double2 ca2 = make_double2(clip0(xa.x), clip0(xa.y)), cb2 = make_double2(clip0(xb.x), clip0(xb.y));
+                            sa = cnt ? make_double2(sa.x + ca2.x, sa.y + ca2.y) : ca2;
+                            sb = cnt ? make_double2(sb.x + cb2.x, sb.y + cb2.y) : cb2;
+                            if (++cnt == a.factor) {      // wave-uniform
+                                cnt = 0;
+                                const bool one = a.factor == 1;
+                                f32x2 fa, fb;
+                                fa.x = (float)(one ? sa.x : sa.x / fdiv); fa.y = (float)(one ? sa.y : sa.y / fdiv);
+                                fb.x = (float)(one ? sb.x : sb.x / fdiv); fb.y = (float)(one ? sb.y : sb.y / fdiv);
+                                const __amdgpu_buffer_rsrc_t dst = make_rsrc(row32, tile_end);
+                                store_f32x2_nt(dst, va, fa);
+                                store_f32x2_nt(dst, vb, fb);
+                                row32 += a.n;
+                            }
+                        } else {
+                            const __amdgpu_buffer_rsrc_t dst = make_rsrc(row, tile_end);
+                            store_f64x2_nt(dst, va, make_double2(clip0(xa.x), clip0(xa.y)));
+                            store_f64x2_nt(dst, vb, make_double2(clip0(xb.x), clip0(xb.y)));
+                            ++rout; row += a.n;
+                            if (rout == a.out_rows) { rout = 0; row = a.out; }
+                        }
                         out_b = out_b + kRowB == wrap ? 0 : out_b + kRowB;
-                        ++rout; row += a.n;
-                        if (rout == a.out_rows) { rout = 0; row = a.out; }
                     }
                     barrier_lds();
                 }

@@ -170,14 +170,14 @@ class Plan:
                                        int(num_substeps)))
 
     # -- work memory --
-    def reserve(self, mode: int, T: int, num_substeps: int = 1, host_rows: bool = False, plain_rows: bool = True) -> dict:
+    def reserve(self, mode: int, T: int, num_substeps: int = 1, host_rows: bool = False, plain_rows: bool = True, f32_out: bool = False) -> dict:
         """rr_plan_reserve: allocate what route calls of up to T rows x num_substeps sub-steps work in (the record ring, events,
         with host_rows the PCIe staging).  The *_dev entry points of the C ABI only enqueue and fail with RR_E_STATE when this
         has not been done; the methods below call it for the shape they are given (no-op once large enough).  plain_rows=False:
-        the call's rows are not plain float64 device rows (float32 rows, fused convolution, gridded runoff), so the direct row
-        path does not apply (RR_ROWS_NOT_PLAIN)."""
+        the call hands over no lateral rows in a device array (fused convolution, gridded runoff), so the direct row path does not
+        apply (RR_ROWS_NOT_PLAIN); f32_out: it writes float32 rows (RR_ROWS_F32_OUT)."""
         info = np.zeros(8, dtype=np.int64)
-        check(_lib.lib().rr_plan_reserve(self._h, int(mode), int(T), int(num_substeps), int(bool(host_rows)) | (0 if plain_rows else 2), ptr(info)))
+        check(_lib.lib().rr_plan_reserve(self._h, int(mode), int(T), int(num_substeps), int(bool(host_rows)) | (0 if plain_rows else 2) | (4 if f32_out else 0), ptr(info)))
         if int(info[0]) == 0 and int(T) * int(num_substeps) >= 32 and self.n > 0 and not getattr(self, '_warned_streaming', False):
             # the time-tiled kernel takes every call of 32 sub-steps or more -- unless the network does not tile, the coefficients give the
             # tributaries of a reach different weights, or its record ring (depth + tile levels x K tick-rows of every reach) does not fit
@@ -233,14 +233,14 @@ class Plan:
 
     # -- device-pointer routing with the routers' post-processing fused in: float32 rows, `factor` routed rows averaged --
     def rapid_route_f32_dev(self, q_t, qlateral, ql_rows, discharge32, T, num_substeps, factor=1, stream=None) -> None:
-        self.reserve(MODE_RAPID, T, num_substeps, plain_rows=False)
+        self.reserve(MODE_RAPID, T, num_substeps, f32_out=True)
         check(_lib.lib().rr_rapid_route_f32_dev(self._h, ptr(q_t), ptr(qlateral), int(ql_rows), ptr(discharge32), int(T),
                                                 int(num_substeps), int(factor), stream))
 
     def rapid_route_f32in_dev(self, q_t, qlateral32, ql_rows, T, num_substeps, discharge=None, out_rows=0, discharge32=None, factor=1,
                               stream=None) -> None:
         """rr_rapid_route_f32in_dev: float32 lateral rows in (exact in float64); exactly one of discharge / discharge32."""
-        self.reserve(MODE_RAPID, T, num_substeps, plain_rows=False)
+        self.reserve(MODE_RAPID, T, num_substeps, f32_out=discharge32 is not None)
         check(_lib.lib().rr_rapid_route_f32in_dev(self._h, ptr(q_t), ptr(qlateral32), int(ql_rows), ptr(discharge), int(out_rows),
                                                   ptr(discharge32), int(factor), int(T), int(num_substeps), stream))
 

@@ -270,8 +270,8 @@ def test_direct_rows_at_1m_reaches_vs_oracle():
 
 @pytest.mark.gpu
 def test_calls_the_direct_path_does_not_take_fall_back_to_records(monkeypatch):
-    """On a post-order plan: sub-steps, channel-only routing and float32 rows keep to the record path, and so does a random order --
-    all against the oracle; a plan whose direct path is switched off says so."""
+    """On a post-order plan: sub-steps keep to the record path (against the oracle), float32 rows out take the direct path since
+    round 5, and the plan goes back and forth between the two."""
     set_env(monkeypatch, {})
     n, T = 50_000, 64
     net, indptr, indices, c1, c2, c3 = _case(n, 31)
@@ -291,7 +291,7 @@ def test_calls_the_direct_path_does_not_take_fall_back_to_records(monkeypatch):
         d_ql32, d_out32 = DeviceBuffer(T * n * 4).upload(ql.astype(np.float32)), DeviceBuffer(T * n * 4)
         d_q.upload(np.zeros(n))
         plan.rapid_route_f32_dev(d_q, d_ql, T, d_out32, T, 1, 1)
-        assert plan.last_kernel() == 'tile'
+        assert plan.last_kernel() == 'direct'
         np.testing.assert_allclose(d_out32.download(np.float32, (T, n)), d_ref.astype(np.float32), rtol=1.2e-7, atol=1e-10 * np.abs(d_ref).max())
         d_q.upload(np.zeros(n))
         plan.rapid_route_dev(d_q, d_ql, T, d_out, T, T, 1)      # and back on the direct path, after the record path used the plan
@@ -514,3 +514,54 @@ def test_partitioned_postorder_network_on_the_direct_path_vs_oracle(monkeypatch)
     _route_parts_on_the_direct_path(200_000, 8, 200, 32, 4, ['direct'] * 7 + ['tile'])
     set_env(monkeypatch, {'RR_WAVE_K': '64'})      # short tasks: the skeleton's ring goes round, exports trail by fewer rows
     _route_parts_on_the_direct_path(400_000, 4, 700, 48, 6, ['direct'] * 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,T,factor,in32,env', [(60_000, 256, 1, False, {}), (60_000, 256, 4, True, {}), (120_001, 640, 8, True, {}), (60_000, 384, 128, False, {}),
+                                                 (60_000, 200, 1, True, {'RR_WAVE_K': '128'}), (300_000, 1024, 4, True, {})])
+def test_float32_rows_on_the_direct_path(monkeypatch, n, T, factor, in32, env):
+    """What the routers call for a qlateral file (TransformMuskingum.py:128-142 fused in): float32 lateral rows in and / or float32 rows
+    out, each the mean of `factor` routed rows, on the direct row path -- equal BIT FOR BIT to the record path (RR_DIRECT=0) and to the
+    float64 direct call followed by numpy's mean and cast; against the oracle to 1 ulp(float32)."""
+    net, indptr, indices, c1, c2, c3 = _case(n, 51)
+    lhs, c4_dt = -c1[indices], (c1 + c2) / 900.0
+    ql = synth.synth_qlateral(n, 0, T)
+    if in32:
+        ql = ql.astype(np.float32).astype(np.float64)      # the float32 file's values
+    q0 = synth.u01(2, np.arange(n))
+    q_ref, d_ref = q0.copy(), np.zeros((T, n))
+    oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql, d_ref, 1)
+    want = d_ref.reshape(T // factor, factor, n).mean(axis=1).astype(np.float32)
+    res = {}
+    for direct in ('1', '0'):
+        set_env(monkeypatch, dict(env, RR_DIRECT=direct))
+        with Plan(indptr, indices) as plan:
+            plan.set_coeffs(lhs, c2, c3, c4_dt)
+            d_q = DeviceBuffer(n * 8).upload(q0)
+            d_out32 = DeviceBuffer((T // factor) * n * 4)
+            if in32:
+                d_ql = DeviceBuffer(T * n * 4).upload(ql.astype(np.float32))
+                plan.rapid_route_f32in_dev(d_q, d_ql, T, T, 1, discharge32=d_out32, factor=factor)
+            else:
+                d_ql = DeviceBuffer(T * n * 8).upload(ql)
+                plan.rapid_route_f32_dev(d_q, d_ql, T, d_out32, T, 1, factor)
+            assert plan.last_kernel() == ('direct' if direct == '1' else 'tile')
+            res[direct] = (d_out32.download(np.float32, (T // factor, n)), d_q.download(np.float64, (n,)))
+            if direct == '1':      # the float64 rows of the same plan, then numpy
+                d_q.upload(q0)
+                d_out = DeviceBuffer(T * n * 8)
+                if in32:
+                    plan.rapid_route_f32in_dev(d_q, d_ql, T, T, 1, discharge=d_out, out_rows=T)
+                else:
+                    plan.rapid_route_dev(d_q, d_ql, T, d_out, T, T, 1)
+                assert plan.last_kernel() == 'direct'
+                full = d_out.download(np.float64, (T, n))
+                d_out.free()
+            for b in (d_q, d_ql, d_out32):
+                b.free()
+    np.testing.assert_array_equal(res['1'][0], res['0'][0])
+    np.testing.assert_array_equal(res['1'][1], res['0'][1])
+    np.testing.assert_array_equal(res['1'][0], full.reshape(T // factor, factor, n).mean(axis=1).astype(np.float32) if factor > 1 else full.astype(np.float32))
+    assert_close(full, d_ref, 'float64 rows')
+    np.testing.assert_allclose(res['1'][0], want, rtol=1.2e-7, atol=1e-10 * float(np.abs(want).max()))
+    assert_close(res['1'][1], q_ref, 'state')

@@ -131,6 +131,28 @@ def test_rapid_resample_to_dt_discharge(backend, case):
     assert got[0][1].shape[0] == 8
 
 
+def test_rapid_on_a_postorder_params_file_takes_the_direct_path(backend, case, tmp_path):
+    """The golden network's table re-sorted with tools.postorder (still valid for the reference, river_route/tools.py:103-104) and the
+    lateral columns with it: RapidMuskingum(config).route() gives the reference's discharge river for river, and on the GPU the
+    routing calls take the direct row path -- float32 rows out fused in (rr_rapid_route_f32_dev), no record ring, no permutation pass."""
+    g = case['g']
+    order = rr.tools.postorder(g['river_ids'], g['downstream_ids'])
+    params = tmp_path / 'params_postorder.parquet'
+    pd.DataFrame({'river_id': g['river_ids'][order], 'downstream_river_id': g['downstream_ids'][order], 'k': g['k'][order], 'x': g['x'][order]}).to_parquet(params)
+    init = tmp_path / 'init_postorder.parquet'
+    pd.DataFrame({'Q': g['q0'][order]}).to_parquet(init)
+    sorted_case = dict(case, params=str(params))
+    r, got = drive(rr.RapidMuskingum, sorted_case, [g['vol0'][:, order], g['vol1'][:, order]], channel_state_init_file=str(init), runoff_processing_mode='ensemble')
+    for i, (d, q, f, rf) in enumerate(got):
+        want = g[f'rapid_ens/q{i}'][:, order]
+        assert q.dtype == np.float32
+        np.testing.assert_allclose(q, want, rtol=1.2e-7, atol=1e-10 * float(np.abs(want).max()))
+    want = g['rapid_ens/final_state'][order]
+    np.testing.assert_allclose(r.channel_state, want, rtol=1e-10, atol=1e-10 * float(np.abs(want).max()))
+    if backend == 'hip':
+        assert r._plan.direct_info()['ok'] and r._plan.last_kernel() == 'direct'
+
+
 def test_rapid_ensemble_state_is_member_mean(backend, case):
     g = case['g']
     r, got = drive(rr.RapidMuskingum, case, [g['vol0'], g['vol1']], channel_state_init_file=case['init'],
