@@ -506,7 +506,7 @@ int rr_stream_begin(rr_plan *P, int has_lateral, const double *q_t, const double
     Rows io; io.dev_in = has_lateral ? lateral : nullptr; io.rows_in = lat_rows; io.dev_out = discharge; io.rows_out = out_rows;
     const Mode mode = has_lateral ? Mode::Rapid : Mode::Muskingum;
     if (P->ses.open) return fail(RR_E_STATE, "a routing call is already open on this plan (rr_stream_end it first)");
-    rc = prepare_call(P, mode, T, nsub, false, false, true, has_lateral != 0, lat_rows, out_rows);
+    rc = prepare_call(P, mode, T, nsub, false, false, true, true, has_lateral ? lat_rows : 0, out_rows);
     if (rc) return rc;
     if (P->h.n > 0 && T > 0) {
         rc = launch_state_in(P, mode, q_t, (hipStream_t)stream);
@@ -675,7 +675,7 @@ int rr_muskingum_route_f32_dev(rr_plan *P, double *q_t, float *discharge32, int6
     if (rc) return rc;
     if (P->h.n > 0 && n_out > 0 && (!q_t || !discharge32)) return fail(RR_E_INVALID, "rr_muskingum_route_f32_dev: null array");
     if (P->h.n == 0 || n_out == 0) return RR_OK;
-    rc = f32_output_applies(P, Mode::Muskingum, n_out, n_per_out, 1);
+    rc = f32_output_applies(P, Mode::Muskingum, n_out, n_per_out, 1, true);
     if (rc) return rc;
     Rows io; io.dev_out32 = discharge32; io.out_factor = 1; io.rows_out = n_out;
     return rapid_like(P, Mode::Muskingum, q_t, io, n_out, n_per_out, (hipStream_t)stream, false);

@@ -263,10 +263,11 @@ int upload_tile_coef(rr_plan *P)
 }
 
 typedef void (*direct_kernel_t)(const DirectArgs);
-direct_kernel_t direct_kernel(bool in32, bool out32)
+direct_kernel_t direct_kernel(bool in32, bool out32, bool sub = false)
 {
-    return in32 ? (out32 ? (direct_kernel_t)k_direct<kDirectAhead, true, true> : (direct_kernel_t)k_direct<kDirectAhead, true, false>)
-                : (out32 ? (direct_kernel_t)k_direct<kDirectAhead, false, true> : (direct_kernel_t)k_direct<kDirectAhead, false, false>);
+#define RR_DK(I_, O_) (sub ? (direct_kernel_t)k_direct<kDirectAhead, I_, O_, true> : (direct_kernel_t)k_direct<kDirectAhead, I_, O_, false>)
+    return in32 ? (out32 ? RR_DK(true, true) : RR_DK(true, false)) : (out32 ? RR_DK(false, true) : RR_DK(false, false));
+#undef RR_DK
 }
 
 // The direct row path's device arrays (rr::DirectPlan): per-column constants, the skeleton's tile arrays, the columns of the holes' out-pass.
@@ -286,8 +287,8 @@ int upload_direct_plan(rr_plan *P)
     const rr::DirectPlan &D = P->dp;
     const rr::TilePlan &K = D.skel;
     const int64_t n = H.n;
-    for (int v = 0; v < 4; ++v)      // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
-        if (hipFuncSetAttribute((const void *)direct_kernel((v & 1) != 0, (v & 2) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)direct_lds_bytes(kDirectMaxWindow)) != hipSuccess) {
+    for (int v = 0; v < 8; ++v)      // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
+        if (hipFuncSetAttribute((const void *)direct_kernel((v & 1) != 0, (v & 2) != 0, (v & 4) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)direct_lds_bytes(kDirectMaxWindow)) != hipSuccess) {
             (void)hipGetLastError();
             P->direct_enabled = false;
         }
@@ -467,8 +468,9 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
     // The direct row path: RapidMuskingum, one sub-step per row, float64 rows in device arrays, one weight per reach -- the
     // headline's call -- on a params order that numbers small subtrees contiguously (boundary reaches of a partitioned network
     // included: rr_plan_set_boundary lays the direct plan out around them).
-    if (plain_rows && P->direct_enabled && P->dp.ok && mode == Mode::Rapid && nsub == 1 && P->weights_uniform && !force_streaming && !host_io &&
-        P->wave_enabled && total >= 8 && n < (int64_t{1} << 29)) {
+    // Sub-steps (up to kDirectMaxSub a row) and channel-only routing take it too; with sub-steps only without boundary ghosts.
+    if (plain_rows && P->direct_enabled && P->dp.ok && (mode == Mode::Rapid || mode == Mode::Muskingum) && nsub <= kDirectMaxSub && (nsub == 1 || P->n_ghost == 0) &&
+        P->weights_uniform && !force_streaming && !host_io && P->wave_enabled && total >= 8 && n < (int64_t{1} << 29)) {
         int64_t K = pick_direct_K(P, T);
         const int64_t levels = P->dp.skel.n_levels, np = P->dp.skel.np;
         if (ring_in > 0 && ring_in < T) K = std::min(K, ring_in / kRec * kRec);
@@ -478,10 +480,10 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
         // The skeleton's own tasks: as long as the lanes' (every tile level costs one task of pipeline and of record ring) -- except in a part
         // that feeds another GPU, whose boundary series every level delays by one task: 64 ticks there (as kc_long below), several of the
         // skeleton's launches per direct launch.  KS divides KC.
-        sch.KS = sch.KC;
-        if (P->n_export > 0 && P->wave_K <= 0) for (sch.KS = std::min<int64_t>(sch.KC, 4); sch.KC % sch.KS; --sch.KS) {}
+        sch.KS = sch.KC * nsub;      // (in ticks: a direct task is K rows = K nsub ticks)
+        if (P->n_export > 0 && P->wave_K <= 0) for (sch.KS = std::min<int64_t>(sch.KC * nsub, 4); (sch.KC * nsub) % sch.KS; --sch.KS) {}
         if (np > 0) {      // a record lives from the launch that forwards its first row to the out-pass behind the skeleton's last level
-            sch.chunks = std::min<int64_t>((levels * sch.KS * kRec + 2 * K + 2 * dmax + kRecRows + 2 * kRec) / kRec + 2, (total + dmax) / kRec + 2);
+            sch.chunks = std::min<int64_t>((levels * sch.KS * kRec + 2 * K * nsub + 2 * dmax + kRecRows + 2 * kRec) / kRec + 2, (total + dmax) / kRec + 2);
             sch.ring = sch.chunks * kRec * np;
         }
         if (K >= 2 * kRec && np < (int64_t{1} << 25) && (P->dev_total_bytes == 0 || sch.ring * 8 <= (int64_t)(P->dev_total_bytes / 2))) return sch;
@@ -619,7 +621,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
 
     if (S.wave || S.rows_direct) { S.KC = P->next_KC; S.rec_chunks = P->next_chunks; }     // ring sized by choose_schedule, allocated by rr_plan_reserve
     if (S.rows_direct) {
-        if (io.uh_kernel || io.runoff || (!io.dev_in && !io.dev_in32) || (!io.dev_out && !io.dev_out32) || mode != Mode::Rapid || nsub != 1 ||
+        if (io.uh_kernel || io.runoff || (S.has_in && !io.dev_in && !io.dev_in32) || (!io.dev_out && !io.dev_out32) || mode == Mode::Unit || nsub > kDirectMaxSub ||
             (io.dev_out32 && (io.out_factor < 1 || (S.KC * kRec) % io.out_factor != 0 || T % io.out_factor != 0))) {
             S.open = false;
             return fail(RR_E_STATE, "route: the direct row path was chosen for a call it does not take");      // (choose_schedule's plain_rows / out32)
@@ -642,8 +644,9 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         DirectArgs &da = S.da;
         da.tiles = P->d_dtiles; da.n_tiles = P->dp.n_tiles; da.lane = P->d_dlane; da.coef = P->d_dcoef; da.q = P->d_dq;
         da.send_ptr = P->d_dsend_ptr; da.send_lane = P->d_dsend_lane;
-        da.in = io.dev_in; da.out = io.dev_out; da.n = n; da.in_rows = (uint32_t)io.rows_in; da.out_rows = (uint32_t)std::max<int64_t>(1, io.rows_out);
-        da.in32 = io.dev_in32; da.out32 = io.dev_out32; da.factor = (int32_t)std::max<int64_t>(1, io.out_factor);
+        da.in = S.has_in ? io.dev_in : nullptr; da.out = io.dev_out; da.n = n; da.in_rows = (uint32_t)std::max<int64_t>(1, io.rows_in); da.out_rows = (uint32_t)std::max<int64_t>(1, io.rows_out);
+        da.in32 = S.has_in ? io.dev_in32 : nullptr; da.out32 = io.dev_out32; da.factor = (int32_t)std::max<int64_t>(1, io.out_factor);
+        da.nsub = (int32_t)nsub; da.inv_nsub = 1.0 / (double)nsub;
         da.rec = P->d_ring; da.rec_chunks = (uint32_t)std::max<int64_t>(1, S.rec_chunks); da.np = (int32_t)TP.np;
         da.K = (int32_t)K; da.total = (int32_t)S.T;
         da.exports = export_series; da.n_export = (int32_t)P->n_export;
@@ -653,7 +656,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         w.exports = export_series; w.n_export = (int32_t)P->n_export;
         w.rec = P->d_ring; w.rec_chunks = Div32((uint32_t)std::max<int64_t>(1, S.rec_chunks));
         w.np = (int32_t)TP.np; w.KC = (int32_t)S.KS; w.n_macro = (int32_t)S.n_macro; w.total = (int32_t)S.total;
-        w.has_lat = 1; w.nsub = Div32(1u); w.inv_nsub = 1.0;
+        w.has_lat = S.has_in ? 1 : 0; w.nsub = Div32((uint32_t)nsub); w.inv_nsub = 1.0 / (double)nsub;
     }
     if (S.wave) {
         const rr::TilePlan &TP = P->tp;
@@ -1083,7 +1086,7 @@ int session_advance_direct(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, 
 {
     Session &S = P->ses;
     const rr::TilePlan &TP = P->dp.skel;
-    const int64_t dmax = P->h.depth - 1, levels = TP.n_levels, K = S.KC * kRec, KS = S.KS * kRec, per = K / KS, n = P->h.n;
+    const int64_t dmax = P->h.depth - 1, levels = TP.n_levels, K = S.KC * kRec, Kt = K * S.nsub, KS = S.KS * kRec, per = Kt / KS, n = P->h.n;      // K rows = Kt ticks per direct task
     rows_ready = std::min(rows_ready, S.T);
     const bool skel = TP.n_tiles > 0, ghosts = skel && P->n_ghost > 0;
     // a record slot is recycled only after every tick-row it can hold has left (the same rule as session_advance_tile's)
@@ -1097,14 +1100,14 @@ int session_advance_direct(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, 
             const int64_t d = S.d_done;
             if (rows_ready < std::min((d + 1) * K, S.T)) break;
             if (skel) {      // this launch writes record slots up to tick (d + 1) K + dmax: whatever they held one revolution earlier must have left
-                const int64_t top = std::min((d + 1) * K + dmax, S.total_ticks) / kRec;
+                const int64_t top = std::min((d + 1) * Kt + dmax, S.total_ticks) / kRec;
                 if (top >= S.rec_chunks && S.ticks_stored < std::min(S.total, kRec * (top - S.rec_chunks + 1))) break;
             }
             const bool sample = S.max_samples > 0 && (size_t)P->prof_brackets < S.max_samples;
             if (sample) HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets], S.stream));
             S.da.m = (int32_t)d;
             const dim3 g((unsigned)std::min<int64_t>(P->dp.n_tiles, (int64_t)P->cu_count));
-            hipLaunchKernelGGL(direct_kernel(S.da.in32 != nullptr, S.da.out32 != nullptr), g, dim3(kDirectThreads), direct_lds_bytes(P->direct_window), S.stream, S.da);
+            hipLaunchKernelGGL(direct_kernel(S.io.dev_in32 != nullptr && S.has_in, S.da.out32 != nullptr, S.nsub > 1), g, dim3(kDirectThreads), direct_lds_bytes(P->direct_window), S.stream, S.da);
             if (sample) {
                 HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));
                 P->ev_reaches.push_back(n * (std::min((d + 1) * K, S.T) - d * K));
@@ -1116,12 +1119,13 @@ int session_advance_direct(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, 
             progressed = true;
         }
         const int64_t rows_routed = S.d_done >= S.n_tasks ? S.T : S.d_done * K;      // by the lanes
+        const int64_t ticks_routed = rows_routed * S.nsub;
         S.rows_loaded = rows_routed;
         // The boundary series of a partitioned network becomes the records of the skeleton's ghosts that mirror the boundary reaches,
         // 128 tick-rows at a time (k_rec_in's batches), never ahead of the rows the lanes have routed: the ring's slots up to there are free.
         while (ghosts && S.ghost_batches < S.n_in_batches) {
             const int64_t need = std::min(kRecRows * (S.ghost_batches + 1), S.total);
-            if (ghost_ready < need || need > rows_routed || !slot_free(S.ghost_batches)) break;
+            if (ghost_ready < need || need > ticks_routed || !slot_free(S.ghost_batches)) break;
             launch_ghost_permute(P, S.ghost_batches);
             ++S.ghost_batches;
             progressed = true;
@@ -1143,7 +1147,7 @@ int session_advance_direct(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, 
             progressed = true;
         }
         // rows the direct tiles have written, and of those the rows whose skeleton reaches are final too
-        int64_t done = rows_routed;
+        int64_t done = ticks_routed;      // in sub-steps
         if (skel) {
             const int64_t m_done = S.diag - levels;      // the tiles of the last level have finished macro-chunk diag - levels
             int64_t sk = S.diag >= S.n_diags ? S.total : (m_done >= 0 ? std::max<int64_t>(0, (m_done + 1) * KS - dmax) : 0);
@@ -1151,28 +1155,31 @@ int session_advance_direct(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, 
             while (S.out_batches < S.n_out_batches && done >= std::min(kRecRows * (S.out_batches + 1), S.total)) {
                 RecPermArgs ra{};
                 ra.rec = P->d_ring; ra.rec_chunks = Div32((uint32_t)S.rec_chunks); ra.n = P->n_kholes; ra.np = TP.np; ra.T = S.T; ra.total = S.total;
-                ra.batch = S.out_batches; ra.nsub = Div32(1u); ra.colmeta = P->d_kholemeta; ra.cols = P->d_kholecol; ra.scale = nullptr;
+                ra.batch = S.out_batches; ra.nsub = Div32((uint32_t)S.nsub); ra.colmeta = P->d_kholemeta; ra.cols = P->d_kholecol; ra.scale = nullptr;
                 ra.rows = RowView{S.io.dev_out, n, 0, (uint32_t)std::max<int64_t>(1, S.io.rows_out)};
                 ra.rows32 = S.io.dev_out32;
-                ra.factor = Div32((uint32_t)std::max<int64_t>(1, S.io.out_factor)); ra.clamp = 1; ra.swizzle = 0;
+                ra.factor = Div32((uint32_t)std::max<int64_t>(1, S.io.out_factor)); ra.clamp = S.nsub > 1 ? 0 : 1; ra.swizzle = 0;
                 const int aux = aux_begin(P, 3, S.stream);
                 const dim3 gh((unsigned)((P->n_kholes + kRecOutCols - 1) / kRecOutCols));
-                if (P->n_kholes > 0 && ra.rows32) hipLaunchKernelGGL((k_rec_out<false, true>), gh, dim3(kRecOutThreads), 0, S.stream, ra);
-                else if (P->n_kholes > 0) hipLaunchKernelGGL((k_rec_out<false, false>), gh, dim3(kRecOutThreads), 0, S.stream, ra);
+                if (P->n_kholes > 0) {
+                    if (S.nsub > 1) { if (ra.rows32) hipLaunchKernelGGL((k_rec_out<true, true>), gh, dim3(kRecOutThreads), 0, S.stream, ra); else hipLaunchKernelGGL((k_rec_out<true, false>), gh, dim3(kRecOutThreads), 0, S.stream, ra); }
+                    else if (ra.rows32) hipLaunchKernelGGL((k_rec_out<false, true>), gh, dim3(kRecOutThreads), 0, S.stream, ra);
+                    else hipLaunchKernelGGL((k_rec_out<false, false>), gh, dim3(kRecOutThreads), 0, S.stream, ra);
+                }
                 aux_end(P, aux, S.stream);
                 ++S.out_batches;
                 S.ticks_stored = std::min(S.total, kRecRows * S.out_batches);
                 progressed = true;
             }
-            S.rows_stored = S.ticks_stored;
+            S.rows_stored = S.ticks_stored / S.nsub;
         } else {
-            S.rows_stored = S.ticks_stored = done;
+            S.ticks_stored = done; S.rows_stored = done / S.nsub;
         }
         if (!progressed) break;
     }
     if (S.d_done >= S.n_tasks && S.diag >= S.n_diags) S.tau = S.total_ticks;
     if (export_ready) {      // a lane's export is final with its row; a skeleton reach's once its tile's level has passed the tick
-        int64_t e = S.d_done >= S.n_tasks ? S.total : S.d_done * K;
+        int64_t e = S.d_done >= S.n_tasks ? S.total : S.d_done * Kt;
         if (S.export_skel) e = std::min(e, S.diag >= S.n_diags ? S.total : S.diag * KS - S.export_skew);
         *export_ready = P->n_export > 0 ? std::max<int64_t>(0, std::min(e, S.total)) : S.total;
     }
@@ -1470,7 +1477,7 @@ int rapid_like(rr_plan *P, Mode mode, double *q_t, const Rows &io_in, int64_t T,
     // host rows reach the time-tiled kernel through the PCIe pipeline's device rings; where it does not apply they are
     // routed chunk by chunk by the streaming kernel
     {   // host rows reach the time-tiled kernel through the PCIe pipeline's device rings (they are "device rows" to the schedule)
-        const bool plain = !host_rows && (io.dev_in || io.dev_in32) && (io.dev_out || io.dev_out32) && !io.uh_kernel && !io.runoff;      // rows in device arrays, float64 or float32: the direct row path applies
+        const bool plain = !host_rows && (mode == Mode::Muskingum || io.dev_in || io.dev_in32) && (io.dev_out || io.dev_out32) && !io.uh_kernel && !io.runoff;      // rows in device arrays, float64 or float32: the direct row path applies
         int rc = prepare_call(P, mode, T, nsub, false, false, !host_rows, plain, 0, 0, io.dev_out32 != nullptr);
         if (rc == RR_OK && host_rows && !P->wave_now) rc = prepare_call(P, mode, T, nsub, true, true, false);
         if (rc == RR_OK && host_rows && P->wave_now) rc = host_pipe_prepare(P);

@@ -63,7 +63,10 @@ struct DirectArgs {
     const float *in32;          // IN32: float32 lateral rows instead of `in` (as qlateral files store them; exact in float64)
     float *out32;               // OUT32: float32 discharge rows, each the mean of `factor` routed rows (TransformMuskingum.py:128-142), (total / factor, n), not cyclic
     int32_t factor;
+    int32_t nsub;               // SUB: routing sub-steps per row (2 ... kDirectMaxSub); the row's output is their mean
+    double inv_nsub;
 };
+constexpr int kDirectMaxSub = 4;      // a hole's lateral value goes into `nsub` ring slots at once: with more the send wave's turn (every eight ticks) could come too late
 constexpr int32_t kDirectHoleBit = rr::kDirectHole;
 constexpr int kDirectLanes = 256, kDirectAhead = 16;
 constexpr int kDirectThreads = kDirectLanes + 4 * 64;      // four routing waves + in, in, out, send: two waves per SIMD
@@ -123,7 +126,12 @@ __device__ __forceinline__ void store_f64x2_nt(__amdgpu_buffer_rsrc_t r, uint32_
 // of the float64 copy bit for bit).  OUT32: the routers' post-processing in the rows-out wave -- the mean over `factor` consecutive rows
 // (sequential sum, one division, as numpy reduces a strided axis) and the float32 cast; K is a multiple of factor (choose_schedule), so
 // every output row lies inside one task.
-template <int PF, bool IN32 = false, bool OUT32 = false>
+// SUB: routing sub-steps (_numba_kernels.py:66-84: the row's lateral value is held over its sub-steps, the output is their mean).  A tick
+// is a sub-step: a lane reads F[its row] at every sub-step of the row and puts the mean there at the last one; rows arrive and leave
+// every nsub ticks; the senders' rings and the skeleton's records are in sub-step space, as k_tile<SUB>'s.  Channel-only routing
+// (Muskingum.py:262-290: no lateral rows) needs no flag: without a lateral array every rows-in load is dropped by its descriptor's range
+// check and returns zero.
+template <int PF, bool IN32 = false, bool OUT32 = false, bool SUB = false>
 __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -145,7 +153,9 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
         const int32_t span = tm.span, wrap = (span + 3) * kRowB;     // bytes of the window in use
         // local tick k: row k + 1 arrives (waves 4, 5), lane with delay d routes row k - d (waves 0-3), row k - 1 - span leaves (wave 6),
         // the values of tick k - 1 are forwarded (wave 7); n_ticks of them, in chunks of PF
-        const int32_t n_ticks = nrows + span + 2;
+        const int32_t nsub = SUB ? a.nsub : 1, total_sub = nrows * nsub;      // sub-steps of the task
+        const int32_t n_ticks = total_sub + span + 2;
+        const int32_t tick0 = r0 * nsub + tm.lag_lo;      // the tile's tick (sub-step + lag) at local tick 0
         __syncthreads();      // every wave has left the previous tile
 
         if (role == 0) {
@@ -207,9 +217,45 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                     barrier_lds();
                 }
             };
-            for (int32_t k0 = 0; k0 < n_ticks; k0 += PF) {
-                if (k0 >= span && k0 + PF <= nrows) ticks(std::false_type(), k0);      // every lane busy on every tick of the chunk
-                else ticks(std::true_type(), k0);
+            if constexpr (SUB) {
+                // sub-steps: the lane stays on its row's window slot for nsub ticks, keeps the running sum and writes the mean at the last one
+                int32_t own = 0, phase = 0;      // byte offset of the row's slot; sub-step of the row
+                double isum = 0.0;
+                for (int32_t k0 = 0; k0 < n_ticks; k0 += PF) {
+#pragma unroll
+                    for (int s = 0; s < PF; ++s) {
+                        const int prev = ((s + 1) & 1) * (THP * 8), cur = (s & 1) * (THP * 8);
+                        const double q_old = q_last;
+                        const double s_cur = (*reinterpret_cast<const double *>(X + prev + up0_b) + *reinterpret_cast<const double *>(X + prev + up1_b)) +
+                                             *reinterpret_cast<const double *>(X + prev + up2_b);
+                        double *mine = reinterpret_cast<double *>(F + own + tid * 8);
+                        const double lat = *mine;
+                        const bool active = (uint32_t)(k0 + s - delta) < (uint32_t)total_sub;
+                        double qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev, __builtin_fma(c3, q_old, lat)));
+                        qk = active ? qk : q_old;
+                        const double acc = (phase == 0 ? 0.0 : isum) + qk;      // (k_tile<SUB>'s order: 0 + first, + second, ...)
+                        const bool last = active && phase + 1 == nsub;
+                        if (last) *mine = acc * a.inv_nsub;      // the row's mean, unclamped: the rows-out wave clips
+                        isum = active ? acc : isum;
+                        own = last ? (own + kRowB == wrap ? 0 : own + kRowB) : own;
+                        phase = active ? (last ? 0 : phase + 1) : phase;
+                        s_prev = s_cur; q_last = qk;
+                        *reinterpret_cast<double *>(X + cur + tid * 8) = qk;
+                        if (wave_sends) {      // wave-uniform
+                            const int32_t slot_b = ((tick0 + k0 + s) & 31) * 8;
+                            *reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + (sender != 0 && active ? stage_b + slot_b : kDummyB + tid * 8)) = qk;
+                        }
+                        if (wave_exports) {
+                            if (exp_slot >= 0 && active) a.exports[(int64_t)(r0 * nsub + k0 + s - delta) * a.n_export + exp_slot] = qk;
+                        }
+                        barrier_lds();
+                    }
+                }
+            } else {
+                for (int32_t k0 = 0; k0 < n_ticks; k0 += PF) {
+                    if (k0 >= span && k0 + PF <= nrows) ticks(std::false_type(), k0);      // every lane busy on every tick of the chunk
+                    else ticks(std::true_type(), k0);
+                }
             }
             if (!idle) a.q[col] = *reinterpret_cast<const double *>(X + THP * 8 + tid * 8);      // PF is even: the last tick wrote buffer 1
         } else if (role == 1) {
@@ -222,14 +268,15 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                 const int4 lm = a.lane[tm.c0 + (c < tm.nc ? c : 0)];
                 const bool hole = c < tm.nc && (lm.x & kDirectHoleBit) != 0 && ((lm.x >> rr::kDirectSenderShift) & kSenderMask) != 0;
                 ring_b = hole ? kStageB + (((lm.x >> rr::kDirectSenderShift) & kSenderMask) - 1) * (2 * kRec * 8) : -1;
-                slot0 = (r0 + lm.w) & 31;      // of local row 0
+                slot0 = (r0 * nsub + lm.w) & 31;      // of local row 0 (its first sub-step)
             };
             int32_t ring0, ring1, hs0, hs1;
             hole_of(ca, ring0, hs0); hole_of(ca + 1, ring1, hs1);
             const int32_t dummy_b = kDummyB + (TH + (wave - 4) * 64 + ln) * 8;      // (the in-waves' dummy slots follow the routing lanes')
             const bool wave_holes = __builtin_amdgcn_ballot_w64(ring0 >= 0 || ring1 >= 0) != 0;
             // a 16-byte load may reach past the tile's last column (the next tile's, or -- past the row's end -- zeros): never used
-            const uint32_t va = ca < tm.nc ? (uint32_t)(tm.c0 + ca) * (IN32 ? 4u : 8u) : kDropAccess;
+            const bool has_lat = IN32 ? a.in32 != nullptr : a.in != nullptr;      // channel-only routing: every load is dropped and returns zero
+            const uint32_t va = ca < tm.nc && has_lat ? (uint32_t)(tm.c0 + ca) * (IN32 ? 4u : 8u) : kDropAccess;
             uint32_t rin = (uint32_t)r0 % a.in_rows;
             const char *row = IN32 ? reinterpret_cast<const char *>(a.in32 + (int64_t)rin * a.n) : reinterpret_cast<const char *>(a.in + (int64_t)rin * a.n);
             const uint32_t in_row_bytes = IN32 ? row_bytes / 2u : row_bytes;
@@ -237,7 +284,8 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             // 32 KB per CU in flight against ~3.5 us under load); the register ring is indexed statically: two chunk bodies alternate
             constexpr int AH = 2 * PF;
             typedef typename std::conditional<IN32, f32x2, double2>::type Pt;
-            Pt Pa[AH];
+            constexpr int AR = SUB ? 8 : AH;      // rows in flight (with sub-steps a row lasts nsub >= 2 ticks)
+            Pt Pa[AR];
             auto request = [&](int32_t arrival, Pt &pa) {      // row r0 + arrival, or nothing past the task's rows
                 const __amdgpu_buffer_rsrc_t src = make_rsrc(row, in_row_bytes);
                 if constexpr (IN32) pa = load_f32x2_(src, arrival < nrows ? va : kDropAccess);
@@ -246,7 +294,7 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                 if (rin == a.in_rows) { rin = 0; row = IN32 ? reinterpret_cast<const char *>(a.in32) : reinterpret_cast<const char *>(a.in); }
             };
 #pragma unroll
-            for (int j = 0; j < AH; ++j) request(j, Pa[j]);
+            for (int j = 0; j < AR; ++j) request(j, Pa[j]);
             int32_t in_b = 0;
             auto park = [&](const Pt &pa, int32_t arrival) {      // into the window, scaled (the ring of k_tile holds c4dt * lateral too)
                 const double x0 = (double)pa.x * c4a0, x1 = (double)pa.y * c4a1;
@@ -254,10 +302,40 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                 in_b = in_b + kRowB == wrap ? 0 : in_b + kRowB;
                 if (wave_holes) {      // wave-uniform
                     const bool real = arrival < nrows;
-                    *reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + (real && ring0 >= 0 ? ring0 + ((hs0 + arrival) & 31) * 8 : dummy_b)) = x0;
-                    *reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + (real && ring1 >= 0 ? ring1 + ((hs1 + arrival) & 31) * 8 : dummy_b)) = x1;
+                    if constexpr (SUB) {      // the row's value in each of its sub-steps' slots (k_rec_in<SUB> does the same for the record path)
+                        for (int32_t p = 0; p < nsub; ++p) {
+                            *reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + (real && ring0 >= 0 ? ring0 + ((hs0 + arrival * nsub + p) & 31) * 8 : dummy_b)) = x0;
+                            *reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + (real && ring1 >= 0 ? ring1 + ((hs1 + arrival * nsub + p) & 31) * 8 : dummy_b)) = x1;
+                        }
+                    } else {
+                        *reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + (real && ring0 >= 0 ? ring0 + ((hs0 + arrival) & 31) * 8 : dummy_b)) = x0;
+                        *reinterpret_cast<double *>(reinterpret_cast<char *>(lds) + (real && ring1 >= 0 ? ring1 + ((hs1 + arrival) & 31) * 8 : dummy_b)) = x1;
+                    }
                 }
             };
+            if constexpr (SUB) {
+                // Row j is parked during tick j nsub - 1 (one tick before the first lane starts it).  Eight rows in flight cover at least
+                // sixteen ticks; the ring is indexed statically: eight bodies a revolution.
+                constexpr int AS = AR;
+                const int32_t total_b = (n_ticks + PF - 1) / PF * PF;      // barriers every wave of the workgroup goes through
+                park(Pa[0], 0);
+                request(AS, Pa[0]);
+                __syncthreads();
+                int32_t k = 0, j = 1;
+                while (k < total_b) {
+#pragma unroll
+                    for (int jj = 0; jj < AS; ++jj) {      // row j + jj sits in Pa[(1 + jj) % AS]
+                        for (int32_t w = 0; w < nsub - 1 && k < total_b; ++w, ++k) barrier_lds();
+                        if (k >= total_b) break;
+                        park(Pa[(1 + jj) % AS], j + jj);
+                        request(j + jj + AS, Pa[(1 + jj) % AS]);
+                        barrier_lds();
+                        ++k;
+                    }
+                    j += AS;
+                }
+                continue;      // next tile
+            }
             park(Pa[0], 0);      // row 0, before the first tick
             request(AH, Pa[0]);
             __syncthreads();
@@ -291,11 +369,20 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             int32_t cnt = 0;
             const double fdiv = (double)a.factor;
             int32_t out_b = 0;
+            int32_t u_sub = -1 - span, u_ph = 0, u_row = 0;      // SUB: the sub-step the slowest lane did one tick ago, its place in its row, the row
             __syncthreads();
             for (int32_t k0 = 0; k0 < n_ticks; k0 += PF) {
 #pragma unroll
-                for (int s = 0; s < PF; ++s) {      // tick k: row k - 1 - span leaves
-                    const int32_t leaving = k0 + s - 1 - span;
+                for (int s = 0; s < PF; ++s) {      // tick k: row k - 1 - span leaves (sub-steps: the row whose last sub-step the slowest lane did at tick k - 1)
+                    int32_t leaving = k0 + s - 1 - span;
+                    if constexpr (SUB) {      // (no integer division: counted along)
+                        leaving = -1;
+                        if (u_sub >= 0) {
+                            if (u_ph == nsub - 1) leaving = u_row;
+                            if (++u_ph == nsub) { u_ph = 0; ++u_row; }
+                        }
+                        ++u_sub;
+                    }
                     if (leaving >= 0 && leaving < nrows) {      // wave-uniform
                         const double2 xa = *reinterpret_cast<const double2 *>(F + out_b + 2 * ln * 8), xb = *reinterpret_cast<const double2 *>(F + out_b + 2 * ln * 8 + 128 * 8);
                         if constexpr (OUT32) {
@@ -348,7 +435,8 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             constexpr int NS = kDirectSenders / 8;    // senders per group of eight lanes
             static_assert(PF % NS == 0, "a sender's turns are the ticks with tick % NS == its place in the group");
             int32_t ring_b[NS];                       // its ring in LDS, or -1
-            uint32_t done[NS], end[NS], avail0[NS];   // ticks (row + lag) written out so far / of the task's last row + 1 / visible at local tick 0
+            bool holef[NS];                           // the sender is a hole (its values arrive row by row, nsub ticks at a time)
+            uint32_t done[NS], end[NS], avail0[NS];   // ticks (sub-step + lag) written out so far / of the task's last sub-step + 1 / visible at local tick 0
             uint32_t chk[NS];                         // ring chunk of the record `done` lies in
             int64_t roff[NS];                         // ... and its offset in the record ring, in doubles
             const int64_t chunk_step = (int64_t)a.np * kRec, ring = (int64_t)a.rec_chunks * a.np * kRec;
@@ -362,11 +450,12 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                 const int4 lm = a.lane[tm.c0 + (sl & 0x3FF)];
                 const bool hole = (sl & kDirectHoleBit) != 0;
                 ring_b[f] = have ? kStageB + i * (2 * kRec * 8) : -1;
-                done[f] = (uint32_t)(r0 + lm.w);
-                end[f] = done[f] + (uint32_t)nrows;
-                // what wave 7 sees at local tick k: an outlet's values of the ticks before k (every lane of the tile is at tick r0 + lag_lo + k),
-                // a hole's rows up to k (row k + 1 is parked during tick k)
-                avail0[f] = hole ? (uint32_t)(r0 + lm.w + 1) : (uint32_t)(r0 + tm.lag_lo);
+                holef[f] = hole;
+                done[f] = (uint32_t)(r0 * nsub + lm.w);
+                end[f] = done[f] + (uint32_t)total_sub;
+                // what wave 7 sees at local tick k: an outlet's values of the ticks before k (every lane of the tile is at tick tick0 + k),
+                // a hole's rows up to k / nsub (row j is parked during tick j nsub - 1), every sub-step of them
+                avail0[f] = hole ? (uint32_t)((r0 + 1) * nsub + lm.w) : (uint32_t)tick0;
                 chk[f] = (done[f] >> 4) % a.rec_chunks;
                 roff[f] = ((int64_t)chk[f] * a.np + (have ? lm.z : 0)) * kRec;
             }
@@ -383,11 +472,14 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                     }
                 }
             };
+            int32_t k_rows = 0, k_ph = 0;      // SUB: (local tick / nsub) * nsub, counted along
             __syncthreads();
             for (int32_t k0 = 0; k0 < n_ticks; k0 += PF) {
 #pragma unroll
                 for (int s = 0; s < PF; ++s) {
-                    turn(s % NS, avail0[s % NS] + (uint32_t)(k0 + s), false);
+                    const uint32_t seen = SUB ? (uint32_t)(holef[s % NS] ? k_rows : k0 + s) : (uint32_t)(k0 + s);
+                    turn(s % NS, avail0[s % NS] + seen, false);
+                    if constexpr (SUB) { if (++k_ph == nsub) { k_ph = 0; k_rows += nsub; } }
                     barrier_lds();
                 }
             }

@@ -245,7 +245,7 @@ class Plan:
                                                   ptr(discharge32), int(factor), int(T), int(num_substeps), stream))
 
     def muskingum_route_f32_dev(self, q_t, discharge32, num_output_steps, num_routing_per_output, stream=None) -> None:
-        self.reserve(MODE_MUSKINGUM, num_output_steps, num_routing_per_output)
+        self.reserve(MODE_MUSKINGUM, num_output_steps, num_routing_per_output, f32_out=True)
         check(_lib.lib().rr_muskingum_route_f32_dev(self._h, ptr(q_t), ptr(discharge32), int(num_output_steps),
                                                     int(num_routing_per_output), stream))
 
@@ -289,7 +289,7 @@ class Plan:
     def stream_begin(self, q_t, lateral, lat_rows, discharge, out_rows, T, num_substeps, ghost_series=None,
                      export_series=None, stream=None) -> None:
         # rings shorter than 32 rows keep to records (include/rr_hip.h, rr_stream_begin): reserve for the schedule the call will get
-        plain = lateral is not None and min(int(lat_rows), int(T)) >= min(32, int(T)) and min(int(out_rows), int(T)) >= min(32, int(T))
+        plain = (lateral is None or min(int(lat_rows), int(T)) >= min(32, int(T))) and min(int(out_rows), int(T)) >= min(32, int(T))
         self.reserve(MODE_MUSKINGUM if lateral is None else MODE_RAPID, T, num_substeps, plain_rows=plain)
         check(_lib.lib().rr_stream_begin(self._h, 0 if lateral is None else 1, ptr(q_t), ptr(lateral), int(lat_rows),
                                          ptr(discharge), int(out_rows), int(T), int(num_substeps), ptr(ghost_series),

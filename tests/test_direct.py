@@ -270,21 +270,21 @@ def test_direct_rows_at_1m_reaches_vs_oracle():
 
 @pytest.mark.gpu
 def test_calls_the_direct_path_does_not_take_fall_back_to_records(monkeypatch):
-    """On a post-order plan: sub-steps keep to the record path (against the oracle), float32 rows out take the direct path since
-    round 5, and the plan goes back and forth between the two."""
+    """On a post-order plan: more sub-steps than the direct path takes (five) keep to the record path (against the oracle), float32 rows
+    out take the direct path since round 5, and the plan goes back and forth between the two."""
     set_env(monkeypatch, {})
     n, T = 50_000, 64
     net, indptr, indices, c1, c2, c3 = _case(n, 31)
-    c1s, c2s, c3s = oracle.muskingum_coefficients(net.k, net.x, 450.0)
+    c1s, c2s, c3s = oracle.muskingum_coefficients(net.k, net.x, 180.0)
     ql = synth.synth_qlateral(n, 0, T)
     with Plan(indptr, indices) as plan:
         plan.set_coeffs(-c1s[indices], c2s, c3s, (c1s + c2s) / 900.0)
         q_ref, d_ref = np.zeros(n), np.zeros((T, n))
-        oracle.rapid_route(indptr, indices, -c1s[indices], c2s, c3s, (c1s + c2s) / 900.0, q_ref, ql, d_ref, 2)
+        oracle.rapid_route(indptr, indices, -c1s[indices], c2s, c3s, (c1s + c2s) / 900.0, q_ref, ql, d_ref, 5)
         d_q, d_ql, d_out = DeviceBuffer(n * 8).upload(np.zeros(n)), DeviceBuffer(ql.nbytes).upload(ql), DeviceBuffer(T * n * 8)
-        plan.rapid_route_dev(d_q, d_ql, T, d_out, T, T, 2)
+        plan.rapid_route_dev(d_q, d_ql, T, d_out, T, T, 5)
         assert plan.last_kernel() == 'tile'
-        assert_close(d_out.download(np.float64, (T, n)), d_ref, 'two sub-steps')
+        assert_close(d_out.download(np.float64, (T, n)), d_ref, 'five sub-steps')
         plan.set_coeffs(-c1[indices], c2, c3, (c1 + c2) / 900.0)
         q_ref, d_ref = np.zeros(n), np.zeros((T, n))
         oracle.rapid_route(indptr, indices, -c1[indices], c2, c3, (c1 + c2) / 900.0, q_ref, ql, d_ref, 1)
@@ -565,3 +565,44 @@ def test_float32_rows_on_the_direct_path(monkeypatch, n, T, factor, in32, env):
     assert_close(full, d_ref, 'float64 rows')
     np.testing.assert_allclose(res['1'][0], want, rtol=1.2e-7, atol=1e-10 * float(np.abs(want).max()))
     assert_close(res['1'][1], q_ref, 'state')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,T,nsub,mode,env', [(60_000, 100, 2, 'rapid', {}), (60_000, 70, 4, 'rapid', {}), (200_000, 130, 3, 'rapid', {'RR_WAVE_K': '64'}),
+                                               (60_000, 96, 1, 'muskingum', {}), (60_000, 60, 4, 'muskingum', {}), (1_000_000, 80, 4, 'rapid', {}),
+                                               (120_000, 300, 2, 'rapid', {'RR_WAVE_K': '32'})])
+def test_substeps_and_channel_only_routing_on_the_direct_path(monkeypatch, n, T, nsub, mode, env):
+    """Routing sub-steps (dt_routing < dt_runoff: _numba_kernels.py:66-84, the row's lateral value held, the output the mean of the
+    sub-steps) and channel-only routing (Muskingum.py:262-290) on the direct row path: two consecutive calls against the oracle, and
+    bit for bit the record path's rows (RR_DIRECT=0)."""
+    net, indptr, indices, c1, c2, c3 = _case(n, 61)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0 / nsub)
+    lhs, c4_dt = -c1[indices], (c1 + c2) / 900.0
+    q0 = 3.0 * synth.u01(6, np.arange(n))
+    res = {}
+    for direct in ('1', '0'):
+        set_env(monkeypatch, dict(env, RR_DIRECT=direct))
+        with Plan(indptr, indices) as plan:
+            plan.set_coeffs(lhs, c2, c3, c4_dt if mode == 'rapid' else None)
+            d_q, d_ql, d_out = DeviceBuffer(n * 8).upload(q0), DeviceBuffer(T * n * 8), DeviceBuffer(T * n * 8)
+            q_ref, rows = q0.copy(), []
+            for call in range(2):
+                d_ref = np.zeros((T, n))
+                if mode == 'rapid':
+                    ql = synth.synth_qlateral(n, call * T, (call + 1) * T)
+                    oracle.rapid_route(indptr, indices, lhs, c2, c3, c4_dt, q_ref, ql, d_ref, nsub)
+                    d_ql.upload(ql)
+                    plan.rapid_route_dev(d_q, d_ql, T, d_out, T, T, nsub)
+                else:
+                    oracle.muskingum_route(indptr, indices, lhs, c2, c3, q_ref, d_ref, T, nsub)
+                    plan.muskingum_route_dev(d_q, d_out, T, T, nsub)
+                assert plan.last_kernel() == ('direct' if direct == '1' else 'tile')
+                got = d_out.download(np.float64, (T, n))
+                assert_close(got, d_ref, f'discharge, call {call}')
+                assert_close(d_q.download(np.float64, (n,)), q_ref, f'q_t, call {call}')
+                rows.append(got)
+            res[direct] = rows
+            for b in (d_q, d_ql, d_out):
+                b.free()
+    for a, b in zip(res['1'], res['0']):
+        np.testing.assert_array_equal(a, b)
