@@ -290,6 +290,19 @@ def test_uhkernels_convolve_equals_incremental_on_the_gpu():
     whole = b.convolve(depth)
     np.testing.assert_allclose(np.vstack([first, second]), whole, rtol=1e-12, atol=1e-12 * np.abs(whole).max())
     np.testing.assert_allclose(a.state, b.state, rtol=1e-12, atol=1e-12 * np.abs(whole).max())
+    # ... and convolve_incrementally (UnitHydrograph.py:64-75) against the ORACLE's definitional form, step by step with the state it
+    # leaves behind (the comparison above is HIP against HIP): 30 steps of 300 basins, 12 taps, non-zero state carried in
+    n_ks, n, T = 12, 300, 30
+    kernel = synth.synth_uh_kernel(n, n_ks)
+    depth = synth.synth_runoff_depth(n, 0, T)
+    state0 = 1e-3 * np.random.default_rng(7).random((n_ks, n))
+    uh, ref = UnitHydrograph.from_array(kernel), oracle.UnitHydrograph(kernel)
+    uh.state[:] = state0
+    ref.state[:] = state0
+    for t in range(T):
+        got, want = uh.convolve_incrementally(depth[t]), ref.convolve_incrementally(depth[t])
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12 * np.abs(want).max(), err_msg=f'step {t}')
+        np.testing.assert_allclose(uh.state, ref.state, rtol=1e-12, atol=1e-12 * np.abs(ref.state).max(), err_msg=f'state after step {t}')
 
 
 @pytest.mark.parametrize('n,T,nsub,factor', [(60_000, 256, 1, 1), (60_000, 256, 1, 4), (60_000, 96, 2, 2), (300_000, 384, 1, 8)])
@@ -793,3 +806,64 @@ def test_float32_depth_rows_equal_their_float64_copy(monkeypatch, n, T, nsub, n_
         if a is not None:
             for x, y in zip(a, b):
                 np.testing.assert_array_equal(x, y)
+
+
+def test_unit_full_year_as_ten_calls_sub_basins_vs_oracle(monkeypatch):
+    """BASELINE config 4 at full length, as bench.py's `year` field times it: ten consecutive calls of 3,504 rows of runoff depths at
+    1M reaches with the 48-step kernel (the reference's loop over runoff files, UnitMuskingum.py:72-98), the convolution's tail
+    (UnitHydrograph.py:99-105) and the channel state (q_ch, q_full) carried from call to call -- against the ORACLE on four
+    sub-basins (a reach's discharge depends on its sub-basin only; the convolution is column-wise) through all 35,040 steps: the
+    oracle convolves and routes the sub-basins' columns call by call with its own carried state."""
+    import torch
+    set_env(monkeypatch, {})
+    n, T, calls, n_ks, dt = 1_000_000, 3_504, 10, 48, 900.0
+    net = synth.synth_network(n)
+    indptr, indices = csc_from_down(net.down_index)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, dt)
+    cols, sub_down = _sub_basins(net.down_index, 2_000, 5_000, 4)
+    s_indptr, s_indices = csc_from_down(sub_down)
+    ns = cols.size
+    hw_idx, inner_idx, A_in, A_hw = unit_split(s_indptr, s_indices, ns)
+    s_c1, s_c2, s_c3 = c1[cols], c2[cols], c3[cols]
+    c1i, c2i, c3i = s_c1[inner_idx], s_c2[inner_idx], s_c3[inner_idx]
+    kern = synth.synth_uh_kernel(n, n_ks, tr=dt)
+    dev = torch.device('cuda:0')
+    cols_t = torch.from_numpy(cols).to(dev)
+    ref_uh = oracle.UnitHydrograph(np.ascontiguousarray(kern[:, cols]))
+    qc_ref, qf_ref = np.zeros(inner_idx.size), np.zeros(inner_idx.size)
+    d_kern = torch.from_numpy(kern).to(dev)
+    d_state = torch.zeros_like(d_kern)
+    worst = 0.0
+    with Plan(indptr, indices) as plan:
+        plan.set_coeffs(-c1[indices], c2, c3, None)
+        n_inner = plan.n_inner
+        q_ch = torch.zeros(n_inner, dtype=torch.float64, device=dev)
+        q_full = torch.zeros(n_inner, dtype=torch.float64, device=dev)
+        q_final = torch.zeros(n, dtype=torch.float64, device=dev)
+        out = torch.empty((T, n), dtype=torch.float64, device=dev)
+        g = torch.Generator(device=dev)
+        for call in range(calls):
+            g.manual_seed(900 + call)      # every file its own depths
+            depth = torch.rand((T, n), dtype=torch.float64, device=dev, generator=g) * 1e-3
+            out.fill_(-1.0)
+            plan.unit_route_uh_dev(q_ch, q_full, q_final, d_kern, d_state, n_ks, depth, T, 1, discharge=out, stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert plan.last_kernel() == 'tile'
+            got = out[:, cols_t].cpu().numpy()
+            conv = ref_uh.convolve(depth[:, cols_t].cpu().numpy())
+            d_ref = np.zeros((T, ns))
+            oracle.unit_route(A_in.indptr, A_in.indices, -c1i[A_in.indices], A_in.indptr, A_in.indices, A_in.data, A_hw.indptr, A_hw.indices, A_hw.data,
+                              c1i, c2i, c3i, hw_idx, inner_idx, qc_ref, qf_ref, conv, d_ref, 1)
+            # the router re-seeds q_ch from the state it keeps (q_full on inner reaches) at every file: UnitMuskingum.py:78-79
+            qc_ref[:] = qf_ref
+            q_ch.copy_(q_full)
+            scale = float(np.abs(d_ref).max())
+            err = float(np.abs(got - d_ref).max()) / scale
+            worst = max(worst, err)
+            assert err <= 1e-10, f'call {call}: {err:.3e} of the largest discharge'
+            del depth
+        st = d_state[:, cols_t].cpu().numpy()
+        np.testing.assert_allclose(st, ref_uh.state, rtol=1e-10, atol=1e-10 * float(np.abs(ref_uh.state).max()), err_msg='carried convolution tail')
+    del out, d_kern, d_state
+    torch.cuda.empty_cache()
+    print(f'UnitMuskingum sub-basins: {ns} reaches x {calls * T} steps in {calls} calls against the oracle, worst difference {worst:.2e} of the largest discharge')
