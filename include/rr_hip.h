@@ -153,6 +153,11 @@ int rr_plan_profile_aux(rr_plan *plan, double aux[12]);
 #define RR_KERNEL_DIRECT 2
 int rr_plan_last_kernel(const rr_plan *plan);
 
+/* Byte order of the FLOAT32 rows of the calls to come (rr_*_f32in_dev's lateral / depth rows, rr_*_f32*_dev's discharge rows): non-zero =
+ * big-endian, as a NetCDF-3 file stores them, so that a file's bytes go to the device and come back from it as they are (rr_rows_upload /
+ * rr_rows_download) and the conversion costs one instruction per value in the kernels that read or write the rows anyway.  Default: native. */
+int rr_plan_set_row_format(rr_plan *plan, int in32_big_endian, int out32_big_endian);
+
 /* Tuning / measurement.  rows_per_chunk: time rows moved per permutation launch of the streaming kernel (default 16).
  * sample_every >= 16: HIP-event brackets on the call's stream around sampled routing launches (every fourth launch of the
  * time-tiled kernel; every sample_every-th tick of the streaming kernel opens a bracket of 16 launches); 0 switches it off. */
@@ -345,6 +350,17 @@ int rr_dev_synchronize(int device);
 /* Measured device copy rate (GB/s, bytes read + bytes written) of a 16-byte-per-lane copy kernel over `bytes` bytes,
  * `reps` launches: the achievable HBM rate bench.py reports beside the nominal 8 TB/s. */
 int rr_copy_bandwidth(int device, int64_t bytes, int reps, double *gbps);
+
+/* Rows between a file and a device array, for the routers' qlateral / discharge files (river_route/routers/TransformMuskingum.py:30-36,
+ * Muskingum.py:319-352): n_rows rows of row_bytes bytes that lie in `path` at file_offset, file_pitch bytes apart (a NetCDF-3 fixed variable:
+ * file_pitch = row_bytes; a record variable: the record size), go to / come from device rows dev_pitch bytes apart through pinned staging
+ * chunks (reader / writer threads beside the copy engine): the (time, river) block never exists as a host array.  Bytes move as they are:
+ * a big-endian float32 variable is converted on the device (rr_plan_set_row_format).  stream (may be NULL): work already enqueued there
+ * is finished before the rows move; the functions return when they have. */
+int rr_rows_upload(int device, void *dst_dev, int64_t dst_pitch, const char *path, int64_t file_offset, int64_t file_pitch, int64_t row_bytes,
+                   int64_t n_rows, void *stream);
+int rr_rows_download(int device, const void *src_dev, int64_t src_pitch, const char *path, int64_t file_offset, int64_t file_pitch,
+                     int64_t row_bytes, int64_t n_rows, void *stream);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ import pandas as pd  # noqa: E402
 from scipy.io import netcdf_file  # noqa: E402
 
 import river_route_amd as rr  # noqa: E402
-from river_route_amd import engine, io, synth, tools  # noqa: E402
+from river_route_amd import engine, io, nc3, synth, tools  # noqa: E402
 from river_route_amd.routers import _device, muskingum  # noqa: E402
 
 try:
@@ -69,6 +69,10 @@ io.write_discharge = timed('io.write_discharge (netCDF write, byte order)', io.w
 _device.Arena.put = timed('Arena.put (hipMalloc + pageable hipMemcpy up)', _device.Arena.put)
 engine.DeviceBuffer.download = timed('DeviceBuffer.download (pageable hipMemcpy down)', engine.DeviceBuffer.download)
 engine.Plan.set_coeffs = timed('Plan.set_coeffs', engine.Plan.set_coeffs)
+engine.rows_upload = timed('engine.rows_upload (file -> pinned chunks -> device)', engine.rows_upload)
+engine.rows_download = timed('engine.rows_download (device -> pinned chunks -> file)', engine.rows_download)
+nc3.create_discharge_file = timed('nc3.create_discharge_file (header, time, ids)', nc3.create_discharge_file)
+nc3.locate_rows = timed('nc3.locate_rows + read_vector (header)', nc3.locate_rows)
 for name in ('rapid_route_f32in_dev', 'rapid_route_f32_dev', 'rapid_route_dev', 'reserve'):
     setattr(engine.Plan, name, timed(f'Plan.{name} (enqueue)', getattr(engine.Plan, name)))
 

@@ -99,6 +99,7 @@ _SIGNATURES = {
     'rr_plan_set_unit_weights': (C.c_int, [_vp, _vp, _vp]),
     'rr_plan_reserve': (C.c_int, [_vp, C.c_int, _i64, _i64, C.c_int, _vp]),
     'rr_plan_set_options': (C.c_int, [_vp, _i64, _i64]),
+    'rr_plan_set_row_format': (C.c_int, [_vp, C.c_int, C.c_int]),
     'rr_plan_profile': (C.c_int, [_vp, _vp]),
     'rr_plan_profile_aux': (C.c_int, [_vp, _vp]),
     'rr_rapid_route': (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64]),
@@ -134,6 +135,8 @@ _SIGNATURES = {
     'rr_dev_download': (C.c_int, [C.c_int, _vp, _vp, _i64]),
     'rr_dev_synchronize': (C.c_int, [C.c_int]),
     'rr_copy_bandwidth': (C.c_int, [C.c_int, _i64, C.c_int, C.POINTER(C.c_double)]),
+    'rr_rows_upload': (C.c_int, [C.c_int, _vp, _i64, C.c_char_p, _i64, _i64, _i64, _i64, _vp]),
+    'rr_rows_download': (C.c_int, [C.c_int, _vp, _i64, C.c_char_p, _i64, _i64, _i64, _i64, _vp]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -4,6 +4,9 @@
 
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>

@@ -254,6 +254,14 @@ int rr_plan_set_options(rr_plan *P, int64_t rows_per_chunk, int64_t sample_every
     return RR_OK;
 }
 
+int rr_plan_set_row_format(rr_plan *P, int in32_big_endian, int out32_big_endian)
+{
+    if (!P) return fail(RR_E_INVALID, "rr_plan_set_row_format: null plan");
+    if (P->ses.open) return fail(RR_E_STATE, "rr_plan_set_row_format: a routing call is open");
+    P->in32_big_endian = in32_big_endian != 0; P->out32_big_endian = out32_big_endian != 0;
+    return RR_OK;
+}
+
 int rr_plan_set_coeffs(rr_plan *P, const double *lhs_off_data, const double *c2, const double *c3, const double *c4_dt)
 {
     int rc = need_device(P);
@@ -1009,6 +1017,138 @@ int rr_copy_bandwidth(int device, int64_t bytes, int reps, double *gbps)
     if (rc) return rc;
     *gbps = 2.0 * (double)count * 16.0 * reps / ((double)ms * 1e-3) / 1e9;      // bytes read + bytes written
     return RR_OK;
+}
+
+// ---- rows between a file and the device (the routers' qlateral / discharge files) ----
+//
+// A (rows, row_bytes) block that lies in a file at `file_offset` with `file_pitch` bytes from row to row (NetCDF-3: a fixed variable is
+// contiguous, a record variable has the other record variables of each record between its rows) goes to / comes from a device array without
+// ever existing as a host array: reader threads pread() whole rows into three pinned chunks while the copy engine uploads the chunk
+// before (downloads: the copy engine fills a chunk while writer threads pwrite() the one before).  Byte order is the device's business
+// (rr_plan_set_row_format).  Returns when the block has moved.
+namespace {
+struct RowPipe {
+    static constexpr int kChunks = 3, kThreads = 4;
+    char *pin[kChunks] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[kChunks] = {nullptr, nullptr, nullptr};
+    hipStream_t st = nullptr;
+    int64_t cap = 0;
+    ~RowPipe()
+    {
+        for (int k = 0; k < kChunks; ++k) { if (pin[k]) (void)hipHostFree(pin[k]); if (ev[k]) (void)hipEventDestroy(ev[k]); }
+        if (st) (void)hipStreamDestroy(st);
+    }
+    int prepare(int64_t bytes)
+    {
+        if (!st) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        for (int k = 0; k < kChunks; ++k) if (!ev[k]) HIPCHK(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
+        if (cap >= bytes) return RR_OK;
+        for (int k = 0; k < kChunks; ++k) {
+            if (pin[k]) { (void)hipHostFree(pin[k]); pin[k] = nullptr; }
+            if (hipHostMalloc((void **)&pin[k], (size_t)bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); cap = 0; return fail(RR_E_ALLOC, "rr_rows_*: pinned staging could not be allocated"); }
+        }
+        cap = bytes;
+        return RR_OK;
+    }
+};
+thread_local RowPipe g_row_pipe;
+
+// rows [r0, r1) of the file block <-> packed rows in `buf`, split over the threads; false on a short read / write
+bool file_rows(int fd, bool write, char *buf, int64_t file_offset, int64_t file_pitch, int64_t row_bytes, int64_t r0, int64_t r1)
+{
+    const int64_t rows = r1 - r0;
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(RowPipe::kThreads, rows));
+    std::vector<std::thread> pool;
+    std::vector<int> ok((size_t)nt, 1);
+    for (int t = 0; t < nt; ++t)
+        pool.emplace_back([&, t] {
+            for (int64_t r = r0 + rows * t / nt; r < r0 + rows * (t + 1) / nt; ++r) {
+                char *p = buf + (r - r0) * row_bytes;
+                int64_t done = 0;
+                while (done < row_bytes) {
+                    const ssize_t got = write ? pwrite(fd, p + done, (size_t)(row_bytes - done), (off_t)(file_offset + r * file_pitch + done))
+                                              : pread(fd, p + done, (size_t)(row_bytes - done), (off_t)(file_offset + r * file_pitch + done));
+                    if (got <= 0) { ok[t] = 0; return; }
+                    done += got;
+                }
+            }
+        });
+    for (auto &th : pool) th.join();
+    for (int v : ok) if (!v) return false;
+    return true;
+}
+}  // namespace
+
+static int rows_transfer(int device, bool upload, void *dev, int64_t dev_pitch, const char *path, int64_t file_offset, int64_t file_pitch, int64_t row_bytes,
+                         int64_t n_rows, void *stream)
+{
+    if (device < 0 || device >= rr_device_count()) return fail(RR_E_NO_DEVICE, "rr_rows_*: no such HIP device");
+    if (!dev || !path || row_bytes < 1 || n_rows < 0 || dev_pitch < row_bytes || file_pitch < row_bytes || file_offset < 0) return fail(RR_E_INVALID, "rr_rows_*: bad argument");
+    if (n_rows == 0) return RR_OK;
+    HIPCHK(hipSetDevice(device));
+    const int fd = open(path, upload ? O_RDONLY : O_WRONLY);
+    if (fd < 0) return fail(RR_E_INVALID, std::string("rr_rows_*: cannot open ") + path);
+    RowPipe &R = g_row_pipe;
+    const int64_t chunk_rows = std::max<int64_t>(1, (int64_t{64} << 20) / row_bytes);      // 64 MB: long enough for the copy engine, short enough to overlap
+    int rc = R.prepare(chunk_rows * row_bytes);
+    const int64_t n_chunks = (n_rows + chunk_rows - 1) / chunk_rows;
+    hipError_t e = hipSuccess;
+    if (!rc) {      // the block is used by / comes from work on the caller's stream (NULL: the default stream)
+        hipEvent_t fence = nullptr;
+        e = hipEventCreateWithFlags(&fence, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(fence, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(R.st, fence, 0);
+        if (fence) (void)hipEventDestroy(fence);
+    }
+    bool io_ok = true;
+    if (!rc && e == hipSuccess) {
+        if (upload) {
+            for (int64_t c = 0; c < n_chunks && io_ok && e == hipSuccess; ++c) {
+                const int k = (int)(c % RowPipe::kChunks);
+                const int64_t r0 = c * chunk_rows, r1 = std::min(n_rows, r0 + chunk_rows);
+                if (c >= RowPipe::kChunks) e = hipEventSynchronize(R.ev[k]);      // the chunk that used this buffer has left
+                if (e != hipSuccess) break;
+                io_ok = file_rows(fd, false, R.pin[k], file_offset, file_pitch, row_bytes, r0, r1);
+                if (!io_ok) break;
+                e = hipMemcpy2DAsync((char *)dev + r0 * dev_pitch, (size_t)dev_pitch, R.pin[k], (size_t)row_bytes, (size_t)row_bytes, (size_t)(r1 - r0), hipMemcpyHostToDevice, R.st);
+                if (e == hipSuccess) e = hipEventRecord(R.ev[k], R.st);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(R.st);
+        } else {
+            // chunk c is downloaded while chunk c - 1 is written
+            auto fetch = [&](int64_t c) {
+                const int k = (int)(c % RowPipe::kChunks);
+                const int64_t r0 = c * chunk_rows, r1 = std::min(n_rows, r0 + chunk_rows);
+                hipError_t ee = hipMemcpy2DAsync(R.pin[k], (size_t)row_bytes, (const char *)dev + r0 * dev_pitch, (size_t)dev_pitch, (size_t)row_bytes, (size_t)(r1 - r0), hipMemcpyDeviceToHost, R.st);
+                if (ee == hipSuccess) ee = hipEventRecord(R.ev[k], R.st);
+                return ee;
+            };
+            e = fetch(0);
+            for (int64_t c = 0; c < n_chunks && io_ok && e == hipSuccess; ++c) {
+                const int k = (int)(c % RowPipe::kChunks);
+                if (c + 1 < n_chunks) e = fetch(c + 1);      // (buffer (c + 1) % 3 was written out two iterations ago)
+                if (e == hipSuccess) e = hipEventSynchronize(R.ev[k]);
+                if (e != hipSuccess) break;
+                const int64_t r0 = c * chunk_rows, r1 = std::min(n_rows, r0 + chunk_rows);
+                io_ok = file_rows(fd, true, R.pin[k], file_offset, file_pitch, row_bytes, r0, r1);
+            }
+        }
+    }
+    (void)close(fd);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(RR_E_HIP, std::string("rr_rows_*: ") + hipGetErrorString(e));
+    if (!io_ok) return fail(RR_E_INVALID, std::string("rr_rows_*: short read or write on ") + path);
+    return RR_OK;
+}
+
+int rr_rows_upload(int device, void *dst_dev, int64_t dst_pitch, const char *path, int64_t file_offset, int64_t file_pitch, int64_t row_bytes, int64_t n_rows, void *stream)
+{
+    return rows_transfer(device, true, dst_dev, dst_pitch, path, file_offset, file_pitch, row_bytes, n_rows, stream);
+}
+
+int rr_rows_download(int device, const void *src_dev, int64_t src_pitch, const char *path, int64_t file_offset, int64_t file_pitch, int64_t row_bytes, int64_t n_rows, void *stream)
+{
+    return rows_transfer(device, false, const_cast<void *>(src_dev), src_pitch, path, file_offset, file_pitch, row_bytes, n_rows, stream);
 }
 
 int rr_dev_synchronize(int device)

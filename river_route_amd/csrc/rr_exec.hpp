@@ -169,6 +169,7 @@ struct rr_plan {
     int32_t direct_block = 0;            // tile capacity the plan was built with (rr_plan_set_boundary lays the direct plan out again)
     int64_t n_kholes = 0;
     int32_t n_kwide = 0;
+    bool in32_big_endian = false, out32_big_endian = false;      // rr_plan_set_row_format: float32 rows as a big-endian file stores them
     bool lean_enabled = true;           // RR_TILE_LEAN=0 (tests): the general tick for every call
     bool uh_pairs = true;               // the fused convolution takes two record batches per launch where it can (RR_UH_PAIRS=0: tests)
     bool perm_ready = false;            // the streaming kernel's tiled permutations are on the device
@@ -647,6 +648,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         da.in = S.has_in ? io.dev_in : nullptr; da.out = io.dev_out; da.n = n; da.in_rows = (uint32_t)std::max<int64_t>(1, io.rows_in); da.out_rows = (uint32_t)std::max<int64_t>(1, io.rows_out);
         da.in32 = S.has_in ? io.dev_in32 : nullptr; da.out32 = io.dev_out32; da.factor = (int32_t)std::max<int64_t>(1, io.out_factor);
         da.nsub = (int32_t)nsub; da.inv_nsub = 1.0 / (double)nsub;
+        da.in32_sel = P->in32_big_endian ? kSelSwap : kSelNative; da.out32_sel = P->out32_big_endian ? kSelSwap : kSelNative;
         da.rec = P->d_ring; da.rec_chunks = (uint32_t)std::max<int64_t>(1, S.rec_chunks); da.np = (int32_t)TP.np;
         da.K = (int32_t)K; da.total = (int32_t)S.T;
         da.exports = export_series; da.n_export = (int32_t)P->n_export;
@@ -923,6 +925,7 @@ void launch_ghost_permute(rr_plan *P, int64_t batch)
 {
     Session &S = P->ses;
     RecPermArgs ra{};
+    ra.in32_sel = P->in32_big_endian ? kSelSwap : kSelNative; ra.out32_sel = P->out32_big_endian ? kSelSwap : kSelNative;
     // (direct row path: the ghosts' records are those of the skeleton's positions that mirror them)
     ra.rec = P->d_ring; ra.rec_chunks = Div32((uint32_t)S.rec_chunks); ra.n = P->n_ghost; ra.np = S.rows_direct ? P->dp.skel.np : P->tp.np; ra.T = S.total; ra.total = S.total;
     ra.batch = batch; ra.nsub = Div32(1u); ra.colmeta = S.rows_direct ? P->d_kghostmeta : P->d_ghostmeta; ra.scale = nullptr;
@@ -952,6 +955,7 @@ void launch_rec_permute(rr_plan *P, bool in, int64_t batch, int count = 1)
     Session &S = P->ses;
     const int64_t n = P->h.n;
     RecPermArgs ra{};
+    ra.in32_sel = P->in32_big_endian ? kSelSwap : kSelNative; ra.out32_sel = P->out32_big_endian ? kSelSwap : kSelNative;
     ra.rec = P->d_ring; ra.rec_chunks = Div32((uint32_t)S.rec_chunks); ra.n = n; ra.np = P->tp.np; ra.T = S.T; ra.total = S.total; ra.batch = batch;
     ra.nsub = Div32((uint32_t)S.nsub);
     ra.colmeta = P->d_colmeta;
@@ -1154,6 +1158,7 @@ int session_advance_direct(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, 
             done = std::min(done, std::min(sk, S.total));
             while (S.out_batches < S.n_out_batches && done >= std::min(kRecRows * (S.out_batches + 1), S.total)) {
                 RecPermArgs ra{};
+    ra.in32_sel = P->in32_big_endian ? kSelSwap : kSelNative; ra.out32_sel = P->out32_big_endian ? kSelSwap : kSelNative;
                 ra.rec = P->d_ring; ra.rec_chunks = Div32((uint32_t)S.rec_chunks); ra.n = P->n_kholes; ra.np = TP.np; ra.T = S.T; ra.total = S.total;
                 ra.batch = S.out_batches; ra.nsub = Div32((uint32_t)S.nsub); ra.colmeta = P->d_kholemeta; ra.cols = P->d_kholecol; ra.scale = nullptr;
                 ra.rows = RowView{S.io.dev_out, n, 0, (uint32_t)std::max<int64_t>(1, S.io.rows_out)};

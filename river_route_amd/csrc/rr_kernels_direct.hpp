@@ -65,6 +65,7 @@ struct DirectArgs {
     int32_t factor;
     int32_t nsub;               // SUB: routing sub-steps per row (2 ... kDirectMaxSub); the row's output is their mean
     double inv_nsub;
+    uint32_t in32_sel, out32_sel;   // byte selectors of the float32 rows (kSelNative / kSelSwap, rr_plan_set_row_format)
 };
 constexpr int kDirectMaxSub = 4;      // a hole's lateral value goes into `nsub` ring slots at once: with more the send wave's turn (every eight ticks) could come too late
 constexpr int32_t kDirectHoleBit = rr::kDirectHole;
@@ -297,7 +298,9 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             for (int j = 0; j < AR; ++j) request(j, Pa[j]);
             int32_t in_b = 0;
             auto park = [&](const Pt &pa, int32_t arrival) {      // into the window, scaled (the ring of k_tile holds c4dt * lateral too)
-                const double x0 = (double)pa.x * c4a0, x1 = (double)pa.y * c4a1;
+                double x0, x1;
+                if constexpr (IN32) { x0 = (double)f32_from_file(pa.x, a.in32_sel) * c4a0; x1 = (double)f32_from_file(pa.y, a.in32_sel) * c4a1; }
+                else { x0 = pa.x * c4a0; x1 = pa.y * c4a1; }
                 *reinterpret_cast<double2 *>(F + in_b + ca * 8) = make_double2(x0, x1);
                 in_b = in_b + kRowB == wrap ? 0 : in_b + kRowB;
                 if (wave_holes) {      // wave-uniform
@@ -393,8 +396,8 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                                 cnt = 0;
                                 const bool one = a.factor == 1;
                                 f32x2 fa, fb;
-                                fa.x = (float)(one ? sa.x : sa.x / fdiv); fa.y = (float)(one ? sa.y : sa.y / fdiv);
-                                fb.x = (float)(one ? sb.x : sb.x / fdiv); fb.y = (float)(one ? sb.y : sb.y / fdiv);
+                                fa.x = f32_to_file((float)(one ? sa.x : sa.x / fdiv), a.out32_sel); fa.y = f32_to_file((float)(one ? sa.y : sa.y / fdiv), a.out32_sel);
+                                fb.x = f32_to_file((float)(one ? sb.x : sb.x / fdiv), a.out32_sel); fb.y = f32_to_file((float)(one ? sb.y : sb.y / fdiv), a.out32_sel);
                                 const __amdgpu_buffer_rsrc_t dst = make_rsrc(row32, tile_end);
                                 store_f32x2_nt(dst, va, fa);
                                 store_f32x2_nt(dst, vb, fb);

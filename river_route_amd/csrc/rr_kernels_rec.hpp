@@ -37,7 +37,20 @@ struct RecPermArgs {
     const int32_t *cols;      // k_rec_out: column of the destination rows each of the n records' columns goes to (the holes of the direct row path), or NULL: column i
     int32_t swizzle;          // column tiles in XCD-contiguous order (rr_common.hpp: xcd_swizzle)
     int32_t clamp;            // k_rec_out: 0 records hold final values (sub-steps), 1 clamp at zero, 2 clamp all but headwater columns (UnitMuskingum)
+    uint32_t in32_sel, out32_sel;   // byte selectors of the float32 rows (rr_plan_set_row_format): kSelNative, or kSelSwap for a big-endian file's rows
 };
+// v_perm_b32 selectors: the four bytes of a word as they are / reversed (a NetCDF-3 file stores big-endian values)
+constexpr uint32_t kSelNative = 0x03020100u, kSelSwap = 0x00010203u;
+__device__ __forceinline__ float f32_from_file(float raw, uint32_t sel)
+{
+    uint32_t bits;
+    __builtin_memcpy(&bits, &raw, 4);
+    bits = __builtin_amdgcn_perm(bits, bits, sel);
+    float v;
+    __builtin_memcpy(&v, &bits, 4);
+    return v;
+}
+__device__ __forceinline__ float f32_to_file(float v, uint32_t sel) { return f32_from_file(v, sel); }
 constexpr int32_t kColHeadwater = 1 << 30;      // colmeta[].y: lag | this flag
 
 constexpr int kRecTileRows = 16 * kRecBatch + 15;      // tick-rows behind one batch of records
@@ -141,7 +154,7 @@ __global__ __launch_bounds__(kRecInThreads) void k_rec_in(const RecPermArgs a)
         for (int q = 0; q < RPT; ++q) {
             const int64_t t = row_first + min(r0 + q * (kRecInThreads / kRecInCols), need - 1);
             const int64_t off = a.rows.offset(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t)) + i;
-            v[q] = IN32 ? (double)a.rows_in32[off] : a.rows.base[off];
+            v[q] = IN32 ? (double)f32_from_file(a.rows_in32[off], a.in32_sel) : a.rows.base[off];
         }
     }
 #pragma unroll
@@ -210,7 +223,7 @@ __global__ __launch_bounds__(uh_threads(BATCHES)) void k_rec_in_uh(const RecPerm
             for (int q = 0; q < DPT; ++q) {
                 const int64_t t = row_first - (NK - 1) + min(g + q * G, need + NK - 2);
                 const int64_t off = a.rows.offset(t < 0 ? 0 : (t >= a.T ? a.T - 1 : t)) + i;
-                dv[q] = IN32 ? (double)a.rows_in32[off] : a.rows.base[off];
+                dv[q] = IN32 ? (double)f32_from_file(a.rows_in32[off], a.in32_sel) : a.rows.base[off];
             }
         } else {
             // load q reads the cyclic row (tb + G q - t0) mod rows: one division, for the first q whose row cannot be negative,
@@ -227,7 +240,7 @@ __global__ __launch_bounds__(uh_threads(BATCHES)) void k_rec_in_uh(const RecPerm
 #pragma unroll
             for (int q = 0; q < DPT; ++q) {
                 const int64_t off = (int64_t)m[q] * a.rows.ld + i;
-                dv[q] = IN32 ? (double)a.rows_in32[off] : a.rows.base[off];
+                dv[q] = IN32 ? (double)f32_from_file(a.rows_in32[off], a.in32_sel) : a.rows.base[off];
             }
         }
 #pragma unroll
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(kRecOutThreads) void k_rec_out(const RecPermArgs a)
             const int nsub = SUB ? (int)a.nsub.d : 1;
             double acc = out(recs[c][o + q * step + nsub - 1]);
             for (int j = 1; j < (int)a.factor.d; ++j) acc += out(recs[c][o + q * step + j * nsub + nsub - 1]);
-            a.rows32[(q0 + q) * a.rows.ld + io] = (float)(a.factor.d > 1 ? acc / (double)a.factor.d : acc);
+            a.rows32[(q0 + q) * a.rows.ld + io] = f32_to_file((float)(a.factor.d > 1 ? acc / (double)a.factor.d : acc), a.out32_sel);
         }
     } else {
         for (int r = tid / kRecOutCols; r < kRecRows; r += kRecOutThreads / kRecOutCols) {

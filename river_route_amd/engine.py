@@ -12,7 +12,7 @@ from . import _lib
 from ._lib import RRError, check, ptr
 
 __all__ = ['Plan', 'RRError', 'uh_convolve', 'uh_convolve_dev', 'runoff_to_qlateral', 'DeviceBuffer', 'partition_forest', 'synchronize',
-           'resample_cast_dev', 'copy_bandwidth', 'runoff_to_qlateral_dev']
+           'resample_cast_dev', 'copy_bandwidth', 'runoff_to_qlateral_dev', 'rows_upload', 'rows_download']
 
 
 MODE_RAPID, MODE_MUSKINGUM, MODE_UNIT = 0, 1, 2      # include/rr_hip.h: RR_MODE_*
@@ -103,6 +103,10 @@ class Plan:
 
     def set_options(self, rows_per_chunk: int = 0, sample_every: int = -1) -> None:
         check(_lib.lib().rr_plan_set_options(self._h, int(rows_per_chunk), int(sample_every)))
+
+    def set_row_format(self, in32_big_endian: bool = False, out32_big_endian: bool = False) -> None:
+        """rr_plan_set_row_format: the float32 rows of the calls to come are big-endian (a NetCDF-3 file's bytes as they are)."""
+        check(_lib.lib().rr_plan_set_row_format(self._h, int(bool(in32_big_endian)), int(bool(out32_big_endian))))
 
     def profile(self) -> dict:
         p = np.zeros(10, dtype=np.float64)
@@ -419,6 +423,16 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def rows_upload(dst, dst_pitch: int, path, file_offset: int, file_pitch: int, row_bytes: int, n_rows: int, device: int = 0, stream=None) -> None:
+    """rr_rows_upload: rows of a file straight into a device array (pinned staging, reader threads beside the copy engine)."""
+    check(_lib.lib().rr_rows_upload(int(device), ptr(dst), int(dst_pitch), str(path).encode(), int(file_offset), int(file_pitch), int(row_bytes), int(n_rows), stream))
+
+
+def rows_download(src, src_pitch: int, path, file_offset: int, file_pitch: int, row_bytes: int, n_rows: int, device: int = 0, stream=None) -> None:
+    """rr_rows_download: device rows straight into (an existing region of) a file."""
+    check(_lib.lib().rr_rows_download(int(device), ptr(src), int(src_pitch), str(path).encode(), int(file_offset), int(file_pitch), int(row_bytes), int(n_rows), stream))
 
 
 def copy_bandwidth(device: int = 0, nbytes: int = 1 << 31, reps: int = 10) -> float:

@@ -39,6 +39,42 @@ class RapidMuskingum(TransformMuskingum):
         with Arena(self.cfg.device) as arena:
             return self._route_on_device(arena, arena.put(ql), ql.shape[0], rows_per_output)
 
+    def _route_file_to_file(self, rows, dates_out, discharge_file, runoff_file):
+        """One qlateral file whose float32 rows lie flat in the file (nc3.RowBlock) -> the discharge file, without the (time, river)
+        block ever being a host array: engine.rows_upload (page cache -> pinned chunks -> device), rr_rapid_route_f32in_dev with the
+        file's byte order converted in the kernels that read and write the rows (Plan.set_row_format), the discharge file's header
+        (nc3.create_discharge_file: the layout of Muskingum.py:337-351), engine.rows_download.  Returns the final state, or None where
+        the fused float32 form does not apply or the file does not fit the card (the caller then takes the file as an array)."""
+        from .. import nc3
+        from .._lib import RR_E_ALLOC, RR_E_UNSUPPORTED, RRError
+        from ..engine import rows_download, rows_upload
+        from ._device import Arena, DeviceOutOfMemory
+        T, n, nsub, per = rows.rows, self.A.shape[0], self.num_routing_steps_per_runoff, self.num_runoff_steps_per_discharge
+        if T != self.num_runoff_steps:
+            raise ValueError(f'lateral inflow has shape ({T}, {rows.cols}), expected ({self.num_runoff_steps}, {n}) from the time options')
+        self._lateral_coefficient()
+        dev = self.cfg.device
+        try:
+            with Arena(dev) as arena:
+                d_ql = arena.empty(T * n * 4)
+                d_out = arena.empty((T // per) * n * 4)
+                d_q = arena.put(np.array(self.channel_state, dtype=np.float64, order='C'))
+                rows_upload(d_ql, n * 4, rows.path, rows.offset, rows.pitch, n * 4, T, device=dev)
+                self._plan.set_row_format(rows.big_endian, True)      # a NetCDF-3 discharge file: big-endian rows out
+                try:
+                    self._plan.rapid_route_f32in_dev(d_q, d_ql, T, T, nsub, discharge32=d_out, factor=per)
+                finally:
+                    self._plan.set_row_format(False, False)
+                out = nc3.create_discharge_file(discharge_file, dates_out, self.river_ids, self.cfg.var_river_id, self.cfg.var_discharge, runoff_file)
+                rows_download(d_out, n * 4, out.path, out.offset, out.pitch, n * 4, T // per, device=dev)
+                return d_q.download(np.float64, (n,))
+        except DeviceOutOfMemory:
+            return None
+        except RRError as e:
+            if e.code not in (RR_E_UNSUPPORTED, RR_E_ALLOC):
+                raise
+            return None
+
     def _route_on_device_f32in(self, arena, d_ql32, T: int, rows_per_output: int) -> tuple[np.ndarray, np.ndarray]:
         """Lateral volumes on the device as (T, n) float32 rows -> (final state, float32 discharge rows): rr_rapid_route_f32in_dev,
         bit for bit what the float64 rows give (float32 -> float64 is exact)."""

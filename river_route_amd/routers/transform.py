@@ -25,6 +25,10 @@ class TransformMuskingum(Muskingum, ABC):
             from ..io import read_qlateral
             for lateral_file, discharge_file in zip(self.cfg.qlateral_files, self.cfg.discharge_files):
                 self.logger.info('-' * 60)
+                rows = self._file_rows(lateral_file)
+                if rows is not None:      # a NetCDF-3 float32 file: its rows go from the page cache to the device as they are (nc3.py)
+                    yield rows[0], rows[1], lateral_file, discharge_file
+                    continue
                 # a router that converts on the device takes a float32 file as float32 (RapidMuskingum: rr_rapid_route_f32in_dev)
                 keep32 = self._device_postprocess and hasattr(self, '_route_on_device_f32in') and \
                     type(self)._router is getattr(type(self), '_engine_router', None)
@@ -49,6 +53,24 @@ class TransformMuskingum(Muskingum, ABC):
                 ds = runoff_to_qlateral(runoff_file, as_volumes=self._as_volumes, **kw)
                 yield (ds['time'].values.astype('datetime64[s]'),
                        ds['qlateral'].values.astype(np.float64, copy=False), runoff_file, discharge_file)
+
+    def _file_rows(self, lateral_file):
+        """(dates, nc3.RowBlock) where the router can take a qlateral file's rows straight from the file -- a flat (NetCDF-3) float32
+        variable, the router's own engine path and the default discharge writer -- else None."""
+        if not (self._device_postprocess and hasattr(self, '_route_file_to_file') and hasattr(self._plan, 'rapid_route_dev')
+                and type(self)._router is getattr(type(self), '_engine_router', None) and '_write_discharges' not in self.__dict__
+                and type(self)._write_discharges is Muskingum._write_discharges):
+            return None
+        from .. import nc3
+        from ..io import _decode_cf_time
+        blk = nc3.locate_rows(lateral_file, 'qlateral')
+        if blk is None or blk.dtype.kind != 'f' or blk.dtype.itemsize != 4 or blk.cols != self.A.shape[0] or blk.rows < 2:
+            return None
+        try:
+            values, atts = nc3.read_vector(lateral_file, self.cfg.var_t)
+            return _decode_cf_time(values, atts['units']), blk
+        except (KeyError, ValueError):
+            return None
 
     def _takes_runoff_source(self) -> bool:
         return (self._device_postprocess and hasattr(self, '_route_on_device') and hasattr(self._plan, 'rapid_route_dev')
@@ -157,7 +179,16 @@ class TransformMuskingum(Muskingum, ABC):
             self._set_network_and_time_dependent_vectors(dates)
             self.logger.debug('Starting routing computation')
             t0 = time.perf_counter()
-            q_t, q_array = self._route_one_file(qlateral)
+            from ..nc3 import RowBlock
+            written = False
+            if isinstance(qlateral, RowBlock):
+                q_t = self._route_file_to_file(qlateral, dates[::self.num_runoff_steps_per_discharge], discharge_file, runoff_file)
+                written = q_t is not None
+                if not written:      # the fused form does not apply to this call, or the file does not fit the card: the file as an array
+                    from ..io import read_qlateral
+                    qlateral = read_qlateral(runoff_file, self.cfg.var_t, keep_float32=True)[1]
+            if not written:
+                q_t, q_array = self._route_one_file(qlateral)
             seconds = time.perf_counter() - t0
             reach_steps = self.A.shape[0] * self.num_runoff_steps * self.num_routing_steps_per_runoff
             self.logger.log(PROGRESS, f'{reach_steps / max(seconds, 1e-9):.3e} reach-steps/s '
@@ -169,8 +200,9 @@ class TransformMuskingum(Muskingum, ABC):
             if self.num_runoff_steps_per_discharge > 1:
                 self.logger.debug('Resampling dates and discharges to specified timestep')
                 dates = dates[::self.num_runoff_steps_per_discharge]
-            self.logger.debug('Writing Discharge Array to File')
-            self._write_discharges(dates, q_array, discharge_file, runoff_file)
+            if not written:
+                self.logger.debug('Writing Discharge Array to File')
+                self._write_discharges(dates, q_array, discharge_file, runoff_file)
         if not sequential:
             self._ensemble_member_states = members
             self.channel_state = np.mean(np.array(members), axis=0)

@@ -291,6 +291,63 @@ def test_float32_qlateral_file_routes_like_its_float64_copy(backend, case):
     np.testing.assert_array_equal(results['f4'][1], results['f8'][1])
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('record', [False, True])
+def test_float32_file_goes_from_file_to_file_without_a_host_array(case, record, monkeypatch):
+    """A float32 NetCDF-3 qlateral file (fixed variable, or `time` as the record dimension: rows with the time values between them) is
+    routed file to file: nc3.locate_rows -> engine.rows_upload -> rr_rapid_route_f32in_dev with the big-endian bytes converted in the
+    kernels -> nc3.create_discharge_file -> engine.rows_download; io.read_qlateral and io.write_discharge are never called.  The
+    discharge file read back through scipy equals what the same files give through the array path (a custom writer switches it on),
+    bit for bit; layout and attributes are the reference's (Muskingum.py:337-351)."""
+    from scipy.io import netcdf_file
+    from river_route_amd import io as rr_io
+    g, tmp = case['g'], case['tmp']
+    files = []
+    series = [np.vstack([g['vol0'], g['vol1']]), np.vstack([g['vol1'], g['vol0']])]      # 48 hourly rows a file: the time-tiled kernel takes calls of 32 rows or more
+    for i in range(2):
+        path = str(tmp / f'f4_{int(record)}_ql{i}.nc')
+        files.append(path)
+        with netcdf_file(path, 'w', version=2) as ds:
+            T, n = series[i].shape
+            ds.createDimension('time', None if record else T)
+            ds.createDimension('river_id', n)
+            tv = ds.createVariable('time', 'f8', ('time',))
+            tv.units = 'seconds since 1970-01-01 00:00:00'
+            tv[:] = float(g['dates0'][0]) + 3600.0 * (T * i + np.arange(T))
+            v = ds.createVariable('qlateral', 'f4', ('time', 'river_id'))
+            v[:] = series[i].astype(np.float32)
+    kw = dict(params_file=case['params'], qlateral_files=files, channel_state_init_file=case['init'], dt_routing=3600, dt_discharge=2 * 3600, log=False)
+    (tmp / 'arrays').mkdir()
+    want = []
+    r0 = rr.RapidMuskingum(discharge_dir=str(tmp / 'arrays'), **kw)
+    r0.set_write_discharges(lambda dates, q, q_file, routed_file='': want.append((np.array(dates), np.array(q))))      # a custom writer: the array path
+    r0.route()
+    (tmp / 'files').mkdir()
+
+    def never(*a, **k):
+        raise AssertionError('the file-to-file path must not read or write the block as a host array')
+    monkeypatch.setattr(rr_io, 'read_qlateral', never)
+    monkeypatch.setattr(rr_io, 'write_discharge', never)
+    r1 = rr.RapidMuskingum(discharge_dir=str(tmp / 'files'), **kw).route()
+    np.testing.assert_array_equal(r1.channel_state, r0.channel_state)
+    for i in range(2):
+        with netcdf_file(str(tmp / 'files' / f'discharge_f4_{int(record)}_ql{i}.nc'), 'r', mmap=False) as ds:
+            q = np.array(ds.variables['Q'][:], dtype=np.float32)
+            np.testing.assert_array_equal(q, want[i][1])
+            np.testing.assert_array_equal(np.array(ds.variables['river_id'][:]), g['river_ids'])
+            secs = np.array(ds.variables['time'][:])
+            assert ds.variables['time'].units.decode() == 'seconds since ' + str(want[i][0][0].astype('datetime64[s]')).replace('T', ' ')
+            np.testing.assert_array_equal(secs, (want[i][0] - want[i][0][0]).astype('timedelta64[s]').astype(np.float64))
+            assert ds.variables['Q'].units == b'm3 s-1' and ds.runoff_file.decode() == files[i]
+    # three rows per output row do not divide a batch of 128: the fused float32 form does not apply, and the file is routed as an array
+    monkeypatch.undo()
+    (tmp / 'thirds').mkdir()
+    r2 = rr.RapidMuskingum(discharge_dir=str(tmp / 'thirds'), **dict(kw, dt_discharge=3 * 3600)).route()
+    with netcdf_file(str(tmp / 'thirds' / f'discharge_f4_{int(record)}_ql0.nc'), 'r', mmap=False) as ds:
+        assert ds.variables['Q'].shape[0] == series[0].shape[0] // 3
+    np.testing.assert_array_equal(r2.channel_state, r0.channel_state)
+
+
 def test_float32_runoff_depths_route_like_their_float64_copy(backend, case):
     """UnitMuskingum fed float32 runoff depths (what a float32 file yields) takes them to the device as float32
     (rr_unit_route_uh_f32in_dev where the engine offers it, its float64 path otherwise): discharge, router state and UH state are
