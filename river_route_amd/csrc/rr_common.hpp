@@ -76,6 +76,19 @@ struct RowView {
     __device__ __forceinline__ double *row(int64_t t) const { return base + offset(t); }
 };
 
+// v_perm_b32 selectors: the four bytes of a word as they are / reversed (a NetCDF-3 file stores big-endian values)
+constexpr uint32_t kSelNative = 0x03020100u, kSelSwap = 0x00010203u;
+__device__ __forceinline__ float f32_from_file(float raw, uint32_t sel)
+{
+    uint32_t bits;
+    __builtin_memcpy(&bits, &raw, 4);
+    bits = __builtin_amdgcn_perm(bits, bits, sel);
+    float v;
+    __builtin_memcpy(&v, &bits, 4);
+    return v;
+}
+__device__ __forceinline__ float f32_to_file(float v, uint32_t sel) { return f32_from_file(v, sel); }
+
 inline dim3 grid1(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
 // Workgroups are handed to the eight XCDs in turn (blockIdx % 8 labels the workgroups that share an XCD and its L2, cdna

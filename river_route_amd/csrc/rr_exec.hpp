@@ -1580,9 +1580,10 @@ int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io_in, int64
         const dim3 gt((unsigned)((n + kUhTailThreads - 1) / kUhTailThreads));
         const int32_t nks = (int32_t)io.uh_nks;
         if (io.dev_in32) {      // float32 depth rows
-            if (nks <= 16) hipLaunchKernelGGL((k_uh_tail<16, float>), gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in32, T, nks, n);
-            else if (nks <= 48) hipLaunchKernelGGL((k_uh_tail<48, float>), gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in32, T, nks, n);
-            else hipLaunchKernelGGL((k_uh_tail<0, float>), gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in32, T, nks, n);
+            const uint32_t sel = P->in32_big_endian ? kSelSwap : kSelNative;
+            if (nks <= 16) hipLaunchKernelGGL((k_uh_tail<16, float>), gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in32, T, nks, n, sel);
+            else if (nks <= 48) hipLaunchKernelGGL((k_uh_tail<48, float>), gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in32, T, nks, n, sel);
+            else hipLaunchKernelGGL((k_uh_tail<0, float>), gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in32, T, nks, n, sel);
         }
         else if (nks <= 16) hipLaunchKernelGGL(k_uh_tail<16>, gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in, T, nks, n);
         else if (nks <= 48) hipLaunchKernelGGL(k_uh_tail<48>, gt, dim3(kUhTailThreads), 0, stream, io.uh_kernel, uh_state_inout, io.dev_in, T, nks, n);

@@ -39,18 +39,7 @@ struct RecPermArgs {
     int32_t clamp;            // k_rec_out: 0 records hold final values (sub-steps), 1 clamp at zero, 2 clamp all but headwater columns (UnitMuskingum)
     uint32_t in32_sel, out32_sel;   // byte selectors of the float32 rows (rr_plan_set_row_format): kSelNative, or kSelSwap for a big-endian file's rows
 };
-// v_perm_b32 selectors: the four bytes of a word as they are / reversed (a NetCDF-3 file stores big-endian values)
-constexpr uint32_t kSelNative = 0x03020100u, kSelSwap = 0x00010203u;
-__device__ __forceinline__ float f32_from_file(float raw, uint32_t sel)
-{
-    uint32_t bits;
-    __builtin_memcpy(&bits, &raw, 4);
-    bits = __builtin_amdgcn_perm(bits, bits, sel);
-    float v;
-    __builtin_memcpy(&v, &bits, 4);
-    return v;
-}
-__device__ __forceinline__ float f32_to_file(float v, uint32_t sel) { return f32_from_file(v, sel); }
+
 constexpr int32_t kColHeadwater = 1 << 30;      // colmeta[].y: lag | this flag
 
 constexpr int kRecTileRows = 16 * kRecBatch + 15;      // tick-rows behind one batch of records

@@ -183,8 +183,12 @@ __global__ __launch_bounds__(kUhThreads) void k_uh_convolve_ring(const double *_
 // registers (static indices, n_ks <= NK); NK == 0: any n_ks, straight from memory.
 template <int NK, typename TIn = double>      // TIn: the rows' type (float: runoff depths as the file stores them, exact in float64)
 __global__ __launch_bounds__(kUhTailThreads) void k_uh_tail(const double *__restrict__ kernel, double *__restrict__ state,
-                                                            const TIn *__restrict__ lateral, int64_t T, int32_t n_ks, int64_t n)
+                                                            const TIn *__restrict__ lateral, int64_t T, int32_t n_ks, int64_t n, uint32_t sel = kSelNative)
 {
+    auto row_value = [&](int64_t off) -> double {      // (float rows may be a big-endian file's: rr_plan_set_row_format)
+        if constexpr (std::is_same<TIn, float>::value) return (double)f32_from_file(lateral[off], sel);
+        else return (double)lateral[off];
+    };
     const int64_t i = (int64_t)blockIdx.x * kUhTailThreads + threadIdx.x;
     if (i >= n) return;
     if (NK > 0) {
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(kUhTailThreads) void k_uh_tail(const double *__rest
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             kv[k] = k < n_ks ? kernel[(int64_t)k * n + i] : 0.0;
-            lat[k] = (k < n_ks - 1 && k < T) ? (double)lateral[(T - 1 - k) * n + i] : 0.0;
+            lat[k] = (k < n_ks - 1 && k < T) ? row_value((T - 1 - k) * n + i) : 0.0;
         }
 #pragma unroll
         for (int s = 0; s < NK; ++s) {
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(kUhTailThreads) void k_uh_tail(const double *__rest
             for (int32_t k = s + 1; k < n_ks; ++k) {
                 const int64_t tt = m - k;
                 if (tt < 0) break;
-                acc += kernel[(int64_t)k * n + i] * (double)lateral[tt * n + i];
+                acc += kernel[(int64_t)k * n + i] * row_value(tt * n + i);
             }
             state[(int64_t)s * n + i] = s == n_ks - 1 ? 0.0 : acc;
         }

@@ -75,6 +75,48 @@ class UnitMuskingum(TransformMuskingum):
         with Arena(self.cfg.device) as arena:
             return self._route_on_device(arena, arena.put(depth), depth.shape[0], rows_per_output)
 
+    def _route_file_to_file(self, rows, dates_out, discharge_file, runoff_file):
+        """One runoff-depth file whose float32 rows lie flat in the file (nc3.RowBlock) -> the discharge file without a host array of
+        either: engine.rows_upload, rr_unit_route_uh_f32in_dev (convolution fused in, the file's byte order converted in the kernels),
+        nc3.create_discharge_file, engine.rows_download.  Returns the router state (UnitMuskingum.py:95-97), or None where the fused
+        form does not apply or the file does not fit the card -- the UH state is then as it was."""
+        from .. import nc3
+        from .._lib import RR_E_ALLOC, RR_E_UNSUPPORTED, RRError
+        from ..engine import rows_download, rows_upload
+        from ._device import Arena, DeviceOutOfMemory
+        self._check_kernel()
+        T, n, nsub, per = rows.rows, self.A.shape[0], self.num_routing_steps_per_runoff, self.num_runoff_steps_per_discharge
+        if T != self.num_runoff_steps:
+            raise ValueError(f'lateral inflow has shape ({T}, {rows.cols}), expected ({self.num_runoff_steps}, {n}) from the time options')
+        n_ks = self._uh.kernel.shape[0]
+        self._upload_coefficients(None, ('unit',))
+        seed = self._seed()
+        dev = self.cfg.device
+        try:
+            with Arena(dev) as arena:
+                d_depth = arena.empty(T * n * 4)
+                d_out = arena.empty((T // per) * n * 4)
+                d_kern = arena.put(self._uh.kernel)
+                d_state = arena.put(np.ascontiguousarray(self._uh.state, dtype=np.float64))
+                d_qch, d_qfull, d_final = arena.put(seed), arena.put(seed), arena.empty(n * 8)
+                rows_upload(d_depth, n * 4, rows.path, rows.offset, rows.pitch, n * 4, T, device=dev)
+                self._plan.set_row_format(rows.big_endian, True)
+                try:
+                    self._plan.unit_route_uh_f32in_dev(d_qch, d_qfull, d_final, d_kern, d_state, n_ks, d_depth, T, nsub, discharge32=d_out, factor=per)
+                finally:
+                    self._plan.set_row_format(False, False)
+                out = nc3.create_discharge_file(discharge_file, dates_out, self.river_ids, self.cfg.var_river_id, self.cfg.var_discharge, runoff_file)
+                rows_download(d_out, n * 4, out.path, out.offset, out.pitch, n * 4, T // per, device=dev)
+                state = d_final.download(np.float64, (n,))
+                self._uh.state = d_state.download(np.float64, self._uh.kernel.shape)
+                return state
+        except DeviceOutOfMemory:
+            return None
+        except RRError as e:
+            if e.code not in (RR_E_UNSUPPORTED, RR_E_ALLOC):
+                raise
+            return None
+
     def _route_on_device_f32in(self, arena, d_depth32, T: int, rows_per_output: int) -> tuple[np.ndarray, np.ndarray]:
         """Runoff depths on the device as (T, n) float32 rows -> (router state, float32 discharge rows): rr_unit_route_uh_f32in_dev,
         bit for bit what the float64 rows give (float32 -> float64 is exact).  RR_E_UNSUPPORTED (a call the time-tiled kernel does not

@@ -348,6 +348,49 @@ def test_float32_file_goes_from_file_to_file_without_a_host_array(case, record, 
     np.testing.assert_array_equal(r2.channel_state, r0.channel_state)
 
 
+@pytest.mark.gpu
+def test_float32_depth_file_goes_from_file_to_file_unit_muskingum(case, monkeypatch):
+    """UnitMuskingum on float32 runoff-depth files with `time` as the record dimension: file to file (rows_upload, the convolution fused
+    into the routing call with the big-endian rows converted in the kernels -- the pass that builds the records and the one that carries the
+    convolution's tail --, rows_download), against the array path on the same files: discharge, router state and UH state bit for bit."""
+    from scipy.io import netcdf_file
+    from river_route_amd import io as rr_io
+    g, tmp = case['g'], case['tmp']
+    kp, us = _unit_files(case)
+    series = [np.vstack([g['depth0'], g['depth1']]), np.vstack([g['depth1'], g['depth0']])]
+    files = []
+    for i in range(2):
+        path = str(tmp / f'depth_f4_{i}.nc')
+        files.append(path)
+        with netcdf_file(path, 'w', version=2) as ds:
+            T, n = series[i].shape
+            ds.createDimension('time', None)
+            ds.createDimension('river_id', n)
+            tv = ds.createVariable('time', 'f8', ('time',))
+            tv.units = 'seconds since 1970-01-01 00:00:00'
+            tv[:] = float(g['dates0'][0]) + 3600.0 * (T * i + np.arange(T))
+            v = ds.createVariable('qlateral', 'f4', ('time', 'river_id'))
+            v[:] = series[i].astype(np.float32)
+    kw = dict(params_file=case['params'], qlateral_files=files, channel_state_init_file=case['init'], uh_kernel_file=kp, uh_state_init_file=us, log=False)
+    (tmp / 'arrays').mkdir()
+    want = []
+    r0 = rr.UnitMuskingum(discharge_dir=str(tmp / 'arrays'), **kw)
+    r0.set_write_discharges(lambda dates, q, q_file, routed_file='': want.append(np.array(q)))
+    r0.route()
+    (tmp / 'files').mkdir()
+
+    def never(*a, **k):
+        raise AssertionError('the file-to-file path must not read or write the block as a host array')
+    monkeypatch.setattr(rr_io, 'read_qlateral', never)
+    monkeypatch.setattr(rr_io, 'write_discharge', never)
+    r1 = rr.UnitMuskingum(discharge_dir=str(tmp / 'files'), **kw).route()
+    np.testing.assert_array_equal(r1.channel_state, r0.channel_state)
+    np.testing.assert_array_equal(r1._uh.state, r0._uh.state)
+    for i in range(2):
+        with netcdf_file(str(tmp / 'files' / f'discharge_depth_f4_{i}.nc'), 'r', mmap=False) as ds:
+            np.testing.assert_array_equal(np.array(ds.variables['Q'][:], dtype=np.float32), want[i])
+
+
 def test_float32_runoff_depths_route_like_their_float64_copy(backend, case):
     """UnitMuskingum fed float32 runoff depths (what a float32 file yields) takes them to the device as float32
     (rr_unit_route_uh_f32in_dev where the engine offers it, its float64 path otherwise): discharge, router state and UH state are
