@@ -251,7 +251,7 @@ def bench_unit(args, device_index):
     # a year as the reference runs it: ten files of T steps, one call each, the discharge and the convolution's tail carried from
     # call to call (UnitMuskingum.py's loop over runoff files); the same depth block stands for each file
     year = None
-    if T * 10 == 35_040:
+    if T * 10 == 35_040 and not args.no_secondary:      # (--no-secondary: the counter passes sum every dispatch of the process)
         def year_pass():
             state.zero_(); q_ch.zero_(); q_full.zero_()
             for _ in range(10):
@@ -568,6 +568,11 @@ def secondary_lines(args, device_index):
     out.append(line)
     del net, indptr, indices, c1, c2, c3, base
     out.extend(bench_dropin(args, device_index))
+    # BASELINE config 5's network (10M reaches, 8 parts) on this one card, the parts one after another, params in depth-first post-order:
+    # every part on the direct row path with its boundary reaches (the random-order run of the same network: profiles/r05_parts_10M.txt)
+    a = copy.copy(args)
+    a.order, a.reaches, a.steps, a.warmup = 'postorder', 1_250_000, 1, 1
+    out.append(bench_sequential_parts(a, device_index, parts=8))
     return out
 
 
