@@ -51,7 +51,7 @@ void rr_plan_destroy(rr_plan *P)
                         P->d_tperm, P->d_tinv, P->d_inner_idx, P->d_colmeta, P->d_ghostmeta, P->d_c4_params,
                         P->d_c3, P->d_c4, P->d_x, P->d_isum, P->d_qch, P->d_a2, P->d_c1own, P->d_z, P->d_ring, P->d_stage, P->d_mrows,
                         P->d_slot_a[0], P->d_slot_a[1], P->d_slot_b[0], P->d_slot_b[1], P->d_m_index[0], P->d_m_index[1],
-                        P->d_dtiles, P->d_dlane, P->d_dsend_ptr, P->d_dsend_lane, P->d_dcoef, P->d_dq, P->d_ktmeta, P->d_kpmeta, P->d_kperm, P->d_kholecol, P->d_kcoef, P->d_ksq, P->d_kss, P->d_ksi,
+                        P->d_dtiles, P->d_dlane, P->d_dsend_ptr, P->d_dsend_lane, P->d_dcoef, P->d_dq, P->d_ktmeta, P->d_kpmeta, P->d_kperm, P->d_kholecol, P->d_kcoef, P->d_ksq, P->d_kss, P->d_ksi, P->d_ksqch,
                         P->d_kholemeta, P->d_kghostmeta};
         for (void *p : ptrs) if (p) (void)hipFree(p);
         P->pipe.destroy();
@@ -697,7 +697,7 @@ int rr_unit_route_f32_dev(rr_plan *P, double *q_ch, double *q_full, const double
     if (P->h.n > 0 && T > 0 && (!conv || !discharge32 || conv_rows < 1 || (!P->h.inner_pos.empty() && (!q_ch || !q_full))))
         return fail(RR_E_INVALID, "rr_unit_route_f32_dev: null array or empty row count");
     if (P->h.n == 0 || T == 0) return RR_OK;
-    rc = f32_output_applies(P, Mode::Unit, T, nsub, factor);
+    rc = f32_output_applies(P, Mode::Unit, T, nsub, factor, true);
     if (rc) return rc;
     Rows io; io.dev_in = conv; io.rows_in = conv_rows; io.dev_out32 = discharge32; io.out_factor = factor; io.rows_out = T / factor;
     return unit_like(P, q_ch, q_full, io, T, nsub, (hipStream_t)stream, false);

@@ -162,7 +162,7 @@ struct rr_plan {
     TileMeta *d_ktmeta = nullptr;        // the skeleton's tiles (TileArgs of its k_tile launches)
     int4 *d_kpmeta = nullptr;
     int32_t *d_kperm = nullptr, *d_kholecol = nullptr;
-    double *d_kcoef = nullptr, *d_ksq = nullptr, *d_kss = nullptr, *d_ksi = nullptr;
+    double *d_kcoef = nullptr, *d_ksq = nullptr, *d_kss = nullptr, *d_ksi = nullptr, *d_ksqch = nullptr;
     int2 *d_kholemeta = nullptr;         // per hole {position in the skeleton, lag}: the out-pass that patches the holes
     int2 *d_kghostmeta = nullptr;        // per boundary ghost {position of the skeleton's ghost that mirrors it, lag}: the in-pass of the ghost series
     std::vector<double> h_dcoef;         // {c1row, c2, c3, c4dt} per column as rr_plan_set_coeffs got them
@@ -264,8 +264,9 @@ int upload_tile_coef(rr_plan *P)
 }
 
 typedef void (*direct_kernel_t)(const DirectArgs);
-direct_kernel_t direct_kernel(bool in32, bool out32, bool sub = false)
+direct_kernel_t direct_kernel(bool in32, bool out32, bool sub = false, int unit = 0)
 {
+    if (unit == 1) return out32 ? (direct_kernel_t)k_direct<kDirectAhead, false, true, false, 1> : (direct_kernel_t)k_direct<kDirectAhead, false, false, false, 1>;      // UnitMuskingum: float64 rows, one sub-step
 #define RR_DK(I_, O_) (sub ? (direct_kernel_t)k_direct<kDirectAhead, I_, O_, true> : (direct_kernel_t)k_direct<kDirectAhead, I_, O_, false>)
     return in32 ? (out32 ? RR_DK(true, true) : RR_DK(true, false)) : (out32 ? RR_DK(false, true) : RR_DK(false, false));
 #undef RR_DK
@@ -276,10 +277,10 @@ direct_kernel_t direct_kernel(bool in32, bool out32, bool sub = false)
 int upload_direct_plan(rr_plan *P)
 {
     void *old[] = {P->d_dtiles, P->d_dlane, P->d_dsend_ptr, P->d_dsend_lane, P->d_dcoef, P->d_dq, P->d_ktmeta, P->d_kpmeta, P->d_kperm, P->d_kholecol, P->d_kcoef,
-                   P->d_ksq, P->d_kss, P->d_ksi, P->d_kholemeta, P->d_kghostmeta};
+                   P->d_ksq, P->d_kss, P->d_ksi, P->d_ksqch, P->d_kholemeta, P->d_kghostmeta};
     for (void *p : old) if (p) (void)hipFree(p);
     P->d_dtiles = nullptr; P->d_dlane = nullptr; P->d_dsend_ptr = P->d_dsend_lane = nullptr; P->d_dcoef = P->d_dq = nullptr; P->d_ktmeta = nullptr; P->d_kpmeta = nullptr;
-    P->d_kperm = P->d_kholecol = nullptr; P->d_kcoef = P->d_ksq = P->d_kss = P->d_ksi = nullptr; P->d_kholemeta = P->d_kghostmeta = nullptr;
+    P->d_kperm = P->d_kholecol = nullptr; P->d_kcoef = P->d_ksq = P->d_kss = P->d_ksi = P->d_ksqch = nullptr; P->d_kholemeta = P->d_kghostmeta = nullptr;
     P->n_kholes = 0; P->n_kwide = 0;
     P->direct_window = 3;
     for (int32_t sp : P->dp.tile_span) P->direct_window = std::max(P->direct_window, sp + 3);
@@ -288,8 +289,8 @@ int upload_direct_plan(rr_plan *P)
     const rr::DirectPlan &D = P->dp;
     const rr::TilePlan &K = D.skel;
     const int64_t n = H.n;
-    for (int v = 0; v < 8; ++v)      // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel
-        if (hipFuncSetAttribute((const void *)direct_kernel((v & 1) != 0, (v & 2) != 0, (v & 4) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)direct_lds_bytes(kDirectMaxWindow)) != hipSuccess) {
+    for (int v = 0; v < 10; ++v)      // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel (v = 8, 9: UnitMuskingum)
+        if (hipFuncSetAttribute((const void *)direct_kernel((v & 1) != 0, (v & 2) != 0, v < 8 && (v & 4) != 0, v >= 8 ? 1 : 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)direct_lds_bytes(kDirectMaxWindow)) != hipSuccess) {
             (void)hipGetLastError();
             P->direct_enabled = false;
         }
@@ -339,6 +340,7 @@ int upload_direct_plan(rr_plan *P)
     if (!rc) rc = dev_alloc(&P->d_ksq, K.np);
     if (!rc) rc = dev_alloc(&P->d_kss, K.np);
     if (!rc) rc = dev_alloc(&P->d_ksi, K.np);
+    if (!rc) rc = dev_alloc(&P->d_ksqch, K.np);
     if (!rc) rc = dev_alloc(&P->d_kholemeta, P->n_kholes);
     if (!rc) rc = dev_upload(P->d_kholemeta, hm);
     if (!rc) rc = dev_alloc(&P->d_kholecol, P->n_kholes);
@@ -470,7 +472,9 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
     // headline's call -- on a params order that numbers small subtrees contiguously (boundary reaches of a partitioned network
     // included: rr_plan_set_boundary lays the direct plan out around them).
     // Sub-steps (up to kDirectMaxSub a row) and channel-only routing take it too; with sub-steps only without boundary ghosts.
-    if (plain_rows && P->direct_enabled && P->dp.ok && (mode == Mode::Rapid || mode == Mode::Muskingum) && nsub <= kDirectMaxSub && (nsub == 1 || P->n_ghost == 0) &&
+    // UnitMuskingum (float64 rows of convolved lateral inflow, one sub-step a row, no boundary reaches) takes it as well.
+    const bool unit_direct = mode == Mode::Unit && nsub == 1 && P->n_ghost == 0 && P->n_export == 0 && !P->unit_general && P->tp.ok;
+    if (plain_rows && P->direct_enabled && P->dp.ok && (mode == Mode::Rapid || mode == Mode::Muskingum || unit_direct) && nsub <= kDirectMaxSub && (nsub == 1 || P->n_ghost == 0) &&
         P->weights_uniform && !force_streaming && !host_io && P->wave_enabled && total >= 8 && n < (int64_t{1} << 29)) {
         int64_t K = pick_direct_K(P, T);
         const int64_t levels = P->dp.skel.n_levels, np = P->dp.skel.np;
@@ -622,7 +626,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
 
     if (S.wave || S.rows_direct) { S.KC = P->next_KC; S.rec_chunks = P->next_chunks; }     // ring sized by choose_schedule, allocated by rr_plan_reserve
     if (S.rows_direct) {
-        if (io.uh_kernel || io.runoff || (S.has_in && !io.dev_in && !io.dev_in32) || (!io.dev_out && !io.dev_out32) || mode == Mode::Unit || nsub > kDirectMaxSub ||
+        if (io.uh_kernel || io.runoff || (S.has_in && !io.dev_in && !io.dev_in32) || (!io.dev_out && !io.dev_out32) || (mode == Mode::Unit && (nsub != 1 || io.dev_in32 || P->n_ghost > 0 || P->n_export > 0)) || nsub > kDirectMaxSub ||
             (io.dev_out32 && (io.out_factor < 1 || (S.KC * kRec) % io.out_factor != 0 || T % io.out_factor != 0))) {
             S.open = false;
             return fail(RR_E_STATE, "route: the direct row path was chosen for a call it does not take");      // (choose_schedule's plain_rows / out32)
@@ -643,7 +647,8 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
             S.export_skew = std::max<int64_t>(S.export_skew, (int64_t)TP.tile_level[TP.tile_of[p]] * S.KS * kRec + (TP.lag[p] & kLagMask));
         }
         DirectArgs &da = S.da;
-        da.tiles = P->d_dtiles; da.n_tiles = P->dp.n_tiles; da.lane = P->d_dlane; da.coef = P->d_dcoef; da.q = P->d_dq;
+        da.tiles = P->d_dtiles; da.n_tiles = P->dp.n_tiles; da.lane = P->d_dlane; da.coef = P->d_dcoef; da.q = P->d_dq; da.qch = nullptr;
+        if (mode == Mode::Unit) { da.q = P->d_full; da.qch = P->d_chan; }      // UnitMuskingum: q_full and q_ch in params order (unit_state_in)
         da.send_ptr = P->d_dsend_ptr; da.send_lane = P->d_dsend_lane;
         da.in = S.has_in ? io.dev_in : nullptr; da.out = io.dev_out; da.n = n; da.in_rows = (uint32_t)std::max<int64_t>(1, io.rows_in); da.out_rows = (uint32_t)std::max<int64_t>(1, io.rows_out);
         da.in32 = S.has_in ? io.dev_in32 : nullptr; da.out32 = io.dev_out32; da.factor = (int32_t)std::max<int64_t>(1, io.out_factor);
@@ -654,7 +659,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
         da.exports = export_series; da.n_export = (int32_t)P->n_export;
         TileArgs &w = S.ta;      // the skeleton's k_tile launches
         w.tiles = P->d_ktmeta; w.pos = P->d_kpmeta; w.coef = P->d_kcoef;
-        w.sq = P->d_ksq; w.ss = P->d_kss; w.si = P->d_ksi; w.sqch = nullptr;
+        w.sq = P->d_ksq; w.ss = P->d_kss; w.si = P->d_ksi; w.sqch = P->d_ksqch;
         w.exports = export_series; w.n_export = (int32_t)P->n_export;
         w.rec = P->d_ring; w.rec_chunks = Div32((uint32_t)std::max<int64_t>(1, S.rec_chunks));
         w.np = (int32_t)TP.np; w.KC = (int32_t)S.KS; w.n_macro = (int32_t)S.n_macro; w.total = (int32_t)S.total;
@@ -1111,7 +1116,7 @@ int session_advance_direct(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, 
             if (sample) HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets], S.stream));
             S.da.m = (int32_t)d;
             const dim3 g((unsigned)std::min<int64_t>(P->dp.n_tiles, (int64_t)P->cu_count));
-            hipLaunchKernelGGL(direct_kernel(S.io.dev_in32 != nullptr && S.has_in, S.da.out32 != nullptr, S.nsub > 1), g, dim3(kDirectThreads), direct_lds_bytes(P->direct_window), S.stream, S.da);
+            hipLaunchKernelGGL(direct_kernel(S.io.dev_in32 != nullptr && S.has_in, S.da.out32 != nullptr, S.nsub > 1, S.mode == Mode::Unit ? 1 : 0), g, dim3(kDirectThreads), direct_lds_bytes(P->direct_window), S.stream, S.da);
             if (sample) {
                 HIPCHK(hipEventRecord(P->ev[2 * P->prof_brackets + 1], S.stream));
                 P->ev_reaches.push_back(n * (std::min((d + 1) * K, S.T) - d * K));
@@ -1518,7 +1523,16 @@ int unit_state_in(rr_plan *P, const double *d_qch, const double *d_qfull, hipStr
 {
     const int64_t n = P->h.n, ni = (int64_t)P->h.inner_pos.size();
     hipError_t e0 = hipSuccess;
-    if (use_wave(P, Mode::Unit)) {   // q_full / q_ch scattered to params order (zeros on headwaters), then gathered position by position
+    if (P->direct_now) {      // the lanes carry q_full and q_ch in params order (zeros on headwaters); the skeleton's positions as k_tile<UNIT> wants them
+        e0 = hipMemsetAsync(P->d_full, 0, n * sizeof(double), stream);
+        if (e0 == hipSuccess) e0 = hipMemsetAsync(P->d_chan, 0, n * sizeof(double), stream);
+        if (e0 == hipSuccess && ni > 0)
+            hipLaunchKernelGGL(k_unit_scatter, grid1(ni), dim3(kBlock), 0, stream, P->d_full, P->d_chan, d_qfull, d_qch, P->d_inner_idx, (int32_t)ni);
+        const int64_t np = P->dp.skel.np;
+        if (e0 == hipSuccess && np > 0)
+            hipLaunchKernelGGL(k_tile_unit_state_in, grid1(np), dim3(kBlock), 0, stream, P->d_ksq, P->d_kss, P->d_ksi, P->d_ksqch,
+                               (const double *)P->d_full, (const double *)P->d_chan, P->d_kperm, P->d_kpmeta, (int32_t)np);
+    } else if (use_wave(P, Mode::Unit)) {   // q_full / q_ch scattered to params order (zeros on headwaters), then gathered position by position
         e0 = hipMemsetAsync(P->d_full, 0, n * sizeof(double), stream);
         if (e0 == hipSuccess) e0 = hipMemsetAsync(P->d_chan, 0, n * sizeof(double), stream);
         if (e0 == hipSuccess && ni > 0)
@@ -1539,7 +1553,14 @@ void unit_state_out(rr_plan *P, double *d_qch, double *d_qfull, int64_t total, h
 {
     const int64_t n = P->h.n, ni = (int64_t)P->h.inner_pos.size();
     if (ni == 0) return;
-    if (use_wave(P, Mode::Unit))
+    if (P->direct_now) {      // the skeleton's reaches back into the params-order arrays the lanes kept, then the inner reaches' pairs
+        const int64_t np = P->dp.skel.np;
+        if (np > 0) {
+            hipLaunchKernelGGL(k_skel_state_out, grid1(np), dim3(kBlock), 0, stream, P->d_full, (const double *)P->d_ksq, P->d_kperm, P->d_kpmeta, (int32_t)np);
+            hipLaunchKernelGGL(k_skel_state_out, grid1(np), dim3(kBlock), 0, stream, P->d_chan, (const double *)P->d_ksqch, P->d_kperm, P->d_kpmeta, (int32_t)np);
+        }
+        hipLaunchKernelGGL(k_unit_gather, grid1(ni), dim3(kBlock), 0, stream, d_qch, d_qfull, (const double *)P->d_chan, (const double *)P->d_full, P->d_inner_idx, (int32_t)ni);
+    } else if (use_wave(P, Mode::Unit))
         hipLaunchKernelGGL(k_tile_unit_state_out, grid1(ni), dim3(kBlock), 0, stream, d_qch, d_qfull,
                            (const double *)P->d_sq, (const double *)P->d_sqch, P->d_inner_idx, P->d_tinv, (int32_t)ni);
     else
@@ -1555,7 +1576,8 @@ int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io_in, int64
     const Rows &io = io_in;
     const bool host_rows = io.host_in != nullptr || io.host_out != nullptr;
     {
-        int rc = prepare_call(P, Mode::Unit, T, nsub, false, false, !host_rows);
+        const bool plain = !host_rows && io.dev_in && (io.dev_out || io.dev_out32) && !io.uh_kernel && !io.runoff;      // float64 rows of convolved lateral inflow in a device array: the direct row path applies
+        int rc = prepare_call(P, Mode::Unit, T, nsub, false, false, !host_rows, plain, 0, 0, io.dev_out32 != nullptr);
         if (rc == RR_OK && host_rows && !P->wave_now) rc = prepare_call(P, Mode::Unit, T, nsub, true, true, false);
         if (rc == RR_OK && host_rows && P->wave_now) rc = host_pipe_prepare(P);
         if (rc) return rc;
@@ -1576,6 +1598,11 @@ int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io_in, int64
     if (rc == RR_OK) rc = piped ? route_host_pipelined(P, Mode::Unit, T, nsub, io.host_in, io.host_out, stream) : route_core(P, Mode::Unit, T, nsub, io, stream);
     if (rc == RR_OK && wave && d_q_final)      // every reach: a headwater's state is its last lateral inflow, an inner reach's q_full
         hipLaunchKernelGGL(k_tile_state_out, grid1(n), dim3(kBlock), 0, stream, d_q_final, (const double *)P->d_sq, P->d_tinv, (int32_t)n);
+    if (rc == RR_OK && P->direct_now && d_q_final) {      // the lanes' columns hold exactly that; the skeleton's reaches join them
+        const int64_t np = P->dp.skel.np;
+        if (np > 0) hipLaunchKernelGGL(k_skel_state_out, grid1(np), dim3(kBlock), 0, stream, P->d_full, (const double *)P->d_ksq, P->d_kperm, P->d_kpmeta, (int32_t)np);
+        (void)hipMemcpyAsync(d_q_final, P->d_full, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, stream);
+    }
     if (rc == RR_OK && io.uh_kernel && uh_state_inout) {      // carry-over state of the fused convolution, in place, after every batch has read the old one
         const dim3 gt((unsigned)((n + kUhTailThreads - 1) / kUhTailThreads));
         const int32_t nks = (int32_t)io.uh_nks;

@@ -50,6 +50,7 @@ struct DirectArgs {
     const int32_t *send_ptr;    // per tile: its senders in send_lane
     const int32_t *send_lane;   // lane | kDirectHole
     double *q;                  // per column: carried discharge
+    double *qch;                // UNIT: per column: carried channel discharge (q_ch; zero on headwaters)
     const double *in;           // lateral rows (in_rows x n), read cyclically
     double *out;                // discharge rows (out_rows x n), written cyclically
     int64_t n;
@@ -132,7 +133,11 @@ __device__ __forceinline__ void store_f64x2_nt(__amdgpu_buffer_rsrc_t r, uint32_
 // every nsub ticks; the senders' rings and the skeleton's records are in sub-step space, as k_tile<SUB>'s.  Channel-only routing
 // (Muskingum.py:262-290: no lateral rows) needs no flag: without a lateral array every rows-in load is dropped by its descriptor's range
 // check and returns zero.
-template <int PF, bool IN32 = false, bool OUT32 = false, bool SUB = false>
+// UNIT: UnitMuskingum's recurrence (_numba_kernels.py:88-171, in k_tile<UNIT>'s gather form, operation for operation): the rows are the
+// convolved lateral inflow, unscaled; a headwater lane publishes its row's value as it is (zero coefficients), an inner lane keeps its
+// channel discharge q_ch beside the published q_full = q_ch + lateral and adds its headwater tributaries (the first `nh` of its upstream
+// lanes) of the SAME row to both the c1 and the c2 term; the rows-out wave leaves headwater columns unclipped (line 122-123).
+template <int PF, bool IN32 = false, bool OUT32 = false, bool SUB = false, int UNIT = 0>
 __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -174,10 +179,16 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             // a boundary export of a partitioned network that a lane routes: its discharge after every step, unclamped, into its column of the export series
             const int32_t exp_slot = (!idle && (lm.x & rr::kDirectExport)) ? lm.z : -1;
             const bool wave_exports = __builtin_amdgcn_ballot_w64(exp_slot >= 0) != 0;
-            const double c1 = idle ? 0.0 : a.coef[4 * (int64_t)col], c2 = idle ? 0.0 : a.coef[4 * (int64_t)col + 1], c3 = idle ? 0.0 : a.coef[4 * (int64_t)col + 2];
-            const double q0 = idle ? 0.0 : a.q[col];
             const int32_t u0 = lm.y & 0x3FF, u1 = (lm.y >> 10) & 0x3FF, u2 = (lm.y >> 20) & 0x3FF;
-            const int32_t up0_b = (u0 == 0x3FF || idle ? TH : u0) * 8, up1_b = (u1 == 0x3FF || idle ? TH : u1) * 8, up2_b = (u2 == 0x3FF || idle ? TH : u2) * 8;
+            const bool no_coef = idle || (UNIT && u0 == 0x3FF);      // UNIT: a headwater computes nothing (zero coefficients republish its row's value)
+            const double c1 = no_coef ? 0.0 : a.coef[4 * (int64_t)col], c2 = no_coef ? 0.0 : a.coef[4 * (int64_t)col + 1], c3 = no_coef ? 0.0 : a.coef[4 * (int64_t)col + 2];
+            const double q0 = idle ? 0.0 : a.q[col];
+            // UNIT: the first nh upstream lanes are headwaters; up*_b are then the inner ones
+            const int32_t nh = UNIT ? (int32_t)((uint32_t)lm.y >> 30) : 0;
+            const int32_t i0 = nh == 0 ? u0 : (nh == 1 ? u1 : (nh == 2 ? u2 : 0x3FF)), i1 = nh == 0 ? u1 : (nh == 1 ? u2 : 0x3FF), i2 = nh == 0 ? u2 : 0x3FF;
+            const int32_t up0_b = (i0 == 0x3FF || idle ? TH : i0) * 8, up1_b = (i1 == 0x3FF || idle ? TH : i1) * 8, up2_b = (i2 == 0x3FF || idle ? TH : i2) * 8;
+            const int32_t hw0_b = (nh >= 1 && !idle ? u0 : TH) * 8, hw1_b = (nh >= 2 && !idle ? u1 : TH) * 8, hw2_b = (nh >= 3 && !idle ? u2 : TH) * 8;
+            double qc = (UNIT && !idle) ? a.qch[col] : 0.0;      // UNIT: the channel discharge
             *reinterpret_cast<double *>(X + tid * 8) = q0;
             *reinterpret_cast<double *>(X + THP * 8 + tid * 8) = q0;
             int32_t own_b = idle || delta == 0 ? 0 : wrap - delta * kRowB;      // window slot of the row this lane routes this tick: (k - delta) mod (span + 3)
@@ -194,13 +205,30 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                                          *reinterpret_cast<const double *>(X + prev + up2_b);
                     double *mine = reinterpret_cast<double *>(F + own_b + tid * 8);
                     const double lat = *mine;
-                    double qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev, __builtin_fma(c3, q_old, lat)));
+                    double qk;
+                    if constexpr (UNIT != 0) {      // _numba_kernels.py:142-167 in gather form, k_tile<UNIT>'s short tick operation for operation
+                        const double s_hw = (*reinterpret_cast<const double *>(X + prev + hw0_b) + *reinterpret_cast<const double *>(X + prev + hw1_b)) +
+                                            *reinterpret_cast<const double *>(X + prev + hw2_b);
+                        const double r = __builtin_fma(c1, s_hw + s_cur, __builtin_fma(c2, s_hw + s_prev, c3 * qc));
+                        qk = r + lat;
+                        if (decltype(tested)::value) {
+                            const bool active = (uint32_t)(k0 + s - delta) < (uint32_t)nrows;
+                            qc = active ? r : qc;
+                            qk = active ? qk : q_old;
+                            *mine = active ? qk : lat;
+                        } else {
+                            qc = r;
+                            *mine = qk;
+                        }
+                    } else {
+                    qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev, __builtin_fma(c3, q_old, lat)));
                     if (decltype(tested)::value) {      // an idle lane keeps its discharge and hands its window slot back as it found it (nobody else writes it this tick)
                         const bool active = (uint32_t)(k0 + s - delta) < (uint32_t)nrows;
                         qk = active ? qk : q_old;
                         *mine = active ? qk : lat;
                     } else {
                         *mine = qk;
+                    }
                     }
                     s_prev = s_cur; q_last = qk;
                     *reinterpret_cast<double *>(X + cur + tid * 8) = qk;
@@ -259,10 +287,11 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                 }
             }
             if (!idle) a.q[col] = *reinterpret_cast<const double *>(X + THP * 8 + tid * 8);      // PF is even: the last tick wrote buffer 1
+            if (UNIT && !idle) a.qch[col] = qc;
         } else if (role == 1) {
             // ---------------------------------------------------------------- waves 4, 5: rows in.  Wave 4 + h, lane -> columns 128 h + 2 ln, 128 h + 2 ln + 1
             const int32_t ca = (wave - 4) * (TH / 2) + 2 * ln;
-            auto c4_of = [&](int32_t c) { return c < tm.nc ? a.coef[4 * (int64_t)(tm.c0 + c) + 3] : 0.0; };
+            auto c4_of = [&](int32_t c) { return UNIT ? 1.0 : (c < tm.nc ? a.coef[4 * (int64_t)(tm.c0 + c) + 3] : 0.0); };      // (UNIT: the rows are discharges already)
             const double c4a0 = c4_of(ca), c4a1 = c4_of(ca + 1);
             // a hole's scaled lateral inflow also goes into its sender ring, at slot (row + lag) % 32
             auto hole_of = [&](int32_t c, int32_t &ring_b, int32_t &slot0) {
@@ -372,6 +401,10 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             int32_t cnt = 0;
             const double fdiv = (double)a.factor;
             int32_t out_b = 0;
+            // UNIT: a headwater's column leaves as it is (_numba_kernels.py:122-123: no clip)
+            auto raw_col = [&](int32_t c) { return UNIT != 0 && c < tm.nc && (a.lane[tm.c0 + c].y & 0x3FF) == 0x3FF; };
+            const bool raw0 = raw_col(2 * ln), raw1 = raw_col(2 * ln + 1), raw2 = raw_col(128 + 2 * ln), raw3 = raw_col(128 + 2 * ln + 1);
+            auto fin = [](double x, bool raw) { return (UNIT != 0 && raw) ? x : clip0(x); };
             int32_t u_sub = -1 - span, u_ph = 0, u_row = 0;      // SUB: the sub-step the slowest lane did one tick ago, its place in its row, the row
             __syncthreads();
             for (int32_t k0 = 0; k0 < n_ticks; k0 += PF) {
@@ -389,7 +422,7 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                     if (leaving >= 0 && leaving < nrows) {      // wave-uniform
                         const double2 xa = *reinterpret_cast<const double2 *>(F + out_b + 2 * ln * 8), xb = *reinterpret_cast<const double2 *>(F + out_b + 2 * ln * 8 + 128 * 8);
                         if constexpr (OUT32) {
-                            const double2 ca2 = make_double2(clip0(xa.x), clip0(xa.y)), cb2 = make_double2(clip0(xb.x), clip0(xb.y));
+                            const double2 ca2 = make_double2(fin(xa.x, raw0), fin(xa.y, raw1)), cb2 = make_double2(fin(xb.x, raw2), fin(xb.y, raw3));
                             sa = cnt ? make_double2(sa.x + ca2.x, sa.y + ca2.y) : ca2;
                             sb = cnt ? make_double2(sb.x + cb2.x, sb.y + cb2.y) : cb2;
                             if (++cnt == a.factor) {      // wave-uniform
@@ -405,8 +438,8 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                             }
                         } else {
                             const __amdgpu_buffer_rsrc_t dst = make_rsrc(row, tile_end);
-                            store_f64x2_nt(dst, va, make_double2(clip0(xa.x), clip0(xa.y)));
-                            store_f64x2_nt(dst, vb, make_double2(clip0(xb.x), clip0(xb.y)));
+                            store_f64x2_nt(dst, va, make_double2(fin(xa.x, raw0), fin(xa.y, raw1)));
+                            store_f64x2_nt(dst, vb, make_double2(fin(xb.x, raw2), fin(xb.y, raw3)));
                             ++rout; row += a.n;
                             if (rout == a.out_rows) { rout = 0; row = a.out; }
                         }

@@ -533,6 +533,14 @@ __global__ __launch_bounds__(kBlock) void k_tile_unit_state_out(double *q_ch, do
     q_ch[k] = sqch[p];
 }
 
+// the direct row path keeps UnitMuskingum's state in params order: the inner reaches' pairs leave from there
+__global__ __launch_bounds__(kBlock) void k_unit_gather(double *q_ch, double *q_full, const double *chan, const double *full, const int32_t *inner_idx, int32_t n_inner)
+{
+    const int32_t k = (int32_t)(blockIdx.x * kBlock + threadIdx.x);
+    if (k >= n_inner) return;
+    q_full[k] = full[inner_idx[k]]; q_ch[k] = chan[inner_idx[k]];
+}
+
 // the skeleton of the direct row path: every position that is not a ghost hands its reach's discharge back
 __global__ __launch_bounds__(kBlock) void k_skel_state_out(double *q_t, const double *sq, const int32_t *perm, const int4 *pos, int32_t np)
 {

@@ -453,6 +453,7 @@ void build_direct_plan(const std::vector<int32_t> &down, const std::vector<int32
             const int32_t lane = (int32_t)(u - D.tile_c0[tile_of[d]]);
             const int k = filled[d]++;
             D.up3[d] = (D.up3[d] & ~(0x3FF << (10 * k))) | (lane << (10 * k));
+            if (pass == 0) D.up3[d] = (int32_t)((uint32_t)D.up3[d] + (1u << 30));      // bits 30, 31: how many of them are headwaters (UnitMuskingum keeps them apart)
         }
     // tall subtrees (long unbranched runs) make most of a chain-like network skeleton: the record path routes that better
     if (D.n_holes * 10 > n) { D.why = "more than a tenth of the reaches have subtrees too large or too tall for a direct tile"; return; }

@@ -127,7 +127,7 @@ struct DirectPlan {
     int64_t n_holes = 0, n_exports = 0;
     std::vector<int32_t> tile_c0, tile_nc, tile_lag_lo, tile_span;   // [n_tiles]; span = largest - smallest lag of the tile's lanes
     std::vector<int32_t> delay;        // [n] lag - tile_lag_lo of the column's tile (bits 0-7) | sender number + 1 (bits 8-14) | kDirectHole
-    std::vector<int32_t> up3;          // [n] three 10-bit lane numbers of the upstream reaches (0x3FF: none)
+    std::vector<int32_t> up3;          // [n] three 10-bit lane numbers of the upstream reaches (0x3FF: none), headwaters first; bits 30, 31: how many are headwaters
     std::vector<int32_t> xinfo;        // [n] hole: position of the reach in `skel`; outlet of a small subtree below a skeleton reach: position of its ghost there; else -1
     std::vector<uint8_t> big;          // [n] 1: skeleton
     std::vector<int32_t> send_ptr;     // [n_tiles + 1] the tile's senders (holes and outlets that feed the skeleton, at most kDirectSenders), in column order

@@ -254,7 +254,7 @@ class Plan:
                                                     int(num_routing_per_output), stream))
 
     def unit_route_f32_dev(self, q_ch, q_full, convolved, conv_rows, discharge32, T, num_substeps, factor=1, stream=None) -> None:
-        self.reserve(MODE_UNIT, T, num_substeps)
+        self.reserve(MODE_UNIT, T, num_substeps, f32_out=True)
         check(_lib.lib().rr_unit_route_f32_dev(self._h, ptr(q_ch), ptr(q_full), ptr(convolved), int(conv_rows),
                                                ptr(discharge32), int(T), int(num_substeps), int(factor), stream))
 
@@ -269,7 +269,7 @@ class Plan:
     def unit_route_uh_dev(self, q_ch, q_full, q_final, uh_kernel, uh_state, n_ks, depth, T, num_substeps, discharge=None,
                           discharge32=None, factor=1, stream=None) -> None:
         """Convolution + routing of one file in one call (rr_unit_route_uh_dev); exactly one of discharge / discharge32."""
-        self.reserve(MODE_UNIT, T, num_substeps)
+        self.reserve(MODE_UNIT, T, num_substeps, plain_rows=False)
         check(_lib.lib().rr_unit_route_uh_dev(self._h, ptr(q_ch), ptr(q_full), ptr(q_final), ptr(uh_kernel), ptr(uh_state),
                                               int(n_ks), ptr(depth), ptr(discharge), ptr(discharge32), int(factor), int(T),
                                               int(num_substeps), stream))
@@ -277,7 +277,7 @@ class Plan:
     def unit_route_uh_f32in_dev(self, q_ch, q_full, q_final, uh_kernel, uh_state, n_ks, depth32, T, num_substeps, discharge=None,
                                 discharge32=None, factor=1, stream=None) -> None:
         """rr_unit_route_uh_f32in_dev: the same from float32 runoff depths (as runoff files store them)."""
-        self.reserve(MODE_UNIT, T, num_substeps)
+        self.reserve(MODE_UNIT, T, num_substeps, plain_rows=False)
         check(_lib.lib().rr_unit_route_uh_f32in_dev(self._h, ptr(q_ch), ptr(q_full), ptr(q_final), ptr(uh_kernel), ptr(uh_state),
                                                     int(n_ks), ptr(depth32), ptr(discharge), ptr(discharge32), int(factor), int(T),
                                                     int(num_substeps), stream))
@@ -309,7 +309,7 @@ class Plan:
 
     def stream_begin_unit(self, q_ch, q_full, lateral, lat_rows, discharge, out_rows, T, num_substeps, ghost_series=None,
                           export_series=None, stream=None) -> None:
-        self.reserve(MODE_UNIT, T, num_substeps)
+        self.reserve(MODE_UNIT, T, num_substeps, plain_rows=False)
         check(_lib.lib().rr_stream_begin_unit(self._h, ptr(q_ch), ptr(q_full), ptr(lateral), int(lat_rows), ptr(discharge),
                                               int(out_rows), int(T), int(num_substeps), ptr(ghost_series), ptr(export_series), stream))
 

@@ -606,3 +606,57 @@ def test_substeps_and_channel_only_routing_on_the_direct_path(monkeypatch, n, T,
                 b.free()
     for a, b in zip(res['1'], res['0']):
         np.testing.assert_array_equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,T,env,f32', [(9, 40, {}, False), (1000, 100, {}, False), (60_000, 200, {'RR_WAVE_K': '64'}, False), (300_000, 150, {}, False),
+                                         (120_000, 600, {'RR_WAVE_K': '256'}, False), (60_000, 256, {}, True)])
+def test_unit_route_on_the_direct_path_vs_oracle(monkeypatch, n, T, env, f32):
+    """rr_unit_route_dev (rows of convolved lateral inflow) on a post-order network: k_direct<UNIT> routes the small sub-basins, the skeleton
+    runs k_tile<UNIT> on records; two files with the state hand-off of UnitMuskingum._router (river_route/routers/UnitMuskingum.py:72-98);
+    headwater columns leave unclipped (_numba_kernels.py:122-123).  f32: rr_unit_route_f32_dev, the routers' float32 means of 4 rows."""
+    from tests_support import unit_split_arrays
+    set_env(monkeypatch, env)
+    net, indptr, indices, c1, c2, c3 = _case(n, 31)
+    hw_idx, inner_idx, A_in, A_hw = unit_split_arrays(indptr, indices, n)
+    c1i, c2i, c3i = c1[inner_idx], c2[inner_idx], c3[inner_idx]
+    args = (A_in.indptr, A_in.indices, -c1i[A_in.indices], A_in.indptr, A_in.indices, A_in.data,
+            A_hw.indptr, A_hw.indices, A_hw.data, c1i, c2i, c3i, hw_idx, inner_idx)
+    uh = oracle.UnitHydrograph(synth.synth_uh_kernel(n, 12))
+    state_ref = 3.0 * synth.u01(7, np.arange(n))
+    state = state_ref.copy()
+    ni = inner_idx.size
+    factor = 4
+    with Plan(indptr, indices) as plan:
+        assert plan.direct_info()['ok'], plan.direct_info()['why']
+        plan.set_coeffs(-c1[indices], c2, c3, None)
+        d_conv, d_out = DeviceBuffer(T * n * 8), DeviceBuffer(T * n * 8)
+        d_qc, d_qf = DeviceBuffer(max(ni, 1) * 8), DeviceBuffer(max(ni, 1) * 8)
+        for f in range(2):
+            conv_ref = uh.convolve(synth.synth_runoff_depth(n, f * T, (f + 1) * T))
+            if f == 1:
+                conv_ref[5, hw_idx[:3]] = -0.25      # a negative headwater inflow stays as it is
+            qc_ref, qf_ref, d_ref = state_ref[inner_idx].copy(), state_ref[inner_idx].copy(), np.zeros((T, n))
+            oracle.unit_route(*args, qc_ref, qf_ref, conv_ref, d_ref, 1)
+            state_ref[hw_idx], state_ref[inner_idx] = conv_ref[-1][hw_idx], qf_ref
+            d_conv.upload(conv_ref)
+            d_qc.upload(state[inner_idx].copy()); d_qf.upload(state[inner_idx].copy())
+            if f32:
+                plan.unit_route_f32_dev(d_qc, d_qf, d_conv, T, d_out, T, 1, factor=factor)
+            else:
+                plan.unit_route_dev(d_qc, d_qf, d_conv, T, d_out, T, T, 1)
+            assert plan.last_kernel() == 'direct'
+            qc, qf = d_qc.download(np.float64, (ni,)), d_qf.download(np.float64, (ni,))
+            state[hw_idx], state[inner_idx] = conv_ref[-1][hw_idx], qf
+            assert_close(qc, qc_ref, f'file {f} q_ch')
+            assert_close(qf, qf_ref, f'file {f} q_full')
+            if f32:
+                want = d_ref.reshape(T // factor, factor, n).mean(axis=1).astype(np.float32)
+                got = d_out.download(np.float32, (T // factor, n))
+                assert np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64)).max() <= 1, 'float32 means differ by more than 1 ulp'
+            else:
+                d = d_out.download(np.float64, (T, n))
+                assert_close(d, d_ref, f'file {f} discharge')
+                np.testing.assert_array_equal(d[:, hw_idx], conv_ref[:, hw_idx])     # headwaters: unclamped, un-averaged
+        for b in (d_conv, d_out, d_qc, d_qf):
+            b.free()
