@@ -232,8 +232,8 @@ def bench_unit(args, device_index):
         chk_kernel = plan.profile()['ticks_per_launch']
         if not np.allclose(got, dd, rtol=1e-10, atol=1e-10 * np.abs(dd).max()):
             raise SystemExit('bench.py: GPU UnitMuskingum result differs from the oracle; refusing to report a number')
-        base['parity_gate'] = (f'{Tc} rows x {n} reaches, fused convolution + routing by the timed kernels '
-                               f'({"k_tile, " + str(chk_kernel) + " ticks per task" if chk_kernel > 1 else "k_tick"}) == oracle, '
+        chk_name = {'direct': f'k_uh_convolve + k_direct<UNIT>, {chk_kernel} rows per task', 'tile': f'k_rec_in_uh + k_tile, {chk_kernel} ticks per task', 'tick': 'k_tick'}[plan.last_kernel()]
+        base['parity_gate'] = (f'{Tc} rows x {n} reaches, convolution + routing by the timed kernels ({chk_name}) == oracle, '
                                f'rtol 1e-10, max |diff| {float(np.abs(got - dd).max()):.3e}')
 
     for _ in range(args.warmup):
@@ -267,17 +267,20 @@ def bench_unit(args, device_index):
                 'note': 'ten consecutive calls of the block above, discharge state and convolution tail carried between them'}
     if base is not None and prof['ticks_per_launch'] > 1 and chk_kernel <= 1:
         raise SystemExit('bench.py: the parity gate did not run the timed kernel; refusing to report a number')
-    traffic = pmc_traffic(args.order, n, T, nsub, key='config4') if n_ks == 48 else None
-    roofline = roofline_from_profile(prof, nsub, HBM_PEAK_GBS, copy_gbs=copy_bandwidth(device_index), unit=True, traffic=traffic)
-    whole_path(roofline, prof, aux, plan.last_kernel(), float(n) * T * nsub * args.steps / elapsed, traffic)
+    kern_name = plan.last_kernel()
+    traffic = pmc_traffic(args.order, n, T, nsub, key='config4' if args.order == 'random' else 'config4_postorder') if n_ks == 48 else None
+    roofline = roofline_from_profile(prof, nsub, HBM_PEAK_GBS, copy_gbs=copy_bandwidth(device_index), unit=True, kernel=kern_name, traffic=traffic)
+    whole_path(roofline, prof, aux, kern_name, float(n) * T * nsub * args.steps / elapsed, traffic)
     if roofline is not None and 'k_rec_in' in roofline['path']['kernels']:
         roofline['path']['kernels'][f'k_rec_in_uh (convolution fused, {n_ks} taps)'] = roofline['path']['kernels'].pop('k_rec_in')
+    how = ('the convolution as a pass of its own into work rows (k_uh_convolve_ring: not bracketed by the sampling events, see the kernel summary), then the direct row path'
+           if kern_name == 'direct' else 'convolution fused into the record in-pass + routing')
     line = {'metric': 'reach-steps/sec', 'value': float(n) * T * nsub * args.steps / elapsed, 'unit': 'reach-steps/s',
             'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': f'UnitMuskingum, {n}-reach synthetic network + {n_ks}-step UH kernel, {T} runoff steps, '
-                                   f'{nsub} sub-step(s), fp64, 1xMI355X (BASELINE config 4; convolution fused into the record in-pass + routing)',
-                       'reaches': n, 'runoff_steps': T, 'uh_steps': n_ks, 'headwaters': plan.n_headwaters},
+                                   f'{nsub} sub-step(s), fp64, 1xMI355X (BASELINE config 4{", params in depth-first post-order" if args.order == "postorder" else ""}; {how})',
+                       'reaches': n, 'runoff_steps': T, 'uh_steps': n_ks, 'headwaters': plan.n_headwaters, 'params_order': args.order, 'kernel': kern_name},
             'roofline': roofline, 'cpu_baseline': base}
     if year is not None:
         line['year'] = year
@@ -553,6 +556,11 @@ def secondary_lines(args, device_index):
     a.workload = 'unit'
     line = bench_unit(a, device_index)
     line['config']['baseline_config'] = 4
+    out.append(line)
+    a = copy.copy(args)      # the same call on the post-order params table: UnitMuskingum on the direct row path
+    a.workload, a.order, a.no_cpu_baseline = 'unit', 'postorder', args.no_cpu_baseline
+    line = bench_unit(a, device_index)
+    line['config']['variant_of_baseline_config'] = 4
     out.append(line)
     out.append(bench_rapid_f32(args, device_index))
     # the headline's network with its params file in depth-first post-order: the direct row path (no record ring and no permutation

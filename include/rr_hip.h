@@ -119,7 +119,9 @@ int rr_plan_set_unit_weights(rr_plan *plan, const double *c1, const double *a_da
  * in a device array (fused convolution, gridded runoff: rr_unit_route_uh*_dev, rr_rapid_route_runoff_dev), so the direct row path
  * -- which rr_rapid_route*_dev and rr_stream_begin take where the params order numbers small subtrees contiguously, see
  * rr_plan_direct_info -- does not apply and the record ring is needed; RR_ROWS_F32_OUT: the call writes float32 rows
- * (rr_*_route_f32*_dev: the direct task is then a multiple of 128 rows).
+ * (rr_*_route_f32*_dev: the direct task is then a multiple of 128 rows); RR_ROWS_UH: the call is rr_unit_route_uh*_dev (runoff
+ * depths + unit-hydrograph kernel): on the direct row path -- which rr_unit_route*_dev take too, with one sub-step per row and no
+ * boundary reaches -- the convolution runs as a pass of its own into T rows of work memory, reserved here.
  * info (may be NULL): [0] 2 = direct row path, 1 = time-tiled kernel, 0 = streaming kernel; [1] routing ticks (rows) per launch K; [2] chunks of the
  * record ring (16 ticks each); [3] bytes of routing work memory now held on the device; [4] bytes of device staging and
  * [5] of pinned host staging of the host-pointer path; [6] depth of the routing pipeline in ticks (network depth + tile
@@ -130,6 +132,7 @@ int rr_plan_set_unit_weights(rr_plan *plan, const double *c1, const double *a_da
 #define RR_MODE_UNIT 2
 #define RR_ROWS_NOT_PLAIN 2
 #define RR_ROWS_F32_OUT 4
+#define RR_ROWS_UH 8
 int rr_plan_reserve(rr_plan *plan, int mode, int64_t T, int64_t nsub, int host_rows, int64_t info[8]);
 
 /* The direct row path: where the params order numbers every small subtree contiguously -- any depth-first

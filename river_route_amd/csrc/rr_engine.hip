@@ -356,7 +356,7 @@ int rr_plan_reserve(rr_plan *P, int mode, int64_t T, int64_t nsub, int host_rows
     Schedule sch;
     // host rows reach the time-tiled kernel through the PCIe pipeline's device rings; where it does not apply they stream
     const bool host = (host_rows & 1) != 0, plain = !host && (host_rows & RR_ROWS_NOT_PLAIN) == 0;      // rows in device arrays (float64 or float32): the direct row path applies
-    rc = reserve_core(P, m, T, nsub, false, false, &sch, plain, (host_rows & RR_ROWS_F32_OUT) != 0);
+    rc = reserve_core(P, m, T, nsub, false, false, &sch, plain, (host_rows & RR_ROWS_F32_OUT) != 0, (host_rows & RR_ROWS_UH) != 0);
     if (rc == RR_OK && host && !sch.tiled) rc = reserve_core(P, m, T, nsub, true, true, &sch);
     if (rc == RR_OK && host && sch.tiled) rc = host_pipe_prepare(P);
     if (rc) return rc;
@@ -637,11 +637,11 @@ int rr_unit_route_dev(rr_plan *P, double *q_ch, double *q_full, const double *co
 
 // float32 output fused into the record pass (k_rec_out): applies when the call is time-tiled and factor x sub-steps divides
 // the tick-rows of a batch (128); otherwise RR_E_UNSUPPORTED and the caller uses the float64 form + rr_resample_cast_dev.
-static int f32_output_applies(rr_plan *P, Mode mode, int64_t T, int64_t nsub, int64_t factor, bool plain = false)
+static int f32_output_applies(rr_plan *P, Mode mode, int64_t T, int64_t nsub, int64_t factor, bool plain = false, bool uh = false)
 {
     if (factor < 1 || T % factor != 0) return fail(RR_E_INVALID, "float32 output: the number of rows must be a multiple of factor >= 1");
     if (kRecRows % (factor * nsub) != 0) return fail(RR_E_UNSUPPORTED, "float32 output: factor x sub-steps must divide the rows of a record batch (128)");
-    const Schedule sch = choose_schedule(P, mode, T, nsub, false, false, plain, 0, 0, true);
+    const Schedule sch = choose_schedule(P, mode, T, nsub, false, false, plain, 0, 0, true, uh);
     if (!sch.tiled && !sch.direct) return fail(RR_E_UNSUPPORTED, "float32 output needs the time-tiled kernel or the direct row path, which this call does not get");
     return RR_OK;
 }
@@ -737,8 +737,8 @@ int rr_unit_route_uh_dev(rr_plan *P, double *q_ch, double *q_full, double *q_fin
         return fail(RR_E_INVALID, "rr_unit_route_uh_dev: null array, both or neither output, or n_ks < 1");
     if (P->h.n == 0 || T == 0) return RR_OK;
     if (n_ks > kUhFusedMaxTaps) return fail(RR_E_UNSUPPORTED, "rr_unit_route_uh_dev: more than 64 kernel steps: convolve with rr_uh_convolve_dev, then rr_unit_route_dev");
-    if (f32) { rc = f32_output_applies(P, Mode::Unit, T, nsub, factor); if (rc) return rc; }
-    else if (!choose_schedule(P, Mode::Unit, T, nsub, false, false).tiled) return fail(RR_E_UNSUPPORTED, "rr_unit_route_uh_dev needs the time-tiled kernel, which this call does not get");
+    if (f32) { rc = f32_output_applies(P, Mode::Unit, T, nsub, factor, true, true); if (rc) return rc; }
+    else { const Schedule sch = choose_schedule(P, Mode::Unit, T, nsub, false, false, true, 0, 0, false, true); if (!sch.tiled && !sch.direct) return fail(RR_E_UNSUPPORTED, "rr_unit_route_uh_dev needs the time-tiled kernel or the direct row path, which this call does not get"); }
     Rows io; io.dev_in = depth; io.rows_in = T;
     if (f32) { io.dev_out32 = discharge32; io.out_factor = factor; io.rows_out = T / factor; }
     else { io.dev_out = discharge; io.rows_out = T; }
@@ -758,8 +758,8 @@ int rr_unit_route_uh_f32in_dev(rr_plan *P, double *q_ch, double *q_full, double 
         return fail(RR_E_INVALID, "rr_unit_route_uh_f32in_dev: null array, both or neither output, or n_ks < 1");
     if (P->h.n == 0 || T == 0) return RR_OK;
     if (n_ks > kUhFusedMaxTaps) return fail(RR_E_UNSUPPORTED, "rr_unit_route_uh_f32in_dev: more than 64 kernel steps: convert the rows, convolve with rr_uh_convolve_dev, then rr_unit_route_dev");
-    if (f32) { rc = f32_output_applies(P, Mode::Unit, T, nsub, factor); if (rc) return rc; }
-    else if (!choose_schedule(P, Mode::Unit, T, nsub, false, false).tiled) return fail(RR_E_UNSUPPORTED, "rr_unit_route_uh_f32in_dev needs the time-tiled kernel, which this call does not get");
+    if (f32) { rc = f32_output_applies(P, Mode::Unit, T, nsub, factor, true, true); if (rc) return rc; }
+    else { const Schedule sch = choose_schedule(P, Mode::Unit, T, nsub, false, false, true, 0, 0, false, true); if (!sch.tiled && !sch.direct) return fail(RR_E_UNSUPPORTED, "rr_unit_route_uh_f32in_dev needs the time-tiled kernel or the direct row path, which this call does not get"); }
     Rows io; io.dev_in32 = depth32; io.dev_in = uh_kernel; io.rows_in = T;      // (dev_in only has to be non-NULL for the executor)
     if (f32) { io.dev_out32 = discharge32; io.out_factor = factor; io.rows_out = T / factor; }
     else { io.dev_out = discharge; io.rows_out = T; }
@@ -773,7 +773,7 @@ int rr_uh_convolve_dev(int device, const double *kernel, double *state, const do
     if (device < 0 || device >= rr_device_count()) return fail(RR_E_NO_DEVICE, "rr_uh_convolve: no such HIP device");
     HIPCHK(hipSetDevice(device));
     if (n > 0 && (!kernel || !state || !lateral || !out)) return fail(RR_E_INVALID, "rr_uh_convolve: null array");
-    return uh_convolve_core(kernel, state, lateral, out, T, n_ks, n, (hipStream_t)stream);
+    return uh_convolve_core<double>(kernel, state, lateral, out, T, n_ks, n, (hipStream_t)stream, kSelNative);
 }
 
 // ---- host-pointer entry points (the reference's kernel boundary) ----
@@ -833,7 +833,7 @@ int rr_uh_convolve(int device, const double *kernel, double *state, const double
         if (e == hipSuccess) e = hipMemcpy(d_l, lateral, (size_t)T * n * sizeof(double), hipMemcpyHostToDevice);
         if (e != hipSuccess) rc = fail(RR_E_HIP, hipGetErrorString(e));
     }
-    if (!rc) rc = uh_convolve_core(d_k, d_s, d_l, d_o, T, n_ks, n, nullptr);
+    if (!rc) rc = uh_convolve_core<double>(d_k, d_s, d_l, d_o, T, n_ks, n, nullptr, kSelNative);
     if (!rc) {
         e = hipMemcpy(out, d_o, (size_t)T * n * sizeof(double), hipMemcpyDeviceToHost);
         if (e == hipSuccess) e = hipMemcpy(state, d_s, (size_t)n_ks * n * sizeof(double), hipMemcpyDeviceToHost);

@@ -463,8 +463,11 @@ int64_t pick_direct_K(const rr_plan *P, int64_t T)
 // tick-rows the caller announces one by one).
 // out32 (float32 output fused in, rr_*_f32*_dev): the direct task is a multiple of 128 rows, so that every output row -- the mean of
 // `factor` routed rows, factor divides 128 -- lies inside one task.
+// uh (rr_unit_route_uh*_dev: runoff depths + unit-hydrograph kernel): on the direct row path the convolution runs first, as a pass of its own
+// into T rows of work memory (mrows) that the lanes then read -- the reference's own two steps (UnitMuskingum.py:72-98) -- where those rows
+// fit a third of the card; otherwise the call keeps to records with the convolution fused into the in-pass.
 Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, bool plain_rows = false,
-                         int64_t ring_in = 0, int64_t ring_out = 0, bool out32 = false)
+                         int64_t ring_in = 0, int64_t ring_out = 0, bool out32 = false, bool uh = false)
 {
     Schedule sch;
     const int64_t total = T * nsub, dmax = P->h.depth - 1, n = P->h.n;
@@ -473,7 +476,8 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
     // included: rr_plan_set_boundary lays the direct plan out around them).
     // Sub-steps (up to kDirectMaxSub a row) and channel-only routing take it too; with sub-steps only without boundary ghosts.
     // UnitMuskingum (float64 rows of convolved lateral inflow, one sub-step a row, no boundary reaches) takes it as well.
-    const bool unit_direct = mode == Mode::Unit && nsub == 1 && P->n_ghost == 0 && P->n_export == 0 && !P->unit_general && P->tp.ok;
+    const bool unit_direct = mode == Mode::Unit && nsub == 1 && P->n_ghost == 0 && P->n_export == 0 && !P->unit_general && P->tp.ok &&
+                             (!uh || P->dev_total_bytes == 0 || T * n * 8 <= (int64_t)(P->dev_total_bytes / 3));
     if (plain_rows && P->direct_enabled && P->dp.ok && (mode == Mode::Rapid || mode == Mode::Muskingum || unit_direct) && nsub <= kDirectMaxSub && (nsub == 1 || P->n_ghost == 0) &&
         P->weights_uniform && !force_streaming && !host_io && P->wave_enabled && total >= 8 && n < (int64_t{1} << 29)) {
         int64_t K = pick_direct_K(P, T);
@@ -491,6 +495,7 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
             sch.chunks = std::min<int64_t>((levels * sch.KS * kRec + 2 * K * nsub + 2 * dmax + kRecRows + 2 * kRec) / kRec + 2, (total + dmax) / kRec + 2);
             sch.ring = sch.chunks * kRec * np;
         }
+        if (uh) sch.mrows = T * n;      // the convolved rows
         if (K >= 2 * kRec && np < (int64_t{1} << 25) && (P->dev_total_bytes == 0 || sch.ring * 8 <= (int64_t)(P->dev_total_bytes / 2))) return sch;
         sch = Schedule();
     }
@@ -532,12 +537,12 @@ int host_pipe_prepare(rr_plan *P);
 
 // Sizes and allocates what a call of this shape works in.  The only place on a route call's path that allocates: the
 // host-pointer entry points come here by themselves, the *_dev ones expect rr_plan_reserve to have been here.
-int reserve_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, Schedule *out, bool plain_rows = false, bool out32 = false)
+int reserve_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, Schedule *out, bool plain_rows = false, bool out32 = false, bool uh = false)
 {
     if (P->h.n == 0 || T <= 0) { if (out) *out = Schedule(); return RR_OK; }
     Schedule sch;
     for (;;) {
-        sch = choose_schedule(P, mode, T, nsub, force_streaming, host_io, plain_rows, 0, 0, out32);
+        sch = choose_schedule(P, mode, T, nsub, force_streaming, host_io, plain_rows, 0, 0, out32, uh);
         if (ensure_cap(&P->d_ring, &P->ring_cap, sch.ring) == RR_OK) break;
         (void)hipGetLastError();
         if (sch.direct) return fail(RR_E_ALLOC, "route: the skeleton's record ring does not fit on the device");
@@ -564,14 +569,14 @@ int reserve_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_stre
 // The schedule of the call about to start.  strict (the *_dev entry points, which only enqueue): everything must have been
 // reserved; otherwise it is reserved here.
 int prepare_call(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_streaming, bool host_io, bool strict, bool plain_rows = false,
-                 int64_t ring_in = 0, int64_t ring_out = 0, bool out32 = false)
+                 int64_t ring_in = 0, int64_t ring_out = 0, bool out32 = false, bool uh = false)
 {
     Schedule sch;
     if (!strict) {
-        int rc = reserve_core(P, mode, T, nsub, force_streaming, host_io, &sch, plain_rows, out32);
+        int rc = reserve_core(P, mode, T, nsub, force_streaming, host_io, &sch, plain_rows, out32, uh);
         if (rc) return rc;
     } else {
-        sch = choose_schedule(P, mode, T, nsub, force_streaming, host_io, plain_rows, ring_in, ring_out, out32);
+        sch = choose_schedule(P, mode, T, nsub, force_streaming, host_io, plain_rows, ring_in, ring_out, out32, uh);
         const size_t samples = P->sample_every >= kSampleGroup ? 1 : 0;
         if (P->h.n > 0 && T > 0 && (sch.ring > P->ring_cap || sch.mrows > P->mrows_cap || sch.stage > P->stage_cap || !P->ev_first || P->ev.size() < 2 * samples ||
                                     (!sch.tiled && !sch.direct && !P->perm_ready && sch.mrows > 0)))
@@ -1568,16 +1573,20 @@ void unit_state_out(rr_plan *P, double *d_qch, double *d_qfull, int64_t total, h
                            (const double *)P->d_x, n, (const double *)P->d_qch, P->d_lag, P->d_inner_pos, (int32_t)ni, total);
 }
 
+template <typename TIn>
+int uh_convolve_core(const double *d_kernel, double *d_state, const TIn *d_lateral, double *d_out, int64_t T, int64_t n_ks, int64_t n, hipStream_t stream, uint32_t sel);
+
 int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io_in, int64_t T, int64_t nsub,
               hipStream_t stream, bool q_on_host, double *d_q_final = nullptr, double *uh_state_inout = nullptr)
 {
     const int64_t n = P->h.n, ni = (int64_t)P->h.inner_pos.size();
     if (n == 0 || T == 0) return RR_OK;
-    const Rows &io = io_in;
+    Rows io = io_in;
     const bool host_rows = io.host_in != nullptr || io.host_out != nullptr;
     {
-        const bool plain = !host_rows && io.dev_in && (io.dev_out || io.dev_out32) && !io.uh_kernel && !io.runoff;      // float64 rows of convolved lateral inflow in a device array: the direct row path applies
-        int rc = prepare_call(P, Mode::Unit, T, nsub, false, false, !host_rows, plain, 0, 0, io.dev_out32 != nullptr);
+        // rows in device arrays -- convolved lateral inflow, or runoff depths (float64 / float32) with the unit-hydrograph kernel: the direct row path applies
+        const bool plain = !host_rows && (io.dev_in || io.dev_in32) && (io.dev_out || io.dev_out32) && !io.runoff && (io.uh_kernel || !io.dev_in32) && (!io.uh_kernel || uh_state_inout);
+        int rc = prepare_call(P, Mode::Unit, T, nsub, false, false, !host_rows, plain, 0, 0, io.dev_out32 != nullptr, io.uh_kernel != nullptr);
         if (rc == RR_OK && host_rows && !P->wave_now) rc = prepare_call(P, Mode::Unit, T, nsub, true, true, false);
         if (rc == RR_OK && host_rows && P->wave_now) rc = host_pipe_prepare(P);
         if (rc) return rc;
@@ -1594,6 +1603,14 @@ int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io_in, int64
     }
     const bool wave = use_wave(P, Mode::Unit);
     int rc = unit_state_in(P, d_qch, d_qfull, stream);
+    if (rc == RR_OK && P->direct_now && io.uh_kernel) {
+        // the direct row path: the convolution first, into the work rows (choose_schedule: uh), carry-over state updated in place;
+        // the lanes then route those rows
+        if (T * n > P->mrows_cap) rc = fail(RR_E_STATE, "route: the convolved rows of the direct row path were not reserved");
+        else if (io.dev_in32) rc = uh_convolve_core<float>(io.uh_kernel, uh_state_inout, io.dev_in32, P->d_mrows, T, io.uh_nks, n, stream, P->in32_big_endian ? kSelSwap : kSelNative);
+        else rc = uh_convolve_core<double>(io.uh_kernel, uh_state_inout, io.dev_in, P->d_mrows, T, io.uh_nks, n, stream, kSelNative);
+        io.dev_in = P->d_mrows; io.dev_in32 = nullptr; io.rows_in = T; io.uh_kernel = nullptr; io.uh_state = nullptr;
+    }
     if (rc) { if (tmp) (void)hipFree(tmp); return rc; }
     if (rc == RR_OK) rc = piped ? route_host_pipelined(P, Mode::Unit, T, nsub, io.host_in, io.host_out, stream) : route_core(P, Mode::Unit, T, nsub, io, stream);
     if (rc == RR_OK && wave && d_q_final)      // every reach: a headwater's state is its last lateral inflow, an inner reach's q_full
@@ -1629,8 +1646,9 @@ int unit_like(rr_plan *P, double *q_ch, double *q_full, const Rows &io_in, int64
     return rc;
 }
 
-int uh_convolve_core(const double *d_kernel, double *d_state, const double *d_lateral, double *d_out, int64_t T,
-                     int64_t n_ks, int64_t n, hipStream_t stream)
+template <typename TIn>
+int uh_convolve_core(const double *d_kernel, double *d_state, const TIn *d_lateral, double *d_out, int64_t T,
+                     int64_t n_ks, int64_t n, hipStream_t stream, uint32_t sel)
 {
     if (T < 1 || n_ks < 1 || n < 0) return fail(RR_E_INVALID, "rr_uh_convolve: need T >= 1, n_ks >= 1, n >= 0");
     if (n == 0) return RR_OK;
@@ -1646,9 +1664,9 @@ int uh_convolve_core(const double *d_kernel, double *d_state, const double *d_la
 #define RR_UH_LAUNCH(NK_, NT_, R_, D_)                                                                             \
         do {                                                                                                       \
             const size_t lds = (size_t)NK_ * kUhThreads * sizeof(double);                                          \
-            (void)hipFuncSetAttribute((const void *)k_uh_convolve_ring<NK_, NT_, R_, D_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((k_uh_convolve_ring<NK_, NT_, R_, D_>), g, dim3(kUhThreads), lds, stream, d_kernel, (const double *)d_state,     \
-                               d_lateral, d_out, T, (int32_t)n_ks, n, seg_rows);                                   \
+            (void)hipFuncSetAttribute((const void *)k_uh_convolve_ring<NK_, NT_, R_, D_, TIn>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((k_uh_convolve_ring<NK_, NT_, R_, D_, TIn>), g, dim3(kUhThreads), lds, stream, d_kernel, (const double *)d_state,     \
+                               d_lateral, d_out, T, (int32_t)n_ks, n, seg_rows, sel);                              \
         } while (0)
         if (n_ks <= 5) RR_UH_LAUNCH(8, 5, 4, 2);            // NK >= NT + R - 1 window slots
         else if (n_ks <= 13) RR_UH_LAUNCH(16, 13, 4, 2);
@@ -1659,14 +1677,14 @@ int uh_convolve_core(const double *d_kernel, double *d_state, const double *d_la
 #undef RR_UH_LAUNCH
     } else {
         dim3 g((unsigned)((n + kBlock - 1) / kBlock), (unsigned)((T + TB - 1) / TB));
-        hipLaunchKernelGGL(k_uh_convolve<TB>, g, dim3(kBlock), 0, stream, d_kernel, (const double *)d_state, d_lateral,
-                           d_out, T, (int32_t)n_ks, n);
+        hipLaunchKernelGGL((k_uh_convolve<TB, TIn>), g, dim3(kBlock), 0, stream, d_kernel, (const double *)d_state, d_lateral,
+                           d_out, T, (int32_t)n_ks, n, sel);
     }
     // carry-over state, in place, after the rows above have read the old one (same stream)
     const dim3 gt((unsigned)((n + kUhTailThreads - 1) / kUhTailThreads));
-    if (n_ks <= 16) hipLaunchKernelGGL(k_uh_tail<16>, gt, dim3(kUhTailThreads), 0, stream, d_kernel, d_state, d_lateral, T, (int32_t)n_ks, n);
-    else if (n_ks <= 48) hipLaunchKernelGGL(k_uh_tail<48>, gt, dim3(kUhTailThreads), 0, stream, d_kernel, d_state, d_lateral, T, (int32_t)n_ks, n);
-    else hipLaunchKernelGGL(k_uh_tail<0>, gt, dim3(kUhTailThreads), 0, stream, d_kernel, d_state, d_lateral, T, (int32_t)n_ks, n);
+    if (n_ks <= 16) hipLaunchKernelGGL((k_uh_tail<16, TIn>), gt, dim3(kUhTailThreads), 0, stream, d_kernel, d_state, d_lateral, T, (int32_t)n_ks, n, sel);
+    else if (n_ks <= 48) hipLaunchKernelGGL((k_uh_tail<48, TIn>), gt, dim3(kUhTailThreads), 0, stream, d_kernel, d_state, d_lateral, T, (int32_t)n_ks, n, sel);
+    else hipLaunchKernelGGL((k_uh_tail<0, TIn>), gt, dim3(kUhTailThreads), 0, stream, d_kernel, d_state, d_lateral, T, (int32_t)n_ks, n, sel);
     HIPCHK(hipGetLastError());
     return RR_OK;
 }

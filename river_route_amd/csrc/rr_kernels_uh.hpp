@@ -8,21 +8,30 @@ namespace {
 //   out[t, i] = [t < n_ks] state[t, i] + sum_{s=0}^{min(t, n_ks-1)} kernel[s, i] * lateral[t - s, i]
 // One reach per lane, TB consecutive outputs per thread held in registers; per tap one kernel value and one
 // new lateral value are loaded and the TB-wide window slides in registers.
-template <int TB>
+// TIn: the rows' type (float: runoff depths as the file stores them, exact in float64; sel: their byte order, rr_plan_set_row_format)
+template <typename TIn>
+__device__ __forceinline__ double uh_row_value(const TIn *__restrict__ rows, int64_t off, uint32_t sel)
+{
+    if constexpr (std::is_same<TIn, float>::value) return (double)f32_from_file(rows[off], sel);
+    else return (double)rows[off];
+}
+
+template <int TB, typename TIn = double>
 __global__ __launch_bounds__(kBlock) void k_uh_convolve(const double *__restrict__ kernel,
                                                         const double *__restrict__ state,
-                                                        const double *__restrict__ lateral,
-                                                        double *__restrict__ out, int64_t T, int32_t n_ks, int64_t n)
+                                                        const TIn *__restrict__ lateral_rows,
+                                                        double *__restrict__ out, int64_t T, int32_t n_ks, int64_t n, uint32_t sel = kSelNative)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
+    auto lateral_at = [&](int64_t off) { return uh_row_value<TIn>(lateral_rows, off, sel); };
     const int64_t t0 = (int64_t)blockIdx.y * TB;
     double acc[TB], win[TB];
 #pragma unroll
     for (int j = 0; j < TB; ++j) {
         const int64_t t = t0 + j;
         acc[j] = (t < n_ks && t < T) ? state[t * n + i] : 0.0;
-        win[j] = (t < T) ? lateral[t * n + i] : 0.0;   // lateral[t0 + j - s] for s = 0
+        win[j] = (t < T) ? lateral_at(t * n + i) : 0.0;   // lateral[t0 + j - s] for s = 0
     }
     for (int32_t s = 0; s < n_ks; ++s) {
         const double kv = kernel[(int64_t)s * n + i];
@@ -32,7 +41,7 @@ __global__ __launch_bounds__(kBlock) void k_uh_convolve(const double *__restrict
 #pragma unroll
         for (int j = TB - 1; j > 0; --j) win[j] = win[j - 1];
         const int64_t tn = t0 - (s + 1);
-        win[0] = (tn >= 0) ? lateral[tn * n + i] : 0.0;
+        win[0] = (tn >= 0) ? lateral_at(tn * n + i) : 0.0;
     }
 #pragma unroll
     for (int j = 0; j < TB; ++j)
@@ -50,14 +59,15 @@ constexpr int kUhTailThreads = 64;
 // D passes of lateral rows in flight.  The window costs NK * 8 B of LDS per thread, which caps the kernel at about
 // one wave per SIMD: latency is hidden by depth instead (R * D rows per lane in flight; registers are free at
 // that occupancy).
-template <int NK, int NT, int R, int D>    // NT taps held in registers (n_ks <= NT <= NK - (R - 1))
+template <int NK, int NT, int R, int D, typename TIn = double>    // NT taps held in registers (n_ks <= NT <= NK - (R - 1))
 __global__ __launch_bounds__(kUhThreads) void k_uh_convolve_ring(const double *__restrict__ kernel,
                                                                 const double *__restrict__ state,
-                                                                const double *__restrict__ lateral,
+                                                                const TIn *__restrict__ lateral_rows,
                                                                 double *__restrict__ out, int64_t T, int32_t n_ks,
-                                                                int64_t n, int64_t seg_rows)
+                                                                int64_t n, int64_t seg_rows, uint32_t sel = kSelNative)
 {
     extern __shared__ __attribute__((aligned(16))) double win[];   // [NK][kUhThreads]
+    auto lateral_at = [&](int64_t off) { return uh_row_value<TIn>(lateral_rows, off, sel); };
     static_assert(NT + R - 1 <= NK, "window ring too small");
     const int tid = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * kUhThreads + tid;
@@ -71,13 +81,13 @@ __global__ __launch_bounds__(kUhThreads) void k_uh_convolve_ring(const double *_
 #pragma unroll
     for (int s = 1; s < NT; ++s) {
         const int64_t t = t0 - s;
-        win[(size_t)((uint64_t)t & (NK - 1)) * kUhThreads + tid] = (t >= 0 && s < n_ks) ? lateral[t * n + col] : 0.0;
+        win[(size_t)((uint64_t)t & (NK - 1)) * kUhThreads + tid] = (t >= 0 && s < n_ks) ? lateral_at(t * n + col) : 0.0;
     }
     double nxt[D][R];
 #pragma unroll
     for (int dd = 0; dd < D; ++dd)
 #pragma unroll
-        for (int j = 0; j < R; ++j) nxt[dd][j] = lateral[min(t0 + dd * R + j, T - 1) * n + col];
+        for (int j = 0; j < R; ++j) nxt[dd][j] = lateral_at(min(t0 + dd * R + j, T - 1) * n + col);
     // window value m = t + R - 1 - d is tap (j + d - (R - 1)) of output t + j.  With one wave per SIMD nothing else
     // hides the LDS latency: the window is read CH values at a time, one chunk ahead of the FMAs.
     constexpr int CH = 8, ND = NT + R - 1, NCH = (ND + CH - 1) / CH;
@@ -90,7 +100,7 @@ __global__ __launch_bounds__(kUhThreads) void k_uh_convolve_ring(const double *_
     for (int64_t tb = t0; tb < t1; tb += NK) {
         const bool fast = STATIC_GROUPS && tb >= n_ks && tb + NK <= t1 && tb + NK + R * D <= T;
         if (fast) {
-            const double *lat_g = lateral + tb * n + col;     // row tb of this column
+            const TIn *lat_g = lateral_rows + tb * n + col;     // row tb of this column
             double *out_g = out + tb * n + col;
 #pragma unroll
             for (int pp = 0; pp < PASSES; ++pp) {
@@ -103,7 +113,7 @@ __global__ __launch_bounds__(kUhThreads) void k_uh_convolve_ring(const double *_
                     acc[j] = 0.0;
                 }
 #pragma unroll
-                for (int j = 0; j < R; ++j) nxt[dd][j] = lat_g[(int64_t)(pp * R + R * D + j) * n];
+                for (int j = 0; j < R; ++j) nxt[dd][j] = uh_row_value<TIn>(lat_g, (int64_t)(pp * R + R * D + j) * n, sel);
                 double wv[2][CH];
                 auto read_chunk = [&](int c, double (&v)[CH]) {
 #pragma unroll
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(kUhThreads) void k_uh_convolve_ring(const double *_
                     acc[j] = (t + j < n_ks && t + j < T) ? state[(t + j) * n + col] : 0.0;
                 }
 #pragma unroll
-                for (int j = 0; j < R; ++j) nxt[dd][j] = lateral[min(t + R * D + j, T - 1) * n + col];     // D passes ahead
+                for (int j = 0; j < R; ++j) nxt[dd][j] = lateral_at(min(t + R * D + j, T - 1) * n + col);     // D passes ahead
                 double wv[2][CH];
                 auto read_chunk = [&](int c, double (&v)[CH]) {
 #pragma unroll

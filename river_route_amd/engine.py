@@ -174,14 +174,15 @@ class Plan:
                                        int(num_substeps)))
 
     # -- work memory --
-    def reserve(self, mode: int, T: int, num_substeps: int = 1, host_rows: bool = False, plain_rows: bool = True, f32_out: bool = False) -> dict:
+    def reserve(self, mode: int, T: int, num_substeps: int = 1, host_rows: bool = False, plain_rows: bool = True, f32_out: bool = False, uh: bool = False) -> dict:
         """rr_plan_reserve: allocate what route calls of up to T rows x num_substeps sub-steps work in (the record ring, events,
         with host_rows the PCIe staging).  The *_dev entry points of the C ABI only enqueue and fail with RR_E_STATE when this
         has not been done; the methods below call it for the shape they are given (no-op once large enough).  plain_rows=False:
         the call hands over no lateral rows in a device array (fused convolution, gridded runoff), so the direct row path does not
-        apply (RR_ROWS_NOT_PLAIN); f32_out: it writes float32 rows (RR_ROWS_F32_OUT)."""
+        apply (RR_ROWS_NOT_PLAIN); f32_out: it writes float32 rows (RR_ROWS_F32_OUT); uh: it is unit_route_uh*_dev (RR_ROWS_UH: on the
+        direct row path the convolved rows are work memory)."""
         info = np.zeros(8, dtype=np.int64)
-        check(_lib.lib().rr_plan_reserve(self._h, int(mode), int(T), int(num_substeps), int(bool(host_rows)) | (0 if plain_rows else 2) | (4 if f32_out else 0), ptr(info)))
+        check(_lib.lib().rr_plan_reserve(self._h, int(mode), int(T), int(num_substeps), int(bool(host_rows)) | (0 if plain_rows else 2) | (4 if f32_out else 0) | (8 if uh else 0), ptr(info)))
         if int(info[0]) == 0 and int(T) * int(num_substeps) >= 32 and self.n > 0 and not getattr(self, '_warned_streaming', False):
             # the time-tiled kernel takes every call of 32 sub-steps or more -- unless the network does not tile, the coefficients give the
             # tributaries of a reach different weights, or its record ring (depth + tile levels x K tick-rows of every reach) does not fit
@@ -269,7 +270,7 @@ class Plan:
     def unit_route_uh_dev(self, q_ch, q_full, q_final, uh_kernel, uh_state, n_ks, depth, T, num_substeps, discharge=None,
                           discharge32=None, factor=1, stream=None) -> None:
         """Convolution + routing of one file in one call (rr_unit_route_uh_dev); exactly one of discharge / discharge32."""
-        self.reserve(MODE_UNIT, T, num_substeps, plain_rows=False)
+        self.reserve(MODE_UNIT, T, num_substeps, f32_out=discharge32 is not None, uh=True)
         check(_lib.lib().rr_unit_route_uh_dev(self._h, ptr(q_ch), ptr(q_full), ptr(q_final), ptr(uh_kernel), ptr(uh_state),
                                               int(n_ks), ptr(depth), ptr(discharge), ptr(discharge32), int(factor), int(T),
                                               int(num_substeps), stream))
@@ -277,7 +278,7 @@ class Plan:
     def unit_route_uh_f32in_dev(self, q_ch, q_full, q_final, uh_kernel, uh_state, n_ks, depth32, T, num_substeps, discharge=None,
                                 discharge32=None, factor=1, stream=None) -> None:
         """rr_unit_route_uh_f32in_dev: the same from float32 runoff depths (as runoff files store them)."""
-        self.reserve(MODE_UNIT, T, num_substeps, plain_rows=False)
+        self.reserve(MODE_UNIT, T, num_substeps, f32_out=discharge32 is not None, uh=True)
         check(_lib.lib().rr_unit_route_uh_f32in_dev(self._h, ptr(q_ch), ptr(q_full), ptr(q_final), ptr(uh_kernel), ptr(uh_state),
                                                     int(n_ks), ptr(depth32), ptr(discharge), ptr(discharge32), int(factor), int(T),
                                                     int(num_substeps), stream))

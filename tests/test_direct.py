@@ -660,3 +660,57 @@ def test_unit_route_on_the_direct_path_vs_oracle(monkeypatch, n, T, env, f32):
                 np.testing.assert_array_equal(d[:, hw_idx], conv_ref[:, hw_idx])     # headwaters: unclamped, un-averaged
         for b in (d_conv, d_out, d_qc, d_qf):
             b.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,T,n_ks,in32,f32out', [(60_000, 200, 48, False, False), (300_000, 150, 48, True, False), (60_000, 256, 12, True, True), (60_007, 300, 33, False, False),
+                                                   (60_000, 100, 60, False, False)])
+def test_unit_route_with_convolution_on_the_direct_path_vs_oracle(monkeypatch, n, T, n_ks, in32, f32out):
+    """rr_unit_route_uh_dev / rr_unit_route_uh_f32in_dev on a post-order network: UnitHydrograph.convolve + unit_route + the router's state
+    bookkeeping (river_route/routers/UnitMuskingum.py:72-98) in one call -- on the direct row path the convolution runs as a pass of its own into
+    work rows, then k_direct<UNIT> routes them; two files, the second shorter than the kernel, so the carry-over state crosses a file boundary."""
+    from tests_support import unit_split_arrays
+    set_env(monkeypatch, {})
+    net, indptr, indices, c1, c2, c3 = _case(n, 23)
+    hw_idx, inner_idx, A_in, A_hw = unit_split_arrays(indptr, indices, n)
+    c1i, c2i, c3i = c1[inner_idx], c2[inner_idx], c3[inner_idx]
+    args = (A_in.indptr, A_in.indices, -c1i[A_in.indices], A_in.indptr, A_in.indices, A_in.data,
+            A_hw.indptr, A_hw.indices, A_hw.data, c1i, c2i, c3i, hw_idx, inner_idx)
+    kern = synth.synth_uh_kernel(n, n_ks)
+    uh = oracle.UnitHydrograph(kern)
+    state_ref = 3.0 * synth.u01(7, np.arange(n))
+    ni = inner_idx.size
+    factor = 4
+    with Plan(indptr, indices) as plan:
+        assert plan.direct_info()['ok'], plan.direct_info()['why']
+        plan.set_coeffs(-c1[indices], c2, c3, None)
+        d_kern, d_state = DeviceBuffer(kern.nbytes).upload(kern), DeviceBuffer(kern.nbytes).upload(np.zeros_like(kern))
+        d_depth, d_out, d_fin = DeviceBuffer(T * n * 8), DeviceBuffer(T * n * 8), DeviceBuffer(n * 8)
+        d_qc, d_qf = DeviceBuffer(ni * 8), DeviceBuffer(ni * 8)
+        state = state_ref.copy()
+        for f, Tf in enumerate((T, max(8, n_ks // 2 // factor * factor))):
+            depth = synth.synth_runoff_depth(n, f * T, f * T + Tf)
+            if in32:
+                depth = depth.astype(np.float32)
+            conv_ref = uh.convolve(depth.astype(np.float64))
+            qc_ref, qf_ref, d_ref = state_ref[inner_idx].copy(), state_ref[inner_idx].copy(), np.zeros((Tf, n))
+            oracle.unit_route(*args, qc_ref, qf_ref, conv_ref, d_ref, 1)
+            state_ref[hw_idx], state_ref[inner_idx] = conv_ref[-1][hw_idx], qf_ref
+            d_depth.upload(depth)
+            d_qc.upload(state[inner_idx].copy()); d_qf.upload(state[inner_idx].copy())
+            call = plan.unit_route_uh_f32in_dev if in32 else plan.unit_route_uh_dev
+            out_kw = dict(discharge32=d_out, factor=factor) if f32out else dict(discharge=d_out)
+            call(d_qc, d_qf, d_fin, d_kern, d_state, n_ks, d_depth, Tf, 1, **out_kw)
+            assert plan.last_kernel() == 'direct'
+            state = d_fin.download(np.float64, (n,))
+            if f32out:
+                want = d_ref.reshape(Tf // factor, factor, n).mean(axis=1).astype(np.float32)
+                got = d_out.download(np.float32, (Tf // factor, n))
+                assert np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64)).max() <= 1, 'float32 means differ by more than 1 ulp'
+            else:
+                assert_close(d_out.download(np.float64, (Tf, n)), d_ref, f'file {f} discharge')
+            assert_close(state, state_ref, f'file {f} router state')
+            assert_close(d_qc.download(np.float64, (ni,)), qc_ref, f'file {f} q_ch')
+            assert_close(d_state.download(np.float64, kern.shape), uh.state, f'file {f} UH state')
+        for b in (d_kern, d_state, d_depth, d_out, d_fin, d_qc, d_qf):
+            b.free()
