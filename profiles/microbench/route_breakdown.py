@@ -41,25 +41,29 @@ def timed(name, fn):
     return wrapper
 
 
-net = synth.synth_network(n, order=order)
-tmp = tempfile.mkdtemp(prefix='rr_breakdown_')
+tmp = os.environ.get('RR_BREAKDOWN_DIR') or tempfile.mkdtemp(prefix='rr_breakdown_')
 params = os.path.join(tmp, 'params.parquet')
-pd.DataFrame({'river_id': net.river_ids, 'downstream_river_id': net.downstream_ids, 'k': net.k, 'x': net.x}).to_parquet(params)
-ql32 = synth.synth_qlateral(n, 0, T, dt=dt).astype(np.float32)
-dates = (np.datetime64('2020-01-01T00:00:00', 's') + np.arange(T) * np.timedelta64(int(dt), 's')).astype('datetime64[s]').astype(np.int64).astype(np.float64)
 qfile = os.path.join(tmp, 'qlateral.nc')
-with netcdf_file(qfile, 'w', version=2) as ds:
-    ds.createDimension('time', None)
-    ds.createDimension('river_id', n)
-    tv = ds.createVariable('time', 'f8', ('time',))
-    tv.units = 'seconds since 1970-01-01 00:00:00'
-    tv[:] = dates
-    rid = ds.createVariable('river_id', 'i4', ('river_id',))
-    rid[:] = net.river_ids.astype(np.int32)
-    v = ds.createVariable('qlateral', 'f4', ('time', 'river_id'))
-    v[:] = ql32
-del ql32
-os.makedirs(os.path.join(tmp, 'out'))
+if os.environ.get('RR_BREAKDOWN_MAKE'):      # the child that writes the input files: its arrays must not count in the router's peak RSS
+    net = synth.synth_network(n, order=order)
+    pd.DataFrame({'river_id': net.river_ids, 'downstream_river_id': net.downstream_ids, 'k': net.k, 'x': net.x}).to_parquet(params)
+    ql32 = synth.synth_qlateral(n, 0, T, dt=dt).astype(np.float32)
+    dates = (np.datetime64('2020-01-01T00:00:00', 's') + np.arange(T) * np.timedelta64(int(dt), 's')).astype('datetime64[s]').astype(np.int64).astype(np.float64)
+    with netcdf_file(qfile, 'w', version=2) as ds:
+        ds.createDimension('time', None)
+        ds.createDimension('river_id', n)
+        tv = ds.createVariable('time', 'f8', ('time',))
+        tv.units = 'seconds since 1970-01-01 00:00:00'
+        tv[:] = dates
+        rid = ds.createVariable('river_id', 'i4', ('river_id',))
+        rid[:] = net.river_ids.astype(np.int32)
+        v = ds.createVariable('qlateral', 'f4', ('time', 'river_id'))
+        v[:] = ql32
+    os.makedirs(os.path.join(tmp, 'out'), exist_ok=True)
+    sys.exit(0)
+import subprocess
+subprocess.check_call([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=dict(os.environ, RR_BREAKDOWN_MAKE='1', RR_BREAKDOWN_DIR=tmp))
+print(f'input files written by a child process; this process before the first route(): peak host RSS {resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6:.2f} GB')
 
 pd.read_parquet = timed('params table read (pd.read_parquet)', pd.read_parquet)
 muskingum.adjacency_matrix = timed('tools.adjacency_matrix', muskingum.adjacency_matrix)
