@@ -293,12 +293,15 @@ def bench_unit(args, device_index):
 def launch_ranks(n_ranks: int) -> int:
     """`python bench.py --gpus N` without torch.distributed.run: this process -- which never touches a GPU -- starts one
     fresh child per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what torchrun would set), relays rank 0's
-    JSON line and returns non-zero if any rank fails.  RR_DIST_BACKEND=gloo lets the ranks share one card (rehearsal)."""
+    JSON line and returns non-zero if any rank fails.  RR_DIST_BACKEND=gloo lets the ranks share one card (rehearsal).
+    The children get HSA_ENABLE_IPC_MODE_LEGACY=0 in their environment (RCCL's device-memory sharing needs dmabuf IPC on these hosts and
+    the variable is read when the HIP runtime starts)"""
     import socket
     import subprocess
+    import threading
     if os.environ.get('RR_DIST_BACKEND', 'nccl') == 'nccl':
-        import torch      # device_count() does not initialise the GPU
-        have = torch.cuda.device_count()
+        import torch      # counts the devices (hipGetDeviceCount on this image: no context, no memory); this process runs nothing on them and
+        have = torch.cuda.device_count()      # the ranks are fresh children, not forks or execs of it
         if have < n_ranks:
             print(f'bench.py --gpus {n_ranks}: {have} GPU(s) visible; RCCL needs one per rank '
                   f'(RR_DIST_BACKEND=gloo rehearses the same run with the ranks sharing a card)', file=sys.stderr)
@@ -310,8 +313,12 @@ def launch_ranks(n_ranks: int) -> int:
     for r in range(n_ranks):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    chunks = []      # rank 0's stdout, drained while it runs (a full pipe would stall it until the deadline)
+    reader = threading.Thread(target=lambda: chunks.extend(iter(lambda: procs[0].stdout.read(65536), b'')), daemon=True)
+    reader.start()
     deadline = time.monotonic() + float(os.environ.get('RR_BENCH_TIMEOUT', '3000'))
     failed = None
     while failed is None and any(p.poll() is None for p in procs):
@@ -330,9 +337,10 @@ def launch_ranks(n_ranks: int) -> int:
         for p in procs:      # exactly the children started above
             if p.poll() is None:
                 p.kill()
-    out = procs[0].stdout.read().decode('utf-8', 'replace') if procs[0].stdout else ''
     for p in procs:
         p.wait()
+    reader.join(timeout=10)
+    out = b''.join(chunks).decode('utf-8', 'replace')
     if failed is not None:
         sys.stderr.write(out)
         print(f'bench.py --gpus {n_ranks}: {failed}', file=sys.stderr)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B on one box: bench line (ms per year, k_tile launch us) for each "LIB[:ENV=VAL[,ENV=VAL]]" argument, ROUNDS times round-robin.
-#   bash profiles/microbench/ab_variants.sh "hip" "hip:RR_REC_STREAM=0" "nt15" ...        (hip = the product library)
+#   bash profiles/microbench/ab_variants.sh "hip" "hip:RR_WAVE_K=128" "nt15" ...        (hip = the product library; an ENV only counts while csrc reads it:
+#   RR_WAVE, RR_WAVE_K, RR_TILE_BLOCK, RR_TILE_LEAN, RR_UH_PAIRS, RR_DIRECT -- the round-3 knobs RR_REC_STREAM, RR_TILE_SLOTS, RR_WAVE_THREADS, RR_RING_EXTRA are gone)
 # BENCH_ARGS adds bench.py arguments (e.g. BENCH_ARGS="--reaches 100000").  GATE=1: with the bench's parity gate against the oracle
 # (a variant build is not covered by the test suite), a second of CPU baseline.
 ROUNDS=${ROUNDS:-2}

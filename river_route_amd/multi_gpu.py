@@ -26,9 +26,17 @@ from dataclasses import dataclass, field
 import numpy as np
 
 # RCCL shares device memory between the ranks of a node through dmabuf IPC on these hosts; the legacy mode fails with
-# `hipIpcGetMemHandle: invalid argument`.  Has to be in the environment before the HIP runtime starts, so any program that
-# drives run_distributed over RCCL should import this module (or set the variable) before it touches the GPU.
-os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+# `hipIpcGetMemHandle: invalid argument`.  The variable is read when the HIP runtime starts: bench.py's launcher puts it into the ranks'
+# environment; a program that drives run_distributed itself sets it before it touches the GPU.  Setting it here only helps when this
+# module is imported first, so say so when it is too late.
+if os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY') is None:
+    os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '0'
+    import sys as _sys
+    _t = _sys.modules.get('torch')
+    if _t is not None and getattr(_t, 'cuda', None) is not None and _t.cuda.is_initialized():
+        import warnings
+        warnings.warn('river_route_amd.multi_gpu: HSA_ENABLE_IPC_MODE_LEGACY was not set before the HIP runtime started; RCCL over several '
+                      'GPUs needs HSA_ENABLE_IPC_MODE_LEGACY=0 in the environment of the process (hipIpcGetMemHandle fails otherwise)')
 
 __all__ = ['PartSpec', 'split_network', 'HipPartEngine', 'HipUnitPartEngine', 'part_driver', 'run_distributed', 'run_in_process',
            'run_sequential', 'bench_main']
