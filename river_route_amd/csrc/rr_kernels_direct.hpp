@@ -399,7 +399,11 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
             float *row32 = OUT32 ? a.out32 + (int64_t)(r0 / a.factor) * a.n : nullptr;      // r0 = m K is a multiple of factor
             double2 sa = make_double2(0.0, 0.0), sb = sa;      // OUT32: the sums of the output row being formed
             int32_t cnt = 0;
-            const double fdiv = (double)a.factor;
+            // the mean's division: by a power of two it is the multiplication by the reciprocal, bit for bit, and a float64 division is ~40
+            // instructions where the rows-out wave has a tick's worth of time (wave-uniform choice)
+            const double fdiv = (double)a.factor, finv = 1.0 / fdiv;
+            const bool pow2 = (a.factor & (a.factor - 1)) == 0;
+            auto mean_of = [&](double sum) { return pow2 ? sum * finv : sum / fdiv; };
             int32_t out_b = 0;
             // UNIT: a headwater's column leaves as it is (_numba_kernels.py:122-123: no clip)
             auto raw_col = [&](int32_t c) { return UNIT != 0 && c < tm.nc && (a.lane[tm.c0 + c].y & 0x3FF) == 0x3FF; };
@@ -427,10 +431,9 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                             sb = cnt ? make_double2(sb.x + cb2.x, sb.y + cb2.y) : cb2;
                             if (++cnt == a.factor) {      // wave-uniform
                                 cnt = 0;
-                                const bool one = a.factor == 1;
                                 f32x2 fa, fb;
-                                fa.x = f32_to_file((float)(one ? sa.x : sa.x / fdiv), a.out32_sel); fa.y = f32_to_file((float)(one ? sa.y : sa.y / fdiv), a.out32_sel);
-                                fb.x = f32_to_file((float)(one ? sb.x : sb.x / fdiv), a.out32_sel); fb.y = f32_to_file((float)(one ? sb.y : sb.y / fdiv), a.out32_sel);
+                                fa.x = f32_to_file((float)mean_of(sa.x), a.out32_sel); fa.y = f32_to_file((float)mean_of(sa.y), a.out32_sel);
+                                fb.x = f32_to_file((float)mean_of(sb.x), a.out32_sel); fb.y = f32_to_file((float)mean_of(sb.y), a.out32_sel);
                                 const __amdgpu_buffer_rsrc_t dst = make_rsrc(row32, tile_end);
                                 store_f32x2_nt(dst, va, fa);
                                 store_f32x2_nt(dst, vb, fb);
