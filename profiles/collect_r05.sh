@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collects the round-5 profiles on the GPU box (run from the repo root through gpurun; everything lands in gpurun_out/r05/, the
 # summaries are then copied to profiles/ by hand).  Counter passes run apart from the kernel trace.
-#   bash profiles/collect_r05.sh stats     kernel summaries: a headline (random order), d the same year in post-order (direct row path), b config 4, f float32 rows
-#   bash profiles/collect_r05.sh pmc       FETCH_SIZE and WRITE_SIZE passes over the whole timed pass of: the headline in both orders, config 2, config 4, the float32 line
+#   bash profiles/collect_r05.sh stats     kernel summaries: a headline (random order), d the same year in post-order (direct row path), b config 4, f float32 rows, u config 4 in post-order
+#   bash profiles/collect_r05.sh pmc [a|b] FETCH_SIZE and WRITE_SIZE passes over the whole timed pass of: (a) the headline in both orders, config 2, (b) config 4 in both orders, the float32 line
 #                                          -> gpurun_out/r05/r05_pmc_traffic.json (no secondary line of bench.py without its own traffic)
 #   bash profiles/collect_r05.sh bench     the default bench line
 set -e -o pipefail
@@ -17,7 +17,8 @@ stats)
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/d -- python3 bench.py --order postorder --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/d.log 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/b -- python3 bench.py --workload unit --steps 2 --warmup 1 --no-cpu-baseline > $OUT/b.log 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/f -- python3 bench.py --workload rapid_f32 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/f.log 2>&1
-  for k in a d b f; do cp $(find $OUT/$k -name '*kernel_stats.csv' | head -1) $OUT/${k}_kernel_stats.csv; rm -rf $OUT/$k; done
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/u -- python3 bench.py --workload unit --order postorder --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > $OUT/u.log 2>&1
+  for k in a d b f u; do cp $(find $OUT/$k -name '*kernel_stats.csv' | head -1) $OUT/${k}_kernel_stats.csv; rm -rf $OUT/$k; done
   ;;
 pmc)
   cp profiles/r05_pmc_traffic.json $OUT/r05_pmc_traffic.json 2>/dev/null || true
@@ -29,11 +30,18 @@ pmc)
         --order $name --main $main --reaches $reaches --runoff-steps $rows --json $OUT/r05_pmc_traffic.json --command "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py $* $ONE"
     rm -rf $OUT/fetch $OUT/write
   }
-  pass random k_tile 1000000 35040 --order random
-  pass postorder k_direct 1000000 35040 --order postorder
-  pass config2 k_tile 100000 35040 --reaches 100000
-  pass config4 k_tile 1000000 3504 --workload unit
-  pass f32 k_tile 1000000 35040 --workload rapid_f32
+  case "${2:-all}" in      # (two gpurun calls of at most 20 minutes: `pmc a`, then `pmc b` with gpurun_out/r05/r05_pmc_traffic.json copied to profiles/ in between)
+  a|all)
+    pass random k_tile 1000000 35040 --order random
+    pass postorder k_direct 1000000 35040 --order postorder
+    pass config2 k_tile 100000 35040 --reaches 100000
+    ;;&
+  b|all)
+    pass config4 k_tile 1000000 3504 --workload unit
+    pass config4_postorder k_direct 1000000 3504 --workload unit --order postorder
+    pass f32 k_tile 1000000 35040 --workload rapid_f32
+    ;;
+  esac
   ;;
 bench)
   python3 bench.py > $OUT/bench_default.log 2> $OUT/bench_default.err
