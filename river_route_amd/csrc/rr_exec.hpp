@@ -490,6 +490,7 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
         // that feeds another GPU, whose boundary series every level delays by one task: 64 ticks there (as kc_long below), several of the
         // skeleton's launches per direct launch.  KS divides KC.
         sch.KS = sch.KC * nsub;      // (in ticks: a direct task is K rows = K nsub ticks)
+        if (const char *e = getenv("RR_DIRECT_KS")) { const int64_t cap = std::max<int64_t>(1, atoll(e) / kRec); for (sch.KS = std::min<int64_t>(sch.KC * nsub, cap); (sch.KC * nsub) % sch.KS; --sch.KS) {} }
         if (P->n_export > 0 && P->wave_K <= 0) for (sch.KS = std::min<int64_t>(sch.KC * nsub, 4); (sch.KC * nsub) % sch.KS; --sch.KS) {}
         if (np > 0) {      // a record lives from the launch that forwards its first row to the out-pass behind the skeleton's last level
             sch.chunks = std::min<int64_t>((levels * sch.KS * kRec + 2 * K * nsub + 2 * dmax + kRecRows + 2 * kRec) / kRec + 2, (total + dmax) / kRec + 2);
