@@ -449,12 +449,21 @@ struct Schedule {
 };
 
 // Rows per task of the direct path: a task costs its tile `span` ticks of fill and drain (lanes start one after the other: 10 % at
-// 512 rows), every tile level of the skeleton one task of pipeline and of record ring (1,024 rows: 213 ms per year against 207,
-// profiles/r04_direct_k_and_fill.txt); short calls take short tasks.
+// 512 rows, 5 % at 1,024).  The skeleton's tasks are cut separately (Schedule::KS, direct_KS below): every tile level of the skeleton costs
+// one of ITS tasks of pipeline and of record ring, so long lane tasks over short skeleton tasks have both -- the year at 1M reaches
+// 196.5 ms with 512 / 512, 186.4 with 1,024 / 512, 185.1 with 2,048 / 512; a 3,504-row call 24.4 ms with 256 / 256, 21.6 with 512 / 128; a
+// 744-row call 7.4 ms with 128 / 128, 6.6 with 256 / 128 (profiles/r05_direct_ks_ab.txt; with the skeleton's tasks as long as the lanes',
+// 1,024 rows lost to 512: 213 against 207 ms, profiles/r04_direct_k_and_fill.txt).
 int64_t pick_direct_K(const rr_plan *P, int64_t T)
 {
     if (P->wave_K > 0) return P->wave_K;
-    return T >= 8192 ? 512 : (T >= 2048 ? 256 : (T >= 512 ? 128 : 64));
+    return T >= 16384 ? 1024 : (T >= 2048 ? 512 : (T >= 512 ? 256 : (T >= 128 ? 128 : 64)));
+}
+int64_t direct_KS(int64_t task_chunks, int64_t total_ticks)      // record chunks per skeleton task: 512 ticks in long calls, 128 in short ones; divides the lanes' task
+{
+    int64_t ks = std::min<int64_t>(task_chunks, (total_ticks >= 16384 ? 512 : 128) / kRec);
+    while (task_chunks % ks) --ks;
+    return ks;
 }
 
 // ring_in / ring_out (streaming calls, rr_stream_begin): rows of the caller's cyclic lateral / discharge arrays where those are shorter
@@ -486,11 +495,10 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
         if (ring_out > 0 && ring_out < T) K = std::min(K, ring_out / kRec * kRec);
         if (out32) K = std::max<int64_t>(kRecRows, K / kRecRows * kRecRows);
         sch.direct = true; sch.KC = K / kRec;
-        // The skeleton's own tasks: as long as the lanes' (every tile level costs one task of pipeline and of record ring) -- except in a part
-        // that feeds another GPU, whose boundary series every level delays by one task: 64 ticks there (as kc_long below), several of the
-        // skeleton's launches per direct launch.  KS divides KC.
-        sch.KS = sch.KC * nsub;      // (in ticks: a direct task is K rows = K nsub ticks)
-        if (const char *e = getenv("RR_DIRECT_KS")) { const int64_t cap = std::max<int64_t>(1, atoll(e) / kRec); for (sch.KS = std::min<int64_t>(sch.KC * nsub, cap); (sch.KC * nsub) % sch.KS; --sch.KS) {} }
+        // The skeleton's own tasks are shorter than the lanes' (several of the skeleton's launches per direct launch; a direct task is K rows =
+        // K nsub ticks): see pick_direct_K -- and 64 ticks in a part that feeds another GPU, whose boundary series every level delays by one
+        // task (as kc_long below).  KS divides KC nsub.
+        sch.KS = direct_KS(sch.KC * nsub, total);
         if (P->n_export > 0 && P->wave_K <= 0) for (sch.KS = std::min<int64_t>(sch.KC * nsub, 4); (sch.KC * nsub) % sch.KS; --sch.KS) {}
         if (np > 0) {      // a record lives from the launch that forwards its first row to the out-pass behind the skeleton's last level
             sch.chunks = std::min<int64_t>((levels * sch.KS * kRec + 2 * K * nsub + 2 * dmax + kRecRows + 2 * kRec) / kRec + 2, (total + dmax) / kRec + 2);

@@ -247,7 +247,7 @@ def test_direct_rows_cyclic_forcing_and_ring_goes_round_vs_oracle(monkeypatch):
 
 @pytest.mark.gpu
 def test_direct_rows_at_1m_reaches_vs_oracle():
-    """BASELINE config 3's network in post-order, 640 rows in tasks of 128 (the schedule's choice for a call of that length): 4,938
+    """BASELINE config 3's network in post-order, 640 rows in tasks of 256 over skeleton tasks of 128 ticks (the schedule's choice for a call of that length): 4,938
     column-range tiles, 50,021 holes patched from the skeleton's 30 tile levels -- all 1M columns of every row against the oracle."""
     n, T = 1_000_000, 640
     net, indptr, indices, c1, c2, c3 = _case(n, synth.NETWORK_SEED)
@@ -261,7 +261,7 @@ def test_direct_rows_at_1m_reaches_vs_oracle():
         plan.set_coeffs(lhs, c2, c3, c4_dt)
         d_q, d_ql, d_out = DeviceBuffer(n * 8).upload(np.zeros(n)), DeviceBuffer(ql.nbytes).upload(ql), DeviceBuffer(T * n * 8)
         plan.rapid_route_dev(d_q, d_ql, T, d_out, T, T, 1)
-        assert plan.last_kernel() == 'direct' and plan.profile()['ticks_per_launch'] == 128
+        assert plan.last_kernel() == 'direct' and plan.profile()['ticks_per_launch'] == 256
         assert_close(d_out.download(np.float64, (T, n)), d_ref, 'discharge')
         assert_close(d_q.download(np.float64, (n,)), q_ref, 'q_t')
         for b in (d_q, d_ql, d_out):
@@ -306,7 +306,7 @@ def test_direct_full_year_at_1m_sub_basins_vs_oracle(monkeypatch):
     """The post-order line of the bench at full length against the ORACLE (the bench's own gate checks 96 rows): four sub-basins of
     3k-6k reaches -- each with skeleton reaches, holes and outlets that feed them -- routed by the oracle on their own through
     all 35,040 steps; the engine's rows for those columns, from two calls of 17,520 rows over the whole 1M-reach network in tasks of
-    512 rows (35 launches of k_direct per call, the skeleton's record ring, state carried between the calls, a 120-row forcing
+    1,024 rows over skeleton tasks of 512 ticks (18 launches of k_direct per call, the skeleton's record ring, state carried between the calls, a 120-row forcing
     ring read 146 times per call) must be theirs row by row."""
     import torch
     from test_gpu_tiles import _sub_basins
@@ -338,7 +338,7 @@ def test_direct_full_year_at_1m_sub_basins_vs_oracle(monkeypatch):
             out.fill_(-1.0)
             plan.rapid_route_dev(q, ql, rows, out, Tc, Tc, 1, torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
-            assert plan.last_kernel() == 'direct' and plan.profile()['ticks_per_launch'] == 512
+            assert plan.last_kernel() == 'direct' and plan.profile()['ticks_per_launch'] == 1024
             kept = out[:, cols_t]
             for r0 in range(0, Tc, rows):
                 oracle.rapid_route(s_indptr, s_indices, s_lhs, s_c2, s_c3, s_c4, q_ref, ql_sub, d_ref, 1)
