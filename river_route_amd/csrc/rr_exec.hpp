@@ -154,6 +154,7 @@ struct rr_plan {
     // direct row path: column-range tiles where the params order numbers small subtrees contiguously (rr_plan.hpp: DirectPlan)
     rr::DirectPlan dp;
     bool direct_enabled = true, direct_now = false;      // RR_DIRECT=0 (tests): records for every call
+    bool uh_rows_ok = true;      // false once the device refused the convolved rows of rr_unit_route_uh*_dev on the direct row path: records from then on
     int direct_window = 1;               // rows of the LDS window: largest span + 1 of the plan's tiles
     DirectTile *d_dtiles = nullptr;
     int4 *d_dlane = nullptr;
@@ -422,7 +423,7 @@ void aux_end(rr_plan *P, int sample, hipStream_t stream)
 // make the ring 50 GB (366.5 / 367.3 ms per year against 374.3 / 382.3 at 64 ticks, profiles/r03_k_sweep.txt).
 int64_t pick_KC(const rr_plan *P, int64_t total_ticks)
 {
-    if (P->wave_K > 0) return std::max<int64_t>(1, P->wave_K / kRec);
+    if (P->wave_K > 0) return std::max<int64_t>(1, std::min<int64_t>(P->wave_K, 256) / kRec);      // (RR_WAVE_K above 256 -- the longest task the schedule itself picks here -- is for the direct row path's lane tasks: the in-pass runs at most four batches of 128 tick-rows ahead of the out-pass)
     return total_ticks >= 32768 ? 16 : (total_ticks >= 16384 ? 8 : (total_ticks >= 4096 ? 4 : (total_ticks >= 512 ? 2 : 1)));
 }
 
@@ -486,7 +487,7 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
     // Sub-steps (up to kDirectMaxSub a row) and channel-only routing take it too; with sub-steps only without boundary ghosts.
     // UnitMuskingum (float64 rows of convolved lateral inflow, one sub-step a row, no boundary reaches) takes it as well.
     const bool unit_direct = mode == Mode::Unit && nsub == 1 && P->n_ghost == 0 && P->n_export == 0 && !P->unit_general && P->tp.ok &&
-                             (!uh || P->dev_total_bytes == 0 || T * n * 8 <= (int64_t)(P->dev_total_bytes / 3));
+                             (!uh || (P->uh_rows_ok && (P->dev_total_bytes == 0 || T * n * 8 <= (int64_t)(P->dev_total_bytes / 3))));
     if (plain_rows && P->direct_enabled && P->dp.ok && (mode == Mode::Rapid || mode == Mode::Muskingum || unit_direct) && nsub <= kDirectMaxSub && (nsub == 1 || P->n_ghost == 0) &&
         P->weights_uniform && !force_streaming && !host_io && P->wave_enabled && total >= 8 && n < (int64_t{1} << 29)) {
         int64_t K = pick_direct_K(P, T);
@@ -552,6 +553,11 @@ int reserve_core(rr_plan *P, Mode mode, int64_t T, int64_t nsub, bool force_stre
     Schedule sch;
     for (;;) {
         sch = choose_schedule(P, mode, T, nsub, force_streaming, host_io, plain_rows, 0, 0, out32, uh);
+        if (sch.direct && uh && ensure_cap(&P->d_mrows, &P->mrows_cap, sch.mrows) != RR_OK) {      // no room for the convolved rows: the fused form on records
+            (void)hipGetLastError();
+            P->uh_rows_ok = false;
+            continue;
+        }
         if (ensure_cap(&P->d_ring, &P->ring_cap, sch.ring) == RR_OK) break;
         (void)hipGetLastError();
         if (sch.direct) return fail(RR_E_ALLOC, "route: the skeleton's record ring does not fit on the device");

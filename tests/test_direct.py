@@ -169,7 +169,8 @@ def _case(n, seed, order='postorder', chainy=False):
 @pytest.mark.gpu
 @pytest.mark.parametrize('n,T,env,chainy', [(9, 40, {}, False), (1000, 100, {}, False), (60_000, 200, {'RR_WAVE_K': '64'}, False),
                                              (60_000, 333, {'RR_WAVE_K': '128'}, True), (300_000, 150, {}, False),
-                                             (120_000, 600, {'RR_WAVE_K': '256'}, False), (60_000, 97, {'RR_TILE_BLOCK': '64', 'RR_WAVE_K': '32'}, False)])
+                                             (120_000, 600, {'RR_WAVE_K': '256'}, False), (60_000, 97, {'RR_TILE_BLOCK': '64', 'RR_WAVE_K': '32'}, False),
+                                             (60_000, 1500, {'RR_WAVE_K': '1024'}, False)])      # lane tasks of 1,024 rows (the second one partial) over skeleton tasks of 128 ticks
 def test_direct_rows_vs_oracle(monkeypatch, n, T, env, chainy):
     """rr_rapid_route_dev on a post-order network: the direct row path runs (plan.last_kernel()), two consecutive calls (state
     carried), non-zero initial state -- discharge rows and state against the oracle."""
@@ -570,7 +571,8 @@ def test_float32_rows_on_the_direct_path(monkeypatch, n, T, factor, in32, env):
 @pytest.mark.gpu
 @pytest.mark.parametrize('n,T,nsub,mode,env', [(60_000, 100, 2, 'rapid', {}), (60_000, 70, 4, 'rapid', {}), (200_000, 130, 3, 'rapid', {'RR_WAVE_K': '64'}),
                                                (60_000, 96, 1, 'muskingum', {}), (60_000, 60, 4, 'muskingum', {}), (1_000_000, 80, 4, 'rapid', {}),
-                                               (120_000, 300, 2, 'rapid', {'RR_WAVE_K': '32'})])
+                                               (120_000, 300, 2, 'rapid', {'RR_WAVE_K': '32'}),
+                                               (20_000, 1100, 2, 'rapid', {'RR_WAVE_K': '1024'}), (20_000, 1100, 1, 'muskingum', {'RR_WAVE_K': '1024'})])      # the year's task length: 1,024 rows over shorter skeleton tasks
 def test_substeps_and_channel_only_routing_on_the_direct_path(monkeypatch, n, T, nsub, mode, env):
     """Routing sub-steps (dt_routing < dt_runoff: _numba_kernels.py:66-84, the row's lateral value held, the output the mean of the
     sub-steps) and channel-only routing (Muskingum.py:262-290) on the direct row path: two consecutive calls against the oracle, and
