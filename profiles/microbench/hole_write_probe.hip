@@ -55,6 +55,26 @@ __global__ __launch_bounds__(256) void k_pairs(const Args a)
     }
 }
 
+// whole 64-byte lines WRITTEN, nothing read (what a patch pass could do if the hole's seven neighbours came from a side buffer): four lanes x
+// 16 bytes per line, LPW lines per workgroup and step
+typedef double d2 __attribute__((ext_vector_type(2)));
+template <int AUX>
+__global__ __launch_bounds__(256) void k_full(const Args a)
+{
+    const int tid = threadIdx.x, g = tid >> 2, part = tid & 3;      // 64 lines per step
+    const int64_t h = (int64_t)blockIdx.x * 64 + g;
+    if (h >= a.n_holes) return;
+    const int32_t c8 = a.cols[h] & ~7;
+    const uint32_t row_bytes = (uint32_t)a.n * 8u;
+    for (int r = 0; r < a.rows; ++r) {
+        double *row = a.out + (a.row0 + r) * a.n;
+        const d2 v = {1.0 + r, 2.0 + part};
+        if (AUX == 0) *reinterpret_cast<d2 *>(row + c8 + 2 * part) = v;
+        else { typedef unsigned int u32x4 __attribute__((ext_vector_type(4))); u32x4 b; __builtin_memcpy(&b, &v, 16);
+               __builtin_amdgcn_raw_buffer_store_b128(b, rsrc_of(row, row_bytes), (c8 + 2 * part) * 8, 0, AUX); }
+    }
+}
+
 // the whole 64-byte line: lanes 8 g ... 8 g + 7 read the line of hole g of this step, lane (col & 7) swaps its value, all write
 template <int AUX>
 __global__ __launch_bounds__(256) void k_rmw(const Args a)
@@ -86,7 +106,7 @@ int main(int argc, char **argv)
     CK(hipMalloc(&d_cols, (size_t)nh * 4)); CK(hipMemcpy(d_cols, cols.data(), (size_t)nh * 4, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     printf("n=%lld holes=%d rows/launch=%d launches=%d (stores per launch %.2fM)\n", (long long)n, nh, rows, launches, (double)nh * rows / 1e6);
-    for (int shape = 0; shape < 17; ++shape) {
+    for (int shape = 0; shape < 19; ++shape) {
         for (int rep = 0; rep < 2; ++rep) {
             CK(hipEventRecord(e0));
             for (int l = 0; l < launches; ++l) {
@@ -107,6 +127,8 @@ int main(int argc, char **argv)
                 case 14: hipLaunchKernelGGL((k_scatter<16, 19>), dim3((nh + 15) / 16), dim3(256), 0, 0, a); break;     // sc0 nt sc1
                 case 15: hipLaunchKernelGGL((k_pairs<0>), dim3((nh / 2 + 15) / 16), dim3(256), 0, 0, a); break;        // two holes in one 64-byte line (half the lines, the same stores)
                 case 16: hipLaunchKernelGGL((k_pairs<1>), dim3((nh / 2 + 15) / 16), dim3(256), 0, 0, a); break;        // ... in one 128-byte line, different 64-byte halves
+                case 17: hipLaunchKernelGGL((k_full<0>), dim3((nh + 63) / 64), dim3(256), 0, 0, a); break;      // whole 64-byte lines written, nothing read
+                case 18: hipLaunchKernelGGL((k_full<2>), dim3((nh + 63) / 64), dim3(256), 0, 0, a); break;      // ... non-temporal
                 case 8: hipLaunchKernelGGL((k_rmw<0>), dim3((nh + 31) / 32), dim3(256), 0, 0, a); break;
                 case 9: hipLaunchKernelGGL((k_rmw<2>), dim3((nh + 31) / 32), dim3(256), 0, 0, a); break;
                 }
