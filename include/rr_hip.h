@@ -312,7 +312,10 @@ int rr_partition_forest(int64_t n, const int32_t *csc_indptr, const int32_t *csc
  * order[k] = the row that comes k-th.  Every reach follows the whole sub-basin of each of its tributaries, so every sub-basin is a run
  * of consecutive rows -- still a valid order for river_route/tools.py:103-104 (upstream before downstream), and the one in which
  * rr_rapid_route_dev / rr_stream_begin route straight from and to the caller's rows (rr_plan_direct_info).  A reach's tributaries
- * are visited largest sub-basin first, outlets in ascending row index.  RR_E_INVALID for an index out of range or a cycle.
+ * are visited small sub-basins first (at most 256 reaches: what one tile of the direct row path holds; the largest of them first), then
+ * the large ones, the largest last -- so the reaches of a main stem end up side by side behind the small sub-basins that join it, and the
+ * 8-byte stores that patch them into the output rows share lines; outlets in ascending row index.  RR_E_INVALID for an index out of
+ * range or a cycle.
  * Host-only, needs no GPU. */
 int rr_postorder(int64_t n, const int64_t *down_index, int64_t *order);
 

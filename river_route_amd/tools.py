@@ -57,7 +57,8 @@ def engine_order(river_ids: np.ndarray, downstream_ids: np.ndarray) -> np.ndarra
 def postorder(river_ids: np.ndarray, downstream_ids: np.ndarray) -> np.ndarray:
     """
     Row order that sorts a network table into depth-first post-order: `order[k]` is the row that comes k-th, every reach right after
-    the sub-basins of its tributaries (largest first).  The rows may come in ANY order -- unlike `adjacency_matrix` this needs no
+    the sub-basins of its tributaries (the small ones -- up to 256 reaches -- first, the main stem last, so that a stem's reaches are
+    neighbours in the table: include/rr_hip.h, rr_postorder).  The rows may come in ANY order -- unlike `adjacency_matrix` this needs no
     topological sort, it makes one.  A params table (and the columns of its qlateral / state files) re-sorted with it,
     `table.iloc[order]`, is still valid for the reference (upstream before downstream, river_route/tools.py:103-104), and every
     sub-basin becomes a run of consecutive rows: the engine then routes RapidMuskingum straight from and to the (time, river) rows,
