@@ -121,6 +121,27 @@ def test_tools_postorder_sorts_any_table_into_column_range_order(n, chainy):
         assert info['ok']
 
 
+def test_tools_postorder_puts_a_main_stem_side_by_side():
+    """tools.postorder visits a reach's small tributaries first and its main stem last, so the reaches with large sub-basins -- the direct
+    row path's holes, patched into the output rows by 8-byte stores -- lie in runs: far fewer 64-byte lines of a row hold one than there
+    are holes (rr_plan.cpp: postorder; 1M reaches: 7,375 lines for 50,021 holes, 26,192 with the largest tributary first)."""
+    from river_route_amd import tools
+    n = 120_000
+    net = synth.synth_network(n, seed=6, order='random')
+    order = tools.postorder(net.river_ids, net.downstream_ids)
+    rid, did = net.river_ids[order], net.downstream_ids[order]
+    A = tools.adjacency_matrix(rid, did)
+    down = np.full(n, -1, dtype=np.int64)
+    coo = A.tocoo()
+    down[coo.col] = coo.row
+    info, L = check_direct_layout(down)
+    holes = np.nonzero(L['hole'])[0]
+    lines = np.unique(holes >> 3).size
+    runs = 1 + np.count_nonzero(np.diff(holes) > 1)
+    assert info['holes'] == holes.size > 4000
+    assert lines < 0.2 * holes.size and runs < 0.05 * holes.size, (holes.size, lines, runs)
+
+
 def test_tools_postorder_rejects_what_is_not_a_forest():
     from river_route_amd import tools
     with pytest.raises(ValueError, match='Unknown downstream_river_id: 99'):
