@@ -1135,6 +1135,7 @@ static int rows_transfer(int device, bool upload, void *dev, int64_t dev_pitch, 
         }
     }
     (void)close(fd);
+    if (R.st && (rc || e != hipSuccess || !io_ok)) (void)hipStreamSynchronize(R.st);      // a failed transfer leaves no copy in flight behind: the caller may free the rows
     if (rc) return rc;
     if (e != hipSuccess) return fail(RR_E_HIP, std::string("rr_rows_*: ") + hipGetErrorString(e));
     if (!io_ok) return fail(RR_E_INVALID, std::string("rr_rows_*: short read or write on ") + path);

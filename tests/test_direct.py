@@ -536,6 +536,8 @@ def test_partitioned_postorder_network_on_the_direct_path_vs_oracle(monkeypatch)
     _route_parts_on_the_direct_path(200_000, 8, 200, 32, 4, ['direct'] * 7 + ['tile'])
     set_env(monkeypatch, {'RR_WAVE_K': '64'})      # short tasks: the skeleton's ring goes round, exports trail by fewer rows
     _route_parts_on_the_direct_path(400_000, 4, 700, 48, 6, ['direct'] * 4)
+    set_env(monkeypatch, {'RR_WAVE_K': '1024'})    # the year's lane tasks (1,024 rows, the second one partial) over the 64-tick skeleton tasks of a part with exports: 16 skeleton launches per direct launch
+    _route_parts_on_the_direct_path(400_000, 4, 1300, 128, 6, ['direct'] * 4)
 
 
 @pytest.mark.gpu

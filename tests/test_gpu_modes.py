@@ -383,3 +383,41 @@ def test_profile_names_every_kernel_of_the_path(monkeypatch):
             assert aux[k]['sampled'] == (aux[k]['launches'] + 3) // 4 and 0 < aux[k]['sampled_ms'] < 1e3
         for b in (d_q, d_ql, d_out):
             b.free()
+
+
+@pytest.mark.gpu
+def test_rows_between_a_file_and_the_device(tmp_path):
+    """rr_rows_upload / rr_rows_download (include/rr_hip.h): rows that lie `pitch` bytes apart in a file <-> device rows, several staging
+    chunks long; a file that ends before the last row, a file that does not exist and bad arguments are refused with an error, not a crash."""
+    from river_route_amd import engine
+    from river_route_amd._lib import RRError
+    rows, cols = 700, 40_000      # 112 MB: two 64 MB staging chunks
+    rng = np.random.default_rng(3)
+    data = rng.standard_normal((rows, cols)).astype(np.float32)
+    pad, head = 24, 128      # bytes between rows (a record variable's other members) and in front of the first row
+    path = tmp_path / 'rows.bin'
+    raw = np.zeros((rows, cols * 4 + pad), dtype=np.uint8)
+    raw[:, :cols * 4] = data.view(np.uint8).reshape(rows, cols * 4)
+    with open(path, 'wb') as f:
+        f.write(b'\0' * head)
+        f.write(raw.tobytes())
+    dev = DeviceBuffer(rows * cols * 4)
+    engine.rows_upload(dev, cols * 4, path, head, cols * 4 + pad, cols * 4, rows)
+    np.testing.assert_array_equal(dev.download(np.float32, (rows, cols)), data)
+    out = tmp_path / 'out.bin'
+    with open(out, 'wb') as f:
+        f.truncate(head + rows * (cols * 4 + pad))
+    engine.rows_download(dev, cols * 4, out, head, cols * 4 + pad, cols * 4, rows)
+    got = np.fromfile(out, dtype=np.uint8)[head:].reshape(rows, cols * 4 + pad)
+    np.testing.assert_array_equal(got[:, :cols * 4].copy().view(np.float32).reshape(rows, cols), data)
+    assert not got[:, cols * 4:].any(), 'the bytes between the rows were left alone'
+    with pytest.raises(RRError, match='short read'):
+        engine.rows_upload(dev, cols * 4, path, head, cols * 4 + pad, cols * 4, rows + 5)
+    with pytest.raises(RRError, match='cannot open'):
+        engine.rows_upload(dev, cols * 4, tmp_path / 'missing.bin', 0, cols * 4, cols * 4, rows)
+    with pytest.raises(RRError, match='cannot open'):
+        engine.rows_download(dev, cols * 4, tmp_path / 'missing_out.bin', 0, cols * 4, cols * 4, rows)
+    with pytest.raises(RRError):
+        engine.rows_upload(dev, cols * 4 - 4, path, head, cols * 4 + pad, cols * 4, rows)      # device pitch shorter than a row
+    np.testing.assert_array_equal(dev.download(np.float32, (rows, cols))[:rows - 5], data[:rows - 5])      # (the failed calls left the device usable)
+    dev.free()
