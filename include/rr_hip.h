@@ -120,7 +120,7 @@ int rr_plan_set_unit_weights(rr_plan *plan, const double *c1, const double *a_da
  * -- which rr_rapid_route*_dev and rr_stream_begin take where the params order numbers small subtrees contiguously, see
  * rr_plan_direct_info -- does not apply and the record ring is needed; RR_ROWS_F32_OUT: the call writes float32 rows
  * (rr_*_route_f32*_dev: the direct task is then a multiple of 128 rows); RR_ROWS_UH: the call is rr_unit_route_uh*_dev (runoff
- * depths + unit-hydrograph kernel): on the direct row path -- which rr_unit_route*_dev take too, with one sub-step per row and no
+ * depths + unit-hydrograph kernel): on the direct row path -- which rr_unit_route*_dev take too, with up to four sub-steps per row and no
  * boundary reaches -- the convolution runs as a pass of its own into T rows of work memory, reserved here.
  * info (may be NULL): [0] 2 = direct row path, 1 = time-tiled kernel, 0 = streaming kernel; [1] routing ticks (rows) per launch K; [2] chunks of the
  * record ring (16 ticks each); [3] bytes of routing work memory now held on the device; [4] bytes of device staging and

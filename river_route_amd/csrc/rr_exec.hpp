@@ -267,7 +267,9 @@ int upload_tile_coef(rr_plan *P)
 typedef void (*direct_kernel_t)(const DirectArgs);
 direct_kernel_t direct_kernel(bool in32, bool out32, bool sub = false, int unit = 0)
 {
-    if (unit == 1) return out32 ? (direct_kernel_t)k_direct<kDirectAhead, false, true, false, 1> : (direct_kernel_t)k_direct<kDirectAhead, false, false, false, 1>;      // UnitMuskingum: float64 rows, one sub-step
+    if (unit == 1)      // UnitMuskingum: float64 rows
+        return sub ? (out32 ? (direct_kernel_t)k_direct<kDirectAhead, false, true, true, 1> : (direct_kernel_t)k_direct<kDirectAhead, false, false, true, 1>)
+                   : (out32 ? (direct_kernel_t)k_direct<kDirectAhead, false, true, false, 1> : (direct_kernel_t)k_direct<kDirectAhead, false, false, false, 1>);
 #define RR_DK(I_, O_) (sub ? (direct_kernel_t)k_direct<kDirectAhead, I_, O_, true> : (direct_kernel_t)k_direct<kDirectAhead, I_, O_, false>)
     return in32 ? (out32 ? RR_DK(true, true) : RR_DK(true, false)) : (out32 ? RR_DK(false, true) : RR_DK(false, false));
 #undef RR_DK
@@ -290,8 +292,8 @@ int upload_direct_plan(rr_plan *P)
     const rr::DirectPlan &D = P->dp;
     const rr::TilePlan &K = D.skel;
     const int64_t n = H.n;
-    for (int v = 0; v < 10; ++v)      // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel (v = 8, 9: UnitMuskingum)
-        if (hipFuncSetAttribute((const void *)direct_kernel((v & 1) != 0, (v & 2) != 0, v < 8 && (v & 4) != 0, v >= 8 ? 1 : 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)direct_lds_bytes(kDirectMaxWindow)) != hipSuccess) {
+    for (int v = 0; v < 12; ++v)      // > 64 KiB of dynamic LDS needs an explicit opt-in per kernel (v = 8 ... 11: UnitMuskingum, float64 rows in)
+        if (hipFuncSetAttribute((const void *)direct_kernel(v < 8 && (v & 1) != 0, (v & 2) != 0, v < 8 ? (v & 4) != 0 : (v & 1) != 0, v >= 8 ? 1 : 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)direct_lds_bytes(kDirectMaxWindow)) != hipSuccess) {
             (void)hipGetLastError();
             P->direct_enabled = false;
         }
@@ -484,9 +486,9 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
     // The direct row path: RapidMuskingum, one sub-step per row, float64 rows in device arrays, one weight per reach -- the
     // headline's call -- on a params order that numbers small subtrees contiguously (boundary reaches of a partitioned network
     // included: rr_plan_set_boundary lays the direct plan out around them).
-    // Sub-steps (up to kDirectMaxSub a row) and channel-only routing take it too; with sub-steps only without boundary ghosts.
-    // UnitMuskingum (float64 rows of convolved lateral inflow, one sub-step a row, no boundary reaches) takes it as well.
-    const bool unit_direct = mode == Mode::Unit && nsub == 1 && P->n_ghost == 0 && P->n_export == 0 && !P->unit_general && P->tp.ok &&
+    // Sub-steps (up to kDirectMaxSub a row) and channel-only routing take it too; with sub-steps only without boundary ghosts.  UnitMuskingum: below.
+    // UnitMuskingum (float64 rows of convolved lateral inflow, no boundary reaches) takes it as well.
+    const bool unit_direct = mode == Mode::Unit && nsub <= kDirectMaxSub && P->n_ghost == 0 && P->n_export == 0 && !P->unit_general && P->tp.ok &&
                              (!uh || (P->uh_rows_ok && (P->dev_total_bytes == 0 || T * n * 8 <= (int64_t)(P->dev_total_bytes / 3))));
     if (plain_rows && P->direct_enabled && P->dp.ok && (mode == Mode::Rapid || mode == Mode::Muskingum || unit_direct) && nsub <= kDirectMaxSub && (nsub == 1 || P->n_ghost == 0) &&
         P->weights_uniform && !force_streaming && !host_io && P->wave_enabled && total >= 8 && n < (int64_t{1} << 29)) {
@@ -646,7 +648,7 @@ int session_begin(rr_plan *P, Mode mode, int64_t T, int64_t nsub, const Rows &io
 
     if (S.wave || S.rows_direct) { S.KC = P->next_KC; S.rec_chunks = P->next_chunks; }     // ring sized by choose_schedule, allocated by rr_plan_reserve
     if (S.rows_direct) {
-        if (io.uh_kernel || io.runoff || (S.has_in && !io.dev_in && !io.dev_in32) || (!io.dev_out && !io.dev_out32) || (mode == Mode::Unit && (nsub != 1 || io.dev_in32 || P->n_ghost > 0 || P->n_export > 0)) || nsub > kDirectMaxSub ||
+        if (io.uh_kernel || io.runoff || (S.has_in && !io.dev_in && !io.dev_in32) || (!io.dev_out && !io.dev_out32) || (mode == Mode::Unit && (io.dev_in32 || P->n_ghost > 0 || P->n_export > 0)) || nsub > kDirectMaxSub ||
             (io.dev_out32 && (io.out_factor < 1 || (S.KC * kRec) % io.out_factor != 0 || T % io.out_factor != 0))) {
             S.open = false;
             return fail(RR_E_STATE, "route: the direct row path was chosen for a call it does not take");      // (choose_schedule's plain_rows / out32)

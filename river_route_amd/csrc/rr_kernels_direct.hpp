@@ -260,11 +260,20 @@ __global__ __launch_bounds__(kDirectThreads, 1) void k_direct(const DirectArgs a
                         double *mine = reinterpret_cast<double *>(F + own + tid * 8);
                         const double lat = *mine;
                         const bool active = (uint32_t)(k0 + s - delta) < (uint32_t)total_sub;
-                        double qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev, __builtin_fma(c3, q_old, lat)));
-                        qk = active ? qk : q_old;
+                        double qk;
+                        if constexpr (UNIT != 0) {      // (the row's lateral value is held over its sub-steps, a headwater republishes it every one of them)
+                            const double s_hw = (*reinterpret_cast<const double *>(X + prev + hw0_b) + *reinterpret_cast<const double *>(X + prev + hw1_b)) +
+                                                *reinterpret_cast<const double *>(X + prev + hw2_b);
+                            const double r = __builtin_fma(c1, s_hw + s_cur, __builtin_fma(c2, s_hw + s_prev, c3 * qc));
+                            qk = active ? r + lat : q_old;
+                            qc = active ? r : qc;
+                        } else {
+                            qk = __builtin_fma(c1, s_cur, __builtin_fma(c2, s_prev, __builtin_fma(c3, q_old, lat)));
+                            qk = active ? qk : q_old;
+                        }
                         const double acc = (phase == 0 ? 0.0 : isum) + qk;      // (k_tile<SUB>'s order: 0 + first, + second, ...)
                         const bool last = active && phase + 1 == nsub;
-                        if (last) *mine = acc * a.inv_nsub;      // the row's mean, unclamped: the rows-out wave clips
+                        if (last && !(UNIT != 0 && no_coef)) *mine = acc * a.inv_nsub;      // the row's mean, unclamped: the rows-out wave clips (UNIT: a headwater's row value stays as it arrived, _numba_kernels.py:122-123)
                         isum = active ? acc : isum;
                         own = last ? (own + kRowB == wrap ? 0 : own + kRowB) : own;
                         phase = active ? (last ? 0 : phase + 1) : phase;

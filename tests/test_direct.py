@@ -634,15 +634,17 @@ def test_substeps_and_channel_only_routing_on_the_direct_path(monkeypatch, n, T,
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('n,T,env,f32', [(9, 40, {}, False), (1000, 100, {}, False), (60_000, 200, {'RR_WAVE_K': '64'}, False), (300_000, 150, {}, False),
-                                         (120_000, 600, {'RR_WAVE_K': '256'}, False), (60_000, 256, {}, True)])
-def test_unit_route_on_the_direct_path_vs_oracle(monkeypatch, n, T, env, f32):
+@pytest.mark.parametrize('n,T,env,f32,nsub', [(9, 40, {}, False, 1), (1000, 100, {}, False, 1), (60_000, 200, {'RR_WAVE_K': '64'}, False, 1), (300_000, 150, {}, False, 1),
+                                              (120_000, 600, {'RR_WAVE_K': '256'}, False, 1), (60_000, 256, {}, True, 1),
+                                              (60_000, 100, {}, False, 2), (120_000, 130, {'RR_WAVE_K': '64'}, False, 3), (60_000, 128, {}, True, 4), (1000, 70, {}, False, 4)])      # sub-steps
+def test_unit_route_on_the_direct_path_vs_oracle(monkeypatch, n, T, env, f32, nsub):
     """rr_unit_route_dev (rows of convolved lateral inflow) on a post-order network: k_direct<UNIT> routes the small sub-basins, the skeleton
     runs k_tile<UNIT> on records; two files with the state hand-off of UnitMuskingum._router (river_route/routers/UnitMuskingum.py:72-98);
     headwater columns leave unclipped (_numba_kernels.py:122-123).  f32: rr_unit_route_f32_dev, the routers' float32 means of 4 rows."""
     from tests_support import unit_split_arrays
     set_env(monkeypatch, env)
     net, indptr, indices, c1, c2, c3 = _case(n, 31)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0 / nsub)
     hw_idx, inner_idx, A_in, A_hw = unit_split_arrays(indptr, indices, n)
     c1i, c2i, c3i = c1[inner_idx], c2[inner_idx], c3[inner_idx]
     args = (A_in.indptr, A_in.indices, -c1i[A_in.indices], A_in.indptr, A_in.indices, A_in.data,
@@ -662,14 +664,14 @@ def test_unit_route_on_the_direct_path_vs_oracle(monkeypatch, n, T, env, f32):
             if f == 1:
                 conv_ref[5, hw_idx[:3]] = -0.25      # a negative headwater inflow stays as it is
             qc_ref, qf_ref, d_ref = state_ref[inner_idx].copy(), state_ref[inner_idx].copy(), np.zeros((T, n))
-            oracle.unit_route(*args, qc_ref, qf_ref, conv_ref, d_ref, 1)
+            oracle.unit_route(*args, qc_ref, qf_ref, conv_ref, d_ref, nsub)
             state_ref[hw_idx], state_ref[inner_idx] = conv_ref[-1][hw_idx], qf_ref
             d_conv.upload(conv_ref)
             d_qc.upload(state[inner_idx].copy()); d_qf.upload(state[inner_idx].copy())
             if f32:
-                plan.unit_route_f32_dev(d_qc, d_qf, d_conv, T, d_out, T, 1, factor=factor)
+                plan.unit_route_f32_dev(d_qc, d_qf, d_conv, T, d_out, T, nsub, factor=factor)
             else:
-                plan.unit_route_dev(d_qc, d_qf, d_conv, T, d_out, T, T, 1)
+                plan.unit_route_dev(d_qc, d_qf, d_conv, T, d_out, T, T, nsub)
             assert plan.last_kernel() == 'direct'
             qc, qf = d_qc.download(np.float64, (ni,)), d_qf.download(np.float64, (ni,))
             state[hw_idx], state[inner_idx] = conv_ref[-1][hw_idx], qf
@@ -688,15 +690,16 @@ def test_unit_route_on_the_direct_path_vs_oracle(monkeypatch, n, T, env, f32):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('n,T,n_ks,in32,f32out', [(60_000, 200, 48, False, False), (300_000, 150, 48, True, False), (60_000, 256, 12, True, True), (60_007, 300, 33, False, False),
-                                                   (60_000, 100, 60, False, False)])
-def test_unit_route_with_convolution_on_the_direct_path_vs_oracle(monkeypatch, n, T, n_ks, in32, f32out):
+@pytest.mark.parametrize('n,T,n_ks,in32,f32out,nsub', [(60_000, 200, 48, False, False, 1), (300_000, 150, 48, True, False, 1), (60_000, 256, 12, True, True, 1), (60_007, 300, 33, False, False, 1),
+                                                        (60_000, 100, 60, False, False, 1), (60_000, 96, 24, True, False, 3), (60_000, 128, 48, False, True, 2)])      # sub-steps
+def test_unit_route_with_convolution_on_the_direct_path_vs_oracle(monkeypatch, n, T, n_ks, in32, f32out, nsub):
     """rr_unit_route_uh_dev / rr_unit_route_uh_f32in_dev on a post-order network: UnitHydrograph.convolve + unit_route + the router's state
     bookkeeping (river_route/routers/UnitMuskingum.py:72-98) in one call -- on the direct row path the convolution runs as a pass of its own into
     work rows, then k_direct<UNIT> routes them; two files, the second shorter than the kernel, so the carry-over state crosses a file boundary."""
     from tests_support import unit_split_arrays
     set_env(monkeypatch, {})
     net, indptr, indices, c1, c2, c3 = _case(n, 23)
+    c1, c2, c3 = oracle.muskingum_coefficients(net.k, net.x, 900.0 / nsub)
     hw_idx, inner_idx, A_in, A_hw = unit_split_arrays(indptr, indices, n)
     c1i, c2i, c3i = c1[inner_idx], c2[inner_idx], c3[inner_idx]
     args = (A_in.indptr, A_in.indices, -c1i[A_in.indices], A_in.indptr, A_in.indices, A_in.data,
@@ -719,13 +722,13 @@ def test_unit_route_with_convolution_on_the_direct_path_vs_oracle(monkeypatch, n
                 depth = depth.astype(np.float32)
             conv_ref = uh.convolve(depth.astype(np.float64))
             qc_ref, qf_ref, d_ref = state_ref[inner_idx].copy(), state_ref[inner_idx].copy(), np.zeros((Tf, n))
-            oracle.unit_route(*args, qc_ref, qf_ref, conv_ref, d_ref, 1)
+            oracle.unit_route(*args, qc_ref, qf_ref, conv_ref, d_ref, nsub)
             state_ref[hw_idx], state_ref[inner_idx] = conv_ref[-1][hw_idx], qf_ref
             d_depth.upload(depth)
             d_qc.upload(state[inner_idx].copy()); d_qf.upload(state[inner_idx].copy())
             call = plan.unit_route_uh_f32in_dev if in32 else plan.unit_route_uh_dev
             out_kw = dict(discharge32=d_out, factor=factor) if f32out else dict(discharge=d_out)
-            call(d_qc, d_qf, d_fin, d_kern, d_state, n_ks, d_depth, Tf, 1, **out_kw)
+            call(d_qc, d_qf, d_fin, d_kern, d_state, n_ks, d_depth, Tf, nsub, **out_kw)
             assert plan.last_kernel() == 'direct'
             state = d_fin.download(np.float64, (n,))
             if f32out:
