@@ -1,6 +1,6 @@
 """Randomised parity sweep of the direct row path against the oracle (round 5; a development aid, not a test: 60 small post-order networks of random size,
 shape and seed -- Remy trees and chain-grown forests with three-way confluences --, RapidMuskingum / channel-only / UnitMuskingum, 1-4 sub-steps, float64 or float32
-rows, random task lengths; every row and the final state at rtol 1e-10).  usage: python profiles/microbench/direct_fuzz.py [cases] [seed]"""
+rows, random task lengths; every row and the final state at rtol 1e-10).  usage: python profiles/microbench/direct_fuzz.py [cases] [seed] [params order: postorder (default) | random | levels | bfs]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), 'tests'))
@@ -21,14 +21,15 @@ def close(a, b, what):
     return err
 
 cases, seed0 = (int(sys.argv[1]) if len(sys.argv) > 1 else 60), (int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+order = sys.argv[3] if len(sys.argv) > 3 else 'postorder'      # 'random' / 'levels' / 'bfs': the same sweep through records (k_tile, k_tick)
 rng = np.random.default_rng(seed0)
 kinds = {}
 for case in range(cases):
     n = int(rng.choice([1, 2, 3, 7, 40, 257, 300, 700, 2000, 6000, 20000]))
     chainy = bool(rng.integers(0, 3) == 0) and n >= 40
     seed = int(rng.integers(1, 1 << 20))
-    net = (synth.synth_network_chain(n, p_chain=float(rng.choice([0.2, 0.5, 0.8])), n_outlets=int(rng.integers(1, 6)), p_third=0.05, seed=seed, order='postorder') if chainy
-           else synth.synth_network(n, seed=seed, order='postorder'))
+    net = (synth.synth_network_chain(n, p_chain=float(rng.choice([0.2, 0.5, 0.8])), n_outlets=int(rng.integers(1, 6)), p_third=0.05, seed=seed, order=order) if chainy
+           else synth.synth_network(n, seed=seed, order=order))
     indptr, indices = csc(net.down_index)
     nsub = int(rng.choice([1, 1, 2, 3, 4]))
     mode = str(rng.choice(['rapid', 'rapid', 'muskingum', 'unit']))
@@ -68,8 +69,14 @@ for case in range(cases):
                 if in32: ql = ql.astype(np.float32)
                 oracle.rapid_route(indptr, indices, -c1[indices], c2, c3, c4, q_ref, ql.astype(np.float64), d_ref, nsub)
                 d_ql = DeviceBuffer(ql.nbytes).upload(ql)
-                if in32: plan.rapid_route_f32in_dev(d_q, d_ql, T, T, nsub, discharge=d_out, out_rows=T)
-                else: plan.rapid_route_dev(d_q, d_ql, T, d_out, T, T, nsub)
+                try:
+                    if in32: plan.rapid_route_f32in_dev(d_q, d_ql, T, T, nsub, discharge=d_out, out_rows=T)
+                    else: plan.rapid_route_dev(d_q, d_ql, T, d_out, T, T, nsub)
+                except Exception as exc:      # the float32 form is refused where the call is not time-tiled (a few sub-steps on records): the float64 form then, as the routers do
+                    from river_route_amd._lib import RR_E_UNSUPPORTED
+                    if not in32 or getattr(exc, 'code', None) != RR_E_UNSUPPORTED: raise
+                    d_ql.free(); d_ql = DeviceBuffer(T * n * 8).upload(ql.astype(np.float64))
+                    plan.rapid_route_dev(d_q, d_ql, T, d_out, T, T, nsub)
                 d_ql.free()
             else:
                 oracle.muskingum_route(indptr, indices, -c1[indices], c2, c3, q_ref, d_ref, T, nsub)
