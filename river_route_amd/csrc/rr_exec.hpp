@@ -504,7 +504,12 @@ Schedule choose_schedule(const rr_plan *P, Mode mode, int64_t T, int64_t nsub, b
         sch.KS = direct_KS(sch.KC * nsub, total);
         if (P->n_export > 0 && P->wave_K <= 0) for (sch.KS = std::min<int64_t>(sch.KC * nsub, 4); (sch.KC * nsub) % sch.KS; --sch.KS) {}
         if (np > 0) {      // a record lives from the launch that forwards its first row to the out-pass behind the skeleton's last level
-            sch.chunks = std::min<int64_t>((levels * sch.KS * kRec + 2 * K * nsub + 2 * dmax + kRecRows + 2 * kRec) / kRec + 2, (total + dmax) / kRec + 2);
+            // a ring cut to the call's length: with boundary ghosts it has to hold their in-pass's batches whole -- k_rec_in writes nine records per position and
+            // batch, zeros past the call's end, and in a ring shorter than that a batch wrapped onto its own first records (a 40- or 130-row call of a shallow part:
+            // wrong boundary inflow; a 200-row call: the last batch waited for its own slots for ever -- both found by profiles/microbench/parts_fuzz.py)
+            int64_t whole_call = (total + dmax) / kRec + 2;
+            if (P->n_ghost > 0) whole_call = std::max<int64_t>(whole_call, kRecBatch * ((total + 14) / kRecRows + 1) + (dmax >> 4) + 2);
+            sch.chunks = std::min<int64_t>((levels * sch.KS * kRec + 2 * K * nsub + 2 * dmax + kRecRows + 2 * kRec) / kRec + 2, whole_call);
             sch.ring = sch.chunks * kRec * np;
         }
         if (uh) sch.mrows = T * n;      // the convolved rows
@@ -1074,7 +1079,7 @@ int session_advance_tile(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, in
             if (have_ghost < std::min(std::max<int64_t>(0, (S.diag + 1) * K - S.ghost_slack), S.total)) break;
             // the tasks of this launch overwrite records in place: nothing they write may still be waiting to leave from
             // one ring revolution earlier (their chunks are at most (d + 1) KC - 1)
-            const int64_t top = std::min(S.diag + 1, S.n_macro) * S.KC - 1;
+            const int64_t top = std::min(std::min(S.diag + 1, S.n_macro) * S.KC - 1, (S.total_ticks - 1) / kRec);      // (a task longer than what is left of the call -- RR_WAVE_K -- ends with the call's last chunk)
             if (top >= S.rec_chunks && S.ticks_stored < std::min(S.total, kRec * (top - S.rec_chunks + 1))) break;
             int rc = session_launch_diag(P, S.diag);
             if (rc) return rc;
@@ -1121,7 +1126,7 @@ int session_advance_direct(rr_plan *P, int64_t rows_ready, int64_t ghost_ready, 
     rows_ready = std::min(rows_ready, S.T);
     const bool skel = TP.n_tiles > 0, ghosts = skel && P->n_ghost > 0;
     // a record slot is recycled only after every tick-row it can hold has left (the same rule as session_advance_tile's)
-    auto slot_free = [&](int64_t j) {
+    auto slot_free = [&](int64_t j) {      // (a batch of the boundary in-pass writes whole records up to tick-row 128 (j + 1) + lag, zeros past the call's end)
         const int64_t must_have_left = kRecRows * (j + 1) + kRec - kRec * S.rec_chunks;
         return must_have_left <= 0 || S.ticks_stored >= std::min(S.total, must_have_left);
     };
@@ -1277,6 +1282,11 @@ int session_end(rr_plan *P)
     if (!S.open) return fail(RR_E_STATE, "no routing call is open on this plan");
     const bool complete = P->h.n == 0 || S.total == 0 || (S.tau >= S.total_ticks && S.rows_stored >= S.T);
     S.open = false;
+    if (!complete && getenv("RR_VERBOSE"))
+        fprintf(stderr, "rr: incomplete call: T=%lld total=%lld tau=%lld/%lld rows_loaded=%lld rows_stored=%lld | direct=%d tasks %lld/%lld diag %lld/%lld in_batches %lld ghost_batches %lld/%lld out_batches %lld/%lld "
+                        "ticks_stored=%lld K=%lld KS=%lld chunks=%lld macro=%lld\n", (long long)S.T, (long long)S.total, (long long)S.tau, (long long)S.total_ticks, (long long)S.rows_loaded, (long long)S.rows_stored,
+                (int)S.rows_direct, (long long)S.d_done, (long long)S.n_tasks, (long long)S.diag, (long long)S.n_diags, (long long)S.in_batches, (long long)S.ghost_batches, (long long)S.n_in_batches,
+                (long long)S.out_batches, (long long)S.n_out_batches, (long long)S.ticks_stored, (long long)(S.KC * kRec), (long long)(S.KS * kRec), (long long)S.rec_chunks, (long long)S.n_macro);
     if (!complete) return fail(RR_E_STATE, "routing call closed before all of its time steps were routed");
     if (P->h.n == 0 || S.total == 0) return RR_OK;
     if (S.bracket_open) P->prof_samples -= P->prof_samples % kSampleGroup;   // incomplete bracket: not counted

@@ -499,10 +499,10 @@ def test_parts_of_a_cut_postorder_network_lay_out_around_their_boundary_reaches(
             assert lane_export.any() and not lane_export.all(), 'this case has both kinds'
 
 
-def _route_parts_on_the_direct_path(n, parts, T, chunk, seed, expect_direct):
+def _route_parts_on_the_direct_path(n, parts, T, chunk, seed, expect_direct, chainy=False):
     from river_route_amd.engine import partition_forest
     from river_route_amd.multi_gpu import HipPartEngine, run_in_process, split_network
-    net, indptr, indices, c1, c2, c3 = _case(n, seed)
+    net, indptr, indices, c1, c2, c3 = _case(n, seed, chainy=chainy)
     c4_dt = (c1 + c2) / 900.0
     q0 = 4.0 * synth.u01(8, np.arange(n))
     ql = synth.synth_qlateral(n, 0, T)
@@ -538,6 +538,19 @@ def test_partitioned_postorder_network_on_the_direct_path_vs_oracle(monkeypatch)
     _route_parts_on_the_direct_path(400_000, 4, 700, 48, 6, ['direct'] * 4)
     set_env(monkeypatch, {'RR_WAVE_K': '1024'})    # the year's lane tasks (1,024 rows, the second one partial) over the 64-tick skeleton tasks of a part with exports: 16 skeleton launches per direct launch
     _route_parts_on_the_direct_path(400_000, 4, 1300, 128, 6, ['direct'] * 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,parts,T,chunk,seed,chainy', [(20_000, 5, 40, 40, 812328, True), (20_000, 5, 130, 64, 812328, True), (3000, 7, 200, 32, 362543, False),
+                                                         (3000, 7, 300, 32, 362543, False)])
+def test_short_calls_of_shallow_parts_on_the_direct_path_vs_oracle(monkeypatch, n, parts, T, chunk, seed, chainy):
+    """Regression (found by profiles/microbench/parts_fuzz.py): the skeleton's record ring is cut to the call's length, and with boundary ghosts it has to
+    hold their in-pass's batches whole -- nine records per position and batch, zeros past the call's end.  In a shorter ring a batch wrapped onto its own
+    first records: a 40- or 130-row call of a shallow part of a chain-grown network routed wrong boundary inflow, a 200-row call of a 3,000-reach network
+    in seven parts never finished."""
+    set_env(monkeypatch, {})
+    specs = _route_parts_on_the_direct_path(n, parts, T, chunk, seed, ['direct'] * parts, chainy=chainy)
+    assert sum(s.n_ghost for s in specs) > 0
 
 
 @pytest.mark.gpu
